@@ -1,0 +1,104 @@
+"""Synthetic Catalina-like planning worlds ("Synthetic world").
+
+The reference builds its world from geopy/shapely (path_planning/catalina.py:32-119,
+sharkOccupancyGrid.py:376-393), which is input generation and out of scope; benches, parity tests
+and golden fixtures use these seeded stand-ins instead.  Pure `random.Random(seed)` so the same
+world can be rebuilt anywhere (GPU box included) from (seed, sizes).
+"""
+import random
+
+import numpy as np
+
+
+def make_world(seed=0, n_obstacles=64, box=(-300.0, -100.0, -100.0, 100.0), cell=10.0,
+               n_bins=10, bin_len=50, n_habitats=10, start=None, obst_radius=None,
+               hab_radius=(8.0, 20.0), pmax=0.3):
+    """Return a dict of fp64 arrays describing one world.
+
+    obstacles [O,3] (x,y,r); habitats [H,3]; polygon [V,2] (rectangle, counter-clockwise);
+    bins [T,2] (t0,t1) integer-valued; cells [C,4] (minx,miny,maxx,maxy) row-major from the
+    bottom-left; prob [T,C]; start (x,y) = box centre unless given.
+    """
+    rng = random.Random(seed)
+    x0, y0, x1, y1 = box
+    if start is None:
+        start = (0.5 * (x0 + x1), 0.5 * (y0 + y1))
+    if obst_radius is None:
+        obst_radius = (1.0, 4.0) if n_obstacles <= 64 else (1.0, 3.0)
+    obstacles = []
+    while len(obstacles) < n_obstacles:
+        ox = rng.uniform(x0 + 5.0, x1 - 5.0)
+        oy = rng.uniform(y0 + 5.0, y1 - 5.0)
+        r = rng.uniform(*obst_radius)
+        if (ox - start[0]) ** 2 + (oy - start[1]) ** 2 <= (r + 5.0) ** 2:
+            continue
+        obstacles.append((ox, oy, r))
+    habitats = [(rng.uniform(x0, x1), rng.uniform(y0, y1), rng.uniform(*hab_radius))
+                for _ in range(n_habitats)]
+    ncol = int(round((x1 - x0) / cell))
+    nrow = int(round((y1 - y0) / cell))
+    cells = []
+    for r_ in range(nrow):
+        for c_ in range(ncol):
+            cells.append((x0 + c_ * cell, y0 + r_ * cell, x0 + (c_ + 1) * cell, y0 + (r_ + 1) * cell))
+    bins = [(float(i * bin_len), float((i + 1) * bin_len)) for i in range(n_bins)]
+    prob = [[rng.uniform(0.0, pmax) for _ in range(len(cells))] for _ in range(n_bins)]
+    return {
+        "seed": seed,
+        "box": np.array(box, dtype=np.float64),
+        "start": np.array(start, dtype=np.float64),
+        "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
+        "habitats": np.array(habitats, dtype=np.float64).reshape(-1, 3),
+        "polygon": np.array([(x0, y0), (x1, y0), (x1, y1), (x0, y1)], dtype=np.float64),
+        "bins": np.array(bins, dtype=np.float64).reshape(-1, 2),
+        "cells": np.array(cells, dtype=np.float64).reshape(-1, 4),
+        "prob": np.array(prob, dtype=np.float64).reshape(n_bins, -1),
+        "grid_shape": (nrow, ncol),
+    }
+
+
+def make_rect_world(seed=0, n_obstacles=256, size=200.0, start=(20.0, 20.0), goal=(170.0, 180.0),
+                    obst_radius=(1.0, 3.0)):
+    """Planner_RRT (gym_rrt) world: rectangle [0,size]^2, circular obstacles clear of start/goal
+    (SURVEY.md section 8(d) config 4)."""
+    rng = random.Random(seed)
+    obstacles = []
+    while len(obstacles) < n_obstacles:
+        ox = rng.uniform(5.0, size - 5.0)
+        oy = rng.uniform(5.0, size - 5.0)
+        r = rng.uniform(*obst_radius)
+        if (ox - start[0]) ** 2 + (oy - start[1]) ** 2 <= (r + 5.0) ** 2:
+            continue
+        if (ox - goal[0]) ** 2 + (oy - goal[1]) ** 2 <= (r + 5.0) ** 2:
+            continue
+        obstacles.append((ox, oy, r))
+    return {
+        "seed": seed,
+        "rect": np.array([0.0, 0.0, size, size], dtype=np.float64),
+        "start": np.array(start, dtype=np.float64),
+        "goal": np.array(goal, dtype=np.float64),
+        "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
+    }
+
+
+def make_lattice_world(seed=0, n_obstacles=10, lo=0, hi=490, r_range=(10, 30)):
+    """astar.astar world (config 1): integer obstacle centres in [50, hi-50], integer radii."""
+    rng = random.Random(seed)
+    obstacles = []
+    while len(obstacles) < n_obstacles:
+        ox = rng.randint(50, hi - 50)
+        oy = rng.randint(50, hi - 50)
+        r = rng.randint(*r_range)
+        # keep the start and goal corners free
+        if (ox - lo) ** 2 + (oy - lo) ** 2 <= (r + 15) ** 2:
+            continue
+        if (ox - hi) ** 2 + (oy - hi) ** 2 <= (r + 15) ** 2:
+            continue
+        obstacles.append((ox, oy, r))
+    return {
+        "seed": seed,
+        "box": np.array([lo, lo, hi, hi], dtype=np.float64),
+        "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
+        "start": (lo, lo),
+        "goal": (hi, hi),
+    }

@@ -1,0 +1,182 @@
+"""ctypes loader for the CPU checker (oracle/liboracle_{libm,portable}.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg -- never by the product package auv_sim_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_int8)
+
+
+class World(C.Structure):
+    _fields_ = [("n_obstacles", C.c_int32), ("n_habitats", C.c_int32), ("n_poly", C.c_int32),
+                ("n_bins", C.c_int32), ("n_cells", C.c_int32), ("_pad", C.c_int32),
+                ("obstacles", _dp), ("habitats", _dp), ("polygon", _dp), ("bins", _dp),
+                ("cells", _dp), ("prob", _dp)]
+
+
+class RRTParams(C.Structure):
+    _fields_ = [("init", C.c_double * 6), ("dist_to_end", C.c_double), ("diff_max", C.c_double),
+                ("freq", C.c_double), ("min_dist", C.c_double), ("bin_interval", C.c_double),
+                ("v", C.c_double), ("max_traj_time", C.c_double), ("max_plan_time", C.c_double),
+                ("w", C.c_double * 3), ("mode", C.c_int32), ("max_iter", C.c_int32)]
+
+
+class RRTOut(C.Structure):
+    _fields_ = [("cap_nodes", C.c_int32), ("cap_points", C.c_int32), ("cap_leaves", C.c_int32),
+                ("cap_bins", C.c_int32),
+                ("n_nodes", C.c_int32), ("n_points", C.c_int32), ("n_leaves", C.c_int32),
+                ("n_bins", C.c_int32), ("iters_run", C.c_int32), ("best_leaf", C.c_int32),
+                ("status", C.c_int32), ("_pad", C.c_int32),
+                ("best_cost", C.c_double * 4), ("best_length", C.c_double), ("rng_after", C.c_double),
+                ("n_draw32", C.c_uint64),
+                ("nodes", _dp), ("parent", _ip), ("pt_off", _ip), ("pt_cnt", _ip), ("points", _dp),
+                ("it_parent", _ip), ("it_accepted", _bp), ("it_npath", _ip),
+                ("leaf_cost", _dp), ("leaf_iter", _ip), ("bin_sizes", _ip)]
+
+
+MODES = {"timebin": 0, "plantime": 1, "nn": 2}
+
+
+def build(force=False):
+    """Compile the checker with gcc (oracle/Makefile).  Building the checker is not using it."""
+    if force:
+        subprocess.check_call(["make", "-C", HERE, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HERE, "-s"], stdout=subprocess.DEVNULL)
+
+
+_libs = {}
+
+
+def lib(kind="libm"):
+    if kind not in _libs:
+        path = os.path.join(HERE, "liboracle_%s.so" % kind)
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_math_name.restype = C.c_char_p
+        L.orc_sin.restype = C.c_double
+        L.orc_sin.argtypes = [C.c_double]
+        L.orc_cos.restype = C.c_double
+        L.orc_cos.argtypes = [C.c_double]
+        L.orc_rrt_explore.restype = C.c_int
+        L.orc_rrt_explore.argtypes = [C.POINTER(World), C.POINTER(RRTParams), C.c_uint64, C.POINTER(RRTOut)]
+        L.orc_check_collision.restype = C.c_int
+        L.orc_check_collision.argtypes = [C.POINTER(World), C.c_int, _dp]
+        L.orc_cost.restype = None
+        L.orc_cost.argtypes = [C.POINTER(World), C.c_int, C.c_int, C.c_int, _dp, C.c_double, _dp, _dp]
+        L.orc_rrt_final_course.restype = C.c_int
+        L.orc_rrt_final_course.argtypes = [C.POINTER(RRTOut), _dp, C.c_int, _dp, C.c_int]
+        L.orc_rng_kat.restype = None
+        L.orc_rng_kat.argtypes = [C.c_uint64, C.c_int, _dp, C.POINTER(C.c_uint32), C.c_int, C.c_uint32,
+                                  C.POINTER(C.c_uint32)]
+        _libs[kind] = L
+    return _libs[kind]
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a, t=_dp):
+    return a.ctypes.data_as(t)
+
+
+class WorldArrays:
+    """Keeps the numpy buffers alive next to the ctypes struct."""
+
+    def __init__(self, obstacles=None, habitats=None, polygon=None, bins=None, cells=None, prob=None):
+        self.obstacles = _f64(obstacles if obstacles is not None else [], (-1, 3))
+        self.habitats = _f64(habitats if habitats is not None else [], (-1, 3))
+        self.polygon = _f64(polygon if polygon is not None else [], (-1, 2))
+        self.bins = _f64(bins if bins is not None else [], (-1, 2))
+        self.cells = _f64(cells if cells is not None else [], (-1, 4))
+        self.prob = _f64(prob if prob is not None else [], (len(self.bins), -1) if len(self.bins) else (0, 0))
+        self.c = World(len(self.obstacles), len(self.habitats), len(self.polygon), len(self.bins),
+                       len(self.cells), 0, _ptr(self.obstacles), _ptr(self.habitats), _ptr(self.polygon),
+                       _ptr(self.bins), _ptr(self.cells), _ptr(self.prob))
+
+
+def rng_kat(seed, n=5, nchoice=8, choice_n=100, kind="libm"):
+    rnd = np.zeros(n)
+    bits = np.zeros(n, dtype=np.uint32)
+    ch = np.zeros(nchoice, dtype=np.uint32)
+    lib(kind).orc_rng_kat(seed, n, _ptr(rnd), bits.ctypes.data_as(C.POINTER(C.c_uint32)), nchoice, choice_n,
+                          ch.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return rnd, bits, ch
+
+
+def check_collision(world, pts_xy, kind="libm"):
+    pts = _f64(pts_xy, (-1, 2))
+    return bool(lib(kind).orc_check_collision(C.byref(world.c), len(pts), _ptr(pts)))
+
+
+def cost(world, bin_lo, bin_hi, pts_xyt, total, weights, kind="libm"):
+    pts = _f64(pts_xyt, (-1, 3))
+    w = _f64(weights)
+    out = np.zeros(4)
+    lib(kind).orc_cost(C.byref(world.c), bin_lo, bin_hi, len(pts), _ptr(pts), float(total), _ptr(w), _ptr(out))
+    return out
+
+
+def rrt_explore(world, seed, n_iter, mode="timebin", init=None, freq=30, bin_interval=5, v=2,
+                max_traj_time=500.0, weights=(-3, -3, -4), dist_to_end=2, diff_max=0.5, min_dist=0.5,
+                max_plan_time=None, kind="libm", want_path=True):
+    """Run the restated RRT.exploring for n_iter virtual-clock iterations; returns a dict."""
+    p = RRTParams()
+    init = list(init) if init is not None else [0.0] * 6
+    init = init + [0.0] * (6 - len(init))
+    for i in range(6):
+        p.init[i] = float(init[i])
+    p.dist_to_end, p.diff_max, p.freq, p.min_dist = float(dist_to_end), float(diff_max), float(freq), float(min_dist)
+    p.bin_interval, p.v, p.max_traj_time = float(bin_interval), float(v), float(max_traj_time)
+    p.max_plan_time = float(n_iter if max_plan_time is None else max_plan_time)
+    for i in range(3):
+        p.w[i] = float(weights[i])
+    p.mode, p.max_iter = MODES[mode], int(n_iter)
+    capn = n_iter + 1
+    capp = n_iter * (int(freq) + 1) + 1
+    K = int(np.ceil(max_traj_time / bin_interval)) if mode == "timebin" else 0
+    a = {
+        "nodes": np.zeros((capn, 6)), "parent": np.zeros(capn, np.int32), "pt_off": np.zeros(capn, np.int32),
+        "pt_cnt": np.zeros(capn, np.int32), "points": np.zeros((capp, 7)),
+        "it_parent": np.zeros(n_iter, np.int32), "it_accepted": np.zeros(n_iter, np.int8),
+        "it_npath": np.zeros(n_iter, np.int32), "leaf_cost": np.zeros((capn, 6)),
+        "leaf_iter": np.zeros(capn, np.int32), "bin_sizes": np.zeros(max(K, 1), np.int32),
+    }
+    o = RRTOut()
+    o.cap_nodes, o.cap_points, o.cap_leaves, o.cap_bins = capn, capp, capn, max(K, 1)
+    o.nodes, o.parent, o.pt_off, o.pt_cnt = _ptr(a["nodes"]), _ptr(a["parent"], _ip), _ptr(a["pt_off"], _ip), _ptr(a["pt_cnt"], _ip)
+    o.points = _ptr(a["points"])
+    o.it_parent, o.it_accepted, o.it_npath = _ptr(a["it_parent"], _ip), _ptr(a["it_accepted"], _bp), _ptr(a["it_npath"], _ip)
+    o.leaf_cost, o.leaf_iter, o.bin_sizes = _ptr(a["leaf_cost"]), _ptr(a["leaf_iter"], _ip), _ptr(a["bin_sizes"], _ip)
+    L = lib(kind)
+    status = L.orc_rrt_explore(C.byref(world.c), C.byref(p), int(seed), C.byref(o))
+    res = {
+        "status": status, "iters_run": o.iters_run, "n_nodes": o.n_nodes, "n_points": o.n_points,
+        "n_leaves": o.n_leaves, "best_leaf": o.best_leaf, "best_cost": np.array(list(o.best_cost)),
+        "best_length": o.best_length, "rng_after": o.rng_after, "n_draw32": o.n_draw32,
+        "nodes": a["nodes"][:o.n_nodes], "parent": a["parent"][:o.n_nodes],
+        "pt_off": a["pt_off"][:o.n_nodes], "pt_cnt": a["pt_cnt"][:o.n_nodes],
+        "points": a["points"][:o.n_points], "it_parent": a["it_parent"][:o.iters_run],
+        "it_accepted": a["it_accepted"][:o.iters_run], "it_npath": a["it_npath"][:o.iters_run],
+        "leaf_cost": a["leaf_cost"][:o.n_leaves], "leaf_iter": a["leaf_iter"][:o.n_leaves],
+        "bin_sizes": a["bin_sizes"][:o.n_bins],
+    }
+    if want_path and o.best_leaf >= 0:
+        init7 = _f64([init[0], init[1], init[2], 0.0, init[3], init[4], init[5]])
+        n = -L.orc_rrt_final_course(C.byref(o), _ptr(init7), o.best_leaf, None, 0)
+        path = np.zeros((n, 7))
+        L.orc_rrt_final_course(C.byref(o), _ptr(init7), o.best_leaf, _ptr(path), n)
+        res["path"] = path
+    return res

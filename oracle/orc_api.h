@@ -1,0 +1,78 @@
+/* orc_api.h -- C interface of the CPU checker (restatement of the reference planners).
+ *
+ * TEST INFRASTRUCTURE (oracle/): a plain-C restatement of the reference algorithm for the hot path,
+ * pinned against tests/golden/ (vectors captured from the reference itself, tests/golden/
+ * make_golden.py).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * it, and only as the checker / the reported CPU baseline.  The product (auv_sim_amd/) never links,
+ * imports or falls back to anything in this directory.
+ */
+#ifndef ORC_API_H
+#define ORC_API_H
+#include <stdint.h>
+
+typedef struct {
+  int32_t n_obstacles, n_habitats, n_poly, n_bins, n_cells, _pad;
+  const double* obstacles; /* [O,3] x,y,r  (list order matters: prefix-min quirk) */
+  const double* habitats;  /* [H,3] x,y,r */
+  const double* polygon;   /* [V,2] boundary polygon vertices, or rect {x0,y0,x1,y1} for Planner_RRT */
+  const double* bins;      /* [T,2] shark-grid time bins (t0,t1), dict order */
+  const double* cells;     /* [C,4] minx,miny,maxx,maxy, cell_list order */
+  const double* prob;      /* [T,C] */
+} orc_world;
+
+enum { ORC_MODE_TIMEBIN = 0, ORC_MODE_PLANTIME = 1, ORC_MODE_NN = 2 };
+
+typedef struct {
+  double init[6];        /* x, y, theta, traj_time_stamp, plan_time_stamp, length of `initial` */
+  double dist_to_end, diff_max, freq, min_dist;
+  double bin_interval, v, max_traj_time, max_plan_time;
+  double w[3];
+  int32_t mode, max_iter;
+} orc_rrt_params;
+
+typedef struct {
+  /* capacities (in) */
+  int32_t cap_nodes, cap_points, cap_leaves, cap_bins;
+  /* counts (out) */
+  int32_t n_nodes, n_points, n_leaves, n_bins, iters_run, best_leaf, status, _pad;
+  double best_cost[4];
+  double best_length;
+  double rng_after;
+  uint64_t n_draw32;
+  /* arrays (caller allocated) */
+  double* nodes;       /* [cap_nodes,6] x,y,theta,traj_t,plan_t,length */
+  int32_t* parent;     /* [cap_nodes] */
+  int32_t* pt_off;     /* [cap_nodes] first appended path point of the node */
+  int32_t* pt_cnt;     /* [cap_nodes] number of appended path points (len(path)-1) */
+  double* points;      /* [cap_points,7] x,y,theta,v,traj_t,plan_t,length */
+  int32_t* it_parent;  /* [max_iter] parent picked (-1: iteration skipped by `continue`) */
+  int8_t* it_accepted; /* [max_iter] */
+  int32_t* it_npath;   /* [max_iter] len(new.path) */
+  double* leaf_cost;   /* [cap_leaves,6] total,c0,c1,c2,len(path),len(shark sub-dict) */
+  int32_t* leaf_iter;  /* [cap_leaves] */
+  int32_t* bin_sizes;  /* [cap_bins] len(time_bin[bin_interval*(i+1)]) */
+} orc_rrt_out;
+
+enum { ORC_OK = 0, ORC_NO_QUALIFYING_LEAF = 1, ORC_ERR_CAPACITY = -1, ORC_ERR_ARG = -2 };
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+const char* orc_math_name(void);
+double orc_sin(double x);
+double orc_cos(double x);
+
+void orc_rng_kat(uint64_t seed, int n, double* out_random, uint32_t* out_bits32, int nchoice,
+                 uint32_t choice_n, uint32_t* out_choice);
+
+int orc_check_collision(const orc_world* w, int npts, const double* pts_xy);
+void orc_cost(const orc_world* w, int bin_lo, int bin_hi, int npts, const double* pts_xyt,
+              double total_traj_time, const double* weights, double* out4);
+int orc_rrt_explore(const orc_world* w, const orc_rrt_params* p, uint64_t seed, orc_rrt_out* out);
+/* leaf -> root concatenation (generate_final_course), then reversed to root -> leaf order.
+ * returns number of elements written (<= cap), or -needed if cap too small */
+int orc_rrt_final_course(const orc_rrt_out* t, const double* init7, int leaf, double* path7, int cap);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU checker (oracle/), built on demand with gcc."""
+    from oracle import orc as _orc
+    _orc.build()
+    return _orc
+
+
+def libm_matches_golden():
+    """True when this machine's libm reproduces the sin/cos/pow known answers captured next to the
+    goldens -- only then can bit-exact equality with the reference floats be asserted."""
+    import json
+    import math
+    k = json.load(open(os.path.join(GOLDEN, "g7_random_kat.json")))["libm"]
+    for x, s, c, a, p in zip(k["x"], k["sin"], k["cos"], k["atan2_x_1"], k["pow2"]):
+        if math.sin(x) != s or math.cos(x) != c or math.atan2(x, 1.0) != a or x ** 2 != p:
+            return False
+    return True

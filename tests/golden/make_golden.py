@@ -1,0 +1,386 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by importing the reference planners.
+
+TEST INFRASTRUCTURE.  Runs ONLY in the build container (needs /root/reference); the GPU box and the
+test-suite read the committed .npz/.json fixtures, never this script's imports.  No reference source
+text is written anywhere: fixtures hold inputs and outputs only.
+
+usage:  python tests/golden/make_golden.py [g7 g5 g4 g3 g2 g1 g6 ...]   (default: all)
+"""
+import contextlib
+import hashlib
+import importlib
+import io
+import json
+import math
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("AUVP_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(HERE, "_refstubs"))
+
+import install as refstubs  # noqa: E402
+from auv_sim_amd import synth  # noqa: E402
+
+
+def _purge(names):
+    for n in list(sys.modules):
+        if n in names or any(n.startswith(p + ".") for p in names):
+            del sys.modules[n]
+
+
+_SHARED = {"cost", "motion_plan_state", "catalina", "sharkOccupancyGrid", "sharkEstimate",
+           "path_planning", "rrt_dubins", "astar", "astar_real", "astar_fixLen", "astar_fixLenSOG"}
+
+
+def import_rrt():
+    """path_planning/rrt_dubins.py with sys.path=[path_planning/, root]."""
+    refstubs.install()
+    _purge(_SHARED)
+    saved = list(sys.path)
+    sys.path[:0] = [os.path.join(REF, "path_planning"), REF]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod = importlib.import_module("rrt_dubins")
+            mps = importlib.import_module("motion_plan_state")
+            cost = importlib.import_module("cost")
+    finally:
+        sys.path[:] = saved
+    return mod, mps, cost
+
+
+def import_astar(name):
+    """astar*.py need root cost.Cost: sys.path=[root, path_planning/]."""
+    refstubs.install()
+    _purge(_SHARED)
+    saved = list(sys.path)
+    sys.path[:0] = [REF, os.path.join(REF, "path_planning")]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod = importlib.import_module(name)
+            mps = importlib.import_module("motion_plan_state")
+    finally:
+        sys.path[:] = saved
+    return mod, mps
+
+
+def import_gym_rrt():
+    refstubs.install()
+    _purge({"gym_rrt"})
+    saved = list(sys.path)
+    sys.path[:0] = [REF]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            mod = importlib.import_module("gym_rrt.envs.rrt_dubins")
+            mps = importlib.import_module("gym_rrt.envs.motion_plan_state_rrt")
+    finally:
+        sys.path[:] = saved
+    return mod, mps
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def save_npz(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+# --------------------------------------------------------------------------------------------
+# G7: CPython random known answers (stdlib only)
+# --------------------------------------------------------------------------------------------
+def g7():
+    out = {}
+    for seed in (0, 1, 7, 1234, 2 ** 32 + 5, 2 ** 63 + 12345):
+        r = random.Random(seed)
+        out[str(seed)] = {
+            "random": [r.random() for _ in range(5)],
+            "getrandbits32": [r.getrandbits(32) for _ in range(4)],
+            "uniform_1_101": r.uniform(1, 101),
+            "uniform_m05_05": r.uniform(-0.5, 0.5),
+            "choice_range100": [r.choice(range(100)) for _ in range(8)],
+            "choice_range3": [r.choice(range(3)) for _ in range(8)],
+            "choice_range1": [r.choice(range(1)) for _ in range(3)],
+            "after": r.random(),
+        }
+        # long stream crossing several 624-word refills
+        r = random.Random(seed)
+        stream = np.array([r.random() for _ in range(2000)])
+        out[str(seed)]["stream2000_sha"] = sha(stream)
+        out[str(seed)]["stream_1999"] = float(stream[1999])
+    # libm known answers of this container: lets the tests decide whether bit-exact equality with
+    # the reference's math.sin/cos/pow can be asserted on the machine running them
+    xs = [0.1 * k - 7.0 for k in range(141)]
+    out["libm"] = {
+        "x": xs,
+        "sin": [math.sin(x) for x in xs],
+        "cos": [math.cos(x) for x in xs],
+        "atan2_x_1": [math.atan2(x, 1.0) for x in xs],
+        "pow2": [x ** 2 for x in xs],
+    }
+    with open(os.path.join(HERE, "g7_random_kat.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote g7_random_kat.json")
+
+
+# --------------------------------------------------------------------------------------------
+# helpers to build reference-side objects from a synth world
+# --------------------------------------------------------------------------------------------
+def ref_world(world, MPS):
+    obstacles = [MPS(o[0], o[1], size=o[2]) for o in world["obstacles"].tolist()]
+    habitats = [MPS(h[0], h[1], size=h[2]) for h in world["habitats"].tolist()]
+    poly = refstubs.Polygon([tuple(p) for p in world["polygon"].tolist()])
+    cell_list = [refstubs.CellStub(*c) for c in world["cells"].tolist()]
+    shark = {}
+    for t, b in enumerate(world["bins"].tolist()):
+        key = (int(b[0]), int(b[1]))
+        shark[key] = {cell_list[i].bounds: p for i, p in enumerate(world["prob"][t].tolist())}
+    return obstacles, habitats, poly, cell_list, shark
+
+
+def world_arrays(world):
+    return {k: world[k] for k in ("obstacles", "habitats", "polygon", "bins", "cells", "prob")}
+
+
+# --------------------------------------------------------------------------------------------
+# G5: check_collision order dependence (prefix-min quirk)
+# --------------------------------------------------------------------------------------------
+def g5():
+    rrt_mod, mpsm, _ = import_rrt()
+    MPS = mpsm.Motion_plan_state
+    poly = refstubs.Polygon([(0, 0), (200, 0), (200, 200), (0, 200)])
+    cases = []
+    rng = random.Random(55)
+
+    def run(points, obstacles, polygon=poly):
+        rrt = rrt_mod.RRT(polygon, [MPS(o[0], o[1], size=o[2]) for o in obstacles], {}, [])
+        node = MPS(points[-1][0], points[-1][1])
+        node.path = [MPS(p[0], p[1]) for p in points]
+        return bool(rrt.check_collision(node, rrt.obstacle_list))
+
+    hand = [
+        ([(50.0, 50.0)], [(52.0, 50.0, 1.0), (120.0, 50.0, 5.0)]),
+        ([(50.0, 50.0)], [(120.0, 50.0, 5.0), (52.0, 50.0, 1.0)]),
+        ([(50.0, 50.0), (60.0, 50.0)], [(70.0, 50.0, 1.0), (61.5, 50.0, 1.0), (150.0, 150.0, 9.5)]),
+        ([(10.0, 10.0), (250.0, 10.0)], [(100.0, 100.0, 1.0)]),       # leaves the polygon
+        ([(10.0, 10.0)], []),
+        ([(100.0, 100.0)], [(100.0, 103.0, 3.0)]),                    # d == size -> collision
+    ]
+    for pts, obs in hand:
+        cases.append((pts, obs, run(pts, obs)))
+    for _ in range(200):
+        npt = rng.randint(1, 14)
+        nob = rng.randint(0, 12)
+        pts = [(rng.uniform(-10, 210), rng.uniform(-10, 210)) for _ in range(npt)]
+        if rng.random() < 0.7:
+            pts = [(min(max(x, 1.0), 199.0), min(max(y, 1.0), 199.0)) for x, y in pts]
+        obs = [(rng.uniform(0, 200), rng.uniform(0, 200), rng.uniform(0.5, 30.0)) for _ in range(nob)]
+        cases.append((pts, obs, run(pts, obs)))
+    # non-rectangular polygon (Catalina-like pentagon)
+    penta = refstubs.Polygon([(0, 0), (180, -20), (240, 90), (120, 200), (-30, 120)])
+    pcases = []
+    for _ in range(200):
+        pts = [(rng.uniform(-40, 250), rng.uniform(-30, 210)) for _ in range(rng.randint(1, 6))]
+        pcases.append((pts, [], run(pts, [], penta)))
+    out = {"rect": [[0, 0], [200, 0], [200, 200], [0, 200]],
+           "penta": [[0, 0], [180, -20], [240, 90], [120, 200], [-30, 120]],
+           "cases": [{"pts": p, "obs": o, "free": r} for p, o, r in cases],
+           "penta_cases": [{"pts": p, "obs": o, "free": r} for p, o, r in pcases]}
+    with open(os.path.join(HERE, "g5_collision.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote g5_collision.json", sum(c[2] for c in cases), "free of", len(cases),
+          "| penta", sum(c[2] for c in pcases), "of", len(pcases))
+
+
+# --------------------------------------------------------------------------------------------
+# G4: habitat_shark_cost_func on fixed paths
+# --------------------------------------------------------------------------------------------
+def g4():
+    _, mpsm, cost = import_rrt()
+    MPS = mpsm.Motion_plan_state
+    rng = random.Random(44)
+    cases = []
+    for k in range(24):
+        world = synth.make_world(seed=100 + k, n_obstacles=4, n_habitats=(0 if k == 5 else 6 + k % 5),
+                                 cell=10.0 if k % 3 else 20.0, n_bins=4 + k % 4)
+        _, habitats, _, _, shark = ref_world(world, MPS)
+        x0, y0, x1, y1 = world["box"].tolist()
+        T = len(world["bins"])
+        npt = rng.randint(1, 120)
+        pts = []
+        for _ in range(npt):
+            # includes points outside the box, on cell edges, and out-of-bin timestamps
+            x = rng.uniform(x0 - 15, x1 + 15)
+            y = rng.uniform(y0 - 15, y1 + 15)
+            if rng.random() < 0.15:
+                x = float(round(x / 10.0) * 10.0)
+            if rng.random() < 0.15:
+                y = float(round(y / 10.0) * 10.0)
+            t = rng.uniform(-20.0, 50.0 * T + 40.0)
+            if rng.random() < 0.1:
+                t = float(50 * rng.randint(0, T))
+            pts.append((x, y, t))
+        # sub-dict of bins as exploring builds it (any subset, order preserved)
+        keys = list(shark.keys())
+        lo = rng.randint(0, len(keys) - 1)
+        hi = rng.randint(lo, len(keys))
+        sub = {kk: shark[kk] for kk in keys[lo:hi]}
+        total = rng.choice([0.0, rng.uniform(1.0, 500.0)])
+        weights = rng.choice([[-3, -3, -4], [-1, -1, -1], [-0.5, -2.25, -1.75]])
+        path = [MPS(p[0], p[1], traj_time_stamp=p[2]) for p in pts]
+        res = cost.habitat_shark_cost_func(path, total, habitats, sub, weights)
+        cases.append({
+            "world_seed": 100 + k, "n_habitats": len(habitats), "cell": 10.0 if k % 3 else 20.0,
+            "n_bins": T, "pts": pts, "bin_lo": lo, "bin_hi": hi, "total": total, "weights": weights,
+            "out": [float(res[0])] + [float(c) for c in res[1]],
+        })
+    with open(os.path.join(HERE, "g4_cost.json"), "w") as f:
+        json.dump({"cases": cases}, f)
+    print("wrote g4_cost.json")
+
+
+# --------------------------------------------------------------------------------------------
+# G3: RRT.exploring under the virtual clock
+# --------------------------------------------------------------------------------------------
+def run_exploring(seed, world, n_iter, mode, freq=30, bin_interval=5, v=2, shark_interval=50,
+                  max_traj_time=500.0, weights=(-3, -3, -4), dist_to_end=2, diff_max=0.5,
+                  keep_points=True):
+    rrt_mod, mpsm, cost_mod = import_rrt()
+    MPS = mpsm.Motion_plan_state
+    obstacles, habitats, poly, cell_list, shark = ref_world(world, MPS)
+    clock = refstubs.VirtualClock()
+    rrt_mod.time = clock
+    rrt = rrt_mod.RRT(poly, obstacles, shark, cell_list, dist_to_end=dist_to_end, diff_max=diff_max,
+                      freq=freq)
+    log = {"parent": [], "accepted": [], "npath": [], "leaf_cost": [], "leaf_iter": []}
+    index_of = {}
+    orig_steer = rrt.steer
+    orig_cc = rrt.check_collision
+    orig_cost = rrt_mod.habitat_shark_cost_func
+    cur = {}
+
+    def steer(m, *a, **k):
+        # the parent's index in mps_list at pick time
+        for i, n in enumerate(rrt.mps_list[len(index_of):], start=len(index_of)):
+            index_of[id(n)] = i
+        cur["parent"] = index_of[id(m)]
+        new = orig_steer(m, *a, **k)
+        cur["npath"] = len(new.path)
+        return new
+
+    def check_collision(m, obs):
+        r = orig_cc(m, obs)
+        log["parent"].append(cur["parent"])
+        log["npath"].append(cur["npath"])
+        log["accepted"].append(bool(r))
+        return r
+
+    def cost_func(path, total, habs, sd, w):
+        r = orig_cost(path, total, habs, sd, w)
+        log["leaf_cost"].append([float(r[0])] + [float(c) for c in r[1]] + [float(len(path)), float(len(sd))])
+        log["leaf_iter"].append(len(log["accepted"]) - 1)
+        return r
+
+    rrt.steer = steer
+    rrt.check_collision = check_collision
+    rrt_mod.habitat_shark_cost_func = cost_func
+    random.seed(seed)
+    start = MPS(float(world["start"][0]), float(world["start"][1]))
+    traj_ts = mode in ("timebin",)
+    plan_time = mode in ("timebin", "plantime")
+    err = None
+    try:
+        res = rrt.exploring(start, habitats, float(n_iter), bin_interval, v, shark_interval,
+                            traj_time_stamp=traj_ts, max_plan_time=float(n_iter),
+                            max_traj_time=max_traj_time, plan_time=plan_time, weights=list(weights))
+    except TypeError as e:  # no qualifying leaf: opt_path is None (rrt_dubins.py:174)
+        res = None
+        err = str(e)
+    rng_after = random.random()
+    nodes = rrt.mps_list
+    for i, n in enumerate(nodes):
+        index_of[id(n)] = i
+    node_arr = np.array([[n.x, n.y, n.theta, n.traj_time_stamp, n.plan_time_stamp, n.length] for n in nodes])
+    parent = np.array([-1 if n.parent is None else index_of[id(n.parent)] for n in nodes], dtype=np.int32)
+    npath = np.array([len(n.path) for n in nodes], dtype=np.int32)
+    pts = []
+    for n in nodes[1:]:
+        for p in n.path[1:]:
+            pts.append([p.x, p.y, p.theta, p.v, p.traj_time_stamp, p.plan_time_stamp, p.length])
+    pts = np.array(pts, dtype=np.float64).reshape(-1, 7)
+    out = {
+        "seed": seed, "n_iter": n_iter, "mode": mode, "freq": freq, "bin_interval": bin_interval, "v": v,
+        "shark_interval": shark_interval, "max_traj_time": max_traj_time, "weights": list(weights),
+        "dist_to_end": dist_to_end, "diff_max": diff_max,
+        "iters_run": len(log["accepted"]),
+        "nodes": node_arr, "parent": parent, "npath": npath,
+        "it_parent": np.array(log["parent"], dtype=np.int32),
+        "it_accepted": np.array(log["accepted"], dtype=np.int8),
+        "it_npath": np.array(log["npath"], dtype=np.int32),
+        "leaf_cost": np.array(log["leaf_cost"], dtype=np.float64).reshape(-1, 6),
+        "leaf_iter": np.array(log["leaf_iter"], dtype=np.int32),
+        "rng_after": rng_after,
+        "points_sha": sha(pts),
+        "n_points": len(pts),
+        "error": err or "",
+    }
+    if keep_points:
+        out["points"] = pts
+    if res is not None:
+        path = res["path"][0]
+        out["res_path_length"] = float(res["path length"])
+        out["res_cost"] = np.array([float(res["cost"][0])] + [float(c) for c in res["cost"][1]])
+        out["res_path"] = np.array([[p.x, p.y, p.theta, p.v, p.traj_time_stamp, p.plan_time_stamp, p.length]
+                                    for p in path])
+        split = res["path"][1]
+        out["res_split_keys"] = np.array([[k[0], k[1]] for k in split.keys()], dtype=np.float64).reshape(-1, 2)
+        out["res_split_counts"] = np.array([len(vv) for vv in split.values()], dtype=np.int32)
+        # bin contents (time-bin mode): sizes per regular key, in key order
+    if traj_ts:
+        keys = sorted(k for k in rrt.time_bin.keys())
+        out["bin_keys"] = np.array(keys, dtype=np.float64)
+        out["bin_sizes"] = np.array([len(rrt.time_bin[k]) for k in keys], dtype=np.int32)
+    return out
+
+
+def g3():
+    specs = [
+        # name, seed, world kwargs, n_iter, mode, extra
+        ("g3_tb_o64_i500", 7, dict(seed=1, n_obstacles=64), 500, "timebin", {}),
+        ("g3_tb_o64_i2000", 7, dict(seed=1, n_obstacles=64), 2000, "timebin", {}),
+        ("g3_tb_o256_i500", 11, dict(seed=2, n_obstacles=256), 500, "timebin", {}),
+        ("g3_nn_o64_i500", 5, dict(seed=1, n_obstacles=64), 500, "nn", {}),
+        ("g3_nn_o256_i2000", 5, dict(seed=2, n_obstacles=256), 2000, "nn", {"keep_points": False}),
+        ("g3_pt_o64_i500", 3, dict(seed=1, n_obstacles=64), 500, "plantime", {}),
+        ("g3_tb_short_traj", 9, dict(seed=3, n_obstacles=64, n_bins=4), 800, "timebin",
+         {"max_traj_time": 120.0, "shark_interval": 30, "weights": (-1, -1, -1)}),
+        ("g3_tb_dense", 13, dict(seed=4, n_obstacles=64, obst_radius=(4.0, 9.0)), 600, "timebin",
+         {"freq": 12}),
+        ("g3_tb_o256_i10000", 7, dict(seed=2, n_obstacles=256), 10000, "timebin", {"keep_points": False}),
+    ]
+    for name, seed, wk, n_iter, mode, extra in specs:
+        world = synth.make_world(**wk)
+        out = run_exploring(seed, world, n_iter, mode, **extra)
+        meta = {"world_kwargs": json.dumps(wk)}
+        save_npz(name + ".npz", **world_arrays(world), start=world["start"], **meta, **out)
+        print(name, "iters", out["iters_run"], "nodes", len(out["nodes"]), "leaves", len(out["leaf_iter"]),
+              "err", out["error"], "cost", out.get("res_cost"))
+
+
+ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3}
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(ALL)
+    for w in which:
+        ALL[w]()
