@@ -1,0 +1,242 @@
+"""ctypes binding of libauvplan.so (include/auvplan.h).
+
+There is no CPU fallback: importing this module without the built library, or creating a context
+without a usable MI355X, raises.  Build with `python __graft_entry__.py build` (hipcc, gfx950).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libauvplan.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_int8)
+
+
+class AuvpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("auvplan error %d: %s" % (code, msg))
+        self.code = code
+
+
+class RRTParams(C.Structure):
+    _fields_ = [("dist_to_end", C.c_double), ("diff_max", C.c_double), ("freq", C.c_double),
+                ("min_dist", C.c_double), ("bin_interval", C.c_double), ("v", C.c_double),
+                ("max_traj_time", C.c_double), ("max_plan_time", C.c_double), ("w", C.c_double * 3),
+                ("mode", C.c_int32), ("max_iter", C.c_int32), ("points_per_iter", C.c_double)]
+
+
+class RRTSummary(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_nodes", C.c_int32), ("n_points", C.c_int32),
+                ("n_leaves", C.c_int32), ("best_leaf", C.c_int32), ("best_path_len", C.c_int32),
+                ("iters_run", C.c_int32), ("_pad", C.c_int32), ("best_cost", C.c_double * 4),
+                ("best_length", C.c_double), ("rng_after", C.c_double)]
+
+
+SUMMARY_DTYPE = np.dtype([("status", "<i4"), ("n_nodes", "<i4"), ("n_points", "<i4"), ("n_leaves", "<i4"),
+                          ("best_leaf", "<i4"), ("best_path_len", "<i4"), ("iters_run", "<i4"), ("_pad", "<i4"),
+                          ("best_cost", "<f8", (4,)), ("best_length", "<f8"), ("rng_after", "<f8")])
+assert SUMMARY_DTYPE.itemsize == C.sizeof(RRTSummary)
+
+MODES = {"timebin": 0, "plantime": 1, "nn": 2}
+FLAG_ITER_LOG, FLAG_LEAF_LOG = 1, 2
+OK, NO_QUALIFYING_LEAF = 0, 1
+
+_lib = None
+
+
+def load():
+    """Load libauvplan.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build the HIP extension first "
+                          "(python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.auvp_version.restype = C.c_char_p
+    L.auvp_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.auvp_destroy.argtypes = [vp]
+    L.auvp_destroy.restype = None
+    L.auvp_last_error.argtypes = [vp]
+    L.auvp_last_error.restype = C.c_char_p
+    L.auvp_world_set.argtypes = [vp, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp,
+                                 C.c_int32, _dp]
+    L.auvp_rrt_explore_batch.argtypes = [vp, C.c_int32, _dp, C.POINTER(C.c_uint64), C.POINTER(RRTParams), C.c_int32]
+    L.auvp_rrt_summaries.argtypes = [vp, C.c_void_p]
+    L.auvp_rrt_paths.argtypes = [vp, C.POINTER(C.c_int64), _dp]
+    L.auvp_rrt_tree.argtypes = [vp, C.c_int32, _dp, _ip, _ip, _ip, _dp]
+    L.auvp_rrt_iter_log.argtypes = [vp, C.c_int32, _ip, _bp, _ip]
+    L.auvp_rrt_leaf_log.argtypes = [vp, C.c_int32, _dp, _ip]
+    L.auvp_rrt_bin_sizes.argtypes = [vp, C.c_int32, _ip, _ip]
+    L.auvp_rrt_summaries_dev.argtypes = [vp]
+    L.auvp_rrt_summaries_dev.restype = C.c_void_p
+    L.auvp_check_collision_batch.argtypes = [vp, C.c_int32, _ip, _dp, _bp]
+    L.auvp_cost_paths.argtypes = [vp, C.c_int32, _ip, _dp, _ip, _ip, _dp, _dp, _dp]
+    L.auvp_sincos_dev.argtypes = [vp, C.c_int32, _dp, _dp, _dp]
+    L.auvp_random_stream_dev.argtypes = [vp, C.c_uint64, C.c_int32, _dp]
+    L.auvp_last_kernel_ms.argtypes = [vp]
+    L.auvp_last_kernel_ms.restype = C.c_double
+    L.auvp_last_launch.argtypes = [vp, _ip, _ip, _ip]
+    _lib = L
+    return L
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return a.reshape(shape) if shape is not None else a
+
+
+def _p(a, t=_dp):
+    return a.ctypes.data_as(t)
+
+
+class Context:
+    """One planner context = one HIP device + stream + device-resident world and tree storage."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.auvp_create(int(device), C.byref(self.h))
+        if rc != 0:
+            raise AuvpError(rc, "auvp_create(device=%d) failed: no usable HIP device (no CPU fallback)" % device)
+        self.n_episodes = 0
+        self.max_iter = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.auvp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise AuvpError(rc, self.L.auvp_last_error(self.h).decode())
+        return rc
+
+    # ---- world ----
+    def set_world(self, obstacles=None, habitats=None, polygon=None, bins=None, cells=None, prob=None):
+        ob = _f64(obstacles if obstacles is not None else [], (-1, 3))
+        hb = _f64(habitats if habitats is not None else [], (-1, 3))
+        pg = _f64(polygon if polygon is not None else [], (-1, 2))
+        bn = _f64(bins if bins is not None else [], (-1, 2))
+        ce = _f64(cells if cells is not None else [], (-1, 4))
+        pr = _f64(prob if prob is not None else [])
+        if pr.size != len(bn) * len(ce):
+            raise ValueError("prob must be [n_bins, n_cells]")
+        self._chk(self.L.auvp_world_set(self.h, _p(ob), len(ob), _p(hb), len(hb), _p(pg), len(pg), _p(bn), len(bn),
+                                        _p(ce), len(ce), _p(pr)))
+        self.world_sizes = dict(O=len(ob), H=len(hb), V=len(pg), T=len(bn), C=len(ce))
+
+    # ---- RRT.exploring batch ----
+    def rrt_explore_batch(self, init, seeds, n_iter, mode="timebin", freq=30, bin_interval=5, v=2,
+                          max_traj_time=500.0, weights=(-3, -3, -4), dist_to_end=2, diff_max=0.5, min_dist=0.5,
+                          max_plan_time=None, points_per_iter=0.0, iter_log=False, leaf_log=False):
+        init = _f64(init, (-1, 6))
+        E = len(init)
+        seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(E))
+        p = RRTParams()
+        p.dist_to_end, p.diff_max, p.freq, p.min_dist = float(dist_to_end), float(diff_max), float(freq), float(min_dist)
+        p.bin_interval, p.v, p.max_traj_time = float(bin_interval), float(v), float(max_traj_time)
+        p.max_plan_time = float(n_iter if max_plan_time is None else max_plan_time)
+        for i in range(3):
+            p.w[i] = float(weights[i])
+        p.mode, p.max_iter, p.points_per_iter = MODES[mode], int(n_iter), float(points_per_iter)
+        flags = (FLAG_ITER_LOG if iter_log else 0) | (FLAG_LEAF_LOG if leaf_log else 0)
+        self._chk(self.L.auvp_rrt_explore_batch(self.h, E, _p(init), seeds.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                C.byref(p), flags))
+        self.n_episodes, self.max_iter = E, int(n_iter)
+        return self.summaries()
+
+    def summaries(self):
+        out = np.zeros(self.n_episodes, dtype=SUMMARY_DTYPE)
+        self._chk(self.L.auvp_rrt_summaries(self.h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def paths(self, summaries):
+        """final course (root -> leaf) of every episode: list of [L,7] arrays"""
+        lens = np.where(summaries["best_leaf"] >= 0, summaries["best_path_len"], 0).astype(np.int64)
+        off = np.zeros(self.n_episodes + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        out = np.zeros((max(int(off[-1]), 1), 7))
+        self._chk(self.L.auvp_rrt_paths(self.h, off.ctypes.data_as(C.POINTER(C.c_int64)), _p(out)))
+        return [out[off[e]:off[e + 1]] for e in range(self.n_episodes)]
+
+    def tree(self, ep, summary):
+        n, npnt = int(summary["n_nodes"]), int(summary["n_points"])
+        nodes = np.zeros((n, 6))
+        parent = np.zeros(n, np.int32)
+        pt_off = np.zeros(n, np.int32)
+        pt_cnt = np.zeros(n, np.int32)
+        points = np.zeros((max(npnt, 1), 7))
+        self._chk(self.L.auvp_rrt_tree(self.h, ep, _p(nodes), _p(parent, _ip), _p(pt_off, _ip), _p(pt_cnt, _ip), _p(points)))
+        return dict(nodes=nodes, parent=parent, pt_off=pt_off, pt_cnt=pt_cnt, points=points[:npnt])
+
+    def iter_log(self, ep):
+        n = self.max_iter
+        a, b, c = np.zeros(n, np.int32), np.zeros(n, np.int8), np.zeros(n, np.int32)
+        self._chk(self.L.auvp_rrt_iter_log(self.h, ep, _p(a, _ip), _p(b, _bp), _p(c, _ip)))
+        return dict(it_parent=a, it_accepted=b, it_npath=c)
+
+    def leaf_log(self, ep, summary):
+        n = int(summary["n_leaves"])
+        lc, li = np.zeros((max(n, 1), 6)), np.zeros(max(n, 1), np.int32)
+        self._chk(self.L.auvp_rrt_leaf_log(self.h, ep, _p(lc), _p(li, _ip)))
+        return lc[:n], li[:n]
+
+    def bin_sizes(self, ep):
+        k = C.c_int32()
+        self._chk(self.L.auvp_rrt_bin_sizes(self.h, ep, None, C.byref(k)))
+        s = np.zeros(max(k.value, 1), np.int32)
+        self._chk(self.L.auvp_rrt_bin_sizes(self.h, ep, _p(s, _ip), C.byref(k)))
+        return s[:k.value]
+
+    # ---- probes ----
+    def check_collision(self, paths_xy):
+        off = np.zeros(len(paths_xy) + 1, np.int32)
+        off[1:] = np.cumsum([len(p) for p in paths_xy])
+        pts = _f64(np.concatenate([_f64(p, (-1, 2)) for p in paths_xy]) if len(paths_xy) else [], (-1, 2))
+        out = np.zeros(len(paths_xy), np.int8)
+        self._chk(self.L.auvp_check_collision_batch(self.h, len(paths_xy), _p(off, _ip), _p(pts), _p(out, _bp)))
+        return out.astype(bool)
+
+    def cost_paths(self, paths_xyt, bin_lo, bin_hi, total, weights):
+        n = len(paths_xyt)
+        off = np.zeros(n + 1, np.int32)
+        off[1:] = np.cumsum([len(p) for p in paths_xyt])
+        pts = _f64(np.concatenate([_f64(p, (-1, 3)) for p in paths_xyt]), (-1, 3))
+        lo = np.ascontiguousarray(bin_lo, dtype=np.int32)
+        hi = np.ascontiguousarray(bin_hi, dtype=np.int32)
+        tt = _f64(total)
+        w = _f64(weights, (n, 3))
+        out = np.zeros((n, 4))
+        self._chk(self.L.auvp_cost_paths(self.h, n, _p(off, _ip), _p(pts), _p(lo, _ip), _p(hi, _ip), _p(tt), _p(w), _p(out)))
+        return out
+
+    def sincos(self, x):
+        x = _f64(x).ravel()
+        s, c = np.zeros_like(x), np.zeros_like(x)
+        self._chk(self.L.auvp_sincos_dev(self.h, len(x), _p(x), _p(s), _p(c)))
+        return s, c
+
+    def random_stream(self, seed, n):
+        out = np.zeros(n)
+        self._chk(self.L.auvp_random_stream_dev(self.h, int(seed), n, _p(out)))
+        return out
+
+    def last_kernel_ms(self):
+        return float(self.L.auvp_last_kernel_ms(self.h))
+
+    def last_launch(self):
+        g, b, l = C.c_int32(), C.c_int32(), C.c_int32()
+        self.L.auvp_last_launch(self.h, C.byref(g), C.byref(b), C.byref(l))
+        return g.value, b.value, l.value

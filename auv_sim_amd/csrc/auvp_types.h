@@ -1,0 +1,65 @@
+// auvp_types.h -- device-side views of the world model and of the per-episode tree storage.
+#ifndef AUVP_TYPES_H
+#define AUVP_TYPES_H
+#include <stdint.h>
+
+namespace auvp {
+
+// World model in HBM (read-only for the kernels; one copy shared by every episode).
+// Obstacles are stored SoA with two derived columns that fold the reference's order-dependent
+// collision test (rrt_dubins.py:535-541) into an elementwise one:
+//   collision  <=>  exists i:  RN(sqrt(min_p d2(p, i))) <= R_i,   R_i = max_{k >= i} size_k
+//              <=>  exists i, p:  d2(p, i) <= T_i,  T_i = largest double s with RN(sqrt(s)) <= R_i
+// (sqrt is monotone, so the running min over "obstacles 0..k" of distances equals the sqrt of the
+// running min of squared distances, and "some k >= i has size_k >= that" is the suffix max).
+struct WorldDev {
+  int32_t n_obstacles, n_habitats, n_poly, n_bins, n_cells, n_xbuckets;
+  const double* ox;   // [O]
+  const double* oy;   // [O]
+  const double* ot;   // [O] T_i threshold on the squared distance
+  const double* hab;  // [H,3]
+  const double* poly; // [V,2]
+  const double* bins; // [T,2]
+  const double* cells;  // [C,4]
+  const double* prob;   // [T,C]
+  // x-bucket index over the cells for the first-match scan of cost.py:181-184: bucket b lists, in
+  // cell_list order, every cell whose [minx, min(maxx,maxy)] meets the bucket's x-range
+  const int32_t* xb_off;    // [NB+1]
+  const int32_t* xb_items;  // [xb_off[NB]]
+  double xb_x0, xb_inv_w;
+  double bb[4];  // polygon bounds xmin,ymin,xmax,ymax (get_random_mps, :334)
+};
+
+struct RrtParamsDev {
+  double dist_to_end, diff_max, freq, min_dist, bin_interval, v, max_traj_time, max_plan_time;
+  double w[3];
+  int32_t mode, max_iter, K, flags;
+};
+
+struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h
+  int32_t status, n_nodes, n_points, n_leaves, best_leaf, best_path_len, iters_run, _pad;
+  double best_cost[4];
+  double best_length;
+  double rng_after;
+};
+
+// Per-episode tree storage, structure-of-arrays, episode-major: array[e * cap + i].
+struct RrtBuffers {
+  int32_t cap_nodes, cap_points, bin_cap, cap_leaves;
+  double *nx, *ny, *nth, *ntt, *nlen;  // [E][cap_nodes]
+  int32_t *nplan, *parent, *pt_off, *pt_cnt;
+  double *px, *py, *pth, *pv, *ptt, *plen;  // [E][cap_points]
+  int32_t* bin_items;                       // [E][K+1][bin_cap]
+  int32_t* bin_count;                       // [E][K+1] (copied out of LDS at the end)
+  uint32_t* mt;                             // [E][624] seeded state in
+  const double* init;                       // [E][6]
+  RrtSummary* summary;                      // [E]
+  int32_t* it_parent;                       // optional logs [E][max_iter]
+  int8_t* it_accepted;
+  int32_t* it_npath;
+  double* leaf_cost;  // optional [E][cap_leaves][6]
+  int32_t* leaf_iter;
+};
+
+}  // namespace auvp
+#endif

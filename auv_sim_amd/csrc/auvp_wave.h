@@ -1,0 +1,130 @@
+// auvp_wave.h -- wave64 building blocks for the gfx950 planner kernels.
+//
+// One wavefront (64 lanes) runs one planning episode.  Everything an episode does in order
+// (RNG stream, tree growth) is wave-uniform control flow; the lanes split the work inside one
+// expansion.  The helpers here are the cross-lane pieces: an in-LDS MT19937 that the whole wave
+// refills cooperatively, ordered reductions, readlane for doubles.
+#ifndef AUVP_WAVE_H
+#define AUVP_WAVE_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace auvp {
+
+constexpr int WAVE = 64;
+
+// LDS traffic between lanes of ONE wave: the hardware keeps a wave's DS operations in order; this
+// only stops the compiler from moving LDS accesses across the hand-off point.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double readfirst_f64(double v) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll));
+  int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// wave-wide min over lanes (values identical on return)
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    double t = __shfl_xor(v, o, 64);
+    v = (t < v) ? t : v;
+  }
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CPython-compatible MT19937 stream, state in LDS (624 words per wave), refilled lazily IN PLACE:
+// logical word q overwrites the slot of word q-624 as soon as that one has been consumed, so up to
+// 624 words ahead of the consumer are available without a second buffer and a refill step is one
+// read-3/write-1 pass of the whole wave (64 words per step; dependencies reach back 227 words, so
+// 64 consecutive words are independent of each other).
+//   new[q] = s[(q+397)%624] ^ twist(upper(s[q%624]) | lower(s[(q+1)%624]))
+// Replaces the `random` module calls of the reference (random.uniform / random.choice:
+// path_planning/rrt_dubins.py:123-129,259-279,336-339; gym_rrt/envs/rrt_dubins.py:186,223,262-267).
+// ---------------------------------------------------------------------------------------------
+struct WaveRng {
+  uint32_t* s;     // LDS, 624 words
+  uint32_t pslot;  // slot of the next unconsumed word
+  uint32_t avail;  // generated, not yet consumed
+};
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+__device__ __forceinline__ void rng_ensure(WaveRng& r, uint32_t need_words) {
+  const uint32_t lane = (uint32_t)lane_id();
+  while (r.avail < need_words) {
+    uint32_t n = 624u - r.avail;
+    n = n < 64u ? n : 64u;
+    uint32_t k = r.pslot + r.avail + lane;
+    k = k >= 624u ? k - 624u : k;
+    k = k >= 624u ? k - 624u : k;
+    uint32_t k1 = (k + 1u == 624u) ? 0u : k + 1u;
+    uint32_t km = k + 397u;
+    km = km >= 624u ? km - 624u : km;
+    uint32_t a = r.s[k], b = r.s[k1], c = r.s[km];
+    uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    uint32_t v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    wave_sync();  // every lane's reads are issued before any lane's write
+    if (lane < n) r.s[k] = v;
+    wave_sync();
+    r.avail = (uint32_t)uni((int)(r.avail + n));
+  }
+}
+
+// tempered 32-bit output number `j` ahead of the consumer (j < avail)
+__device__ __forceinline__ uint32_t rng_word(const WaveRng& r, uint32_t j) {
+  uint32_t k = r.pslot + j;
+  k = k >= 624u ? k - 624u : k;
+  k = k >= 624u ? k - 624u : k;
+  return mt_temper(r.s[k]);
+}
+
+// random.random() number `j` ahead (consumes words 2j, 2j+1)
+__device__ __forceinline__ double rng_random_at(const WaveRng& r, uint32_t j) {
+  uint32_t a = rng_word(r, 2u * j) >> 5, b = rng_word(r, 2u * j + 1u) >> 6;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ void rng_advance_words(WaveRng& r, uint32_t nwords) {
+  uint32_t p = r.pslot + nwords;
+  while (p >= 624u) p -= 624u;
+  r.pslot = (uint32_t)uni((int)p);
+  r.avail = (uint32_t)uni((int)(r.avail - nwords));
+}
+
+// one uniform random() for the whole wave (every lane returns the same value)
+__device__ __forceinline__ double rng_next_random(WaveRng& r) {
+  rng_ensure(r, 2u);
+  double v = rng_random_at(r, 0u);
+  rng_advance_words(r, 2u);
+  return v;
+}
+
+// random.uniform(a, b) = a + (b-a) * random()
+__device__ __forceinline__ double py_uniform(double a, double b, double u) { return a + (b - a) * u; }
+
+}  // namespace auvp
+#endif

@@ -1,0 +1,458 @@
+// auvplan.hip -- C-ABI (include/auvplan.h) + host runtime of libauvplan.so for MI355X / gfx950.
+//
+// Host side of the hot path: owns the device copy of the world model and the per-episode tree
+// storage in HBM, seeds the per-episode MT19937 states the way CPython's random.seed() does,
+// launches the persistent expansion kernel (one wavefront per episode) on the handle's own HIP
+// stream and times it with HIP events on that stream.  No CPU compute path exists here: if the
+// device or the code object is unusable every entry point fails with AUVP_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/auvplan.h"
+#include "rrt_explore_kernel.h"
+
+using namespace auvp;
+
+static_assert(sizeof(auvp_rrt_summary) == sizeof(RrtSummary), "summary layout");
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e == hipSuccess) cap = bytes ? bytes : 16;
+    return e;
+  }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct auvp_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  // world
+  bool have_world = false;
+  WorldDev W{};
+  DevBuf d_ox, d_oy, d_ot, d_hab, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems;
+  // rrt batch
+  int E = 0;
+  RrtParamsDev P{};
+  RrtBuffers B{};
+  int max_pts = 0;
+  DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_init, d_summary, d_itlog_i, d_itlog_b,
+      d_leaf_c, d_leaf_i, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+  bool have_batch = false;
+  double last_ms = 0.0;
+  int last_grid = 0, last_block = 0, last_lds = 0;
+};
+
+namespace {
+
+int fail(auvp_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+#define HIPCHK(h, call)                                                                        \
+  do {                                                                                         \
+    hipError_t e__ = (call);                                                                   \
+    if (e__ != hipSuccess) return fail(h, AUVP_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+// CPython random.seed(int) -> init_by_array over the 32-bit limbs of the seed
+// (Modules/_randommodule.c; restated from the MT19937 reference algorithm)
+void seed_mt(uint64_t seed, uint32_t* mt) {
+  uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+  const int klen = key[1] ? 2 : 1;
+  mt[0] = 19650218u;
+  for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  int i = 1, j = 0;
+  for (int k = 624; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+    i++; j++;
+    if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    if (j >= klen) j = 0;
+  }
+  for (int k = 623; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+    i++;
+    if (i >= 624) { mt[0] = mt[623]; i = 1; }
+  }
+  mt[0] = 0x80000000u;
+}
+
+// largest double s with RN(sqrt(s)) <= R  (R < 0 -> -1: `d <= size` can never hold)
+double sq_threshold(double R) {
+  if (!(R >= 0.0)) return -1.0;
+  double s = R * R;
+  if (std::isinf(s)) return s;
+  while (std::sqrt(s) > R) s = std::nextafter(s, -INFINITY);
+  for (;;) {
+    double n = std::nextafter(s, INFINITY);
+    if (std::isinf(n) || std::sqrt(n) > R) break;
+    s = n;
+  }
+  return s;
+}
+
+template <class T>
+int upload(auvp_handle* h, DevBuf& b, const T* src, size_t n) {
+  HIPCHK(h, b.reserve(n * sizeof(T)));
+  if (n) HIPCHK(h, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  return AUVP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* auvp_version(void) { return "auvplan 0.1 (gfx950)"; }
+
+int auvp_create(int device, auvp_handle** out) {
+  if (!out) return AUVP_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AUVP_ERR_HIP;
+  auvp_handle* h = new auvp_handle();
+  h->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    delete h;
+    return AUVP_ERR_HIP;
+  }
+  *out = h;
+  return AUVP_OK;
+}
+
+void auvp_destroy(auvp_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* auvp_last_error(auvp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const double* habitats, int32_t H,
+                   const double* polygon, int32_t V, const double* bins, int32_t T, const double* cells, int32_t C,
+                   const double* prob) {
+  if (!h) return AUVP_ERR_ARG;
+  if (O < 0 || H < 0 || V < 0 || T < 0 || C < 0) return fail(h, AUVP_ERR_ARG, "negative size");
+  if (H > RRT_MAX_HAB) return fail(h, AUVP_ERR_ARG, "n_habitats %d > %d", H, RRT_MAX_HAB);
+  if (V > RRT_MAX_POLY) return fail(h, AUVP_ERR_ARG, "n_poly %d > %d", V, RRT_MAX_POLY);
+  if (T > RRT_MAX_BINS) return fail(h, AUVP_ERR_ARG, "n_bins %d > %d", T, RRT_MAX_BINS);
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> ox(O), oy(O), ot(O);
+  double run = -INFINITY;
+  for (int i = O - 1; i >= 0; i--) {  // suffix max of the radii, list order
+    double r = obstacles[3 * i + 2];
+    if (r > run) run = r;
+    ox[i] = obstacles[3 * i];
+    oy[i] = obstacles[3 * i + 1];
+    ot[i] = sq_threshold(run);
+  }
+  // x-bucket index over the cells
+  std::vector<int32_t> xoff, xitems;
+  double X0 = 0.0, inv_w = 0.0;
+  int NB = 0;
+  if (C > 0) {
+    double lo = INFINITY, hi = -INFINITY, wmin = INFINITY;
+    for (int c = 0; c < C; c++) {
+      double a = cells[4 * c], b = std::min(cells[4 * c + 2], cells[4 * c + 3]);
+      double wdt = cells[4 * c + 2] - cells[4 * c];
+      if (wdt > 0 && wdt < wmin) wmin = wdt;
+      if (b < a) continue;
+      lo = std::min(lo, a);
+      hi = std::max(hi, b);
+    }
+    if (!(hi >= lo)) { lo = 0.0; hi = 1.0; }
+    double span = hi - lo;
+    NB = 1;
+    if (span > 0 && std::isfinite(wmin)) NB = (int)std::min(8192.0, std::max(1.0, std::ceil(span / wmin)));
+    X0 = lo;
+    inv_w = span > 0 ? (double)NB / span : 0.0;
+    std::vector<std::vector<int32_t>> lists(NB);
+    for (int c = 0; c < C; c++) {
+      double a = cells[4 * c], b = std::min(cells[4 * c + 2], cells[4 * c + 3]);
+      if (b < a) continue;
+      int b0 = (int)std::floor((a - X0) * inv_w) - 1, b1 = (int)std::floor((b - X0) * inv_w) + 1;
+      b0 = std::max(0, std::min(NB - 1, b0));
+      b1 = std::max(0, std::min(NB - 1, b1));
+      for (int k = b0; k <= b1; k++) lists[k].push_back(c);
+    }
+    xoff.resize(NB + 1);
+    xoff[0] = 0;
+    for (int k = 0; k < NB; k++) {
+      xoff[k + 1] = xoff[k] + (int32_t)lists[k].size();
+      xitems.insert(xitems.end(), lists[k].begin(), lists[k].end());
+    }
+  } else {
+    xoff.assign(2, 0);
+  }
+  int rc;
+  if ((rc = upload(h, h->d_ox, ox.data(), O))) return rc;
+  if ((rc = upload(h, h->d_oy, oy.data(), O))) return rc;
+  if ((rc = upload(h, h->d_ot, ot.data(), O))) return rc;
+  if ((rc = upload(h, h->d_hab, habitats, (size_t)H * 3))) return rc;
+  if ((rc = upload(h, h->d_poly, polygon, (size_t)V * 2))) return rc;
+  if ((rc = upload(h, h->d_bins, bins, (size_t)T * 2))) return rc;
+  if ((rc = upload(h, h->d_cells, cells, (size_t)C * 4))) return rc;
+  if ((rc = upload(h, h->d_prob, prob, (size_t)T * C))) return rc;
+  if ((rc = upload(h, h->d_xoff, xoff.data(), xoff.size()))) return rc;
+  if ((rc = upload(h, h->d_xitems, xitems.data(), xitems.size()))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors go out of scope
+  WorldDev& W = h->W;
+  W.n_obstacles = O; W.n_habitats = H; W.n_poly = V; W.n_bins = T; W.n_cells = C; W.n_xbuckets = NB;
+  W.ox = h->d_ox.as<double>(); W.oy = h->d_oy.as<double>(); W.ot = h->d_ot.as<double>();
+  W.hab = h->d_hab.as<double>(); W.poly = h->d_poly.as<double>(); W.bins = h->d_bins.as<double>();
+  W.cells = h->d_cells.as<double>(); W.prob = h->d_prob.as<double>();
+  W.xb_off = h->d_xoff.as<int32_t>(); W.xb_items = h->d_xitems.as<int32_t>();
+  W.xb_x0 = X0; W.xb_inv_w = inv_w;
+  double bb[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
+  for (int i = 0; i < V; i++) {
+    bb[0] = std::min(bb[0], polygon[2 * i]); bb[1] = std::min(bb[1], polygon[2 * i + 1]);
+    bb[2] = std::max(bb[2], polygon[2 * i]); bb[3] = std::max(bb[3], polygon[2 * i + 1]);
+  }
+  memcpy(W.bb, bb, sizeof bb);
+  h->have_world = true;
+  return AUVP_OK;
+}
+
+int auvp_rrt_explore_batch(auvp_handle* h, int32_t E, const double* init, const uint64_t* seeds,
+                           const auvp_rrt_params* p, int32_t flags) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->have_world) return fail(h, AUVP_ERR_STATE, "auvp_world_set not called");
+  if (E <= 0 || !init || !seeds || !p) return fail(h, AUVP_ERR_ARG, "bad batch arguments");
+  if (p->max_iter <= 0 || !(p->freq >= 0) || p->mode < 0 || p->mode > 2) return fail(h, AUVP_ERR_ARG, "bad params");
+  if (p->mode == AUVP_MODE_TIMEBIN && !(p->bin_interval > 0)) return fail(h, AUVP_ERR_ARG, "bin_interval <= 0");
+  if (h->W.n_obstacles > 16 * 64) return fail(h, AUVP_ERR_ARG, "n_obstacles %d > 1024", h->W.n_obstacles);
+  HIPCHK(h, hipSetDevice(h->device));
+  RrtParamsDev& P = h->P;
+  P.dist_to_end = p->dist_to_end; P.diff_max = p->diff_max; P.freq = p->freq; P.min_dist = p->min_dist;
+  P.bin_interval = p->bin_interval; P.v = p->v; P.max_traj_time = p->max_traj_time; P.max_plan_time = p->max_plan_time;
+  P.w[0] = p->w[0]; P.w[1] = p->w[1]; P.w[2] = p->w[2];
+  P.mode = p->mode; P.max_iter = p->max_iter; P.flags = flags;
+  P.K = p->mode == AUVP_MODE_TIMEBIN ? (int)std::ceil(p->max_traj_time / p->bin_interval) : 0;
+  if (P.K > 1 << 20) return fail(h, AUVP_ERR_ARG, "too many time bins (%d)", P.K);
+  const int nfreq = (int)std::floor(p->freq);
+  h->max_pts = nfreq + 2;
+  double ppi = p->points_per_iter > 0 ? p->points_per_iter : 0.6 * p->freq + 2.0;
+  RrtBuffers& B = h->B;
+  B.cap_nodes = p->max_iter + 1;
+  double cp = std::ceil(ppi * (double)p->max_iter) + nfreq + 64;
+  if (cp > 2.0e9) return fail(h, AUVP_ERR_ARG, "point capacity too large");
+  B.cap_points = (int32_t)cp;
+  B.bin_cap = P.K > 0 ? B.cap_nodes : 1;
+  B.cap_leaves = (flags & AUVP_FLAG_LEAF_LOG) ? B.cap_nodes : 1;
+  const size_t cn = (size_t)E * B.cap_nodes, cpnt = (size_t)E * B.cap_points;
+  HIPCHK(h, h->d_nodes_f.reserve(cn * 5 * sizeof(double)));
+  HIPCHK(h, h->d_nodes_i.reserve(cn * 4 * sizeof(int32_t)));
+  HIPCHK(h, h->d_points.reserve(cpnt * 6 * sizeof(double)));
+  HIPCHK(h, h->d_bin_items.reserve((size_t)E * (P.K + 1) * B.bin_cap * sizeof(int32_t)));
+  HIPCHK(h, h->d_bin_count.reserve((size_t)E * (P.K + 1) * sizeof(int32_t)));
+  HIPCHK(h, h->d_summary.reserve((size_t)E * sizeof(RrtSummary)));
+  double* nf = h->d_nodes_f.as<double>();
+  B.nx = nf; B.ny = nf + cn; B.nth = nf + 2 * cn; B.ntt = nf + 3 * cn; B.nlen = nf + 4 * cn;
+  int32_t* ni = h->d_nodes_i.as<int32_t>();
+  B.nplan = ni; B.parent = ni + cn; B.pt_off = ni + 2 * cn; B.pt_cnt = ni + 3 * cn;
+  double* pf = h->d_points.as<double>();
+  B.px = pf; B.py = pf + cpnt; B.pth = pf + 2 * cpnt; B.pv = pf + 3 * cpnt; B.ptt = pf + 4 * cpnt; B.plen = pf + 5 * cpnt;
+  B.bin_items = h->d_bin_items.as<int32_t>();
+  B.bin_count = h->d_bin_count.as<int32_t>();
+  B.summary = h->d_summary.as<RrtSummary>();
+  B.it_parent = nullptr; B.it_accepted = nullptr; B.it_npath = nullptr; B.leaf_cost = nullptr; B.leaf_iter = nullptr;
+  if (flags & AUVP_FLAG_ITER_LOG) {
+    const size_t n = (size_t)E * p->max_iter;
+    HIPCHK(h, h->d_itlog_i.reserve(n * 2 * sizeof(int32_t)));
+    HIPCHK(h, h->d_itlog_b.reserve(n));
+    B.it_parent = h->d_itlog_i.as<int32_t>();
+    B.it_npath = B.it_parent + n;
+    B.it_accepted = h->d_itlog_b.as<int8_t>();
+  }
+  if (flags & AUVP_FLAG_LEAF_LOG) {
+    HIPCHK(h, h->d_leaf_c.reserve((size_t)E * B.cap_leaves * 6 * sizeof(double)));
+    HIPCHK(h, h->d_leaf_i.reserve((size_t)E * B.cap_leaves * sizeof(int32_t)));
+    B.leaf_cost = h->d_leaf_c.as<double>();
+    B.leaf_iter = h->d_leaf_i.as<int32_t>();
+  }
+  // seeds -> MT states (host), uploaded once per batch
+  std::vector<uint32_t> mt((size_t)E * 624);
+  for (int e = 0; e < E; e++) seed_mt(seeds[e], mt.data() + (size_t)e * 624);
+  int rc;
+  if ((rc = upload(h, h->d_mt, mt.data(), mt.size()))) return rc;
+  if ((rc = upload(h, h->d_init, init, (size_t)E * 6))) return rc;
+  B.mt = h->d_mt.as<uint32_t>();
+  B.init = h->d_init.as<double>();
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+
+  const size_t lds = rrt_lds_bytes(P.K, h->max_pts);
+  if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB (K=%d, freq=%d)", lds, P.K, nfreq);
+  const int grid = (E + RRT_WAVES - 1) / RRT_WAVES;
+  const int O = h->W.n_obstacles;
+  auto launch = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(RRT_WAVES * 64), lds, h->stream, h->W, P, B, (int)E, h->max_pts);
+    return hipGetLastError();
+  };
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  hipError_t le;
+  if (O <= 64) le = launch(rrt_explore_kernel<1>);
+  else if (O <= 128) le = launch(rrt_explore_kernel<2>);
+  else if (O <= 256) le = launch(rrt_explore_kernel<4>);
+  else if (O <= 512) le = launch(rrt_explore_kernel<8>);
+  else le = launch(rrt_explore_kernel<16>);
+  HIPCHK(h, le);
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->last_ms = ms;
+  h->last_grid = grid; h->last_block = RRT_WAVES * 64; h->last_lds = (int)lds;
+  h->E = E;
+  h->have_batch = true;
+  return AUVP_OK;
+}
+
+int auvp_rrt_summaries(auvp_handle* h, auvp_rrt_summary* out) {
+  if (!h || !out) return AUVP_ERR_ARG;
+  if (!h->have_batch) return fail(h, AUVP_ERR_STATE, "no batch has run");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(out, h->B.summary, (size_t)h->E * sizeof(RrtSummary), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+void* auvp_rrt_summaries_dev(auvp_handle* h) { return (h && h->have_batch) ? (void*)h->B.summary : nullptr; }
+
+int auvp_rrt_paths(auvp_handle* h, const int64_t* offsets, double* out) {
+  if (!h || !offsets || !out) return AUVP_ERR_ARG;
+  if (!h->have_batch) return fail(h, AUVP_ERR_STATE, "no batch has run");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int E = h->E;
+  const size_t total = (size_t)offsets[E];
+  HIPCHK(h, h->d_tmp0.reserve((size_t)(E + 1) * sizeof(int64_t)));
+  HIPCHK(h, h->d_tmp1.reserve(std::max<size_t>(total, 1) * 7 * sizeof(double)));
+  HIPCHK(h, hipMemcpyAsync(h->d_tmp0.p, offsets, (size_t)(E + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(rrt_final_course_kernel, dim3(E), dim3(64), 0, h->stream, h->B, h->d_tmp0.as<int64_t>(),
+                     h->d_tmp1.as<double>(), E);
+  HIPCHK(h, hipGetLastError());
+  if (total) HIPCHK(h, hipMemcpyAsync(out, h->d_tmp1.p, total * 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_rrt_tree(auvp_handle* h, int32_t ep, double* nodes6, int32_t* parent, int32_t* pt_off, int32_t* pt_cnt,
+                  double* points7) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->have_batch || ep < 0 || ep >= h->E) return fail(h, AUVP_ERR_STATE, "bad episode");
+  HIPCHK(h, hipSetDevice(h->device));
+  RrtSummary s;
+  HIPCHK(h, hipMemcpy(&s, h->B.summary + ep, sizeof s, hipMemcpyDeviceToHost));
+  const RrtBuffers& B = h->B;
+  const size_t nb = (size_t)ep * B.cap_nodes, pb = (size_t)ep * B.cap_points;
+  const int N = s.n_nodes, NP = s.n_points;
+  std::vector<double> col(std::max(N, NP) + 1);
+  std::vector<int32_t> icol(N + 1);
+  auto getd = [&](const double* src, int n) { return hipMemcpy(col.data(), src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost); };
+  if (nodes6) {
+    const double* cols[5] = {B.nx + nb, B.ny + nb, B.nth + nb, B.ntt + nb, B.nlen + nb};
+    const int dst[5] = {0, 1, 2, 3, 5};
+    for (int c = 0; c < 5; c++) {
+      HIPCHK(h, getd(cols[c], N));
+      for (int i = 0; i < N; i++) nodes6[6 * (size_t)i + dst[c]] = col[i];
+    }
+    HIPCHK(h, hipMemcpy(icol.data(), B.nplan + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; i++) nodes6[6 * (size_t)i + 4] = (double)icol[i];
+  }
+  if (parent) HIPCHK(h, hipMemcpy(parent, B.parent + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (pt_off) HIPCHK(h, hipMemcpy(pt_off, B.pt_off + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (pt_cnt) HIPCHK(h, hipMemcpy(pt_cnt, B.pt_cnt + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (points7) {
+    // plan_time_stamp of a path point = iteration of the node that owns it
+    std::vector<int32_t> off(N), cnt(N), plan(N);
+    HIPCHK(h, hipMemcpy(off.data(), B.pt_off + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(cnt.data(), B.pt_cnt + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(plan.data(), B.nplan + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const double* cols[6] = {B.px + pb, B.py + pb, B.pth + pb, B.pv + pb, B.ptt + pb, B.plen + pb};
+    const int dst[6] = {0, 1, 2, 3, 4, 6};
+    for (int c = 0; c < 6; c++) {
+      HIPCHK(h, getd(cols[c], NP));
+      for (int i = 0; i < NP; i++) points7[7 * (size_t)i + dst[c]] = col[i];
+    }
+    for (int m = 0; m < N; m++)
+      for (int k = 0; k < cnt[m]; k++) points7[7 * (size_t)(off[m] + k) + 5] = (double)plan[m];
+  }
+  return AUVP_OK;
+}
+
+int auvp_rrt_iter_log(auvp_handle* h, int32_t ep, int32_t* it_parent, int8_t* it_accepted, int32_t* it_npath) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->have_batch || ep < 0 || ep >= h->E || !h->B.it_parent) return fail(h, AUVP_ERR_STATE, "no iteration log");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = h->P.max_iter, o = (size_t)ep * n;
+  if (it_parent) HIPCHK(h, hipMemcpy(it_parent, h->B.it_parent + o, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (it_accepted) HIPCHK(h, hipMemcpy(it_accepted, h->B.it_accepted + o, n, hipMemcpyDeviceToHost));
+  if (it_npath) HIPCHK(h, hipMemcpy(it_npath, h->B.it_npath + o, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+int auvp_rrt_leaf_log(auvp_handle* h, int32_t ep, double* leaf_cost6, int32_t* leaf_iter) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->have_batch || ep < 0 || ep >= h->E || !h->B.leaf_cost) return fail(h, AUVP_ERR_STATE, "no leaf log");
+  HIPCHK(h, hipSetDevice(h->device));
+  RrtSummary s;
+  HIPCHK(h, hipMemcpy(&s, h->B.summary + ep, sizeof s, hipMemcpyDeviceToHost));
+  const size_t n = std::min(s.n_leaves, h->B.cap_leaves), o = (size_t)ep * h->B.cap_leaves;
+  if (leaf_cost6 && n) HIPCHK(h, hipMemcpy(leaf_cost6, h->B.leaf_cost + o * 6, n * 6 * sizeof(double), hipMemcpyDeviceToHost));
+  if (leaf_iter && n) HIPCHK(h, hipMemcpy(leaf_iter, h->B.leaf_iter + o, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+int auvp_rrt_bin_sizes(auvp_handle* h, int32_t ep, int32_t* sizes, int32_t* n_bins) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->have_batch || ep < 0 || ep >= h->E) return fail(h, AUVP_ERR_STATE, "bad episode");
+  HIPCHK(h, hipSetDevice(h->device));
+  const int K = h->P.K;
+  if (n_bins) *n_bins = K;
+  if (sizes && K > 0)
+    HIPCHK(h, hipMemcpy(sizes, h->B.bin_count + (size_t)ep * (K + 1) + 1, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+double auvp_last_kernel_ms(auvp_handle* h) { return h ? h->last_ms : -1.0; }
+
+int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds_bytes) {
+  if (!h) return AUVP_ERR_ARG;
+  if (grid) *grid = h->last_grid;
+  if (block) *block = h->last_block;
+  if (lds_bytes) *lds_bytes = h->last_lds;
+  return AUVP_OK;
+}
+
+}  // extern "C"
+
+#include "probe_kernels.h"

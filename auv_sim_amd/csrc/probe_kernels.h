@@ -1,0 +1,177 @@
+// probe_kernels.h -- standalone device evaluations of the building blocks (collision test, cost
+// function, portable sin/cos, wave-level MT19937).  They run the same device functions the planner
+// kernels use, one wavefront per path, so the parity tests can pin each block against the golden
+// vectors on its own.  Included at the end of auvplan.hip (same translation unit).
+#ifndef AUVP_PROBE_KERNELS_H
+#define AUVP_PROBE_KERNELS_H
+
+namespace auvp {
+
+// RRT.check_collision (path_planning/rrt_dubins.py:530-549): one wave per path
+__global__ __launch_bounds__(64) void collision_probe_kernel(WorldDev W, int n_paths, const int32_t* __restrict__ off,
+                                                             const double* __restrict__ pts, int8_t* __restrict__ out) {
+  __shared__ double poly[RRT_MAX_POLY][2];
+  const int lane = lane_id();
+  for (int i = lane; i < W.n_poly * 2; i += 64) (&poly[0][0])[i] = W.poly[i];
+  __syncthreads();
+  const int p = blockIdx.x;
+  if (p >= n_paths) return;
+  const int b = off[p], e = off[p + 1];
+  bool hit = false;
+  for (int i = lane; i < W.n_obstacles; i += 64) {
+    const double ox = W.ox[i], oy = W.oy[i], ot = W.ot[i];
+    for (int k = b; k < e; k++) {
+      double dx = pts[2 * k] - ox, dy = pts[2 * k + 1] - oy;
+      hit = hit || (dx * dx + dy * dy <= ot);
+    }
+  }
+  bool outside = false;
+  for (int k = b + lane; k < e; k += 64) outside = outside || !point_within(poly, W.n_poly, pts[2 * k], pts[2 * k + 1]);
+  bool ok = !__any(hit) && !__any(outside);
+  if (lane == 0) out[p] = ok ? 1 : 0;
+}
+
+// habitat_shark_cost_func (path_planning/cost.py:145-207): one wave per path
+__global__ __launch_bounds__(64) void cost_probe_kernel(WorldDev W, int n_paths, const int32_t* __restrict__ off,
+                                                        const double* __restrict__ pts, const int32_t* __restrict__ blo,
+                                                        const int32_t* __restrict__ bhi, const double* __restrict__ total,
+                                                        const double* __restrict__ w, double* __restrict__ out) {
+  __shared__ RrtSharedLds S;
+  const int lane = lane_id();
+  for (int i = lane; i < W.n_habitats * 3; i += 64) (&S.hab[0][0])[i] = W.hab[i];
+  for (int i = lane; i < W.n_bins * 2; i += 64) (&S.bins[0][0])[i] = W.bins[i];
+  __syncthreads();
+  const int p = blockIdx.x;
+  if (p >= n_paths) return;
+  const int b = off[p], e = off[p + 1];
+  const double w1 = w[3 * p], w2 = w[3 * p + 1], w3 = w[3 * p + 2];
+  CostAcc acc;
+  acc.c2 = 0.0; acc.visited = 0ull; acc.hits = 0;
+  for (int s0 = b; s0 < e; s0 += 64) {
+    int k = s0 + lane;
+    bool valid = k < e;
+    double x = valid ? pts[3 * k] : 0.0, y = valid ? pts[3 * k + 1] : 0.0, t = valid ? pts[3 * k + 2] : 0.0;
+    cost_segment(W, S, blo[p], bhi[p], w3, valid, x, y, t, acc);
+  }
+  double c0 = 0.0, c1 = 0.0, c2 = acc.c2;
+  if (w2 == auvp_rint(w2) && auvp_fabs(w2) < 1048576.0) c1 = w2 * (double)acc.hits;
+  else for (int h = 0; h < acc.hits; h++) c1 = c1 + w2;
+  const double tt = total[p];
+  if (tt > 0) { c1 = c1 / tt; c2 = c2 / tt; }
+  if (W.n_habitats != 0) c0 = w1 * (double)__popcll(acc.visited) / (double)W.n_habitats;
+  if (lane == 0) {
+    out[4 * p] = ((0.0 + c0) + c1) + c2;
+    out[4 * p + 1] = c0; out[4 * p + 2] = c1; out[4 * p + 3] = c2;
+  }
+}
+
+__global__ void sincos_probe_kernel(int n, const double* __restrict__ x, double* __restrict__ s, double* __restrict__ c) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) auvp_sincos(x[i], &s[i], &c[i]);
+}
+
+__global__ __launch_bounds__(64) void random_probe_kernel(const uint32_t* __restrict__ mt, int n, double* __restrict__ out) {
+  __shared__ uint32_t s[624];
+  const int lane = lane_id();
+  for (int i = lane; i < 624; i += 64) s[i] = mt[i];
+  WaveRng r;
+  r.s = s; r.pslot = 0; r.avail = 0;
+  wave_sync();
+  // mix the two access patterns the planners use: single draws and lane-parallel windows
+  int done = 0;
+  while (done < n) {
+    int w = (done % 7 == 0) ? 1 : ((done * 13) % 150 + 1);
+    if (w > n - done) w = n - done;
+    if (w == 1) {
+      double v = rng_next_random(r);
+      if (lane == 0) out[done] = v;
+    } else {
+      rng_ensure(r, (uint32_t)(2 * w));
+      for (int j = lane; j < w; j += 64) out[done + j] = rng_random_at(r, (uint32_t)j);
+      rng_advance_words(r, (uint32_t)(2 * w));
+    }
+    done += w;
+  }
+}
+
+}  // namespace auvp
+
+extern "C" {
+
+int auvp_check_collision_batch(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xy, int8_t* out_free) {
+  if (!h || n_paths < 0 || !off || !out_free) return AUVP_ERR_ARG;
+  if (!h->have_world) return fail(h, AUVP_ERR_STATE, "auvp_world_set not called");
+  if (n_paths == 0) return AUVP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t npts = (size_t)off[n_paths];
+  int rc;
+  if ((rc = upload(h, h->d_tmp0, off, (size_t)n_paths + 1))) return rc;
+  if ((rc = upload(h, h->d_tmp1, pts_xy, npts * 2))) return rc;
+  HIPCHK(h, h->d_tmp2.reserve((size_t)n_paths));
+  hipLaunchKernelGGL(collision_probe_kernel, dim3(n_paths), dim3(64), 0, h->stream, h->W, (int)n_paths,
+                     h->d_tmp0.as<int32_t>(), h->d_tmp1.as<double>(), h->d_tmp2.as<int8_t>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out_free, h->d_tmp2.p, (size_t)n_paths, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_cost_paths(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xyt, const int32_t* bin_lo,
+                    const int32_t* bin_hi, const double* total_traj_time, const double* weights3, double* out4) {
+  if (!h || n_paths < 0 || !off || !out4) return AUVP_ERR_ARG;
+  if (!h->have_world) return fail(h, AUVP_ERR_STATE, "auvp_world_set not called");
+  if (n_paths == 0) return AUVP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t npts = (size_t)off[n_paths];
+  int rc;
+  if ((rc = upload(h, h->d_tmp0, off, (size_t)n_paths + 1))) return rc;
+  if ((rc = upload(h, h->d_tmp1, pts_xyt, npts * 3))) return rc;
+  if ((rc = upload(h, h->d_tmp2, bin_lo, (size_t)n_paths))) return rc;
+  if ((rc = upload(h, h->d_tmp3, bin_hi, (size_t)n_paths))) return rc;
+  if ((rc = upload(h, h->d_tmp4, total_traj_time, (size_t)n_paths))) return rc;
+  if ((rc = upload(h, h->d_tmp5, weights3, (size_t)n_paths * 3))) return rc;
+  HIPCHK(h, h->d_leaf_c.reserve((size_t)n_paths * 4 * sizeof(double)));
+  hipLaunchKernelGGL(cost_probe_kernel, dim3(n_paths), dim3(64), 0, h->stream, h->W, (int)n_paths, h->d_tmp0.as<int32_t>(),
+                     h->d_tmp1.as<double>(), h->d_tmp2.as<int32_t>(), h->d_tmp3.as<int32_t>(), h->d_tmp4.as<double>(),
+                     h->d_tmp5.as<double>(), h->d_leaf_c.as<double>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out4, h->d_leaf_c.p, (size_t)n_paths * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_sincos_dev(auvp_handle* h, int32_t n, const double* x, double* s, double* c) {
+  if (!h || n < 0 || !x || !s || !c) return AUVP_ERR_ARG;
+  if (n == 0) return AUVP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if ((rc = upload(h, h->d_tmp0, x, (size_t)n))) return rc;
+  HIPCHK(h, h->d_tmp1.reserve((size_t)n * sizeof(double)));
+  HIPCHK(h, h->d_tmp2.reserve((size_t)n * sizeof(double)));
+  hipLaunchKernelGGL(sincos_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (int)n, h->d_tmp0.as<double>(),
+                     h->d_tmp1.as<double>(), h->d_tmp2.as<double>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(s, h->d_tmp1.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(c, h->d_tmp2.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_random_stream_dev(auvp_handle* h, uint64_t seed, int32_t n, double* out) {
+  if (!h || n < 0 || !out) return AUVP_ERR_ARG;
+  if (n == 0) return AUVP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  uint32_t mt[624];
+  seed_mt(seed, mt);
+  int rc;
+  if ((rc = upload(h, h->d_tmp0, mt, 624))) return rc;
+  HIPCHK(h, h->d_tmp1.reserve((size_t)n * sizeof(double)));
+  hipLaunchKernelGGL(random_probe_kernel, dim3(1), dim3(64), 0, h->stream, h->d_tmp0.as<uint32_t>(), (int)n, h->d_tmp1.as<double>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out, h->d_tmp1.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+}  // extern "C"
+#endif

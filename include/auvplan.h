@@ -1,0 +1,115 @@
+/* auvplan.h -- C-ABI of libauvplan.so: the MI355X (gfx950) path-planning hot path.
+ *
+ * The reference (hmc-lair-shark-tracking/auv-sim) is pure Python and has no FFI; its boundary for
+ * this path is the Python planner API.  The Python drop-in classes in auv_sim_amd/
+ * keep those signatures and call the entry points below through ctypes.  Each entry point cites the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions: plain C types; host pointers unless a name ends in _dev; caller-allocated outputs;
+ * sizes queried first (two-phase) where variable; integer status (0 ok, >0 reference-defined
+ * outcome, <0 error + auvp_last_error()); nothing throws across the ABI; one HIP stream per handle;
+ * a handle is thread-compatible (no internal global state), not thread-safe.
+ */
+#ifndef AUVPLAN_H
+#define AUVPLAN_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct auvp_handle auvp_handle;
+
+enum {
+  AUVP_OK = 0,
+  AUVP_NO_QUALIFYING_LEAF = 1, /* exploring(): opt_path stayed None -> TypeError at rrt_dubins.py:174 */
+  AUVP_ERR_ARG = -1,
+  AUVP_ERR_CAPACITY = -2, /* a device buffer sized from the budget overflowed; nothing is truncated silently */
+  AUVP_ERR_HIP = -3,
+  AUVP_ERR_STATE = -4,
+  AUVP_ERR_KEY = -5 /* time-bin key outside 1..K: KeyError at rrt_dubins.py:124 */
+};
+
+enum { AUVP_MODE_TIMEBIN = 0, AUVP_MODE_PLANTIME = 1, AUVP_MODE_NN = 2 };
+enum { AUVP_FLAG_ITER_LOG = 1, AUVP_FLAG_LEAF_LOG = 2 };
+
+const char* auvp_version(void);
+/* create a planner context on HIP device `device`; fails (AUVP_ERR_HIP) when no gfx950 GPU is
+ * usable -- there is no CPU fallback */
+int auvp_create(int device, auvp_handle** out);
+void auvp_destroy(auvp_handle* h);
+const char* auvp_last_error(auvp_handle* h);
+
+/* World model shared by every episode of a batch.
+ * Replaces the Python-side arguments of RRT.__init__ (path_planning/rrt_dubins.py:26: boundary
+ * polygon, obstacle list, sharkGrid dict, cell_list) and the `habitats` list of exploring() (:92).
+ *   obstacles [O,3] x,y,size in LIST ORDER (check_collision is order dependent, :535-541)
+ *   habitats  [H,3]
+ *   polygon   [V,2] boundary vertices (Point.within, :545-546)
+ *   bins      [T,2] shark-grid time bins in dict order; cells [C,4] bounds in cell_list order;
+ *   prob      [T,C] (createSharkGrid, :612-630) */
+int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t n_obstacles, const double* habitats,
+                   int32_t n_habitats, const double* polygon, int32_t n_poly, const double* bins,
+                   int32_t n_bins, const double* cells, int32_t n_cells, const double* prob);
+
+typedef struct {
+  double dist_to_end, diff_max, freq; /* RRT.__init__ kwargs, rrt_dubins.py:26 */
+  double min_dist;                     /* steer(min_dist=0.5), call site :141 */
+  double bin_interval, v;              /* exploring() args, :92 */
+  double max_traj_time;
+  double max_plan_time;                /* only feeds ran_time in plan-time mode (:129) */
+  double w[3];                         /* weights */
+  int32_t mode;                        /* AUVP_MODE_*: (plan_time, traj_time_stamp) flags of :121-139 */
+  int32_t max_iter;                    /* iteration budget = virtual clock of SURVEY 8(c) */
+  double points_per_iter;              /* device path-point capacity per iteration; 0 -> 0.6*freq+2 */
+} auvp_rrt_params;
+
+typedef struct {
+  int32_t status, n_nodes, n_points, n_leaves, best_leaf, best_path_len, iters_run, _pad;
+  double best_cost[4]; /* sum, c0, c1, c2 (habitat_shark_cost_func, path_planning/cost.py:145) */
+  double best_length;  /* "path length" of the returned dict, rrt_dubins.py:171,176 */
+  double rng_after;    /* next random() of the episode's stream (parity probe: same draw count) */
+} auvp_rrt_summary;
+
+/* RRT.exploring (path_planning/rrt_dubins.py:92-176) for E independent episodes, one wavefront
+ * each.  init [E,6] = x,y,theta,traj_time_stamp,plan_time_stamp,length of `initial`;
+ * seeds [E]: the episode draws the stream `random.seed(seeds[e])` would give. */
+int auvp_rrt_explore_batch(auvp_handle* h, int32_t n_episodes, const double* init, const uint64_t* seeds,
+                           const auvp_rrt_params* params, int32_t flags);
+int auvp_rrt_summaries(auvp_handle* h, auvp_rrt_summary* out /* [E] */);
+/* generate_final_course (:321-331) of every episode's best leaf, reversed to root->leaf (:174).
+ * offsets [E+1] = exclusive prefix sum of best_path_len; out [offsets[E],7] =
+ * x,y,theta,v,traj_time_stamp,plan_time_stamp,length per element */
+int auvp_rrt_paths(auvp_handle* h, const int64_t* offsets, double* out);
+/* whole tree of one episode (tests / RRT.mps_list): nodes [n_nodes,6] x,y,theta,traj_t,plan_t,length */
+int auvp_rrt_tree(auvp_handle* h, int32_t episode, double* nodes6, int32_t* parent, int32_t* pt_off,
+                  int32_t* pt_cnt, double* points7);
+int auvp_rrt_iter_log(auvp_handle* h, int32_t episode, int32_t* it_parent, int8_t* it_accepted,
+                      int32_t* it_npath);
+int auvp_rrt_leaf_log(auvp_handle* h, int32_t episode, double* leaf_cost6, int32_t* leaf_iter);
+int auvp_rrt_bin_sizes(auvp_handle* h, int32_t episode, int32_t* sizes /* [K] */, int32_t* n_bins);
+
+/* device-side result records for the multi-GPU gather: pointer to [E] auvp_rrt_summary in HBM */
+void* auvp_rrt_summaries_dev(auvp_handle* h);
+
+/* standalone evaluations on the device (parity probes for the building blocks) */
+/* RRT.check_collision (:530-549) of n_paths paths; pts [sum(npts),2], path i = pts[off[i]:off[i+1]] */
+int auvp_check_collision_batch(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xy,
+                               int8_t* out_free);
+/* habitat_shark_cost_func (path_planning/cost.py:145-207) over bins [bin_lo,bin_hi) */
+int auvp_cost_paths(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xyt,
+                    const int32_t* bin_lo, const int32_t* bin_hi, const double* total_traj_time,
+                    const double* weights3, double* out4);
+/* portable sin/cos evaluated on the device (bit-exactness probe for auvp_math.h) */
+int auvp_sincos_dev(auvp_handle* h, int32_t n, const double* x, double* s, double* c);
+/* CPython random() stream of `seed` generated by the wave-level device MT19937 */
+int auvp_random_stream_dev(auvp_handle* h, uint64_t seed, int32_t n, double* out);
+
+/* HIP-event time (ms) of the last batch kernel on the handle's stream, and its launch geometry */
+double auvp_last_kernel_ms(auvp_handle* h);
+int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
