@@ -33,16 +33,16 @@ class RRTSummary(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_nodes", C.c_int32), ("n_points", C.c_int32),
                 ("n_leaves", C.c_int32), ("best_leaf", C.c_int32), ("best_path_len", C.c_int32),
                 ("iters_run", C.c_int32), ("_pad", C.c_int32), ("best_cost", C.c_double * 4),
-                ("best_length", C.c_double), ("rng_after", C.c_double)]
+                ("best_length", C.c_double), ("rng_after", C.c_double), ("leaf_elems", C.c_int64), ("n_draw32", C.c_uint64)]
 
 
 SUMMARY_DTYPE = np.dtype([("status", "<i4"), ("n_nodes", "<i4"), ("n_points", "<i4"), ("n_leaves", "<i4"),
                           ("best_leaf", "<i4"), ("best_path_len", "<i4"), ("iters_run", "<i4"), ("_pad", "<i4"),
-                          ("best_cost", "<f8", (4,)), ("best_length", "<f8"), ("rng_after", "<f8")])
+                          ("best_cost", "<f8", (4,)), ("best_length", "<f8"), ("rng_after", "<f8"), ("leaf_elems", "<i8"), ("n_draw32", "<u8")])
 assert SUMMARY_DTYPE.itemsize == C.sizeof(RRTSummary)
 
 MODES = {"timebin": 0, "plantime": 1, "nn": 2}
-FLAG_ITER_LOG, FLAG_LEAF_LOG = 1, 2
+FLAG_ITER_LOG, FLAG_LEAF_LOG, FLAG_PHASE_CLOCKS = 1, 2, 4
 OK, NO_QUALIFYING_LEAF = 0, 1
 
 _lib = None
@@ -67,6 +67,11 @@ def load():
     L.auvp_world_set.argtypes = [vp, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _dp,
                                  C.c_int32, _dp]
     L.auvp_rrt_explore_batch.argtypes = [vp, C.c_int32, _dp, C.POINTER(C.c_uint64), C.POINTER(RRTParams), C.c_int32]
+    L.auvp_rrt_prepare.argtypes = [vp, C.c_int32, _dp, C.POINTER(C.c_uint64), C.POINTER(RRTParams), C.c_int32]
+    L.auvp_rrt_prepare_states.argtypes = [vp, C.c_int32, _dp, C.POINTER(C.c_uint32), _ip, C.POINTER(RRTParams), C.c_int32]
+    L.auvp_world_set_habitats.argtypes = [vp, _dp, C.c_int32]
+    L.auvp_rrt_run.argtypes = [vp]
+    L.auvp_rrt_paths_dev.argtypes = [vp, C.POINTER(C.c_int64), C.c_void_p]
     L.auvp_rrt_summaries.argtypes = [vp, C.c_void_p]
     L.auvp_rrt_paths.argtypes = [vp, C.POINTER(C.c_int64), _dp]
     L.auvp_rrt_tree.argtypes = [vp, C.c_int32, _dp, _ip, _ip, _ip, _dp]
@@ -79,6 +84,7 @@ def load():
     L.auvp_cost_paths.argtypes = [vp, C.c_int32, _ip, _dp, _ip, _ip, _dp, _dp, _dp]
     L.auvp_sincos_dev.argtypes = [vp, C.c_int32, _dp, _dp, _dp]
     L.auvp_random_stream_dev.argtypes = [vp, C.c_uint64, C.c_int32, _dp]
+    L.auvp_rrt_phase_clocks.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.auvp_last_kernel_ms.argtypes = [vp]
     L.auvp_last_kernel_ms.restype = C.c_double
     L.auvp_last_launch.argtypes = [vp, _ip, _ip, _ip]
@@ -137,13 +143,35 @@ class Context:
                                         _p(ce), len(ce), _p(pr)))
         self.world_sizes = dict(O=len(ob), H=len(hb), V=len(pg), T=len(bn), C=len(ce))
 
+    def set_habitats(self, habitats):
+        hb = _f64(habitats if habitats is not None else [], (-1, 3))
+        self._chk(self.L.auvp_world_set_habitats(self.h, _p(hb), len(hb)))
+        self.world_sizes["H"] = len(hb)
+
     # ---- RRT.exploring batch ----
     def rrt_explore_batch(self, init, seeds, n_iter, mode="timebin", freq=30, bin_interval=5, v=2,
                           max_traj_time=500.0, weights=(-3, -3, -4), dist_to_end=2, diff_max=0.5, min_dist=0.5,
-                          max_plan_time=None, points_per_iter=0.0, iter_log=False, leaf_log=False):
+                          max_plan_time=None, points_per_iter=0.0, iter_log=False, leaf_log=False, phase_clocks=False):
+        self.rrt_prepare(init, seeds, n_iter, mode, freq, bin_interval, v, max_traj_time, weights, dist_to_end,
+                         diff_max, min_dist, max_plan_time, points_per_iter, iter_log, leaf_log, phase_clocks)
+        self.rrt_run()
+        return self.summaries()
+
+    def rrt_run(self):
+        """launch the kernel on the prepared batch (inputs already resident in HBM); repeatable"""
+        self._chk(self.L.auvp_rrt_run(self.h))
+
+    def rrt_prepare(self, init, seeds, n_iter, mode="timebin", freq=30, bin_interval=5, v=2,
+                    max_traj_time=500.0, weights=(-3, -3, -4), dist_to_end=2, diff_max=0.5, min_dist=0.5,
+                    max_plan_time=None, points_per_iter=0.0, iter_log=False, leaf_log=False, phase_clocks=False):
         init = _f64(init, (-1, 6))
         E = len(init)
-        seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(E))
+        states = None
+        if isinstance(seeds, tuple):  # (mt [E,624] uint32, index [E]) as random.getstate() reports
+            states = np.ascontiguousarray(np.asarray(seeds[0], dtype=np.uint32).reshape(E, 624))
+            sidx = np.ascontiguousarray(np.asarray(seeds[1], dtype=np.int32).reshape(E))
+        else:
+            seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64).reshape(E))
         p = RRTParams()
         p.dist_to_end, p.diff_max, p.freq, p.min_dist = float(dist_to_end), float(diff_max), float(freq), float(min_dist)
         p.bin_interval, p.v, p.max_traj_time = float(bin_interval), float(v), float(max_traj_time)
@@ -151,11 +179,14 @@ class Context:
         for i in range(3):
             p.w[i] = float(weights[i])
         p.mode, p.max_iter, p.points_per_iter = MODES[mode], int(n_iter), float(points_per_iter)
-        flags = (FLAG_ITER_LOG if iter_log else 0) | (FLAG_LEAF_LOG if leaf_log else 0)
-        self._chk(self.L.auvp_rrt_explore_batch(self.h, E, _p(init), seeds.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                                C.byref(p), flags))
+        flags = (FLAG_ITER_LOG if iter_log else 0) | (FLAG_LEAF_LOG if leaf_log else 0) | (FLAG_PHASE_CLOCKS if phase_clocks else 0)
+        if states is not None:
+            self._chk(self.L.auvp_rrt_prepare_states(self.h, E, _p(init), states.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                     _p(sidx, _ip), C.byref(p), flags))
+        else:
+            self._chk(self.L.auvp_rrt_prepare(self.h, E, _p(init), seeds.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                              C.byref(p), flags))
         self.n_episodes, self.max_iter = E, int(n_iter)
-        return self.summaries()
 
     def summaries(self):
         out = np.zeros(self.n_episodes, dtype=SUMMARY_DTYPE)
@@ -170,6 +201,12 @@ class Context:
         out = np.zeros((max(int(off[-1]), 1), 7))
         self._chk(self.L.auvp_rrt_paths(self.h, off.ctypes.data_as(C.POINTER(C.c_int64)), _p(out)))
         return [out[off[e]:off[e + 1]] for e in range(self.n_episodes)]
+
+    def paths_dev(self, offsets, out_dev_ptr):
+        """final courses written to a caller-owned device buffer [offsets[E],7] f64 (e.g. a torch tensor's
+        data_ptr()) -- stays in HBM for the multi-GPU gather"""
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        self._chk(self.L.auvp_rrt_paths_dev(self.h, off.ctypes.data_as(C.POINTER(C.c_int64)), C.c_void_p(out_dev_ptr)))
 
     def tree(self, ep, summary):
         n, npnt = int(summary["n_nodes"]), int(summary["n_points"])
@@ -231,6 +268,11 @@ class Context:
     def random_stream(self, seed, n):
         out = np.zeros(n)
         self._chk(self.L.auvp_random_stream_dev(self.h, int(seed), n, _p(out)))
+        return out
+
+    def phase_clocks(self):
+        out = np.zeros((self.n_episodes, 5), dtype=np.uint64)
+        self._chk(self.L.auvp_rrt_phase_clocks(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out
 
     def last_kernel_ms(self):

@@ -25,7 +25,10 @@ struct WorldDev {
   // x-bucket index over the cells for the first-match scan of cost.py:181-184: bucket b lists, in
   // cell_list order, every cell whose [minx, min(maxx,maxy)] meets the bucket's x-range
   const int32_t* xb_off;    // [NB+1]
-  const int32_t* xb_items;  // [xb_off[NB]]
+  const int32_t* xb_items;  // [xb_off[NB]] cell ids
+  // per item, in bucket order: {minx, min(maxx,maxy), miny, min over this and all later items of
+  // the bucket of miny}; the last column lets the scan stop as soon as no later cell can match
+  const double* xb_data;    // [xb_off[NB]][4]
   double xb_x0, xb_inv_w;
   double bb[4];  // polygon bounds xmin,ymin,xmax,ymax (get_random_mps, :334)
 };
@@ -41,6 +44,8 @@ struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h
   double best_cost[4];
   double best_length;
   double rng_after;
+  long long leaf_elems;
+  unsigned long long n_draw32;
 };
 
 // Per-episode tree storage, structure-of-arrays, episode-major: array[e * cap + i].
@@ -51,7 +56,8 @@ struct RrtBuffers {
   double *px, *py, *pth, *pv, *ptt, *plen;  // [E][cap_points]
   int32_t* bin_items;                       // [E][K+1][bin_cap]
   int32_t* bin_count;                       // [E][K+1] (copied out of LDS at the end)
-  uint32_t* mt;                             // [E][624] seeded state in
+  uint32_t* mt;                             // [E][624] generator state in
+  const int32_t* mt_index;                  // [E] position inside the state (624 = fresh seed)
   const double* init;                       // [E][6]
   RrtSummary* summary;                      // [E]
   int32_t* it_parent;                       // optional logs [E][max_iter]
@@ -59,6 +65,7 @@ struct RrtBuffers {
   int32_t* it_npath;
   double* leaf_cost;  // optional [E][cap_leaves][6]
   int32_t* leaf_iter;
+  unsigned long long* phase_clocks;  // optional [E][5] shader clocks per phase
 };
 
 }  // namespace auvp

@@ -63,6 +63,7 @@ struct WaveRng {
   uint32_t* s;     // LDS, 624 words
   uint32_t pslot;  // slot of the next unconsumed word
   uint32_t avail;  // generated, not yet consumed
+  unsigned long long drawn;  // 32-bit outputs consumed so far
 };
 
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
@@ -113,6 +114,7 @@ __device__ __forceinline__ void rng_advance_words(WaveRng& r, uint32_t nwords) {
   while (p >= 624u) p -= 624u;
   r.pslot = (uint32_t)uni((int)p);
   r.avail = (uint32_t)uni((int)(r.avail - nwords));
+  r.drawn += nwords;
 }
 
 // one uniform random() for the whole wave (every lane returns the same value)

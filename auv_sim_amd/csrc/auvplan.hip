@@ -48,15 +48,15 @@ struct auvp_handle {
   // world
   bool have_world = false;
   WorldDev W{};
-  DevBuf d_ox, d_oy, d_ot, d_hab, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems;
+  DevBuf d_ox, d_oy, d_ot, d_hab, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems, d_xdata;
   // rrt batch
   int E = 0;
   RrtParamsDev P{};
   RrtBuffers B{};
   int max_pts = 0;
-  DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
-  bool have_batch = false;
+  DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_init, d_summary, d_itlog_i, d_itlog_b,
+      d_leaf_c, d_leaf_i, d_phase, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+  bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
 };
@@ -176,6 +176,7 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   }
   // x-bucket index over the cells
   std::vector<int32_t> xoff, xitems;
+  std::vector<double> xdata;
   double X0 = 0.0, inv_w = 0.0;
   int NB = 0;
   if (C > 0) {
@@ -209,6 +210,18 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
       xoff[k + 1] = xoff[k] + (int32_t)lists[k].size();
       xitems.insert(xitems.end(), lists[k].begin(), lists[k].end());
     }
+    xdata.resize(xitems.size() * 4);
+    for (int k = 0; k < NB; k++) {
+      double suf = INFINITY;
+      for (int i = xoff[k + 1] - 1; i >= xoff[k]; i--) {
+        const double* cb = cells + 4 * (size_t)xitems[i];
+        suf = std::min(suf, cb[1]);
+        xdata[4 * (size_t)i] = cb[0];
+        xdata[4 * (size_t)i + 1] = std::min(cb[2], cb[3]);
+        xdata[4 * (size_t)i + 2] = cb[1];
+        xdata[4 * (size_t)i + 3] = suf;
+      }
+    }
   } else {
     xoff.assign(2, 0);
   }
@@ -223,13 +236,14 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   if ((rc = upload(h, h->d_prob, prob, (size_t)T * C))) return rc;
   if ((rc = upload(h, h->d_xoff, xoff.data(), xoff.size()))) return rc;
   if ((rc = upload(h, h->d_xitems, xitems.data(), xitems.size()))) return rc;
+  if ((rc = upload(h, h->d_xdata, xdata.data(), xdata.size()))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));  // host vectors go out of scope
   WorldDev& W = h->W;
   W.n_obstacles = O; W.n_habitats = H; W.n_poly = V; W.n_bins = T; W.n_cells = C; W.n_xbuckets = NB;
   W.ox = h->d_ox.as<double>(); W.oy = h->d_oy.as<double>(); W.ot = h->d_ot.as<double>();
   W.hab = h->d_hab.as<double>(); W.poly = h->d_poly.as<double>(); W.bins = h->d_bins.as<double>();
   W.cells = h->d_cells.as<double>(); W.prob = h->d_prob.as<double>();
-  W.xb_off = h->d_xoff.as<int32_t>(); W.xb_items = h->d_xitems.as<int32_t>();
+  W.xb_off = h->d_xoff.as<int32_t>(); W.xb_items = h->d_xitems.as<int32_t>(); W.xb_data = h->d_xdata.as<double>();
   W.xb_x0 = X0; W.xb_inv_w = inv_w;
   double bb[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
   for (int i = 0; i < V; i++) {
@@ -241,11 +255,46 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   return AUVP_OK;
 }
 
-int auvp_rrt_explore_batch(auvp_handle* h, int32_t E, const double* init, const uint64_t* seeds,
-                           const auvp_rrt_params* p, int32_t flags) {
+int auvp_world_set_habitats(auvp_handle* h, const double* habitats, int32_t H) {
   if (!h) return AUVP_ERR_ARG;
   if (!h->have_world) return fail(h, AUVP_ERR_STATE, "auvp_world_set not called");
-  if (E <= 0 || !init || !seeds || !p) return fail(h, AUVP_ERR_ARG, "bad batch arguments");
+  if (H < 0 || H > RRT_MAX_HAB) return fail(h, AUVP_ERR_ARG, "n_habitats %d outside 0..%d", H, RRT_MAX_HAB);
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if ((rc = upload(h, h->d_hab, habitats, (size_t)H * 3))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->W.n_habitats = H;
+  h->W.hab = h->d_hab.as<double>();
+  return AUVP_OK;
+}
+
+int auvp_rrt_explore_batch(auvp_handle* h, int32_t E, const double* init, const uint64_t* seeds,
+                           const auvp_rrt_params* p, int32_t flags) {
+  int rc = auvp_rrt_prepare(h, E, init, seeds, p, flags);
+  if (rc != AUVP_OK) return rc;
+  return auvp_rrt_run(h);
+}
+
+static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const uint64_t* seeds, const uint32_t* states,
+                            const int32_t* state_index, const auvp_rrt_params* p, int32_t flags);
+
+int auvp_rrt_prepare(auvp_handle* h, int32_t E, const double* init, const uint64_t* seeds,
+                     const auvp_rrt_params* p, int32_t flags) {
+  if (!seeds) return h ? fail(h, AUVP_ERR_ARG, "seeds is null") : AUVP_ERR_ARG;
+  return rrt_prepare_impl(h, E, init, seeds, nullptr, nullptr, p, flags);
+}
+
+int auvp_rrt_prepare_states(auvp_handle* h, int32_t E, const double* init, const uint32_t* mt, const int32_t* mt_index,
+                            const auvp_rrt_params* p, int32_t flags) {
+  if (!mt || !mt_index) return h ? fail(h, AUVP_ERR_ARG, "mt state is null") : AUVP_ERR_ARG;
+  return rrt_prepare_impl(h, E, init, nullptr, mt, mt_index, p, flags);
+}
+
+static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const uint64_t* seeds, const uint32_t* states,
+                            const int32_t* state_index, const auvp_rrt_params* p, int32_t flags) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->have_world) return fail(h, AUVP_ERR_STATE, "auvp_world_set not called");
+  if (E <= 0 || !init || !p) return fail(h, AUVP_ERR_ARG, "bad batch arguments");
   if (p->max_iter <= 0 || !(p->freq >= 0) || p->mode < 0 || p->mode > 2) return fail(h, AUVP_ERR_ARG, "bad params");
   if (p->mode == AUVP_MODE_TIMEBIN && !(p->bin_interval > 0)) return fail(h, AUVP_ERR_ARG, "bin_interval <= 0");
   if (h->W.n_obstacles > 16 * 64) return fail(h, AUVP_ERR_ARG, "n_obstacles %d > 1024", h->W.n_obstacles);
@@ -298,16 +347,43 @@ int auvp_rrt_explore_batch(auvp_handle* h, int32_t E, const double* init, const 
     B.leaf_cost = h->d_leaf_c.as<double>();
     B.leaf_iter = h->d_leaf_i.as<int32_t>();
   }
+  B.phase_clocks = nullptr;
+  if (flags & AUVP_FLAG_PHASE_CLOCKS) {
+    HIPCHK(h, h->d_phase.reserve((size_t)E * 5 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemsetAsync(h->d_phase.p, 0, (size_t)E * 5 * sizeof(unsigned long long), h->stream));
+    B.phase_clocks = h->d_phase.as<unsigned long long>();
+  }
   // seeds -> MT states (host), uploaded once per batch
-  std::vector<uint32_t> mt((size_t)E * 624);
-  for (int e = 0; e < E; e++) seed_mt(seeds[e], mt.data() + (size_t)e * 624);
   int rc;
-  if ((rc = upload(h, h->d_mt, mt.data(), mt.size()))) return rc;
+  B.mt_index = nullptr;
+  if (seeds) {
+    std::vector<uint32_t> mt((size_t)E * 624);
+    for (int e = 0; e < E; e++) seed_mt(seeds[e], mt.data() + (size_t)e * 624);
+    if ((rc = upload(h, h->d_mt, mt.data(), mt.size()))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  } else {
+    if ((rc = upload(h, h->d_mt, states, (size_t)E * 624))) return rc;
+    if ((rc = upload(h, h->d_mtidx, state_index, (size_t)E))) return rc;
+    B.mt_index = h->d_mtidx.as<int32_t>();
+  }
   if ((rc = upload(h, h->d_init, init, (size_t)E * 6))) return rc;
   B.mt = h->d_mt.as<uint32_t>();
   B.init = h->d_init.as<double>();
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->E = E;
+  h->prepared = true;
+  h->have_batch = false;
+  return AUVP_OK;
+}
 
+int auvp_rrt_run(auvp_handle* h) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->prepared) return fail(h, AUVP_ERR_STATE, "auvp_rrt_prepare not called");
+  HIPCHK(h, hipSetDevice(h->device));
+  const RrtParamsDev& P = h->P;
+  const RrtBuffers& B = h->B;
+  const int E = h->E;
+  const int nfreq = (int)std::floor(P.freq);
   const size_t lds = rrt_lds_bytes(P.K, h->max_pts);
   if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB (K=%d, freq=%d)", lds, P.K, nfreq);
   const int grid = (E + RRT_WAVES - 1) / RRT_WAVES;
@@ -332,7 +408,6 @@ int auvp_rrt_explore_batch(auvp_handle* h, int32_t E, const double* init, const 
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
   h->last_grid = grid; h->last_block = RRT_WAVES * 64; h->last_lds = (int)lds;
-  h->E = E;
   h->have_batch = true;
   return AUVP_OK;
 }
@@ -348,18 +423,28 @@ int auvp_rrt_summaries(auvp_handle* h, auvp_rrt_summary* out) {
 
 void* auvp_rrt_summaries_dev(auvp_handle* h) { return (h && h->have_batch) ? (void*)h->B.summary : nullptr; }
 
-int auvp_rrt_paths(auvp_handle* h, const int64_t* offsets, double* out) {
-  if (!h || !offsets || !out) return AUVP_ERR_ARG;
+int auvp_rrt_paths_dev(auvp_handle* h, const int64_t* offsets, void* out_dev) {
+  if (!h || !offsets || !out_dev) return AUVP_ERR_ARG;
   if (!h->have_batch) return fail(h, AUVP_ERR_STATE, "no batch has run");
   HIPCHK(h, hipSetDevice(h->device));
   const int E = h->E;
-  const size_t total = (size_t)offsets[E];
   HIPCHK(h, h->d_tmp0.reserve((size_t)(E + 1) * sizeof(int64_t)));
-  HIPCHK(h, h->d_tmp1.reserve(std::max<size_t>(total, 1) * 7 * sizeof(double)));
   HIPCHK(h, hipMemcpyAsync(h->d_tmp0.p, offsets, (size_t)(E + 1) * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(rrt_final_course_kernel, dim3(E), dim3(64), 0, h->stream, h->B, h->d_tmp0.as<int64_t>(),
-                     h->d_tmp1.as<double>(), E);
+                     reinterpret_cast<double*>(out_dev), E);
   HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_rrt_paths(auvp_handle* h, const int64_t* offsets, double* out) {
+  if (!h || !offsets || !out) return AUVP_ERR_ARG;
+  if (!h->have_batch) return fail(h, AUVP_ERR_STATE, "no batch has run");
+  const size_t total = (size_t)offsets[h->E];
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, h->d_tmp1.reserve(std::max<size_t>(total, 1) * 7 * sizeof(double)));
+  int rc = auvp_rrt_paths_dev(h, offsets, h->d_tmp1.p);
+  if (rc != AUVP_OK) return rc;
   if (total) HIPCHK(h, hipMemcpyAsync(out, h->d_tmp1.p, total * 7 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return AUVP_OK;
@@ -440,6 +525,14 @@ int auvp_rrt_bin_sizes(auvp_handle* h, int32_t ep, int32_t* sizes, int32_t* n_bi
   if (n_bins) *n_bins = K;
   if (sizes && K > 0)
     HIPCHK(h, hipMemcpy(sizes, h->B.bin_count + (size_t)ep * (K + 1) + 1, (size_t)K * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+int auvp_rrt_phase_clocks(auvp_handle* h, uint64_t* out) {
+  if (!h || !out) return AUVP_ERR_ARG;
+  if (!h->have_batch || !h->B.phase_clocks) return fail(h, AUVP_ERR_STATE, "no phase clocks (AUVP_FLAG_PHASE_CLOCKS)");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(out, h->B.phase_clocks, (size_t)h->E * 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
   return AUVP_OK;
 }
 

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void random_probe_kernel(const uint32_t* __rest
   const int lane = lane_id();
   for (int i = lane; i < 624; i += 64) s[i] = mt[i];
   WaveRng r;
-  r.s = s; r.pslot = 0; r.avail = 0;
+  r.s = s; r.pslot = 0; r.avail = 0; r.drawn = 0ull;
   wave_sync();
   // mix the two access patterns the planners use: single draws and lane-parallel windows
   int done = 0;

@@ -72,10 +72,10 @@ __device__ __forceinline__ int cell_lookup(const WorldDev& W, double x, double y
   int b = fb < 0.0 ? 0 : (fb >= (double)W.n_xbuckets ? W.n_xbuckets - 1 : (int)fb);
   int e = W.xb_off[b + 1];
   for (int k = W.xb_off[b]; k < e; k++) {
-    int c = W.xb_items[k];
-    const double* cb = W.cells + 4 * (size_t)c;
-    // sic: x is compared with maxy (path_planning/cost.py:182)
-    if (x >= cb[0] && x <= cb[2] && y >= cb[1] && x <= cb[3]) return c;
+    const double4 d = reinterpret_cast<const double4*>(W.xb_data)[k];
+    if (y < d.w) return -1;  // every remaining candidate has miny > y
+    // sic: x is compared with maxy as well as maxx (path_planning/cost.py:182): d.y = min(maxx, maxy)
+    if (x >= d.x && x <= d.y && y >= d.z) return W.xb_items[k];
   }
   return -1;
 }
@@ -173,8 +173,14 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
   WaveRng rng;
   rng.s = L.mt;
   for (int i = lane; i < 624; i += 64) L.mt[i] = B.mt[(size_t)ep * 624 + i];
-  rng.pslot = 0;
-  rng.avail = 0;
+  {
+    // words [idx, 624) of the incoming state are generated and unconsumed (CPython's index)
+    int idx = B.mt_index ? uni(B.mt_index[ep]) : 624;
+    idx = idx < 0 ? 0 : (idx > 624 ? 624 : idx);
+    rng.pslot = idx == 624 ? 0u : (uint32_t)idx;
+    rng.avail = (uint32_t)(624 - idx);
+    rng.drawn = 0ull;
+  }
   for (int i = lane; i < K + 2; i += 64) bin_count[i] = 0;
   wave_sync();
 
@@ -189,7 +195,13 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
   int n_nodes = 1, n_points = 0, n_leaves = 0, status = 0, best_leaf = -1, best_L = 0;
   double best[4] = {__builtin_inf(), 0.0, 0.0, 0.0};
   double best_len = 0.0;
+  long long leaf_elems = 0;
   int it = 0;
+  // optional per-phase shader-clock accounting (AUVP_FLAG_PHASE_CLOCKS): select, steer, collision,
+  // accept, cost walk
+  const bool clk = (P.flags & 4) != 0;
+  unsigned long long tph[5] = {0, 0, 0, 0, 0}, t_prev = 0;
+#define AUVP_PHASE(i) do { if (clk) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); tph[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
   for (; it < P.max_iter; it++) {
     if (log_it && lane == 0) {
@@ -198,6 +210,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       B.it_npath[(size_t)ep * P.max_iter + it] = 0;
     }
     // ------------------------------------------------------------ parent selection (:121-139)
+    if (clk) t_prev = __builtin_amdgcn_s_memtime();
     int par;
     if (P.mode == 0) {
       int rb, cnt;
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       if (ntt[par] > P.max_traj_time) continue;
     }
 
+    AUVP_PHASE(0);
     // ------------------------------------------------------------ steer (:252-295)
     const double par_x = nx[par], par_y = ny[par];
     double cx = par_x, cy = par_y, cth = nth[par], ctt = ntt[par], clen = nlen[par];
@@ -363,6 +377,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
     wave_sync();
     const int P_n = cnt + 1;
 
+    AUVP_PHASE(1);
     // ------------------------------------------------------------ check_collision (:530-549)
     bool hit = false;
     for (int p = 0; p < P_n; p++) {
@@ -382,6 +397,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       B.it_accepted[(size_t)ep * P.max_iter + it] = ok ? 1 : 0;
       B.it_npath[(size_t)ep * P.max_iter + it] = P_n;
     }
+    AUVP_PHASE(2);
     if (!ok) continue;
     if (n_nodes >= B.cap_nodes) { status = -2; break; }
 
@@ -411,6 +427,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       wave_sync();
     }
 
+    AUVP_PHASE(3);
     // ------------------------------------------------------------ qualifying leaf (:158-171)
     if (ctt >= P.max_traj_time - 30) {
       __threadfence_block();  // this wave's own stores above are re-read below through L1
@@ -465,6 +482,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
         B.leaf_iter[(size_t)ep * B.cap_leaves + n_leaves] = it;
       }
       n_leaves++;
+      leaf_elems += Lp;
+      AUVP_PHASE(4);
       if (tot < best[0]) {
         best[0] = tot; best[1] = c0; best[2] = c1; best[3] = c2;
         best_leaf = me; best_L = Lp; best_len = clen;
@@ -472,6 +491,10 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
     }
   }
 
+  if (clk && lane == 0 && B.phase_clocks) {
+    for (int i = 0; i < 5; i++) B.phase_clocks[(size_t)ep * 5 + i] = tph[i];
+  }
+  const unsigned long long drawn = rng.drawn;
   double after = rng_next_random(rng);
   for (int i = lane; i < K + 1; i += 64) B.bin_count[(size_t)ep * (K + 1) + i] = bin_count[i];
   if (lane == 0) {
@@ -480,7 +503,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
     s.status = status; s.n_nodes = n_nodes; s.n_points = n_points; s.n_leaves = n_leaves;
     s.best_leaf = best_leaf; s.best_path_len = best_L; s.iters_run = it; s._pad = 0;
     s.best_cost[0] = best[0]; s.best_cost[1] = best[1]; s.best_cost[2] = best[2]; s.best_cost[3] = best[3];
-    s.best_length = best_len; s.rng_after = after;
+    s.best_length = best_len; s.rng_after = after; s.leaf_elems = leaf_elems; s.n_draw32 = drawn;
   }
 }
 

@@ -31,7 +31,7 @@ enum {
 };
 
 enum { AUVP_MODE_TIMEBIN = 0, AUVP_MODE_PLANTIME = 1, AUVP_MODE_NN = 2 };
-enum { AUVP_FLAG_ITER_LOG = 1, AUVP_FLAG_LEAF_LOG = 2 };
+enum { AUVP_FLAG_ITER_LOG = 1, AUVP_FLAG_LEAF_LOG = 2, AUVP_FLAG_PHASE_CLOCKS = 4 };
 
 const char* auvp_version(void);
 /* create a planner context on HIP device `device`; fails (AUVP_ERR_HIP) when no gfx950 GPU is
@@ -52,6 +52,9 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t n_obstacles,
                    int32_t n_habitats, const double* polygon, int32_t n_poly, const double* bins,
                    int32_t n_bins, const double* cells, int32_t n_cells, const double* prob);
 
+/* replace only the habitat list (exploring() takes it per call, rrt_dubins.py:92) */
+int auvp_world_set_habitats(auvp_handle* h, const double* habitats, int32_t n_habitats);
+
 typedef struct {
   double dist_to_end, diff_max, freq; /* RRT.__init__ kwargs, rrt_dubins.py:26 */
   double min_dist;                     /* steer(min_dist=0.5), call site :141 */
@@ -69,6 +72,8 @@ typedef struct {
   double best_cost[4]; /* sum, c0, c1, c2 (habitat_shark_cost_func, path_planning/cost.py:145) */
   double best_length;  /* "path length" of the returned dict, rrt_dubins.py:171,176 */
   double rng_after;    /* next random() of the episode's stream (parity probe: same draw count) */
+  int64_t leaf_elems;  /* sum over qualifying leaves of len(path) (cost-walk reads; bench byte count) */
+  uint64_t n_draw32;   /* 32-bit MT19937 outputs consumed: lets the host advance Python's global `random` */
 } auvp_rrt_summary;
 
 /* RRT.exploring (path_planning/rrt_dubins.py:92-176) for E independent episodes, one wavefront
@@ -76,11 +81,23 @@ typedef struct {
  * seeds [E]: the episode draws the stream `random.seed(seeds[e])` would give. */
 int auvp_rrt_explore_batch(auvp_handle* h, int32_t n_episodes, const double* init, const uint64_t* seeds,
                            const auvp_rrt_params* params, int32_t flags);
+/* the same in two steps: prepare() sizes the HBM buffers and uploads init/seeds (MT states are
+ * seeded on the host like random.seed), run() launches the kernel on the prepared batch and can be
+ * repeated (every run restarts from the prepared inputs) */
+int auvp_rrt_prepare(auvp_handle* h, int32_t n_episodes, const double* init, const uint64_t* seeds,
+                     const auvp_rrt_params* params, int32_t flags);
+/* as prepare(), but every episode continues an existing generator: mt [E,624] words + mt_index [E]
+ * exactly as random.getstate() reports them (drop-in use: the global `random` state) */
+int auvp_rrt_prepare_states(auvp_handle* h, int32_t n_episodes, const double* init, const uint32_t* mt,
+                            const int32_t* mt_index, const auvp_rrt_params* params, int32_t flags);
+int auvp_rrt_run(auvp_handle* h);
 int auvp_rrt_summaries(auvp_handle* h, auvp_rrt_summary* out /* [E] */);
 /* generate_final_course (:321-331) of every episode's best leaf, reversed to root->leaf (:174).
  * offsets [E+1] = exclusive prefix sum of best_path_len; out [offsets[E],7] =
  * x,y,theta,v,traj_time_stamp,plan_time_stamp,length per element */
 int auvp_rrt_paths(auvp_handle* h, const int64_t* offsets, double* out);
+/* the same, left in HBM: out_dev is a device pointer to [offsets[E],7] doubles (multi-GPU gather) */
+int auvp_rrt_paths_dev(auvp_handle* h, const int64_t* offsets, void* out_dev);
 /* whole tree of one episode (tests / RRT.mps_list): nodes [n_nodes,6] x,y,theta,traj_t,plan_t,length */
 int auvp_rrt_tree(auvp_handle* h, int32_t episode, double* nodes6, int32_t* parent, int32_t* pt_off,
                   int32_t* pt_cnt, double* points7);
@@ -105,6 +122,9 @@ int auvp_sincos_dev(auvp_handle* h, int32_t n, const double* x, double* s, doubl
 /* CPython random() stream of `seed` generated by the wave-level device MT19937 */
 int auvp_random_stream_dev(auvp_handle* h, uint64_t seed, int32_t n, double* out);
 
+/* diagnostic: shader clocks each episode spent in {parent selection, steer, collision, accept, cost
+ * walk} (needs AUVP_FLAG_PHASE_CLOCKS); out [E,5] */
+int auvp_rrt_phase_clocks(auvp_handle* h, uint64_t* out);
 /* HIP-event time (ms) of the last batch kernel on the handle's stream, and its launch geometry */
 double auvp_last_kernel_ms(auvp_handle* h);
 int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds_bytes);

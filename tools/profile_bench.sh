@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats + PMC passes of bench.py.
+# usage: tools/profile_bench.sh <tag> [bench args...]; writes gpurun_out/prof_<tag>/
+set -u
+TAG=${1:-r1}; shift || true
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="$@"
+# 1) un-profiled bench line
+python3 $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
+# 2) kernel trace + stats of the same command
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $R/bench.py $ARGS --no-cpu > $OUT/trace_bench.json 2> $OUT/trace.err
+# 3) PMC passes (separate runs, counters only)
+for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
+  N=$(echo $P | cut -d" " -f1)
+  rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_$N -o pmc -- python3 $R/bench.py $ARGS --no-cpu --steps 1 --warmup 0 > $OUT/pmc_$N.json 2> $OUT/pmc_$N.err
+done
+find $OUT -name "*.csv" | head -30
