@@ -84,6 +84,7 @@ def main():
     import torch
     import torch.distributed as dist
     from auv_sim_amd import _lib, synth
+    from auv_sim_amd import distributed as D
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -112,20 +113,12 @@ def main():
         off = np.zeros(E + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
         total = int(off[-1])
+        paths = torch.empty((max(total, 1), 7), dtype=torch.float64, device=dev)
+        ctx.paths_dev(off, paths.data_ptr())  # best paths stay in HBM
         if world_size > 1:
-            tot = torch.tensor([total], dtype=torch.int64, device=dev)
-            dist.all_reduce(tot, op=dist.ReduceOp.MAX)
-            cap = int(tot.item())
-        else:
-            cap = total
-        paths = torch.zeros((max(cap, 1), 7), dtype=torch.float64, device=dev)
-        ctx.paths_dev(off, paths.data_ptr())
-        if world_size > 1:
-            rec = torch.from_numpy(summ.view(np.uint8).reshape(E, -1).copy()).to(dev)
-            all_rec = torch.empty((world_size,) + tuple(rec.shape), dtype=torch.uint8, device=dev)
-            all_paths = torch.empty((world_size,) + tuple(paths.shape), dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(all_rec, rec)
-            dist.all_gather_into_tensor(all_paths, paths)
+            # RCCL gather of the fixed-stride result records + the variable-length paths (two-phase)
+            D.gather_records(D.summaries_to_tensor(summ, dev))
+            D.gather_paths(paths[:total], torch.from_numpy(lens).to(dev))
         return ms, summ
 
     def fence():
