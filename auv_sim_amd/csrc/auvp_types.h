@@ -18,6 +18,7 @@ struct WorldDev {
   const double* oy;   // [O]
   const double* ot;   // [O] T_i threshold on the squared distance
   const double* hab;  // [H,3]
+  const double* hab_t;  // [H] T(size): `dist <= size` as a test on the squared distance
   const double* poly; // [V,2]
   const double* bins; // [T,2]
   const double* cells;  // [C,4]
@@ -48,12 +49,13 @@ struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h
   unsigned long long n_draw32;
 };
 
-// Per-episode tree storage, structure-of-arrays, episode-major: array[e * cap + i].
+// Per-episode tree storage, episode-major.  Nodes are records (one 16-B + one 64-B access per
+// node: they are read one at a time by the whole wave); path points are SoA (lane-parallel).
 struct RrtBuffers {
   int32_t cap_nodes, cap_points, bin_cap, cap_leaves;
-  double *nx, *ny, *nth, *ntt, *nlen;  // [E][cap_nodes]
-  int32_t *nplan, *parent, *pt_off, *pt_cnt;
-  double *px, *py, *pth, *pv, *ptt, *plen;  // [E][cap_points]
+  double* node_f;    // [E][cap_nodes][8]  x, y, theta, traj_t, length, -, -, -   (64 B per node)
+  int32_t* node_i;   // [E][cap_nodes][4]  plan_iter, parent, pt_off, pt_cnt       (16 B per node)
+  double* points;    // [E][6][cap_points] SoA x, y, theta, v, traj_t, length
   int32_t* bin_items;                       // [E][K+1][bin_cap]
   int32_t* bin_count;                       // [E][K+1] (copied out of LDS at the end)
   uint32_t* mt;                             // [E][624] generator state in

@@ -48,7 +48,7 @@ struct auvp_handle {
   // world
   bool have_world = false;
   WorldDev W{};
-  DevBuf d_ox, d_oy, d_ot, d_hab, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems, d_xdata;
+  DevBuf d_ox, d_oy, d_ot, d_hab, d_habt, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems, d_xdata;
   // rrt batch
   int E = 0;
   RrtParamsDev P{};
@@ -230,6 +230,12 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   if ((rc = upload(h, h->d_oy, oy.data(), O))) return rc;
   if ((rc = upload(h, h->d_ot, ot.data(), O))) return rc;
   if ((rc = upload(h, h->d_hab, habitats, (size_t)H * 3))) return rc;
+  {
+    std::vector<double> ht(H);
+    for (int i = 0; i < H; i++) ht[i] = sq_threshold(habitats[3 * i + 2]);
+    if ((rc = upload(h, h->d_habt, ht.data(), (size_t)H))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   if ((rc = upload(h, h->d_poly, polygon, (size_t)V * 2))) return rc;
   if ((rc = upload(h, h->d_bins, bins, (size_t)T * 2))) return rc;
   if ((rc = upload(h, h->d_cells, cells, (size_t)C * 4))) return rc;
@@ -241,7 +247,7 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   WorldDev& W = h->W;
   W.n_obstacles = O; W.n_habitats = H; W.n_poly = V; W.n_bins = T; W.n_cells = C; W.n_xbuckets = NB;
   W.ox = h->d_ox.as<double>(); W.oy = h->d_oy.as<double>(); W.ot = h->d_ot.as<double>();
-  W.hab = h->d_hab.as<double>(); W.poly = h->d_poly.as<double>(); W.bins = h->d_bins.as<double>();
+  W.hab = h->d_hab.as<double>(); W.hab_t = h->d_habt.as<double>(); W.poly = h->d_poly.as<double>(); W.bins = h->d_bins.as<double>();
   W.cells = h->d_cells.as<double>(); W.prob = h->d_prob.as<double>();
   W.xb_off = h->d_xoff.as<int32_t>(); W.xb_items = h->d_xitems.as<int32_t>(); W.xb_data = h->d_xdata.as<double>();
   W.xb_x0 = X0; W.xb_inv_w = inv_w;
@@ -262,9 +268,13 @@ int auvp_world_set_habitats(auvp_handle* h, const double* habitats, int32_t H) {
   HIPCHK(h, hipSetDevice(h->device));
   int rc;
   if ((rc = upload(h, h->d_hab, habitats, (size_t)H * 3))) return rc;
+  std::vector<double> ht(H);
+  for (int i = 0; i < H; i++) ht[i] = sq_threshold(habitats[3 * i + 2]);
+  if ((rc = upload(h, h->d_habt, ht.data(), (size_t)H))) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->W.n_habitats = H;
   h->W.hab = h->d_hab.as<double>();
+  h->W.hab_t = h->d_habt.as<double>();
   return AUVP_OK;
 }
 
@@ -317,18 +327,15 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   B.bin_cap = P.K > 0 ? B.cap_nodes : 1;
   B.cap_leaves = (flags & AUVP_FLAG_LEAF_LOG) ? B.cap_nodes : 1;
   const size_t cn = (size_t)E * B.cap_nodes, cpnt = (size_t)E * B.cap_points;
-  HIPCHK(h, h->d_nodes_f.reserve(cn * 5 * sizeof(double)));
+  HIPCHK(h, h->d_nodes_f.reserve(cn * 8 * sizeof(double)));
   HIPCHK(h, h->d_nodes_i.reserve(cn * 4 * sizeof(int32_t)));
   HIPCHK(h, h->d_points.reserve(cpnt * 6 * sizeof(double)));
   HIPCHK(h, h->d_bin_items.reserve((size_t)E * (P.K + 1) * B.bin_cap * sizeof(int32_t)));
   HIPCHK(h, h->d_bin_count.reserve((size_t)E * (P.K + 1) * sizeof(int32_t)));
   HIPCHK(h, h->d_summary.reserve((size_t)E * sizeof(RrtSummary)));
-  double* nf = h->d_nodes_f.as<double>();
-  B.nx = nf; B.ny = nf + cn; B.nth = nf + 2 * cn; B.ntt = nf + 3 * cn; B.nlen = nf + 4 * cn;
-  int32_t* ni = h->d_nodes_i.as<int32_t>();
-  B.nplan = ni; B.parent = ni + cn; B.pt_off = ni + 2 * cn; B.pt_cnt = ni + 3 * cn;
-  double* pf = h->d_points.as<double>();
-  B.px = pf; B.py = pf + cpnt; B.pth = pf + 2 * cpnt; B.pv = pf + 3 * cpnt; B.ptt = pf + 4 * cpnt; B.plen = pf + 5 * cpnt;
+  B.node_f = h->d_nodes_f.as<double>();
+  B.node_i = h->d_nodes_i.as<int32_t>();
+  B.points = h->d_points.as<double>();
   B.bin_items = h->d_bin_items.as<int32_t>();
   B.bin_count = h->d_bin_count.as<int32_t>();
   B.summary = h->d_summary.as<RrtSummary>();
@@ -384,7 +391,7 @@ int auvp_rrt_run(auvp_handle* h) {
   const RrtBuffers& B = h->B;
   const int E = h->E;
   const int nfreq = (int)std::floor(P.freq);
-  const size_t lds = rrt_lds_bytes(P.K, h->max_pts);
+  const size_t lds = (size_t)rrt_lds_plan(P.K, h->max_pts, nfreq).total;
   if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB (K=%d, freq=%d)", lds, P.K, nfreq);
   const int grid = (E + RRT_WAVES - 1) / RRT_WAVES;
   const int O = h->W.n_obstacles;
@@ -458,38 +465,34 @@ int auvp_rrt_tree(auvp_handle* h, int32_t ep, double* nodes6, int32_t* parent, i
   RrtSummary s;
   HIPCHK(h, hipMemcpy(&s, h->B.summary + ep, sizeof s, hipMemcpyDeviceToHost));
   const RrtBuffers& B = h->B;
-  const size_t nb = (size_t)ep * B.cap_nodes, pb = (size_t)ep * B.cap_points;
   const int N = s.n_nodes, NP = s.n_points;
-  std::vector<double> col(std::max(N, NP) + 1);
-  std::vector<int32_t> icol(N + 1);
-  auto getd = [&](const double* src, int n) { return hipMemcpy(col.data(), src, (size_t)n * sizeof(double), hipMemcpyDeviceToHost); };
-  if (nodes6) {
-    const double* cols[5] = {B.nx + nb, B.ny + nb, B.nth + nb, B.ntt + nb, B.nlen + nb};
-    const int dst[5] = {0, 1, 2, 3, 5};
-    for (int c = 0; c < 5; c++) {
-      HIPCHK(h, getd(cols[c], N));
-      for (int i = 0; i < N; i++) nodes6[6 * (size_t)i + dst[c]] = col[i];
+  const size_t capp = (size_t)B.cap_points;
+  std::vector<double> nf((size_t)N * 8);
+  std::vector<int32_t> ni((size_t)N * 4);
+  HIPCHK(h, hipMemcpy(nf.data(), B.node_f + (size_t)ep * B.cap_nodes * 8, nf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(ni.data(), B.node_i + (size_t)ep * B.cap_nodes * 4, ni.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int i = 0; i < N; i++) {
+    if (nodes6) {
+      double* d = nodes6 + 6 * (size_t)i;
+      const double* f = nf.data() + 8 * (size_t)i;
+      d[0] = f[0]; d[1] = f[1]; d[2] = f[2]; d[3] = f[3]; d[4] = (double)ni[4 * (size_t)i]; d[5] = f[4];
     }
-    HIPCHK(h, hipMemcpy(icol.data(), B.nplan + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
-    for (int i = 0; i < N; i++) nodes6[6 * (size_t)i + 4] = (double)icol[i];
+    if (parent) parent[i] = ni[4 * (size_t)i + 1];
+    if (pt_off) pt_off[i] = ni[4 * (size_t)i + 2];
+    if (pt_cnt) pt_cnt[i] = ni[4 * (size_t)i + 3];
   }
-  if (parent) HIPCHK(h, hipMemcpy(parent, B.parent + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (pt_off) HIPCHK(h, hipMemcpy(pt_off, B.pt_off + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (pt_cnt) HIPCHK(h, hipMemcpy(pt_cnt, B.pt_cnt + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (points7) {
-    // plan_time_stamp of a path point = iteration of the node that owns it
-    std::vector<int32_t> off(N), cnt(N), plan(N);
-    HIPCHK(h, hipMemcpy(off.data(), B.pt_off + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(cnt.data(), B.pt_cnt + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(plan.data(), B.nplan + nb, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
-    const double* cols[6] = {B.px + pb, B.py + pb, B.pth + pb, B.pv + pb, B.ptt + pb, B.plen + pb};
+  if (points7 && NP > 0) {
+    std::vector<double> col((size_t)NP);
     const int dst[6] = {0, 1, 2, 3, 4, 6};
     for (int c = 0; c < 6; c++) {
-      HIPCHK(h, getd(cols[c], NP));
+      HIPCHK(h, hipMemcpy(col.data(), B.points + ((size_t)ep * 6 + c) * capp, (size_t)NP * sizeof(double), hipMemcpyDeviceToHost));
       for (int i = 0; i < NP; i++) points7[7 * (size_t)i + dst[c]] = col[i];
     }
-    for (int m = 0; m < N; m++)
-      for (int k = 0; k < cnt[m]; k++) points7[7 * (size_t)(off[m] + k) + 5] = (double)plan[m];
+    // plan_time_stamp of a path point = iteration of the node that owns it
+    for (int m = 0; m < N; m++) {
+      const int off = ni[4 * (size_t)m + 2], cnt = ni[4 * (size_t)m + 3], plan = ni[4 * (size_t)m];
+      for (int k = 0; k < cnt; k++) points7[7 * (size_t)(off + k) + 5] = (double)plan;
+    }
   }
   return AUVP_OK;
 }

@@ -25,9 +25,8 @@ __global__ __launch_bounds__(64) void collision_probe_kernel(WorldDev W, int n_p
       hit = hit || (dx * dx + dy * dy <= ot);
     }
   }
-  bool outside = false;
-  for (int k = b + lane; k < e; k += 64) outside = outside || !point_within(poly, W.n_poly, pts[2 * k], pts[2 * k + 1]);
-  bool ok = !__any(hit) && !__any(outside);
+  const bool outside = any_point_outside(poly, W.n_poly, reinterpret_cast<const double(*)[2]>(pts + 2 * (size_t)b), e - b);
+  bool ok = !__any(hit) && !outside;
   if (lane == 0) out[p] = ok ? 1 : 0;
 }
 
@@ -38,7 +37,11 @@ __global__ __launch_bounds__(64) void cost_probe_kernel(WorldDev W, int n_paths,
                                                         const double* __restrict__ w, double* __restrict__ out) {
   __shared__ RrtSharedLds S;
   const int lane = lane_id();
-  for (int i = lane; i < W.n_habitats * 3; i += 64) (&S.hab[0][0])[i] = W.hab[i];
+  __shared__ double term[64];
+  for (int i = lane; i < W.n_habitats; i += 64) {
+    S.hab[i][0] = W.hab[3 * i]; S.hab[i][1] = W.hab[3 * i + 1]; S.hab[i][2] = W.hab[3 * i + 2];
+    S.hab[i][3] = W.hab_t[i];
+  }
   for (int i = lane; i < W.n_bins * 2; i += 64) (&S.bins[0][0])[i] = W.bins[i];
   __syncthreads();
   const int p = blockIdx.x;
@@ -50,8 +53,9 @@ __global__ __launch_bounds__(64) void cost_probe_kernel(WorldDev W, int n_paths,
   for (int s0 = b; s0 < e; s0 += 64) {
     int k = s0 + lane;
     bool valid = k < e;
+    int nv = (e - s0) < 64 ? (e - s0) : 64;
     double x = valid ? pts[3 * k] : 0.0, y = valid ? pts[3 * k + 1] : 0.0, t = valid ? pts[3 * k + 2] : 0.0;
-    cost_segment(W, S, blo[p], bhi[p], w3, valid, x, y, t, acc);
+    cost_pass(W, S, blo[p], bhi[p], w3, nv, x, y, t, term, acc);
   }
   double c0 = 0.0, c1 = 0.0, c2 = acc.c2;
   if (w2 == auvp_rint(w2) && auvp_fabs(w2) < 1048576.0) c1 = w2 * (double)acc.hits;

@@ -2,18 +2,22 @@
 //
 // One wavefront = one episode, persistent over the whole iteration budget.  A 256-thread workgroup
 // carries 4 independent episodes that share the LDS copy of the small world tables (habitats,
-// polygon, time bins); obstacles live in registers (J per lane), the tree lives in HBM as SoA.
+// polygon, time bins); obstacles live in registers (J per lane), the tree lives in HBM.
 //
 // Inside one expansion the 64 lanes split the work:
 //   steer        lane s = sub-arc s: RNG window tempering, arc geometry and sin/cos in parallel;
-//                only the running sums (theta, x, y, t, length) are serial, and they must be, to
-//                keep the reference's left-to-right fp64 addition order
+//                only the running sums (theta; then x, y, t, length on four lanes) are serial, and
+//                they must be, to keep the reference's left-to-right fp64 addition order
 //   collision    lane = obstacle (J each), loop over the path points broadcast from LDS
 //   polygon      lane = path point
-//   cost         lane = path element of one ancestor segment; ordered accumulation of the shark term
-// The steer draw count is data dependent (a sub-arc consumes 2 or 3 random() values), so the lanes
+//   cost         lane = path element; the leaf->root walk only collects element ids, the lookups
+//                run 64 elements per pass, the shark term is summed in path order
+// The steer draw count is data dependent (a sub-arc consumes 2 or 3 random() values): the lanes
 // temper a window of the stream, ballot the "taken" predicate for every possible start offset, and
-// a short scalar loop resolves where each sub-arc starts.
+// a lane-parallel fixed-point iteration resolves where each sub-arc starts.
+//
+// Everything that is the same for all lanes of an episode is forced into SGPRs (readfirstlane), so
+// episode-level control flow is scalar branches and the VGPR budget stays with the per-lane work.
 #ifndef AUVP_RRT_EXPLORE_KERNEL_H
 #define AUVP_RRT_EXPLORE_KERNEL_H
 #include "auvp_math.h"
@@ -22,47 +26,77 @@
 
 namespace auvp {
 
-constexpr int RRT_WAVES = 4;         // episodes per workgroup
-constexpr int RRT_MAX_CHUNK = 63;    // sub-arcs per steer pass; lane 63 stays idle (chunk-entry theta)
-constexpr int RRT_MAX_HAB = 64;      // visited-habitat mask is one 64-bit word
+constexpr int RRT_WAVES = 4;       // episodes per workgroup
+constexpr int RRT_MAX_CHUNK = 63;  // sub-arcs per steer pass (one lane stays idle: chunk-entry angle)
+constexpr int RRT_MAX_HAB = 64;    // visited-habitat mask is one 64-bit word
 constexpr int RRT_MAX_POLY = 64;
 constexpr int RRT_MAX_BINS = 64;
-
-// Per-wave LDS block (doubles first for alignment)
-struct RrtWaveLds {
-  double u[3 * RRT_MAX_CHUNK + 3];  // random() window
-  double inc[64][4];                // dx,dy,dt,movement -> running x,y,t,length
-  double sc[64][2];                 // sin,cos per sub-arc end angle
-  double phi[64];
-  uint32_t mt[624];
-};
+constexpr int RRT_ELIST = 192;     // path elements collected per cost pass group
 
 struct RrtSharedLds {
-  double hab[RRT_MAX_HAB][3];
+  double hab[RRT_MAX_HAB][4];  // x, y, size, T(size)
   double poly[RRT_MAX_POLY][2];
   double bins[RRT_MAX_BINS][2];
 };
 
-__host__ __device__ inline size_t rrt_lds_bytes(int K, int max_pts) {
-  size_t b = sizeof(RrtSharedLds) + RRT_WAVES * sizeof(RrtWaveLds);
-  b += (size_t)RRT_WAVES * (size_t)(max_pts) * 2 * sizeof(double);  // path points x,y
-  b += (size_t)RRT_WAVES * (size_t)(K + 2) * sizeof(int32_t);        // bin counts
-  return (b + 15) & ~(size_t)15;
+// Per-wave LDS layout (bytes), all sizes multiples of 16:
+//   [scratch]  steer: u[3C+3] | {inc[(C+1)*4], sc[(C+1)*2], phi[C+1]}   cost: elist[192] i32 + term[64] f64
+//   [mt]       624 u32
+//   [pts]      max_pts * 2 f64
+//   [bins]     (K+2) i32
+struct RrtLdsPlan {
+  int chunk;  // C
+  int scratch, mt, pts, bins, per_wave, total;
+};
+
+__host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq) {
+  RrtLdsPlan p;
+  p.chunk = nfreq < 1 ? 1 : (nfreq > RRT_MAX_CHUNK ? RRT_MAX_CHUNK : nfreq);
+  const int C = p.chunk;
+  int steer_u = (3 * C + 3) * 8;
+  int steer_s = ((C + 1) * 7) * 8;
+  int cost = RRT_ELIST * 4 + 64 * 8;
+  int s = steer_u > steer_s ? steer_u : steer_s;
+  s = s > cost ? s : cost;
+  p.scratch = (s + 15) & ~15;
+  p.mt = 624 * 4;
+  p.pts = ((max_pts * 16) + 15) & ~15;
+  p.bins = (((K + 2) * 4) + 15) & ~15;
+  p.per_wave = p.scratch + p.mt + p.pts + p.bins;
+  p.total = (int)sizeof(RrtSharedLds) + RRT_WAVES * p.per_wave;
+  return p;
 }
 
 // Point(x,y).within(polygon): even-odd crossing number with strict comparisons -- the definition
 // pinned in tests/golden/_refstubs/install.py (shapely itself is absent).
-__device__ __forceinline__ bool point_within(const double (*poly)[2], int nv, double x, double y) {
-  bool inside = false;
-  int j = nv - 1;
-  for (int i = 0; i < nv; i++) {
-    double xi = poly[i][0], yi = poly[i][1], xj = poly[j][0], yj = poly[j][1];
-    if ((yi > y) != (yj > y)) {
-      if (x < (xj - xi) * (y - yi) / (yj - yi) + xi) inside = !inside;
+// Wave-parallel over (point, edge) pairs: lane = p_local * nv + e, so one pass evaluates the edge
+// test (with its fp64 division) for floor(64/nv) points at once; a point is inside iff the number
+// of crossing edges in its nv-bit group of the ballot is odd.  Returns true when ANY of the
+// n_pts points is not strictly inside.
+__device__ __forceinline__ bool any_point_outside(const double (*poly)[2], int nv, const double (*pts)[2], int n_pts) {
+  const int lane = lane_id();
+  const int per = 64 / nv;  // points per pass (nv <= 64)
+  const int e = lane % nv, pl = lane / nv;
+  const int ej = e == 0 ? nv - 1 : e - 1;  // j trails i by one vertex
+  const double xi = poly[e][0], yi = poly[e][1], xj = poly[ej][0], yj = poly[ej][1];
+  bool outside = false;
+  for (int p0 = 0; p0 < n_pts; p0 += per) {
+    const int p = p0 + pl;
+    const bool live = pl < per && p < n_pts;
+    bool cross = false;
+    if (live) {
+      const double x = pts[p][0], y = pts[p][1];
+      if ((yi > y) != (yj > y)) cross = x < (xj - xi) * (y - yi) / (yj - yi) + xi;
     }
-    j = i;
+    const unsigned long long cm = __ballot(cross);
+    // lanes 0..per-1 each judge one point of this pass
+    const int q = p0 + lane;
+    if (lane < per && q < n_pts) {
+      const unsigned long long grp = (cm >> (lane * nv)) & (nv == 64 ? ~0ull : ((1ull << nv) - 1ull));
+      outside = outside | ((__popcll(grp) & 1) == 0);
+    }
   }
-  return inside;
+  return __any(outside);
 }
 
 // cost.py:181-184 first-match cell scan through the x-bucket index; returns cell id or -1
@@ -81,50 +115,52 @@ __device__ __forceinline__ int cell_lookup(const WorldDev& W, double x, double y
 }
 
 struct CostAcc {
-  double c2;
-  unsigned long long visited;
-  int hits;
+  double c2;                   // running shark term, summed in path order
+  unsigned long long visited;  // habitat bit set
+  int hits;                    // number of path points inside some habitat
 };
 
-// One segment of path elements (one per lane, `valid` lanes) in path order = lane order.
-// habitat_shark_cost_func body, path_planning/cost.py:171-193.
-__device__ __forceinline__ void cost_segment(const WorldDev& W, const RrtSharedLds& S, int bin_lo, int bin_hi,
-                                             double w3, bool valid, double x, double y, double t, CostAcc& acc) {
+// One pass of up to 64 path elements (lane order = path order).
+// habitat_shark_cost_func body, path_planning/cost.py:171-193.  `term` is 64 doubles of wave LDS.
+__device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtSharedLds& S, int bin_lo, int bin_hi, double w3,
+                                          int n_valid, double x, double y, double t, double* term, CostAcc& acc) {
+  const int lane = lane_id();
+  const bool valid = lane < n_valid;
   int tb = -1;
   if (valid) {
     for (int b = bin_lo; b < bin_hi; b++) {
       if (t >= S.bins[b][0] && t <= S.bins[b][1]) { tb = b; break; }
     }
   }
-  bool inbin = valid && tb >= 0;
-  double term = 0.0;
-  bool has_term = false;
+  double tv = 0.0;  // x + 0.0 == x: elements without a shark term add an exact zero
   int hab = -1;
-  if (inbin) {
+  if (tb >= 0) {
     int c = cell_lookup(W, x, y);
-    if (c >= 0) { term = w3 * W.prob[(size_t)tb * W.n_cells + c]; has_term = true; }
+    if (c >= 0) tv = w3 * W.prob[(size_t)tb * W.n_cells + c];
     for (int h = 0; h < W.n_habitats; h++) {
+      // dist <= size  <=>  d2 <= T(size): same decision as RN(sqrt(d2)) <= size, no sqrt
       double ddx = S.hab[h][0] - x, ddy = S.hab[h][1] - y;
-      double d = auvp_sqrt(ddx * ddx + ddy * ddy);
-      if (d <= S.hab[h][2]) { hab = h; break; }
+      if (ddx * ddx + ddy * ddy <= S.hab[h][3]) { hab = h; break; }
     }
   }
-  // ordered accumulation: cost[2] += w3*prob in path order
-  unsigned long long m = __ballot(has_term);
-  double c2 = acc.c2;
-  while (m) {
-    int l = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    c2 = c2 + readlane_f64(term, l);
-  }
-  acc.c2 = c2;
+  term[lane] = tv;
   unsigned long long hm = __ballot(hab >= 0);
   acc.hits += __popcll(hm);
   unsigned long long vis = acc.visited;
-  for (int h = 0; h < W.n_habitats; h++) {
-    if (__ballot(hab == h)) vis |= (1ull << h);
+  while (hm) {  // at most H distinct habitats; usually one or two per pass
+    int l = __ffsll((long long)hm) - 1;
+    int h = __builtin_amdgcn_readlane(hab, l);
+    vis |= (1ull << h);
+    hm &= ~__ballot(hab == h);
   }
   acc.visited = vis;
+  wave_sync();
+  // cost[2] += w3*prob in path order: one dependent add per element, LDS reads run ahead
+  double c2 = acc.c2;
+#pragma unroll 8
+  for (int i = 0; i < n_valid; i++) c2 = c2 + term[i];
+  acc.c2 = c2;
+  wave_sync();
 }
 
 template <int J>
@@ -132,16 +168,28 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
                                                                      int n_episodes, int max_pts) {
   extern __shared__ __align__(16) unsigned char smem[];
   RrtSharedLds& S = *reinterpret_cast<RrtSharedLds*>(smem);
-  const int wave = (int)(threadIdx.x >> 6);
+  const int wave = uni((int)(threadIdx.x >> 6));  // wave-uniform: keeps every per-episode address scalar
   const int lane = lane_id();
-  RrtWaveLds& L = reinterpret_cast<RrtWaveLds*>(smem + sizeof(RrtSharedLds))[wave];
-  unsigned char* tail = smem + sizeof(RrtSharedLds) + RRT_WAVES * sizeof(RrtWaveLds);
-  double(*pts)[2] = reinterpret_cast<double(*)[2]>(tail) + (size_t)wave * max_pts;
-  int32_t* bin_count =
-      reinterpret_cast<int32_t*>(tail + (size_t)RRT_WAVES * max_pts * 2 * sizeof(double)) + (size_t)wave * (P.K + 2);
+  const int nfreq = (int)P.freq;
+  const RrtLdsPlan plan = rrt_lds_plan(P.K, max_pts, nfreq);
+  const int C = plan.chunk;
+  unsigned char* wbase = smem + sizeof(RrtSharedLds) + (size_t)wave * plan.per_wave;
+  double* scratch = reinterpret_cast<double*>(wbase);
+  double* u_win = scratch;                         // [3C+3]      (steer, phase 1)
+  double* inc = scratch;                           // [(C+1)*4]   (steer, phase 2: aliases u_win)
+  double* sc = scratch + (size_t)(C + 1) * 4;      // [(C+1)*2]
+  double* phi_l = scratch + (size_t)(C + 1) * 6;   // [C+1]
+  int32_t* elist = reinterpret_cast<int32_t*>(wbase);                  // [192]  (cost walk)
+  double* term = reinterpret_cast<double*>(wbase + RRT_ELIST * 4);     // [64]
+  uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + plan.scratch);
+  double(*pts)[2] = reinterpret_cast<double(*)[2]>(wbase + plan.scratch + plan.mt);
+  int32_t* bin_count = reinterpret_cast<int32_t*>(wbase + plan.scratch + plan.mt + plan.pts);
 
   // ---- stage the shared world tables (whole workgroup) ----
-  for (int i = threadIdx.x; i < W.n_habitats * 3; i += blockDim.x) (&S.hab[0][0])[i] = W.hab[i];
+  for (int i = threadIdx.x; i < W.n_habitats; i += blockDim.x) {
+    S.hab[i][0] = W.hab[3 * i]; S.hab[i][1] = W.hab[3 * i + 1]; S.hab[i][2] = W.hab[3 * i + 2];
+    S.hab[i][3] = W.hab_t[i];
+  }
   for (int i = threadIdx.x; i < W.n_poly * 2; i += blockDim.x) (&S.poly[0][0])[i] = W.poly[i];
   for (int i = threadIdx.x; i < W.n_bins * 2; i += blockDim.x) (&S.bins[0][0])[i] = W.bins[i];
   __syncthreads();
@@ -160,19 +208,20 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
     ot[j] = ok ? W.ot[i] : -1.0;  // d2 >= 0 > -1: padding never collides
   }
 
-  // ---- per-episode views ----
-  const size_t nb = (size_t)ep * B.cap_nodes, pb = (size_t)ep * B.cap_points;
-  double *nx = B.nx + nb, *ny = B.ny + nb, *nth = B.nth + nb, *ntt = B.ntt + nb, *nlen = B.nlen + nb;
-  int32_t *nplan = B.nplan + nb, *parent = B.parent + nb, *pt_off = B.pt_off + nb, *pt_cnt = B.pt_cnt + nb;
-  double *px = B.px + pb, *py = B.py + pb, *pth = B.pth + pb, *pv = B.pv + pb, *ptt = B.ptt + pb, *plen = B.plen + pb;
-  int32_t* bin_items = B.bin_items + (size_t)ep * (P.K + 1) * B.bin_cap;
+  // ---- per-episode views (scalar bases) ----
+  const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
+  double* nodeF = B.node_f + (size_t)ep * capn * 8;                       // [capn][8] x,y,theta,t,length
+  int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;    // plan_iter,parent,pt_off,pt_cnt
+  double* ptF = B.points + (size_t)ep * capp * 6;                         // SoA [6][capp]
+  int32_t* bin_items = B.bin_items + (size_t)ep * (P.K + 1) * bcap;
   const double* init = B.init + (size_t)ep * 6;
   const int K = P.K;
   const bool log_it = (P.flags & 1) != 0, log_leaf = (P.flags & 2) != 0;
+  const size_t logb = (size_t)ep * P.max_iter;
 
   WaveRng rng;
-  rng.s = L.mt;
-  for (int i = lane; i < 624; i += 64) L.mt[i] = B.mt[(size_t)ep * 624 + i];
+  rng.s = mt;
+  for (int i = lane; i < 624; i += 64) mt[i] = B.mt[(size_t)ep * 624 + i];
   {
     // words [idx, 624) of the incoming state are generated and unconsumed (CPython's index)
     int idx = B.mt_index ? uni(B.mt_index[ep]) : 624;
@@ -186,15 +235,14 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
 
   // mps_list = [initial]; time_bin[bin_interval].append(initial)  (:105,:114)
   if (lane == 0) {
-    nx[0] = init[0]; ny[0] = init[1]; nth[0] = init[2]; ntt[0] = init[3]; nlen[0] = init[5];
-    nplan[0] = 0; parent[0] = -1; pt_off[0] = 0; pt_cnt[0] = 0;
-    if (P.mode == 0) { bin_items[(size_t)(K >= 1 ? 1 : 0) * B.bin_cap] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
+    nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
+    nodeI[0] = make_int4(0, -1, 0, 0);
+    if (P.mode == 0) { bin_items[(size_t)(K >= 1 ? 1 : 0) * bcap] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
   }
   wave_sync();
-  const double init_t = init[3];
+  const double init_t = readfirst_f64(init[3]);
   int n_nodes = 1, n_points = 0, n_leaves = 0, status = 0, best_leaf = -1, best_L = 0;
-  double best[4] = {__builtin_inf(), 0.0, 0.0, 0.0};
-  double best_len = 0.0;
+  double best_tot = __builtin_inf();
   long long leaf_elems = 0;
   int it = 0;
   // optional per-phase shader-clock accounting (AUVP_FLAG_PHASE_CLOCKS): select, steer, collision,
@@ -205,9 +253,9 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
 
   for (; it < P.max_iter; it++) {
     if (log_it && lane == 0) {
-      B.it_parent[(size_t)ep * P.max_iter + it] = -1;
-      B.it_accepted[(size_t)ep * P.max_iter + it] = 0;
-      B.it_npath[(size_t)ep * P.max_iter + it] = 0;
+      B.it_parent[logb + it] = -1;
+      B.it_accepted[logb + it] = 0;
+      B.it_npath[logb + it] = 0;
     }
     // ------------------------------------------------------------ parent selection (:121-139)
     if (clk) t_prev = __builtin_amdgcn_s_memtime();
@@ -224,20 +272,20 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       if (status) break;
       double u = rng_next_random(rng);
       int ri = uni((int)py_uniform(0.0, (double)cnt, u));
-      par = uni(bin_items[(size_t)rb * B.bin_cap + ri]);
+      par = uni(bin_items[(size_t)rb * bcap + ri]);
     } else if (P.mode == 1) {
       double u = rng_next_random(rng);
       double ran_time = py_uniform(0.0, P.max_plan_time * P.freq, u);
       int lo = 0, hi = n_nodes;  // list slicing of get_closest_mps_time (:515-528)
       while (hi - lo > 3) {
         int n = hi - lo;
-        double ld = auvp_fabs((double)nplan[lo + n / 2 - 1] - ran_time);
-        double rd = auvp_fabs((double)nplan[lo + n / 2 + 1] - ran_time);
+        double ld = auvp_fabs((double)nodeI[lo + n / 2 - 1].x - ran_time);
+        double rd = auvp_fabs((double)nodeI[lo + n / 2 + 1].x - ran_time);
         if (ld >= rd) lo += n / 2; else hi = lo + n / 2;
         lo = uni(lo); hi = uni(hi);
       }
       par = lo;
-      if (ntt[par] > P.max_traj_time) continue;
+      if (nodeF[(size_t)par * 8 + 3] > P.max_traj_time) continue;
     } else {
       // get_random_mps (:333-343): x, y, theta, size draws; only x,y are used
       rng_ensure(rng, 8);
@@ -248,7 +296,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       double bd = __builtin_inf();
       int bi = 0x7fffffff;
       for (int m = lane; m < n_nodes; m += 64) {
-        double ddx = rx - nx[m], ddy = ry - ny[m];
+        const double2 xy = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8);
+        double ddx = rx - xy.x, ddy = ry - xy.y;
         double d = auvp_sqrt(ddx * ddx + ddy * ddy);
         if (d < bd) { bd = d; bi = m; }
       }
@@ -260,26 +309,31 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
         cand = t < cand ? t : cand;
       }
       par = uni(cand);
-      if (ntt[par] > P.max_traj_time) continue;
+      if (nodeF[(size_t)par * 8 + 3] > P.max_traj_time) continue;
     }
 
     AUVP_PHASE(0);
     // ------------------------------------------------------------ steer (:252-295)
-    const double par_x = nx[par], par_y = ny[par];
-    double cx = par_x, cy = par_y, cth = nth[par], ctt = ntt[par], clen = nlen[par];
+    double cx, cy, cth, ctt, clen;
+    {
+      const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 8);
+      const double2 b = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 8 + 2);
+      cx = readfirst_f64(a.x); cy = readfirst_f64(a.y); cth = readfirst_f64(b.x); ctt = readfirst_f64(b.y);
+      clen = readfirst_f64(nodeF[(size_t)par * 8 + 4]);
+    }
     int n_total;
     {
       double u = rng_next_random(rng);
       n_total = uni((int)auvp_floor(py_uniform(0.0, P.freq, u) / 1));
     }
     int cnt = 0;  // appended path points
-    if (lane == 0) { pts[0][0] = par_x; pts[0][1] = par_y; }
+    if (lane == 0) { pts[0][0] = cx; pts[0][1] = cy; }
     bool cap_err = false;
-    for (int c0 = 0; c0 < n_total; c0 += RRT_MAX_CHUNK) {
-      const int n = (n_total - c0) < RRT_MAX_CHUNK ? (n_total - c0) : RRT_MAX_CHUNK;
+    for (int c0 = 0; c0 < n_total; c0 += C) {
+      const int n = (n_total - c0) < C ? (n_total - c0) : C;
       const int nwin = 3 * n;
       rng_ensure(rng, (uint32_t)(2 * nwin));
-      for (int jj = lane; jj < nwin; jj += 64) L.u[jj] = rng_random_at(rng, (uint32_t)jj);
+      for (int jj = lane; jj < nwin; jj += 64) u_win[jj] = rng_random_at(rng, (uint32_t)jj);
       wave_sync();
       // "taken" predicate for every possible start offset
       unsigned long long msk[3];
@@ -288,79 +342,86 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
         int jj = lane + 64 * t;
         bool f = false;
         if (jj + 1 < nwin) {
-          double dist = py_uniform(0.0, P.dist_to_end, L.u[jj]);
-          double diff = py_uniform(-P.diff_max, P.diff_max, L.u[jj + 1]);
+          double dist = py_uniform(0.0, P.dist_to_end, u_win[jj]);
+          double diff = py_uniform(-P.diff_max, P.diff_max, u_win[jj + 1]);
           f = auvp_fabs(dist) > auvp_fabs(diff);
         }
         msk[t] = __ballot(f);
       }
-      // where does sub-arc s start?  pos += 2 + taken(pos)
-      int pos = 0, mypos = 0;
-      for (int s = 0; s < n; s++) {
-        if (lane == s) mypos = pos;
-        unsigned long long mm = pos < 64 ? msk[0] : (pos < 128 ? msk[1] : msk[2]);
-        int bit = (int)((mm >> (pos & 63)) & 1ull);
-        pos = uni(pos + 2 + bit);
-      }
-      const int used = pos;
+      // Where does sub-arc s start?  pos_s = 2s + (#taken among sub-arcs < s).  Fixed point of
+      //   taken_s = T[2s + c_s],  c_s = popcount(taken below s)
+      // started from "everything taken"; sub-arcs 0..k are exact after k+1 rounds, and in practice
+      // the loop ends after (number of untaken sub-arcs + 1) rounds.
       const bool active = lane < n;
+      int cbelow = lane;
+      unsigned long long tmask;
+      for (;;) {
+        int pos = 2 * lane + cbelow;
+        unsigned long long mm = pos < 64 ? msk[0] : (pos < 128 ? msk[1] : msk[2]);
+        bool tk = active && ((mm >> (pos & 63)) & 1ull);
+        tmask = __ballot(tk);
+        int cnew = __popcll(tmask & ((1ull << lane) - 1ull));
+        bool changed = active && (cnew != cbelow);
+        cbelow = cnew;
+        if (!__any(changed)) break;
+      }
+      const int mypos = 2 * lane + cbelow;
+      const int used = 2 * n + __popcll(tmask);
+      const bool taken = (tmask >> lane) & 1ull;
       double radius = 0.0, phi = 0.0, vt = 1.0;
-      bool taken = false;
-      if (active) {
-        double dist = py_uniform(0.0, P.dist_to_end, L.u[mypos]);
-        double diff = py_uniform(-P.diff_max, P.diff_max, L.u[mypos + 1]);
-        taken = auvp_fabs(dist) > auvp_fabs(diff);
-        if (taken) {
-          double s1 = dist + diff, s2 = dist - diff;
-          radius = (s1 + s2) / (-s1 + s2);
-          phi = (s1 + s2) / (2 * radius);
-          vt = py_uniform(0.0, 2 * P.v, L.u[mypos + 2]);
-        }
+      if (taken) {
+        double dist = py_uniform(0.0, P.dist_to_end, u_win[mypos]);
+        double diff = py_uniform(-P.diff_max, P.diff_max, u_win[mypos + 1]);
+        double s1 = dist + diff, s2 = dist - diff;
+        radius = (s1 + s2) / (-s1 + s2);
+        phi = (s1 + s2) / (2 * radius);
+        vt = py_uniform(0.0, 2 * P.v, u_win[mypos + 2]);
       }
-      const unsigned long long tmask = __ballot(taken);
-      L.phi[lane] = phi;
+      wave_sync();  // the window is dead: its LDS becomes the steer scratch
+      if (lane <= C) phi_l[lane] = phi;  // untaken / idle lanes add an exact 0.0
       wave_sync();
-      // theta += phi, left to right
-      double th = cth, myth = cth;
-      for (int s = 0; s < n; s++) {
-        if ((tmask >> s) & 1ull) th = th + L.phi[s];
-        if (lane == s) myth = th;
+      // theta += phi, left to right, by one lane; prefix angles written back in place
+      if (lane == 0) {
+        double th = cth;
+#pragma unroll 4
+        for (int s = 0; s < n; s++) { th = th + phi_l[s]; phi_l[s] = th; }
       }
+      wave_sync();
+      const double myth = active ? phi_l[lane] : cth;  // idle lanes evaluate the chunk-entry angle
       double sn, cs;
-      auvp_sincos(myth, &sn, &cs);  // idle lanes evaluate the chunk-entry angle
-      L.sc[lane][0] = sn;
-      L.sc[lane][1] = cs;
+      auvp_sincos(myth, &sn, &cs);
+      if (lane <= C) { sc[2 * lane] = sn; sc[2 * lane + 1] = cs; }
       wave_sync();
       double dx = 0.0, dy = 0.0, mv = 0.0, dt = 0.0;
       if (taken) {
         unsigned long long below = tmask & ((1ull << lane) - 1ull);
-        int prev = below ? (63 - __clzll((long long)below)) : 63;  // lane 63 holds the entry angle
-        double so = L.sc[prev][0], co = L.sc[prev][1];
+        int prev = below ? (63 - __clzll((long long)below)) : C;  // lane C is idle: entry angle
+        double so = sc[2 * prev], co = sc[2 * prev + 1];
         dx = radius * (sn - so);
         dy = radius * (-cs + co);
         mv = auvp_sqrt(dx * dx + dy * dy);
         dt = mv / vt;
       }
-      L.inc[lane][0] = dx; L.inc[lane][1] = dy; L.inc[lane][2] = dt; L.inc[lane][3] = mv;
+      if (active) { inc[4 * lane] = dx; inc[4 * lane + 1] = dy; inc[4 * lane + 2] = dt; inc[4 * lane + 3] = mv; }
       wave_sync();
       // x += dx; y += dy; t += dt; length += movement: four serial chains, one lane each
       if (lane < 4) {
         double acc = lane == 0 ? cx : (lane == 1 ? cy : (lane == 2 ? ctt : clen));
-        for (int s = 0; s < n; s++) {
-          if ((tmask >> s) & 1ull) acc = acc + L.inc[s][lane];
-          L.inc[s][lane] = acc;
-        }
+#pragma unroll 4
+        for (int s = 0; s < n; s++) { acc = acc + inc[4 * s + lane]; inc[4 * s + lane] = acc; }
       }
       wave_sync();
-      const double mx = L.inc[lane][0], my = L.inc[lane][1], mt_ = L.inc[lane][2], ml = L.inc[lane][3];
+      double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
+      if (active) { mx = inc[4 * lane]; my = inc[4 * lane + 1]; mt_ = inc[4 * lane + 2]; ml = inc[4 * lane + 3]; }
       const bool app = taken && (mv >= P.min_dist);
       const unsigned long long amask = __ballot(app);
       const int napp = __popcll(amask);
-      if (n_points + cnt + napp > B.cap_points || cnt + napp + 1 > max_pts) { cap_err = true; break; }
+      if (n_points + cnt + napp > capp || cnt + napp + 1 > max_pts) { cap_err = true; break; }
       if (app) {
         int rank = __popcll(amask & ((1ull << lane) - 1ull));
-        int gi = n_points + cnt + rank;  // speculative: committed only if the node is accepted
-        px[gi] = mx; py[gi] = my; pth[gi] = myth; pv[gi] = vt; ptt[gi] = mt_; plen[gi] = ml;
+        size_t gi = (size_t)(n_points + cnt + rank);  // speculative: committed only if the node is accepted
+        ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * (size_t)capp + gi] = myth; ptF[3 * (size_t)capp + gi] = vt;
+        ptF[4 * (size_t)capp + gi] = mt_; ptF[5 * (size_t)capp + gi] = ml;
         pts[cnt + rank + 1][0] = mx;
         pts[cnt + rank + 1][1] = my;
       }
@@ -368,7 +429,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       if (n > 0) {
         cx = readlane_f64(mx, n - 1); cy = readlane_f64(my, n - 1);
         ctt = readlane_f64(mt_, n - 1); clen = readlane_f64(ml, n - 1);
-        cth = th;
+        cth = readlane_f64(myth, n - 1);
       }
       rng_advance_words(rng, (uint32_t)(2 * used));
       wave_sync();
@@ -379,33 +440,39 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
 
     AUVP_PHASE(1);
     // ------------------------------------------------------------ check_collision (:530-549)
-    bool hit = false;
-    for (int p = 0; p < P_n; p++) {
-      const double qx = pts[p][0], qy = pts[p][1];
+    int hit = 0;
+    {
+      double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
+      for (int p = 0; p < P_n; p++) {
+        // next point's LDS read is in flight while this one is tested (pts has room for P_n + 1)
+        const double2 qn = *reinterpret_cast<const double2*>(&pts[p + 1][0]);
 #pragma unroll
-      for (int j = 0; j < J; j++) {
-        double ddx = qx - ox[j], ddy = qy - oy[j];
-        double d2 = ddx * ddx + ddy * ddy;
-        hit = hit || (d2 <= ot[j]);
+        for (int j = 0; j < J; j++) {
+          double ddx = q.x - ox[j], ddy = q.y - oy[j];
+          double d2 = ddx * ddx + ddy * ddy;
+          hit |= (d2 <= ot[j]) ? 1 : 0;  // no short-circuit: straight-line code
+        }
+        q = qn;
       }
     }
-    bool outside = false;
-    for (int p = lane; p < P_n; p += 64) outside = outside || !point_within(S.poly, W.n_poly, pts[p][0], pts[p][1]);
-    const bool ok = !__any(hit) && !__any(outside);
+    const bool ok = !__any(hit != 0) && !any_point_outside(S.poly, W.n_poly, pts, P_n);
     if (log_it && lane == 0) {
-      B.it_parent[(size_t)ep * P.max_iter + it] = par;
-      B.it_accepted[(size_t)ep * P.max_iter + it] = ok ? 1 : 0;
-      B.it_npath[(size_t)ep * P.max_iter + it] = P_n;
+      B.it_parent[logb + it] = par;
+      B.it_accepted[logb + it] = ok ? 1 : 0;
+      B.it_npath[logb + it] = P_n;
     }
     AUVP_PHASE(2);
     if (!ok) continue;
-    if (n_nodes >= B.cap_nodes) { status = -2; break; }
+    if (n_nodes >= capn) { status = -2; break; }
 
     // ------------------------------------------------------------ accept (:144-151)
     const int me = n_nodes;
     if (lane == 0) {
-      nx[me] = cx; ny[me] = cy; nth[me] = cth; ntt[me] = ctt; nlen[me] = clen;
-      nplan[me] = it; parent[me] = par; pt_off[me] = n_points; pt_cnt[me] = cnt;
+      double* nf = nodeF + (size_t)me * 8;
+      *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
+      *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
+      nf[4] = clen;
+      nodeI[me] = make_int4(it, par, n_points, cnt);
     }
     n_nodes++;
     n_points += cnt;
@@ -419,10 +486,10 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       double curr_bin = fi * P.bin_interval;
       bool over = curr_bin > P.max_traj_time;
       if (!over || fi <= (double)K) {
-        int bi = (int)fi;
-        int c = over ? 0 : bin_count[bi];  // an overflowing regular key is reset first (:149-151)
-        if (c >= B.bin_cap) { status = -2; break; }
-        if (lane == 0) { bin_items[(size_t)bi * B.bin_cap + c] = me; bin_count[bi] = c + 1; }
+        int bi = uni((int)fi);
+        int c = over ? 0 : uni(bin_count[bi]);  // an overflowing regular key is reset first (:149-151)
+        if (c >= bcap) { status = -2; break; }
+        if (lane == 0) { bin_items[(size_t)bi * bcap + c] = me; bin_count[bi] = c + 1; }
       }
       wave_sync();
     }
@@ -430,7 +497,6 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
     AUVP_PHASE(3);
     // ------------------------------------------------------------ qualifying leaf (:158-171)
     if (ctt >= P.max_traj_time - 30) {
-      __threadfence_block();  // this wave's own stores above are re-read below through L1
       int blo = -1, bhi = -1, nsel = 0;
       bool contiguous = true;
       for (int b = 0; b < W.n_bins; b++) {
@@ -444,31 +510,53 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       }
       if (nsel == 0) blo = bhi = 0;
       if (!contiguous) { status = -1; break; }
+      blo = uni(blo); bhi = uni(bhi);
       CostAcc acc;
       acc.c2 = 0.0; acc.visited = 0ull; acc.hits = 0;
-      int Lp = 1;
+      int Lp = 0;
       // path = [leaf] + reversed(leaf.path) + reversed(parent.path) + ...   (:321-331)
-      cost_segment(W, S, blo, bhi, P.w[2], lane == 0, cx, cy, ctt, acc);
+      // element id: >= 0 path point index, < 0 node ~id.  The walk only collects ids (one 16-B node
+      // record per ancestor); the lookups run over 64 elements at a time.
+      int fill = 0;
+      auto flush = [&]() {
+        for (int b0 = 0; b0 < fill; b0 += 64) {
+          const int nv = (fill - b0) < 64 ? (fill - b0) : 64;
+          double ex = 0.0, ey = 0.0, et = 0.0;
+          if (lane < nv) {
+            int id = elist[b0 + lane];
+            if (id >= 0) { ex = ptF[id]; ey = ptF[(size_t)capp + id]; et = ptF[4 * (size_t)capp + id]; }
+            else {
+              const double* nf = nodeF + (size_t)(~id) * 8;
+              const double2 a = *reinterpret_cast<const double2*>(nf);
+              ex = a.x; ey = a.y; et = nf[3];
+            }
+          }
+          wave_sync();
+          cost_pass(W, S, blo, bhi, P.w[2], nv, ex, ey, et, term, acc);
+        }
+        Lp += fill;
+        fill = 0;
+      };
+      if (lane == 0) elist[0] = ~me;
+      fill = 1;
       int m = me, mcnt = cnt, moff = n_points - cnt, mpar = par;
       for (;;) {
         // segment of node m: its appended points last-to-first, then the node it grew from
-        const int seg = mcnt + 1;
-        for (int s0 = 0; s0 < seg; s0 += 64) {
+        for (int s0 = 0; s0 < mcnt + 1; s0 += 64) {
+          const int seg = (mcnt + 1 - s0) < 64 ? (mcnt + 1 - s0) : 64;
+          if (fill + seg > RRT_ELIST) { wave_sync(); flush(); }
           int i = s0 + lane;
-          bool valid = i < seg;
-          double ex = 0.0, ey = 0.0, et = 0.0;
-          if (valid) {
-            if (i < mcnt) { int gi = moff + (mcnt - 1 - i); ex = px[gi]; ey = py[gi]; et = ptt[gi]; }
-            else { ex = nx[mpar]; ey = ny[mpar]; et = ntt[mpar]; }
-          }
-          cost_segment(W, S, blo, bhi, P.w[2], valid, ex, ey, et, acc);
+          if (lane < seg) elist[fill + lane] = (i < mcnt) ? (moff + (mcnt - 1 - i)) : ~mpar;
+          fill += seg;
         }
-        Lp += seg;
         m = mpar;
-        int gp = uni(parent[m]);
+        const int4 rec = nodeI[m];
+        const int gp = uni(rec.y);
         if (gp < 0) break;
-        mcnt = uni(pt_cnt[m]); moff = uni(pt_off[m]); mpar = gp;
+        mcnt = uni(rec.w); moff = uni(rec.z); mpar = gp;
       }
+      wave_sync();
+      flush();
       double c0 = 0.0, c1 = 0.0, c2 = acc.c2;
       const double w2 = P.w[1];
       if (w2 == auvp_rint(w2) && auvp_fabs(w2) < 1048576.0) c1 = w2 * (double)acc.hits;  // exact
@@ -476,6 +564,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       if (ctt > 0) { c1 = c1 / ctt; c2 = c2 / ctt; }
       if (W.n_habitats != 0) c0 = P.w[0] * (double)__popcll(acc.visited) / (double)W.n_habitats;
       double tot = ((0.0 + c0) + c1) + c2;
+      tot = readfirst_f64(tot);
       if (log_leaf && n_leaves < B.cap_leaves && lane == 0) {
         double* lc = B.leaf_cost + ((size_t)ep * B.cap_leaves + n_leaves) * 6;
         lc[0] = tot; lc[1] = c0; lc[2] = c1; lc[3] = c2; lc[4] = (double)Lp; lc[5] = (double)nsel;
@@ -483,11 +572,16 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       }
       n_leaves++;
       leaf_elems += Lp;
-      AUVP_PHASE(4);
-      if (tot < best[0]) {
-        best[0] = tot; best[1] = c0; best[2] = c1; best[3] = c2;
-        best_leaf = me; best_L = Lp; best_len = clen;
+      if (tot < best_tot) {
+        best_tot = tot;
+        best_leaf = me; best_L = Lp;
+        if (lane == 0) {
+          RrtSummary& s = B.summary[ep];
+          s.best_cost[0] = tot; s.best_cost[1] = c0; s.best_cost[2] = c1; s.best_cost[3] = c2;
+          s.best_length = clen;
+        }
       }
+      AUVP_PHASE(4);
     }
   }
 
@@ -502,8 +596,11 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
     if (status == 0 && best_leaf < 0) status = 1;
     s.status = status; s.n_nodes = n_nodes; s.n_points = n_points; s.n_leaves = n_leaves;
     s.best_leaf = best_leaf; s.best_path_len = best_L; s.iters_run = it; s._pad = 0;
-    s.best_cost[0] = best[0]; s.best_cost[1] = best[1]; s.best_cost[2] = best[2]; s.best_cost[3] = best[3];
-    s.best_length = best_len; s.rng_after = after; s.leaf_elems = leaf_elems; s.n_draw32 = drawn;
+    if (best_leaf < 0) {
+      s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;
+      s.best_length = 0.0;
+    }
+    s.rng_after = after; s.leaf_elems = leaf_elems; s.n_draw32 = drawn;
   }
 }
 
@@ -515,33 +612,41 @@ __global__ __launch_bounds__(64) void rrt_final_course_kernel(RrtBuffers B, cons
   const int lane = lane_id();
   const RrtSummary s = B.summary[ep];
   if (s.best_leaf < 0) return;
-  const size_t nb = (size_t)ep * B.cap_nodes, pb = (size_t)ep * B.cap_points;
+  const int capn = B.cap_nodes;
+  const size_t capp = (size_t)B.cap_points;
+  const double* nodeF = B.node_f + (size_t)ep * capn * 8;
+  const int4* nodeI = reinterpret_cast<const int4*>(B.node_i) + (size_t)ep * capn;
+  const double* ptF = B.points + (size_t)ep * capp * 6;
   const double* init = B.init + (size_t)ep * 6;
   double* o = out + 7 * (size_t)offsets[ep];
   int pos = s.best_path_len - 1;  // element index of the leaf
   auto node_elem = [&](int m, int at) {
     double* e = o + 7 * (size_t)at;
-    if (B.parent[nb + m] < 0) {
+    const int4 r = nodeI[m];
+    if (r.y < 0) {
       e[0] = init[0]; e[1] = init[1]; e[2] = init[2]; e[3] = 0.0; e[4] = init[3]; e[5] = init[4]; e[6] = init[5];
     } else {
-      e[0] = B.nx[nb + m]; e[1] = B.ny[nb + m]; e[2] = B.nth[nb + m]; e[3] = 0.0; e[4] = B.ntt[nb + m];
-      e[5] = (double)B.nplan[nb + m]; e[6] = B.nlen[nb + m];
+      const double* nf = nodeF + (size_t)m * 8;
+      e[0] = nf[0]; e[1] = nf[1]; e[2] = nf[2]; e[3] = 0.0; e[4] = nf[3]; e[5] = (double)r.x; e[6] = nf[4];
     }
   };
   if (lane == 0) node_elem(s.best_leaf, pos);
   pos--;
-  for (int m = s.best_leaf; B.parent[nb + m] >= 0; m = B.parent[nb + m]) {
-    const int cnt = B.pt_cnt[nb + m], off = B.pt_off[nb + m];
+  for (int m = s.best_leaf;;) {
+    const int4 r = nodeI[m];
+    if (r.y < 0) break;
+    const int cnt = r.w, off = r.z;
     for (int k = lane; k < cnt; k += 64) {
       // point k of the node sits k places after the node it grew from
       double* e = o + 7 * (size_t)(pos - cnt + 1 + k);
-      size_t gi = pb + off + k;
-      e[0] = B.px[gi]; e[1] = B.py[gi]; e[2] = B.pth[gi]; e[3] = B.pv[gi]; e[4] = B.ptt[gi];
-      e[5] = (double)B.nplan[nb + m]; e[6] = B.plen[gi];
+      size_t gi = (size_t)off + k;
+      e[0] = ptF[gi]; e[1] = ptF[capp + gi]; e[2] = ptF[2 * capp + gi]; e[3] = ptF[3 * capp + gi];
+      e[4] = ptF[4 * capp + gi]; e[5] = (double)r.x; e[6] = ptF[5 * capp + gi];
     }
     pos -= cnt;
-    if (lane == 0) node_elem(B.parent[nb + m], pos);
+    if (lane == 0) node_elem(r.y, pos);
     pos--;
+    m = r.y;
   }
 }
 
