@@ -402,12 +402,24 @@ int auvp_rrt_run(auvp_handle* h) {
     return hipGetLastError();
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  hipError_t le;
-  if (O <= 64) le = launch(rrt_explore_kernel<1>);
-  else if (O <= 128) le = launch(rrt_explore_kernel<2>);
-  else if (O <= 256) le = launch(rrt_explore_kernel<4>);
-  else if (O <= 512) le = launch(rrt_explore_kernel<8>);
-  else le = launch(rrt_explore_kernel<16>);
+  hipError_t le = hipSuccess;
+  // compile-time specialisation: obstacles per lane (J), parent-sampling mode, diagnostics on/off
+  const int jsel = O <= 64 ? 0 : (O <= 128 ? 1 : (O <= 256 ? 2 : (O <= 512 ? 3 : 4)));
+  const bool diag = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_LEAF_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
+#define AUVP_LAUNCH_J(JV)                                                                   \
+  do {                                                                                      \
+    if (P.mode == 0) le = diag ? launch(rrt_explore_kernel<JV, 0, true>) : launch(rrt_explore_kernel<JV, 0, false>); \
+    else if (P.mode == 1) le = diag ? launch(rrt_explore_kernel<JV, 1, true>) : launch(rrt_explore_kernel<JV, 1, false>); \
+    else le = diag ? launch(rrt_explore_kernel<JV, 2, true>) : launch(rrt_explore_kernel<JV, 2, false>); \
+  } while (0)
+  switch (jsel) {
+    case 0: AUVP_LAUNCH_J(1); break;
+    case 1: AUVP_LAUNCH_J(2); break;
+    case 2: AUVP_LAUNCH_J(4); break;
+    case 3: AUVP_LAUNCH_J(8); break;
+    default: AUVP_LAUNCH_J(16); break;
+  }
+#undef AUVP_LAUNCH_J
   HIPCHK(h, le);
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

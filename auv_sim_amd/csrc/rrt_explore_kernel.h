@@ -163,8 +163,8 @@ __device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtSharedLds&
   wave_sync();
 }
 
-template <int J>
-__global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
+template <int J, int MODE, bool DIAG>
+__global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
                                                                      int n_episodes, int max_pts) {
   extern __shared__ __align__(16) unsigned char smem[];
   RrtSharedLds& S = *reinterpret_cast<RrtSharedLds*>(smem);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
   int32_t* bin_items = B.bin_items + (size_t)ep * (P.K + 1) * bcap;
   const double* init = B.init + (size_t)ep * 6;
   const int K = P.K;
-  const bool log_it = (P.flags & 1) != 0, log_leaf = (P.flags & 2) != 0;
+  const bool log_it = DIAG && (P.flags & 1) != 0, log_leaf = DIAG && (P.flags & 2) != 0;
   const size_t logb = (size_t)ep * P.max_iter;
 
   WaveRng rng;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
   if (lane == 0) {
     nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
     nodeI[0] = make_int4(0, -1, 0, 0);
-    if (P.mode == 0) { bin_items[(size_t)(K >= 1 ? 1 : 0) * bcap] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
+    if (MODE == 0) { bin_items[(size_t)(K >= 1 ? 1 : 0) * bcap] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
   }
   wave_sync();
   const double init_t = readfirst_f64(init[3]);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
   int it = 0;
   // optional per-phase shader-clock accounting (AUVP_FLAG_PHASE_CLOCKS): select, steer, collision,
   // accept, cost walk
-  const bool clk = (P.flags & 4) != 0;
+  const bool clk = DIAG && (P.flags & 4) != 0;
   unsigned long long tph[5] = {0, 0, 0, 0, 0}, t_prev = 0;
 #define AUVP_PHASE(i) do { if (clk) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); tph[i] += t_now - t_prev; t_prev = t_now; } } while (0)
 
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
     // ------------------------------------------------------------ parent selection (:121-139)
     if (clk) t_prev = __builtin_amdgcn_s_memtime();
     int par;
-    if (P.mode == 0) {
+    if (MODE == 0) {
       int rb, cnt;
       for (;;) {
         double u = rng_next_random(rng);
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
       double u = rng_next_random(rng);
       int ri = uni((int)py_uniform(0.0, (double)cnt, u));
       par = uni(bin_items[(size_t)rb * bcap + ri]);
-    } else if (P.mode == 1) {
+    } else if (MODE == 1) {
       double u = rng_next_random(rng);
       double ran_time = py_uniform(0.0, P.max_plan_time * P.freq, u);
       int lo = 0, hi = n_nodes;  // list slicing of get_closest_mps_time (:515-528)
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64) void rrt_explore_kernel(WorldDev W,
     }
     n_nodes++;
     n_points += cnt;
-    if (P.mode == 0) {
+    if (MODE == 0) {
       // curr_bin = (t // bin_interval + 1) * bin_interval, exact floor of the true quotient
       double q = auvp_floor(ctt / P.bin_interval);
       double r = auvp_fma(-q, P.bin_interval, ctt);

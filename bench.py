@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--episodes", type=int, default=2048, help="episodes per GPU per step")
+    ap.add_argument("--episodes", type=int, default=4096, help="episodes per GPU per step")
     ap.add_argument("--iters", type=int, default=10000, help="expansion budget per episode (10k-node budget)")
     ap.add_argument("--obstacles", type=int, default=256)
     ap.add_argument("--grid", type=int, default=200, help="grid is grid x grid cells of 10 m")
