@@ -378,7 +378,161 @@ def g3():
               "err", out["error"], "cost", out.get("res_cost"))
 
 
-ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3}
+# --------------------------------------------------------------------------------------------
+# G2: Planner_RRT.planning (gym_rrt/envs/rrt_dubins.py:162) -- step bounded, deterministic under seed
+# --------------------------------------------------------------------------------------------
+def main_layout_obstacles():
+    """the deterministic 23-obstacle layout of gym_rrt/envs/rrt_dubins.py main() (:611-644)"""
+    obs = []
+    x, y = 15.0, 15.0
+    for _ in range(5):
+        obs.append((x, y, 3.0)); x -= 3.0; y += 3.0
+    x, y = 3.0, 33.0
+    for _ in range(2):
+        obs.append((x, y, 3.0)); y += 6.0
+    x, y = 9.0, 39.0
+    for _ in range(4):
+        obs.append((x, y, 3.0)); x += 6.0
+    x, y = 25.0, 24.0
+    for _ in range(8):
+        obs.append((x, y, 3.0)); x += 3.0; y -= 3.0
+    x, y = 33.0, 39.0
+    for _ in range(4):
+        obs.append((x, y, 3.0)); x += 3.0; y -= 3.0
+    return obs
+
+
+def run_planner_rrt(seed, rect, start, goal, obstacles, max_step, freq, cell, subs, exp_rate=1, dist_to_end=2,
+                    diff_max=0.5, keep_points=True):
+    mod, mpsm = import_gym_rrt()
+    MPS = mpsm.Motion_plan_state
+    clock = refstubs.VirtualClock()
+    mod.time = clock
+    obs = [MPS(o[0], o[1], size=o[2]) for o in obstacles]
+    bnd = [MPS(rect[0], rect[1]), MPS(rect[2], rect[3])]
+    s = MPS(start[0], start[1], z=-5.0, theta=start[2] if len(start) > 2 else 0.0)
+    g = MPS(goal[0], goal[1], z=-5.0, theta=0.0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rrt = mod.Planner_RRT(s, g, bnd, obs, [], exp_rate=exp_rate, dist_to_end=dist_to_end, diff_max=diff_max,
+                              freq=freq, cell_side_length=cell, subsections_in_cell=subs)
+    log = {"bucket": [], "picked": [], "accepted": [], "done": [], "npath": [], "arc_n": [], "arc_free": []}
+    index_of = {id(s): 0}
+    orig_gon = rrt.generate_one_node
+    orig_steer = rrt.steer
+    orig_cc = rrt.check_collision_free
+    orig_conn = rrt.connect_to_goal_curve_alt
+    ncols = len(rrt.env_grid[0])
+    cur = {}
+
+    def steer(m, *a, **k):
+        for i, n in enumerate(rrt.mps_list):
+            index_of.setdefault(id(n), i)
+        cur["picked"] = index_of[id(m)]
+        new = orig_steer(m, *a, **k)
+        cur["npath"] = len(new.path)
+        cur["phase"] = 0
+        return new
+
+    def cc(m, obs_):
+        r = orig_cc(m, obs_)
+        if cur.get("phase") == 0:
+            cur["accepted"] = bool(r)
+            cur["phase"] = 1
+        else:
+            cur["arc_free"] = bool(r)
+        return r
+
+    def conn(m, *a, **k):
+        f = orig_conn(m, *a, **k)
+        cur["arc_n"] = -1 if f is None else len(f.path)
+        return f
+
+    rrt.steer = steer
+    rrt.check_collision_free = cc
+    rrt.connect_to_goal_curve_alt = conn
+
+    def gon(cellobj, step_num=None, min_length=250):
+        # bucket id = (row * ncols + col) * S + sub
+        bid = -1
+        for r_, row in enumerate(rrt.env_grid):
+            for c_, gc in enumerate(row):
+                for k_, sub in enumerate(gc.subsection_cells):
+                    if sub is cellobj:
+                        bid = (r_ * ncols + c_) * subs + k_
+        cur.clear()
+        done, out = orig_gon(cellobj, step_num, min_length)
+        log["bucket"].append(bid)
+        log["picked"].append(cur["picked"])
+        log["accepted"].append(cur["accepted"])
+        log["npath"].append(cur["npath"])
+        log["arc_n"].append(cur["arc_n"])
+        log["arc_free"].append(cur.get("arc_free", False))
+        log["done"].append(bool(done))
+        return done, out
+
+    rrt.generate_one_node = gon
+    random.seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        path, step, _ = rrt.planning(max_step=max_step)
+    rng_after = random.random()
+    nodes = rrt.mps_list
+    for i, n in enumerate(nodes):
+        index_of[id(n)] = i
+    node_arr = np.array([[n.x, n.y, n.theta, n.traj_time_stamp, n.length] for n in nodes])
+    parent = np.array([-1 if n.parent is None else index_of[id(n.parent)] for n in nodes], dtype=np.int32)
+    npath = np.array([len(n.path) for n in nodes], dtype=np.int32)
+    pts = []
+    for n in nodes[1:]:
+        for p in n.path[1:]:
+            pts.append([p.x, p.y, p.theta, p.traj_time_stamp])
+    pts = np.array(pts, dtype=np.float64).reshape(-1, 4)
+    occ = np.array([(r_ * ncols + c_) * subs + k_ for (r_, c_, k_) in rrt.occupied_grid_cells_array], dtype=np.int32)
+    counts = np.array([len(sub.node_array) for row in rrt.env_grid for gc in row for sub in gc.subsection_cells],
+                      dtype=np.int32)
+    done = bool(log["done"][-1]) if log["done"] else False
+    out = {
+        "seed": seed, "rect": np.array(rect, dtype=np.float64), "start": np.array(start, dtype=np.float64),
+        "goal": np.array(goal, dtype=np.float64), "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
+        "max_step": max_step, "freq": freq, "cell": cell, "subs": subs, "exp_rate": exp_rate,
+        "dist_to_end": dist_to_end, "diff_max": diff_max,
+        "steps": step, "done": done, "nodes": node_arr, "parent": parent, "npath": npath,
+        "points_sha": sha(pts), "n_points": len(pts),
+        "st_bucket": np.array(log["bucket"], dtype=np.int32), "st_picked": np.array(log["picked"], dtype=np.int32),
+        "st_accepted": np.array(log["accepted"], dtype=np.int8), "st_done": np.array(log["done"], dtype=np.int8),
+        "st_npath": np.array(log["npath"], dtype=np.int32), "st_arc_n": np.array(log["arc_n"], dtype=np.int32),
+        "st_arc_free": np.array(log["arc_free"], dtype=np.int8),
+        "occupied": occ, "bucket_counts": counts, "grid_rows": len(rrt.env_grid), "grid_cols": ncols,
+        "rng_after": rng_after,
+    }
+    if keep_points:
+        out["points"] = pts
+    if done:
+        out["path"] = np.array([[p.x, p.y, p.theta, p.traj_time_stamp, p.length] for p in path])
+    return out
+
+
+def g2():
+    lay = main_layout_obstacles()
+    specs = []
+    for seed in range(5):
+        specs.append(("g2_main_s%d" % seed, seed, (0.0, 0.0, 50.0, 50.0), (10.0, 10.0), (35.0, 45.0), lay, 2000, 10, 5, 1,
+                      {}))
+    specs.append(("g2_main_subs8", 11, (0.0, 0.0, 50.0, 50.0), (10.0, 10.0, 0.7), (35.0, 45.0), lay, 1500, 50, 2, 8, {}))
+    w = synth.make_rect_world(seed=3, n_obstacles=256)
+    specs.append(("g2_o256_200m", 5, tuple(w["rect"].tolist()), tuple(w["start"].tolist()), tuple(w["goal"].tolist()),
+                  [tuple(o) for o in w["obstacles"].tolist()], 2000, 10, 5, 1, {"keep_points": False}))
+    w = synth.make_rect_world(seed=4, n_obstacles=64, size=100.0, start=(10.0, 10.0), goal=(85.0, 80.0),
+                              obst_radius=(2.0, 5.0))
+    specs.append(("g2_o64_100m", 6, tuple(w["rect"].tolist()), tuple(w["start"].tolist()), tuple(w["goal"].tolist()),
+                  [tuple(o) for o in w["obstacles"].tolist()], 1500, 20, 5, 4, {"exp_rate": 0.5}))
+    for name, seed, rect, start, goal, obs, max_step, freq, cell, subs, extra in specs:
+        out = run_planner_rrt(seed, rect, start, goal, obs, max_step, freq, cell, subs, **extra)
+        save_npz(name + ".npz", **out)
+        print(name, "steps", out["steps"], "done", out["done"], "nodes", len(out["nodes"]),
+              "path", None if "path" not in out else out["path"].shape)
+
+
+ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)
