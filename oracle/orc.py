@@ -66,6 +66,9 @@ def lib(kind="libm"):
         L.orc_sin.argtypes = [C.c_double]
         L.orc_cos.restype = C.c_double
         L.orc_cos.argtypes = [C.c_double]
+        for fn in (L.orc_atan2, L.orc_hypot):
+            fn.restype = C.c_double
+            fn.argtypes = [C.c_double, C.c_double]
         L.orc_rrt_explore.restype = C.c_int
         L.orc_rrt_explore.argtypes = [C.POINTER(World), C.POINTER(RRTParams), C.c_uint64, C.POINTER(RRTOut)]
         L.orc_check_collision.restype = C.c_int

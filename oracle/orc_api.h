@@ -55,12 +55,46 @@ typedef struct {
 
 enum { ORC_OK = 0, ORC_NO_QUALIFYING_LEAF = 1, ORC_ERR_CAPACITY = -1, ORC_ERR_ARG = -2 };
 
+/* Planner_RRT (gym_rrt/envs/rrt_dubins.py) */
+typedef struct {
+  double start[4];  /* x, y, theta, traj_time_stamp */
+  double goal[2];
+  double rect[4];   /* boundary corners x0,y0,x1,y1 */
+  double exp_rate, dist_to_end, diff_max, freq, cell_side_length;
+  int32_t subsections, max_step;
+} orc_prrt_params;
+
+typedef struct {
+  int32_t cap_nodes, cap_points, cap_path, cap_buckets;                       /* in */
+  int32_t n_nodes, n_points, steps, done, status, n_occ, n_buckets, grid_rows, grid_cols, path_len; /* out */
+  double rng_after;
+  uint64_t n_draw32;
+  double* nodes;          /* [cap_nodes,5] x,y,theta,traj_t,length */
+  int32_t* parent;        /* [cap_nodes] */
+  int32_t* pt_off;
+  int32_t* pt_cnt;
+  int32_t* node_bucket;   /* [cap_nodes] bucket id or -1 */
+  double* points;         /* [cap_points,4] x,y,theta,traj_t */
+  int32_t* st_bucket;     /* per step [max_step] */
+  int32_t* st_picked;
+  int8_t* st_accepted;
+  int8_t* st_done;
+  int32_t* st_npath;
+  int32_t* st_arc_n;      /* -1: connect_to_goal returned None */
+  int8_t* st_arc_free;
+  int32_t* occupied;      /* [cap_nodes] occupied_grid_cells_array as bucket ids */
+  int32_t* bucket_counts; /* [cap_buckets] */
+  double* path;           /* [cap_path,5] generate_final_course order (goal end first) */
+} orc_prrt_out;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 const char* orc_math_name(void);
 double orc_sin(double x);
 double orc_cos(double x);
+double orc_atan2(double y, double x);
+double orc_hypot(double x, double y);
 
 void orc_rng_kat(uint64_t seed, int n, double* out_random, uint32_t* out_bits32, int nchoice,
                  uint32_t choice_n, uint32_t* out_choice);
@@ -72,6 +106,8 @@ int orc_rrt_explore(const orc_world* w, const orc_rrt_params* p, uint64_t seed, 
 /* leaf -> root concatenation (generate_final_course), then reversed to root -> leaf order.
  * returns number of elements written (<= cap), or -needed if cap too small */
 int orc_rrt_final_course(const orc_rrt_out* t, const double* init7, int leaf, double* path7, int cap);
+/* Planner_RRT(...).planning(max_step) with `random.seed(seed)`; w carries the obstacle list only */
+int orc_prrt_planning(const orc_world* w, const orc_prrt_params* p, uint64_t seed, orc_prrt_out* out);
 #ifdef __cplusplus
 }
 #endif

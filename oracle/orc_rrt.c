@@ -27,6 +27,8 @@
 const char* orc_math_name(void) { return ORC_MATH_NAME; }
 double orc_sin(double x) { return ORC_SIN(x); }
 double orc_cos(double x) { return ORC_COS(x); }
+double orc_atan2(double y, double x) { return ORC_ATAN2(y, x); }
+double orc_hypot(double x, double y) { return ORC_HYPOT(x, y); }
 
 void orc_rng_kat(uint64_t seed, int n, double* out_random, uint32_t* out_bits32, int nchoice,
                  uint32_t choice_n, uint32_t* out_choice) {
