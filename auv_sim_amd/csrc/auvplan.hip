@@ -59,6 +59,11 @@ struct auvp_handle {
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
+  // planner families that live in their own headers keep their state behind an opaque pointer
+  void* prrt = nullptr;
+  void (*prrt_free)(void*) = nullptr;
+  void* astar = nullptr;
+  void (*astar_free)(void*) = nullptr;
 };
 
 namespace {
@@ -148,6 +153,8 @@ void auvp_destroy(auvp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->prrt && h->prrt_free) h->prrt_free(h->prrt);
+  if (h->astar && h->astar_free) h->astar_free(h->astar);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -564,3 +571,15 @@ int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds
 }  // extern "C"
 
 #include "probe_kernels.h"
+#include "planner_rrt_kernel.h"
+#include "planner_rrt_host.h"
+
+namespace {
+PrrtState* prrt_of(auvp_handle* h) {
+  if (!h->prrt) {
+    h->prrt = new PrrtState();
+    h->prrt_free = [](void* p) { delete static_cast<PrrtState*>(p); };
+  }
+  return static_cast<PrrtState*>(h->prrt);
+}
+}  // namespace

@@ -1,0 +1,274 @@
+// planner_rrt_host.h -- C-ABI entry points for Planner_RRT (auvp_prrt_*), host side.
+// Included at the end of auvplan.hip (same translation unit: uses auvp_handle, fail, HIPCHK, upload).
+#ifndef AUVP_PLANNER_RRT_HOST_H
+#define AUVP_PLANNER_RRT_HOST_H
+
+static_assert(sizeof(auvp_prrt_summary) == sizeof(auvp::PrrtSummary), "prrt summary layout");
+
+namespace {
+
+struct PrrtState {
+  bool ready = false;
+  int E = 0;
+  auvp::PrrtParamsDev P{};
+  auvp::PrrtBuffers B{};
+  DevBuf node_f, node_i, node_bucket, points, occupied, bcount, mt, rng_state, start, goal, step_bucket, summary, st_log,
+      tmp_off, tmp_out;
+};
+
+PrrtState* prrt_of(auvp_handle* h);
+
+int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode) {
+  S.P.step_mode = step_mode;
+  const int nfreq = (int)std::floor(S.P.freq);
+  const size_t lds = (size_t)auvp::RRT_WAVES * auvp::prrt_lds_per_wave(S.B.max_pts, nfreq);
+  if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB", lds);
+  const int grid = (S.E + auvp::RRT_WAVES - 1) / auvp::RRT_WAVES;
+  const int O = h->W.n_obstacles;
+  auto launch = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(auvp::RRT_WAVES * 64), lds, h->stream, h->W, S.P, S.B, S.E);
+    return hipGetLastError();
+  };
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  hipError_t le;
+  if (O <= 64) le = launch(auvp::prrt_kernel<1>);
+  else if (O <= 128) le = launch(auvp::prrt_kernel<2>);
+  else if (O <= 256) le = launch(auvp::prrt_kernel<4>);
+  else if (O <= 512) le = launch(auvp::prrt_kernel<8>);
+  else le = launch(auvp::prrt_kernel<16>);
+  HIPCHK(h, le);
+  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  h->last_ms = ms;
+  h->last_grid = grid; h->last_block = auvp::RRT_WAVES * 64; h->last_lds = (int)lds;
+  return AUVP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int auvp_prrt_create_batch(auvp_handle* h, int32_t E, const double* starts, const double* goals,
+                           const auvp_prrt_params* p, const uint64_t* seeds, const uint32_t* mt, const int32_t* mt_index,
+                           int32_t flags) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->have_world) return fail(h, AUVP_ERR_STATE, "auvp_world_set not called (obstacle list)");
+  if (E <= 0 || !starts || !goals || !p || (!seeds && !(mt && mt_index))) return fail(h, AUVP_ERR_ARG, "bad batch arguments");
+  if (h->W.n_obstacles > 16 * 64) return fail(h, AUVP_ERR_ARG, "n_obstacles %d > 1024", h->W.n_obstacles);
+  const int ics = (int)p->cell_side_length;
+  if (ics <= 0 || p->subsections <= 0 || p->max_step <= 0 || !(p->freq >= 0)) return fail(h, AUVP_ERR_ARG, "bad params");
+  HIPCHK(h, hipSetDevice(h->device));
+  PrrtState& S = *prrt_of(h);
+  S.ready = false;
+  auvp::PrrtParamsDev& P = S.P;
+  for (int i = 0; i < 4; i++) P.rect[i] = p->rect[i];
+  P.exp_rate = p->exp_rate; P.dist_to_end = p->dist_to_end; P.diff_max = p->diff_max; P.freq = p->freq;
+  P.cell = p->cell_side_length;
+  P.S = p->subsections;
+  // discretize_env (gym_rrt/envs/rrt_dubins.py:77-93): int(height) // int(cell), int(width) // int(cell)
+  P.rows = (int)(p->rect[3] - p->rect[1]) / ics;
+  P.cols = (int)(p->rect[2] - p->rect[0]) / ics;
+  if (P.rows <= 0 || P.cols <= 0) return fail(h, AUVP_ERR_ARG, "empty grid");
+  const double nbd = (double)P.rows * P.cols * P.S;
+  if (nbd > 5.0e7) return fail(h, AUVP_ERR_ARG, "too many buckets");
+  P.n_buckets = (int)nbd;
+  P.max_step = p->max_step; P.flags = flags; P.step_mode = 0;
+  P.delta_theta = (double)(2.0 * M_PI) / (double)P.S;  // grid_cell_rrt.py:49
+  auvp::PrrtBuffers& B = S.B;
+  const int nfreq = (int)std::floor(p->freq);
+  B.cap_nodes = p->max_step + 1;
+  B.max_pts = nfreq + 3;
+  double cp = (double)p->max_step * (double)(nfreq > 0 ? nfreq : 1) + 64;  // every taken sub-arc is stored
+  if (cp > 2.0e9) return fail(h, AUVP_ERR_ARG, "point capacity too large");
+  B.cap_points = (int32_t)cp;
+  const size_t cn = (size_t)E * B.cap_nodes;
+  HIPCHK(h, S.node_f.reserve(cn * 4 * sizeof(double)));
+  HIPCHK(h, S.node_i.reserve(cn * 4 * sizeof(int32_t)));
+  HIPCHK(h, S.node_bucket.reserve(cn * sizeof(int32_t)));
+  HIPCHK(h, S.points.reserve((size_t)E * B.cap_points * 4 * sizeof(double)));
+  HIPCHK(h, S.occupied.reserve(cn * sizeof(int32_t)));
+  HIPCHK(h, S.bcount.reserve((size_t)E * P.n_buckets * sizeof(int32_t)));
+  HIPCHK(h, S.mt.reserve((size_t)E * 624 * sizeof(uint32_t)));
+  HIPCHK(h, S.rng_state.reserve((size_t)E * 4 * sizeof(int32_t)));
+  HIPCHK(h, S.summary.reserve((size_t)E * sizeof(auvp::PrrtSummary)));
+  HIPCHK(h, S.step_bucket.reserve((size_t)E * sizeof(int32_t)));
+  B.node_f = S.node_f.as<double>(); B.node_i = S.node_i.as<int32_t>(); B.node_bucket = S.node_bucket.as<int32_t>();
+  B.points = S.points.as<double>(); B.occupied = S.occupied.as<int32_t>(); B.bucket_counts = S.bcount.as<int32_t>();
+  B.mt = S.mt.as<uint32_t>(); B.rng_state = S.rng_state.as<int32_t>(); B.summary = S.summary.as<auvp::PrrtSummary>();
+  B.step_bucket = S.step_bucket.as<int32_t>();
+  B.st_log = nullptr;
+  if (flags & AUVP_FLAG_ITER_LOG) {
+    HIPCHK(h, S.st_log.reserve((size_t)E * p->max_step * 8 * sizeof(int32_t)));
+    HIPCHK(h, hipMemsetAsync(S.st_log.p, 0xff, (size_t)E * p->max_step * 8 * sizeof(int32_t), h->stream));
+    B.st_log = S.st_log.as<int32_t>();
+  }
+  int rc;
+  if ((rc = upload(h, S.start, starts, (size_t)E * 4))) return rc;
+  if ((rc = upload(h, S.goal, goals, (size_t)E * 2))) return rc;
+  B.start = S.start.as<double>(); B.goal = S.goal.as<double>();
+  // generator states
+  std::vector<uint32_t> words((size_t)E * 624);
+  std::vector<int32_t> rs((size_t)E * 4, 0);
+  for (int e = 0; e < E; e++) {
+    if (seeds) seed_mt(seeds[e], words.data() + (size_t)e * 624);
+    else {
+      memcpy(words.data() + (size_t)e * 624, mt + (size_t)e * 624, 624 * sizeof(uint32_t));
+      int idx = mt_index[e] < 0 ? 0 : (mt_index[e] > 624 ? 624 : mt_index[e]);
+      rs[4 * (size_t)e] = idx == 624 ? 0 : idx;
+      rs[4 * (size_t)e + 1] = 624 - idx;
+    }
+  }
+  if ((rc = upload(h, S.mt, words.data(), words.size()))) return rc;
+  if ((rc = upload(h, S.rng_state, rs.data(), rs.size()))) return rc;
+  // mps_list = [start]; add_node_to_grid(start)  (:53,:108-159) -- done on the host, same arithmetic
+  HIPCHK(h, hipMemsetAsync(S.bcount.p, 0, (size_t)E * P.n_buckets * sizeof(int32_t), h->stream));
+  std::vector<auvp::PrrtSummary> sums(E);
+  std::vector<double> nf0(4);
+  for (int e = 0; e < E; e++) {
+    const double* st = starts + 4 * (size_t)e;
+    auvp::PrrtSummary& s = sums[e];
+    memset(&s, 0, sizeof s);
+    s.n_nodes = 1; s.last_new_node = -1;
+    int row = (int)(st[1] / P.cell), col = (int)(st[0] / P.cell);
+    bool err = false;
+    if (row < 0) { row += P.rows; err |= row < 0; }
+    if (col < 0) { col += P.cols; err |= col < 0; }
+    int bk = -1;
+    if (!err && row < P.rows && col < P.cols) {
+      int sub = (int)std::floor(st[2] / P.delta_theta);
+      if (sub < 0) sub = (int)(P.S + sub);
+      if (sub == P.S) sub -= 1;
+      if (sub < 0) { sub += P.S; err |= sub < 0; }
+      err |= sub >= P.S;
+      bk = (row * P.cols + col) * P.S + sub;
+    }
+    if (err) { s.status = AUVP_ERR_ARG; bk = -1; }
+    int32_t ni[4] = {0, -1, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(B.node_f + (size_t)e * B.cap_nodes * 4, st, 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(B.node_i + (size_t)e * B.cap_nodes * 4, ni, sizeof ni, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(B.node_bucket + (size_t)e * B.cap_nodes, &bk, sizeof bk, hipMemcpyHostToDevice, h->stream));
+    if (bk >= 0) {
+      const int32_t one = 1;
+      HIPCHK(h, hipMemcpyAsync(B.bucket_counts + (size_t)e * P.n_buckets + bk, &one, sizeof one, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(B.occupied + (size_t)e * B.cap_nodes, &bk, sizeof bk, hipMemcpyHostToDevice, h->stream));
+      s.n_occ = 1;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // the small host temporaries above are reused per episode
+  }
+  if ((rc = upload(h, S.summary, sums.data(), sums.size()))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  S.E = E;
+  S.ready = true;
+  return AUVP_OK;
+}
+
+int auvp_prrt_plan(auvp_handle* h) {
+  if (!h) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "auvp_prrt_create_batch not called");
+  HIPCHK(h, hipSetDevice(h->device));
+  return prrt_launch(h, S, 0);
+}
+
+int auvp_prrt_step(auvp_handle* h, const int32_t* bucket_ids, const uint32_t* mt, const int32_t* mt_index) {
+  if (!h || !bucket_ids) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "auvp_prrt_create_batch not called");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if ((rc = upload(h, S.step_bucket, bucket_ids, (size_t)S.E))) return rc;
+  if (mt && mt_index) {  // continue an external generator (the global `random` state) for this step
+    std::vector<int32_t> rs((size_t)S.E * 4, 0);
+    for (int e = 0; e < S.E; e++) {
+      int idx = mt_index[e] < 0 ? 0 : (mt_index[e] > 624 ? 624 : mt_index[e]);
+      rs[4 * (size_t)e] = idx == 624 ? 0 : idx;
+      rs[4 * (size_t)e + 1] = 624 - idx;
+    }
+    if ((rc = upload(h, S.mt, mt, (size_t)S.E * 624))) return rc;
+    if ((rc = upload(h, S.rng_state, rs.data(), rs.size()))) return rc;
+  }
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return prrt_launch(h, S, 1);
+}
+
+int auvp_prrt_summaries(auvp_handle* h, auvp_prrt_summary* out) {
+  if (!h || !out) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(out, S.B.summary, (size_t)S.E * sizeof(auvp::PrrtSummary), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+int auvp_prrt_paths(auvp_handle* h, const int64_t* offsets, double* out) {
+  if (!h || !offsets || !out) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t total = (size_t)offsets[S.E];
+  int rc;
+  if ((rc = upload(h, S.tmp_off, offsets, (size_t)S.E + 1))) return rc;
+  HIPCHK(h, S.tmp_out.reserve(std::max<size_t>(total, 1) * 5 * sizeof(double)));
+  hipLaunchKernelGGL(auvp::prrt_final_course_kernel, dim3(S.E), dim3(64), 0, h->stream, S.B, S.tmp_off.as<int64_t>(),
+                     S.tmp_out.as<double>(), S.E);
+  HIPCHK(h, hipGetLastError());
+  if (total) HIPCHK(h, hipMemcpyAsync(out, S.tmp_out.p, total * 5 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_prrt_tree(auvp_handle* h, int32_t ep, double* nodes4, int32_t* node_i4, int32_t* node_bucket, double* points4) {
+  if (!h) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready || ep < 0 || ep >= S.E) return fail(h, AUVP_ERR_STATE, "bad episode");
+  HIPCHK(h, hipSetDevice(h->device));
+  auvp::PrrtSummary s;
+  HIPCHK(h, hipMemcpy(&s, S.B.summary + ep, sizeof s, hipMemcpyDeviceToHost));
+  const size_t N = (size_t)s.n_nodes, NP = (size_t)s.n_points, capp = (size_t)S.B.cap_points;
+  if (nodes4) HIPCHK(h, hipMemcpy(nodes4, S.B.node_f + (size_t)ep * S.B.cap_nodes * 4, N * 4 * sizeof(double), hipMemcpyDeviceToHost));
+  if (node_i4) HIPCHK(h, hipMemcpy(node_i4, S.B.node_i + (size_t)ep * S.B.cap_nodes * 4, N * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (node_bucket) HIPCHK(h, hipMemcpy(node_bucket, S.B.node_bucket + (size_t)ep * S.B.cap_nodes, N * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (points4 && NP) {
+    std::vector<double> col(NP);
+    for (int c = 0; c < 4; c++) {
+      HIPCHK(h, hipMemcpy(col.data(), S.B.points + ((size_t)ep * 4 + c) * capp, NP * sizeof(double), hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < NP; i++) points4[4 * i + c] = col[i];
+    }
+  }
+  return AUVP_OK;
+}
+
+int auvp_prrt_grid(auvp_handle* h, int32_t ep, int32_t* occupied, int32_t* bucket_counts, int32_t* dims4) {
+  if (!h) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready || ep < 0 || ep >= S.E) return fail(h, AUVP_ERR_STATE, "bad episode");
+  HIPCHK(h, hipSetDevice(h->device));
+  auvp::PrrtSummary s;
+  HIPCHK(h, hipMemcpy(&s, S.B.summary + ep, sizeof s, hipMemcpyDeviceToHost));
+  if (dims4) { dims4[0] = S.P.rows; dims4[1] = S.P.cols; dims4[2] = S.P.S; dims4[3] = s.n_occ; }
+  if (occupied && s.n_occ) HIPCHK(h, hipMemcpy(occupied, S.B.occupied + (size_t)ep * S.B.cap_nodes, (size_t)s.n_occ * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (bucket_counts) HIPCHK(h, hipMemcpy(bucket_counts, S.B.bucket_counts + (size_t)ep * S.P.n_buckets, (size_t)S.P.n_buckets * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+int auvp_prrt_step_log(auvp_handle* h, int32_t ep, int32_t* log8) {
+  if (!h || !log8) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready || ep < 0 || ep >= S.E || !S.B.st_log) return fail(h, AUVP_ERR_STATE, "no step log");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(log8, S.B.st_log + (size_t)ep * S.P.max_step * 8, (size_t)S.P.max_step * 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+void* auvp_prrt_summaries_dev(auvp_handle* h) {
+  if (!h) return nullptr;
+  PrrtState& S = *prrt_of(h);
+  return S.ready ? (void*)S.B.summary : nullptr;
+}
+
+}  // extern "C"
+#endif

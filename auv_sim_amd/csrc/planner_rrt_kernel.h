@@ -1,0 +1,523 @@
+// planner_rrt_kernel.h -- Planner_RRT (gym_rrt/envs/rrt_dubins.py) on gfx950: the goal-directed RRT
+// the RL environment drives one node at a time (RRTEnv.step -> generate_one_node, rrt_env.py:224) and
+// that planning() (:162-202) loops over.
+//
+// One wavefront = one episode; the tree, the (cell, theta-subsection) bucket table and the RNG
+// state stay in HBM between launches, so the same kernel serves
+//   * planning(max_step): device-side loop, bucket drawn on the device (random.choice, :186)
+//   * generate_one_node(bucket): one step per launch with the bucket chosen by the caller (:205)
+// Per step: pick a node of the bucket (random.choice :223), steer (:251-289; lane = sub-arc),
+// collision + closed-rectangle test (:435-484), grid insert (:108-159), then the arc from the LAST
+// list node to the goal (:374-423), sampled 64 points per pass with an early exit at the first
+// obstacle / boundary hit.  Obstacle tests use the same suffix-max / squared-threshold form as the
+// exploring kernel, plus an exact bounding-box cull of obstacle slots per pass.
+#ifndef AUVP_PLANNER_RRT_KERNEL_H
+#define AUVP_PLANNER_RRT_KERNEL_H
+#include "auvp_math.h"
+#include "auvp_types.h"
+#include "auvp_wave.h"
+
+namespace auvp {
+
+struct PrrtParamsDev {
+  double rect[4];
+  double exp_rate, dist_to_end, diff_max, freq, cell;
+  int32_t S, rows, cols, n_buckets, max_step, flags, step_mode, _pad;
+  double delta_theta;
+};
+
+struct PrrtSummary {  // must match auvp_prrt_summary in include/auvplan.h
+  int32_t status, n_nodes, n_points, n_occ, steps, done, path_len, last_node;
+  int32_t last_accepted, last_new_node, n_arc, _pad;
+  double arc[6];  // x_C, y_C, radius, ang_vel, theta_0, length  (of the successful goal connection)
+  double rng_after;
+  unsigned long long n_draw32;
+};
+
+struct PrrtBuffers {
+  int32_t cap_nodes, cap_points, max_pts, _pad;
+  double* node_f;        // [E][cap_nodes][4]  x, y, theta, traj_t   (length stays 0, :232)
+  int32_t* node_i;       // [E][cap_nodes][4]  step, parent, pt_off, pt_cnt
+  int32_t* node_bucket;  // [E][cap_nodes]
+  double* points;        // [E][4][cap_points] SoA x, y, theta, traj_t
+  int32_t* occupied;     // [E][cap_nodes]
+  int32_t* bucket_counts;  // [E][n_buckets]
+  uint32_t* mt;          // [E][624] generator words (lazy in-place format between launches)
+  int32_t* rng_state;    // [E][4] pslot, avail, drawn_lo, drawn_hi
+  const double* start;   // [E][4] x, y, theta, traj_t
+  const double* goal;    // [E][2]
+  const int32_t* step_bucket;  // step mode: [E] bucket id chosen by the caller (<0: skip episode)
+  PrrtSummary* summary;  // [E]
+  int32_t* st_log;       // optional [E][max_step][8]: bucket, picked, accepted, done, npath, arc_n, arc_free, -
+};
+
+__host__ __device__ inline int prrt_lds_per_wave(int max_pts, int nfreq) {
+  int C = nfreq < 1 ? 1 : (nfreq > 63 ? 63 : nfreq);
+  int u = (2 * C + 2) * 8;
+  int s = (C + 1) * 6 * 8;  // inc[(C+1)*3], sc[(C+1)*2], phi[C+1]
+  int scratch = (((u > s ? u : s) > 1040 ? (u > s ? u : s) : 1040) + 15) & ~15;  // >= one 64(+1)-point arc chunk
+  return scratch + 624 * 4 + ((max_pts * 16 + 15) & ~15);
+}
+
+// angle_wrap (:425-433)
+__device__ __forceinline__ double prrt_angle_wrap(double a) {
+  for (int guard = 0; guard < 64; guard++) {
+    if (-AUVP_PI <= a && a <= AUVP_PI) return a;
+    if (a > AUVP_PI) a += (-2 * AUVP_PI);
+    else if (a < -AUVP_PI) a += (2 * AUVP_PI);
+    else return a;
+  }
+  return a;
+}
+
+// random._randbelow(n): getrandbits(bit_length(n)) until < n; one 32-bit output per try.
+// Eight tries are tempered at once (lanes 0..7); the first success is taken.
+__device__ __forceinline__ uint32_t rng_randbelow(WaveRng& r, uint32_t n) {
+  const int lane = lane_id();
+  const int k = 32 - __clz((int)n);  // bit_length
+  for (;;) {
+    rng_ensure(r, 8u);
+    uint32_t v = 0xffffffffu;
+    if (lane < 8) v = rng_word(r, (uint32_t)lane) >> (32 - k);
+    unsigned long long okm = __ballot(lane < 8 && v < n);
+    if (okm) {
+      int f = __ffsll((long long)okm) - 1;
+      uint32_t res = (uint32_t)__builtin_amdgcn_readlane((int)v, f);
+      rng_advance_words(r, (uint32_t)(f + 1));
+      return res;
+    }
+    rng_advance_words(r, 8u);
+  }
+}
+
+// any of n points (x,y in LDS) inside an obstacle's effective disc?  lanes = obstacles (J each);
+// slot j is skipped when no obstacle of the slot can reach the points' bounding box (exact cull:
+// a point inside the box is at least as far from the centre as the box is).
+template <int J>
+__device__ __forceinline__ bool prrt_hits(const double (&ox)[J], const double (&oy)[J], const double (&ot)[J],
+                                          const double (*pts)[2], int n, double bx0, double by0, double bx1, double by1) {
+  int hit = 0;
+#pragma unroll
+  for (int j = 0; j < J; j++) {
+    double ddx = ox[j] < bx0 ? bx0 - ox[j] : (ox[j] > bx1 ? ox[j] - bx1 : 0.0);
+    double ddy = oy[j] < by0 ? by0 - oy[j] : (oy[j] > by1 ? oy[j] - by1 : 0.0);
+    bool cand = ddx * ddx + ddy * ddy <= ot[j] * (1.0 + 0x1p-40);
+    if (__any(cand)) {
+      double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
+      for (int p = 0; p < n; p++) {
+        const double2 qn = *reinterpret_cast<const double2*>(&pts[p + 1][0]);  // room for n + 1
+        double ex = q.x - ox[j], ey = q.y - oy[j];
+        hit |= (ex * ex + ey * ey <= ot[j]) ? 1 : 0;
+        q = qn;
+      }
+    }
+  }
+  return __any(hit != 0);
+}
+
+template <int J>
+__global__ __launch_bounds__(RRT_WAVES * 64) void prrt_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  const int ep = (int)blockIdx.x * RRT_WAVES + wave;
+  if (ep >= n_episodes) return;
+  const int nfreq = (int)P.freq;
+  const int C = nfreq < 1 ? 1 : (nfreq > 63 ? 63 : nfreq);
+  const int per_wave = prrt_lds_per_wave(B.max_pts, nfreq);
+  unsigned char* wbase = smem + (size_t)wave * per_wave;
+  const int u_b = (2 * C + 2) * 8, s_b = (C + 1) * 6 * 8;
+  const int scratch_b = ((((u_b > s_b ? u_b : s_b) > 1040 ? (u_b > s_b ? u_b : s_b) : 1040)) + 15) & ~15;
+  double* scratch = reinterpret_cast<double*>(wbase);
+  double* u_win = scratch;                        // [2C+2]
+  double* inc = scratch;                          // [(C+1)*3]  aliases u_win
+  double* sc = scratch + (size_t)(C + 1) * 3;     // [(C+1)*2]
+  double* phi_l = scratch + (size_t)(C + 1) * 5;  // [C+1]
+  double(*arc_pts)[2] = reinterpret_cast<double(*)[2]>(wbase);  // [64 (+1)] arc chunk, aliases the steer scratch
+  uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + scratch_b);
+  double(*pts)[2] = reinterpret_cast<double(*)[2]>(wbase + scratch_b + 624 * 4);
+
+  const int step_bucket = P.step_mode ? uni(B.step_bucket[ep]) : 0;
+  if (P.step_mode && step_bucket < 0) return;
+
+  double ox[J], oy[J], ot[J];
+#pragma unroll
+  for (int j = 0; j < J; j++) {
+    int i = j * 64 + lane;
+    bool ok = i < W.n_obstacles;
+    ox[j] = ok ? W.ox[i] : 0.0;
+    oy[j] = ok ? W.oy[i] : 0.0;
+    ot[j] = ok ? W.ot[i] : -1.0;
+  }
+
+  const int capn = B.cap_nodes;
+  const size_t capp = (size_t)B.cap_points;
+  double* nodeF = B.node_f + (size_t)ep * capn * 4;
+  int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;
+  int32_t* nbucket = B.node_bucket + (size_t)ep * capn;
+  double* ptF = B.points + (size_t)ep * capp * 4;
+  int32_t* occupied = B.occupied + (size_t)ep * capn;
+  int32_t* bcount = B.bucket_counts + (size_t)ep * P.n_buckets;
+  PrrtSummary& sum = B.summary[ep];
+  const double gx = readfirst_f64(B.goal[2 * (size_t)ep]), gy = readfirst_f64(B.goal[2 * (size_t)ep + 1]);
+  const bool logst = (P.flags & 1) != 0 && B.st_log != nullptr;
+
+  WaveRng rng;
+  rng.s = mt;
+  for (int i = lane; i < 624; i += 64) mt[i] = B.mt[(size_t)ep * 624 + i];
+  rng.pslot = (uint32_t)uni(B.rng_state[4 * (size_t)ep]);
+  rng.avail = (uint32_t)uni(B.rng_state[4 * (size_t)ep + 1]);
+  rng.drawn = ((unsigned long long)(uint32_t)uni(B.rng_state[4 * (size_t)ep + 2])) |
+              ((unsigned long long)(uint32_t)uni(B.rng_state[4 * (size_t)ep + 3]) << 32);
+  wave_sync();
+
+  int n_nodes = uni(sum.n_nodes), n_points = uni(sum.n_points), n_occ = uni(sum.n_occ), step = uni(sum.steps);
+  int done = uni(sum.done), status = uni(sum.status);
+  int last_accepted = 0, last_new = -1;
+  const int step_end = P.step_mode ? step + 1 : P.max_step;
+
+  while (status == 0 && !done && step < step_end) {
+    // ---------------------------------------------------------------- bucket + node choice
+    int b;
+    if (P.step_mode) {
+      b = step_bucket;
+      if (b >= P.n_buckets) { status = -1; break; }
+    } else {
+      if (n_occ == 0) { status = -1; break; }
+      b = uni(occupied[rng_randbelow(rng, (uint32_t)n_occ)]);
+    }
+    const int cnt_b = uni(bcount[b]);
+    last_accepted = 0; last_new = -1;
+    if (cnt_b == 0) {  // generate_one_node on an empty bucket: (False, None) (:214-220, input() not reproduced)
+      if (logst && lane == 0) {
+        int32_t* l = B.st_log + ((size_t)ep * P.max_step + step) * 8;
+        l[0] = b; l[1] = -1; l[2] = 0; l[3] = 0; l[4] = 0; l[5] = -1; l[6] = 0; l[7] = 0;
+      }
+      step++;
+      continue;
+    }
+    const int rsel = (int)rng_randbelow(rng, (uint32_t)cnt_b);
+    int par = -1;
+    for (int base = 0, seen = 0; base < n_nodes; base += 64) {
+      int m = base + lane;
+      bool is = m < n_nodes && nbucket[m] == b;
+      unsigned long long bal = __ballot(is);
+      int c = __popcll(bal);
+      if (seen + c > rsel) {
+        int want = rsel - seen;
+        unsigned long long sel = __ballot(is && __popcll(bal & ((1ull << lane) - 1ull)) == want);
+        par = base + (__ffsll((long long)sel) - 1);
+        break;
+      }
+      seen += c;
+    }
+    par = uni(par);
+    if (par < 0) { status = -4; break; }
+
+    // ---------------------------------------------------------------- steer (:251-289)
+    double cx, cy, cth, ctt;
+    {
+      const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 4);
+      const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 4 + 2);
+      cx = readfirst_f64(a.x); cy = readfirst_f64(a.y); cth = readfirst_f64(c.x); ctt = readfirst_f64(c.y);
+    }
+    int n_total;
+    {
+      double u = rng_next_random(rng);
+      n_total = uni((int)auvp_floor(py_uniform(0.0, P.freq, u) / 1));
+    }
+    int cnt = 0;
+    if (lane == 0) { pts[0][0] = cx; pts[0][1] = cy; }
+    bool cap_err = false;
+    for (int c0 = 0; c0 < n_total; c0 += C) {
+      const int n = (n_total - c0) < C ? (n_total - c0) : C;
+      rng_ensure(rng, (uint32_t)(4 * n));
+      for (int jj = lane; jj < 2 * n; jj += 64) u_win[jj] = rng_random_at(rng, (uint32_t)jj);
+      wave_sync();
+      const bool active = lane < n;
+      double radius = 0.0, phi = 0.0;
+      bool taken = false;
+      if (active) {
+        double dist = py_uniform(0.0, P.dist_to_end, u_win[2 * lane]);
+        double diff = py_uniform(-P.diff_max, P.diff_max, u_win[2 * lane + 1]);
+        taken = auvp_fabs(dist) > auvp_fabs(diff);
+        if (taken) {
+          double s1 = dist + diff, s2 = dist - diff;
+          radius = (s1 + s2) / (-s1 + s2);
+          phi = (s1 + s2) / (2 * radius);
+        }
+      }
+      const unsigned long long tmask = __ballot(taken);
+      wave_sync();
+      if (lane <= C) phi_l[lane] = phi;
+      wave_sync();
+      // theta = angle_wrap(theta + phi) for the taken sub-arcs only, left to right, one lane
+      if (lane == 0) {
+        double th = cth;
+        for (int s = 0; s < n; s++) {
+          if ((tmask >> s) & 1ull) th = prrt_angle_wrap(th + phi_l[s]);
+          phi_l[s] = th;
+        }
+      }
+      wave_sync();
+      const double myth = active ? phi_l[lane] : cth;
+      double sn, cs;
+      auvp_sincos(myth, &sn, &cs);
+      if (lane <= C) { sc[2 * lane] = sn; sc[2 * lane + 1] = cs; }
+      wave_sync();
+      double dx = 0.0, dy = 0.0, dt = 0.0;
+      if (taken) {
+        unsigned long long below = tmask & ((1ull << lane) - 1ull);
+        int prev = below ? (63 - __clzll((long long)below)) : C;
+        double so = sc[2 * prev], co = sc[2 * prev + 1];
+        dx = radius * (sn - so);
+        dy = radius * (-cs + co);
+        dt = auvp_sqrt(dx * dx + dy * dy) / 1;
+      }
+      if (active) { inc[3 * lane] = dx; inc[3 * lane + 1] = dy; inc[3 * lane + 2] = dt; }
+      wave_sync();
+      if (lane < 3) {
+        double acc = lane == 0 ? cx : (lane == 1 ? cy : ctt);
+#pragma unroll 4
+        for (int s = 0; s < n; s++) { acc = acc + inc[3 * s + lane]; inc[3 * s + lane] = acc; }
+      }
+      wave_sync();
+      double mx = 0.0, my = 0.0, mt_ = 0.0;
+      if (active) { mx = inc[3 * lane]; my = inc[3 * lane + 1]; mt_ = inc[3 * lane + 2]; }
+      const int napp = __popcll(tmask);
+      if (n_points + cnt + napp > (int)capp || cnt + napp + 2 > B.max_pts) { cap_err = true; break; }
+      if (taken) {
+        int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+        size_t gi = (size_t)(n_points + cnt + rank);
+        ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * capp + gi] = myth; ptF[3 * capp + gi] = mt_;
+        pts[cnt + rank + 1][0] = mx;
+        pts[cnt + rank + 1][1] = my;
+      }
+      cnt += napp;
+      if (n > 0) {
+        cx = readlane_f64(mx, n - 1); cy = readlane_f64(my, n - 1); ctt = readlane_f64(mt_, n - 1);
+        cth = readlane_f64(myth, n - 1);
+      }
+      rng_advance_words(rng, (uint32_t)(4 * n));
+      wave_sync();
+    }
+    if (cap_err) { status = -2; break; }
+    wave_sync();
+    const int P_n = cnt + 1;
+
+    // ---------------------------------------------------------------- check_collision_free (:435-458)
+    bool ok;
+    {
+      // bounding box of the path points (lanes = points)
+      double lx0 = __builtin_inf(), ly0 = __builtin_inf(), lx1 = -__builtin_inf(), ly1 = -__builtin_inf();
+      bool outside = false;
+      for (int p = lane; p < P_n; p += 64) {
+        double x = pts[p][0], y = pts[p][1];
+        lx0 = x < lx0 ? x : lx0; lx1 = x > lx1 ? x : lx1; ly0 = y < ly0 ? y : ly0; ly1 = y > ly1 ? y : ly1;
+        bool wx = (x >= P.rect[0]) && (x <= P.rect[2]);
+        bool wy = (y >= P.rect[1]) && (y <= P.rect[3]);
+        outside = outside | !(wx && wy);
+      }
+      const double bx0 = wave_min_f64(lx0), by0 = wave_min_f64(ly0), bx1 = -wave_min_f64(-lx1), by1 = -wave_min_f64(-ly1);
+      ok = !prrt_hits<J>(ox, oy, ot, pts, P_n, bx0, by0, bx1, by1) && !__any(outside);
+    }
+    int me = -1;
+    if (ok) {
+      if (n_nodes >= capn) { status = -2; break; }
+      me = n_nodes;
+      // add_node_to_grid (:108-159): int(y / cs), int(x / cs) with Python's negative-index wrap
+      int row = (int)(cy / P.cell), col = (int)(cx / P.cell);
+      bool idx_err = false;
+      if (row < 0) { row += P.rows; idx_err |= row < 0; }
+      if (col < 0) { col += P.cols; idx_err |= col < 0; }
+      int bk = -1;
+      if (!idx_err && row < P.rows && col < P.cols) {
+        double raw = cth / P.delta_theta;
+        int sub = (int)auvp_floor(raw);
+        if (sub < 0) sub = (int)(P.S + sub);
+        if (sub == P.S) sub -= 1;
+        if (sub < 0) { sub += P.S; idx_err |= sub < 0; }
+        idx_err |= sub >= P.S;
+        bk = (row * P.cols + col) * P.S + sub;
+      }
+      if (__any(idx_err)) { status = -1; break; }
+      bk = uni(bk);
+      const int c_before = bk >= 0 ? uni(bcount[bk]) : -1;
+      if (lane == 0) {
+        double* nf = nodeF + (size_t)me * 4;
+        *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
+        *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
+        nodeI[me] = make_int4(step, par, n_points, cnt);
+        nbucket[me] = bk;
+        if (bk >= 0) {
+          bcount[bk] = c_before + 1;
+          if (c_before == 0) occupied[n_occ] = bk;  // first node of the bucket (:157-159)
+        }
+      }
+      if (c_before == 0) n_occ++;
+      n_nodes++;
+      n_points += cnt;
+      last_accepted = 1; last_new = me;
+    }
+    // ---------------------------------------------------------------- connect_to_goal_curve_alt(mps_list[-1]) (:374-423)
+    const int last = n_nodes - 1;
+    double lx, ly, th0, ltt;
+    if (ok) { lx = cx; ly = cy; th0 = cth; ltt = ctt; }
+    else {
+      const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)last * 4);
+      const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)last * 4 + 2);
+      lx = readfirst_f64(a.x); ly = readfirst_f64(a.y); th0 = readfirst_f64(c.x); ltt = readfirst_f64(c.y);
+    }
+    int n_arc = -1, arc_free = 0;
+    {
+      const double theta = auvp_atan2(gy - ly, gx - lx);
+      const double diff = prrt_angle_wrap(theta - th0);
+      if (!(auvp_fabs(diff) > AUVP_PI / 2)) {
+        const double r_G = auvp_hypot(gx - lx, gy - ly);
+        const double phi_G = theta;  // same atan2 arguments (:387)
+        if (phi_G - th0 != 0) {
+          double phi = 2 * prrt_angle_wrap(phi_G - th0);
+          const double sn0 = auvp_sin(phi_G - th0);
+          if (sn0 != 0) {
+            const double radius = r_G / (2 * sn0);
+            double length = radius * phi;
+            if (phi > AUVP_PI) { phi -= 2 * AUVP_PI; length = -radius * phi; }
+            else if (phi < -AUVP_PI) { phi += 2 * AUVP_PI; length = -radius * phi; }
+            const double ang_vel = phi / (length / P.exp_rate);
+            double s0, c0;
+            auvp_sincos(th0, &s0, &c0);
+            const double x_C = lx - radius * s0;
+            const double y_C = ly + radius * c0;
+            const double ne = auvp_floor(length / P.exp_rate);
+            n_arc = (ne >= 0 && ne < 1e8) ? (int)ne + 1 : 0;
+            n_arc = uni(n_arc);
+            // sample the arc 64 points per pass; stop at the first pass that is not free
+            bool free_ = true;
+            for (int i0 = 0; i0 < n_arc && free_; i0 += 64) {
+              const int nv = (n_arc - i0) < 64 ? (n_arc - i0) : 64;
+              const int i = i0 + lane;
+              double ax = 0.0, ay = 0.0;
+              bool outside = false;
+              if (lane < nv) {
+                double sa, ca;
+                auvp_sincos(ang_vel * i + th0, &sa, &ca);
+                ax = x_C + radius * sa;
+                ay = y_C - radius * ca;
+                bool wx = (ax >= P.rect[0]) && (ax <= P.rect[2]);
+                bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
+                outside = !(wx && wy);
+              }
+              wave_sync();
+              if (lane < nv) { arc_pts[lane][0] = ax; arc_pts[lane][1] = ay; }
+              const double inf = __builtin_inf();
+              const double bx0 = wave_min_f64(lane < nv ? ax : inf), by0 = wave_min_f64(lane < nv ? ay : inf);
+              const double bx1 = -wave_min_f64(lane < nv ? -ax : inf), by1 = -wave_min_f64(lane < nv ? -ay : inf);
+              wave_sync();
+              if (__any(outside) || prrt_hits<J>(ox, oy, ot, arc_pts, nv, bx0, by0, bx1, by1)) free_ = false;
+            }
+            arc_free = free_ ? 1 : 0;
+            if (free_) {
+              done = 1;
+              int L = 1 + n_arc;
+              for (int m = last;;) {
+                const int4 r = nodeI[m];
+                const int gp = uni(r.y);
+                if (gp < 0) break;
+                L += uni(r.w) + 1;
+                m = gp;
+              }
+              if (lane == 0) {
+                sum.path_len = L; sum.last_node = last; sum.n_arc = n_arc;
+                sum.arc[0] = x_C; sum.arc[1] = y_C; sum.arc[2] = radius; sum.arc[3] = ang_vel; sum.arc[4] = th0;
+                sum.arc[5] = length;
+              }
+            }
+          }
+        }
+      }
+    }
+    (void)ltt;
+    if (logst && lane == 0) {
+      int32_t* l = B.st_log + ((size_t)ep * P.max_step + step) * 8;
+      l[0] = b; l[1] = par; l[2] = ok ? 1 : 0; l[3] = done; l[4] = P_n; l[5] = n_arc; l[6] = arc_free; l[7] = me;
+    }
+    step++;
+  }
+
+  // ---- persist the episode state for the next launch ----
+  const unsigned long long drawn = rng.drawn;
+  for (int i = lane; i < 624; i += 64) B.mt[(size_t)ep * 624 + i] = mt[i];
+  if (lane == 0) {
+    B.rng_state[4 * (size_t)ep] = (int32_t)rng.pslot;
+    B.rng_state[4 * (size_t)ep + 1] = (int32_t)rng.avail;
+    B.rng_state[4 * (size_t)ep + 2] = (int32_t)(uint32_t)(drawn & 0xffffffffull);
+    B.rng_state[4 * (size_t)ep + 3] = (int32_t)(uint32_t)(drawn >> 32);
+  }
+  // peek the next random() without consuming it (parity probe)
+  WaveRng peek = rng;
+  wave_sync();
+  rng_ensure(peek, 2u);  // may generate ahead in LDS only; the stored words above are untouched
+  const double after = rng_random_at(peek, 0u);
+  if (lane == 0) {
+    sum.status = status; sum.n_nodes = n_nodes; sum.n_points = n_points; sum.n_occ = n_occ; sum.steps = step;
+    sum.done = done; sum.last_accepted = last_accepted; sum.last_new_node = last_new;
+    sum.rng_after = after; sum.n_draw32 = drawn;
+    if (!done) { sum.path_len = 0; }
+  }
+}
+
+// generate_final_course(final_node) (:317-327) in the order planning() returns it: final node, arc
+// points last to first, then every ancestor segment down to the start.  Element = x,y,theta,traj_t,length.
+__global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, const int64_t* __restrict__ offsets,
+                                                               double* __restrict__ out, int n_episodes) {
+  const int ep = blockIdx.x;
+  if (ep >= n_episodes) return;
+  const int lane = lane_id();
+  const PrrtSummary s = B.summary[ep];
+  if (!s.done || s.path_len <= 0) return;
+  const int capn = B.cap_nodes;
+  const size_t capp = (size_t)B.cap_points;
+  const double* nodeF = B.node_f + (size_t)ep * capn * 4;
+  const int4* nodeI = reinterpret_cast<const int4*>(B.node_i) + (size_t)ep * capn;
+  const double* ptF = B.points + (size_t)ep * capp * 4;
+  double* o = out + 5 * (size_t)offsets[ep];
+  const double x_C = s.arc[0], y_C = s.arc[1], radius = s.arc[2], ang_vel = s.arc[3], th0 = s.arc[4];
+  const int n_arc = s.n_arc;
+  // arc point i sits at element 1 + (n_arc - 1 - i); the final node repeats the last arc point
+  for (int i = lane; i < n_arc; i += 64) {
+    double sa, ca;
+    const double a = ang_vel * i + th0;
+    auvp_sincos(a, &sa, &ca);
+    double* e = o + 5 * (size_t)(1 + (n_arc - 1 - i));
+    e[0] = x_C + radius * sa; e[1] = y_C - radius * ca; e[2] = a; e[3] = 0.0; e[4] = 0.0;
+    if (i == n_arc - 1) {
+      o[0] = e[0]; o[1] = e[1]; o[2] = a; o[3] = nodeF[(size_t)s.last_node * 4 + 3]; o[4] = s.arc[5];
+    }
+  }
+  if (n_arc == 0 && lane == 0) {
+    const double* nf = nodeF + (size_t)s.last_node * 4;
+    o[0] = nf[0]; o[1] = nf[1]; o[2] = nf[2]; o[3] = nf[3]; o[4] = s.arc[5];
+  }
+  int pos = 1 + n_arc;
+  for (int m = s.last_node;;) {
+    const int4 r = nodeI[m];
+    if (r.y < 0) break;
+    const int cnt = r.w, off = r.z;
+    for (int k = lane; k < cnt; k += 64) {
+      double* e = o + 5 * (size_t)(pos + (cnt - 1 - k));
+      size_t gi = (size_t)off + k;
+      e[0] = ptF[gi]; e[1] = ptF[capp + gi]; e[2] = ptF[2 * capp + gi]; e[3] = ptF[3 * capp + gi]; e[4] = 0.0;
+    }
+    pos += cnt;
+    if (lane == 0) {
+      const double* nf = nodeF + (size_t)r.y * 4;
+      double* e = o + 5 * (size_t)pos;
+      e[0] = nf[0]; e[1] = nf[1]; e[2] = nf[2]; e[3] = nf[3]; e[4] = 0.0;
+    }
+    pos++;
+    m = r.y;
+  }
+}
+
+}  // namespace auvp
+#endif

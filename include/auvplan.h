@@ -109,6 +109,52 @@ int auvp_rrt_bin_sizes(auvp_handle* h, int32_t episode, int32_t* sizes /* [K] */
 /* device-side result records for the multi-GPU gather: pointer to [E] auvp_rrt_summary in HBM */
 void* auvp_rrt_summaries_dev(auvp_handle* h);
 
+/* ---------------------------------------------------------------------------------------------
+ * Planner_RRT (gym_rrt/envs/rrt_dubins.py:34): goal-directed RRT driven by the RL environment.
+ * Obstacles come from auvp_world_set (list order matters, :445-451); everything else is here.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  double rect[4];          /* boundary corners x0,y0,x1,y1 (boundary[0], boundary[1], :45) */
+  double exp_rate, dist_to_end, diff_max, freq, cell_side_length; /* constructor kwargs, :34 */
+  int32_t subsections;     /* subsections_in_cell */
+  int32_t max_step;        /* node / step capacity of the batch (planning(max_step), :162) */
+} auvp_prrt_params;
+
+typedef struct {
+  int32_t status, n_nodes, n_points, n_occ, steps, done, path_len, last_node;
+  int32_t last_accepted, last_new_node, n_arc, _pad; /* outcome of the most recent step */
+  double arc[6];           /* successful goal arc: x_C, y_C, radius, ang_vel, theta_0, length */
+  double rng_after;        /* next random() of the episode's stream (not consumed) */
+  uint64_t n_draw32;
+} auvp_prrt_summary;
+
+/* Planner_RRT.__init__ for E episodes: starts [E,4] x,y,theta,traj_time_stamp; goals [E,2]; the start
+ * node is put into the (row, col, theta-subsection) bucket grid (:53,:108-159).  RNG: seeds [E]
+ * (random.seed(seed) streams) or, if seeds is NULL, mt [E,624] + mt_index [E] (random.getstate()). */
+int auvp_prrt_create_batch(auvp_handle* h, int32_t n_episodes, const double* starts, const double* goals,
+                           const auvp_prrt_params* params, const uint64_t* seeds, const uint32_t* mt,
+                           const int32_t* mt_index, int32_t flags);
+/* Planner_RRT.planning(max_step) (:162-202) for every episode: device-side loop until done / budget */
+int auvp_prrt_plan(auvp_handle* h);
+/* Planner_RRT.generate_one_node(grid_cell) (:205-248), one step per episode: bucket_ids [E] =
+ * (row*cols + col)*subsections + k of the chosen cell (<0 skips the episode).  mt/mt_index optional:
+ * continue that generator for this step (the caller's global `random` state) */
+int auvp_prrt_step(auvp_handle* h, const int32_t* bucket_ids, const uint32_t* mt, const int32_t* mt_index);
+int auvp_prrt_summaries(auvp_handle* h, auvp_prrt_summary* out /* [E] */);
+/* generate_final_course(final_node) (:317-327) in planning()'s return order (goal end first);
+ * offsets [E+1] prefix sums of path_len; out [offsets[E],5] = x,y,theta,traj_time_stamp,length */
+int auvp_prrt_paths(auvp_handle* h, const int64_t* offsets, double* out);
+/* one episode's tree: nodes4 [n,4] x,y,theta,traj_t; node_i4 [n,4] step,parent,pt_off,pt_cnt;
+ * node_bucket [n]; points4 [n_points,4] x,y,theta,traj_t */
+int auvp_prrt_tree(auvp_handle* h, int32_t episode, double* nodes4, int32_t* node_i4, int32_t* node_bucket,
+                   double* points4);
+/* env_grid state: occupied_grid_cells_array as bucket ids, len(node_array) per bucket, dims4 =
+ * rows, cols, subsections, n_occupied */
+int auvp_prrt_grid(auvp_handle* h, int32_t episode, int32_t* occupied, int32_t* bucket_counts, int32_t* dims4);
+/* per-step log (AUVP_FLAG_ITER_LOG): [max_step,8] bucket, picked, accepted, done, npath, arc_n, arc_free, new_node */
+int auvp_prrt_step_log(auvp_handle* h, int32_t episode, int32_t* log8);
+void* auvp_prrt_summaries_dev(auvp_handle* h);
+
 /* standalone evaluations on the device (parity probes for the building blocks) */
 /* RRT.check_collision (:530-549) of n_paths paths; pts [sum(npts),2], path i = pts[off[i]:off[i+1]] */
 int auvp_check_collision_batch(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xy,

@@ -251,8 +251,8 @@ int orc_prrt_planning(const orc_world* w, const orc_prrt_params* p, uint64_t see
   }
   o->steps = step; o->done = done; o->n_nodes = T.n_nodes; o->n_points = T.n_points; o->n_occ = T.n_occ;
   o->n_buckets = n_buckets;
+  o->n_draw32 = rng.n_draw32; /* outputs consumed by the planner itself */
   o->rng_after = cpy_random(&rng);
-  o->n_draw32 = rng.n_draw32;
   o->status = status;
   free(path_xy); free(tmp); free(arc); free(arc_xy);
   return status;
