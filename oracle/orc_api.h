@@ -87,9 +87,31 @@ typedef struct {
   double* path;           /* [cap_path,5] generate_final_course order (goal end first) */
 } orc_prrt_out;
 
+/* A* variants (path_planning/astar*.py); world: obstacles, habitats, polygon, bins, cells, prob */
+typedef struct {
+  int32_t variant;   /* 0 astar, 1 astar_real, 2 astar_fixLen, 3 astar_fixLenSOG */
+  int32_t cap_nodes;
+  double start[2], goal[2];
+  double box[4];     /* variant 0: min_bound.x, min_bound.y, max_bound.x, max_bound.y */
+  double limit, velocity;
+  double w[4];
+} orc_astar_params;
+
+typedef struct {
+  int32_t cap_exp, cap_path;                                       /* in */
+  int32_t n_nodes, n_expansions, n_children, found, status, path_len, smooth_len, n_hab_left, visited_count, _pad;
+  double* exp_log;     /* [cap_exp,8] popped node x,y,g,h,f,cost,pathLen,time_stamp */
+  double* path;        /* [cap_path,3] root -> leaf: x, y, round(time_stamp,2) */
+  double* cost_list;   /* [cap_path] leaf -> root */
+  double* node_path;   /* [cap_path,8] root -> leaf node fields */
+  double* smooth_path; /* [cap_path,3] variant 3 */
+  int32_t* hab_left;   /* [H] indices of the habitats still in habitat_open_list (variant 2) */
+} orc_astar_out;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int orc_astar_run(const orc_world* w, const orc_astar_params* p, orc_astar_out* o);
 const char* orc_math_name(void);
 double orc_sin(double x);
 double orc_cos(double x);

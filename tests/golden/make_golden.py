@@ -532,7 +532,152 @@ def g2():
               "path", None if "path" not in out else out["path"].shape)
 
 
-ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2}
+# --------------------------------------------------------------------------------------------
+# G1 / G6: the A* variants (path_planning/astar.py, astar_real.py, astar_fixLen.py, astar_fixLenSOG.py)
+# --------------------------------------------------------------------------------------------
+def _log_expansions(solver, log):
+    """every expansion calls curr_neighbors(current_node, ...) once: record the popped node there"""
+    orig = solver.curr_neighbors
+
+    def wrapped(node, *a):
+        log.append([float(node.position[0]), float(node.position[1]), float(node.g), float(node.h), float(node.f),
+                    float(getattr(node, "cost", 0.0)), float(getattr(node, "pathLen", 0.0)),
+                    float(getattr(node, "time_stamp", 0.0))])
+        return orig(node, *a)
+
+    solver.curr_neighbors = wrapped
+
+
+def run_astar_basic(world, start, goal):
+    mod, mpsm = import_astar("astar")
+    MPS = mpsm.Motion_plan_state
+    obs = [MPS(o[0], o[1], size=o[2]) for o in world["obstacles"].tolist()]
+    box = world["box"].tolist()
+    bnd = [MPS(box[0], box[1]), MPS(box[2], box[3])]
+    solver = mod.astar(start, goal, obs, bnd)
+    log = []
+    _log_expansions(solver, log)
+    with contextlib.redirect_stdout(io.StringIO()):
+        path = solver.astar(obs, start, goal)
+    return {"variant": "astar", "obstacles": world["obstacles"], "box": world["box"], "start": np.array(start, dtype=np.float64),
+            "goal": np.array(goal, dtype=np.float64), "found": path is not None,
+            "path": np.array([[p.x, p.y] for p in (path or [])], dtype=np.float64).reshape(-1, 2),
+            "expansions": np.array(log, dtype=np.float64).reshape(-1, 8)}
+
+
+def run_astar_real(obstacles, polygon, start, goal):
+    mod, mpsm = import_astar("astar_real")
+    MPS = mpsm.Motion_plan_state
+    obs = [MPS(o[0], o[1], size=o[2]) for o in obstacles]
+    bnd = [MPS(p[0], p[1]) for p in polygon]
+    solver = mod.astar(start, goal, obs, bnd)
+    log = []
+    _log_expansions(solver, log)
+    with contextlib.redirect_stdout(io.StringIO()):
+        path = solver.astar(obs, bnd)
+    return {"variant": "astar_real", "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
+            "polygon": np.array(polygon, dtype=np.float64), "start": np.array(start, dtype=np.float64),
+            "goal": np.array(goal, dtype=np.float64), "found": path is not None,
+            "path": np.array([[p.x, p.y] for p in (path or [])], dtype=np.float64).reshape(-1, 2),
+            "expansions": np.array(log, dtype=np.float64).reshape(-1, 8)}
+
+
+def run_astar_fixlen(obstacles, habitats, polygon, start, limit, weights):
+    mod, mpsm = import_astar("astar_fixLen")
+    MPS = mpsm.Motion_plan_state
+    obs = [MPS(o[0], o[1], size=o[2]) for o in obstacles]
+    hab = [MPS(h[0], h[1], size=h[2]) for h in habitats]
+    bnd = [MPS(p[0], p[1]) for p in polygon]
+    solver = mod.astar(start, obs, bnd)
+    log = []
+    _log_expansions(solver, log)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = solver.astar(hab, obs, bnd, start, limit, list(weights))
+    out = {"variant": "astar_fixLen", "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
+           "habitats": np.array(habitats, dtype=np.float64).reshape(-1, 3), "polygon": np.array(polygon, dtype=np.float64),
+           "start": np.array(start, dtype=np.float64), "limit": float(limit), "weights": np.array(weights, dtype=np.float64),
+           "found": res is not None, "expansions": np.array(log, dtype=np.float64).reshape(-1, 8),
+           "habitats_left": np.array([[h.x, h.y, h.size] for h in hab], dtype=np.float64).reshape(-1, 3),
+           "visited_count": int(solver.visited_nodes.sum())}
+    if res is not None:
+        out["path"] = np.array([[p.x, p.y] for p in res[0]], dtype=np.float64).reshape(-1, 2)
+        out["cost_list"] = np.array([float(c) for c in res[1]], dtype=np.float64)
+    return out
+
+
+def run_astar_sog(world, start, limit, weights, velocity=1):
+    mod, mpsm = import_astar("astar_fixLenSOG")
+    MPS = mpsm.Motion_plan_state
+    obstacles, habitats, poly, cell_list, shark = ref_world(world, MPS)
+    mod.splitCell = lambda polygon, size: cell_list  # shapely.ops.split is absent; cells come from the world
+    bnd = [MPS(p[0], p[1]) for p in world["polygon"].tolist()]
+    with contextlib.redirect_stdout(io.StringIO()):
+        solver = mod.astar(start, obstacles, bnd, habitats, shark, {}, velocity)
+    log = []
+    _log_expansions(solver, log)
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = solver.astar(limit, list(weights), {})
+    out = dict(world_arrays(world))
+    out.update({"variant": "astar_fixLenSOG", "start": np.array(start, dtype=np.float64), "limit": float(limit),
+                "weights": np.array(weights, dtype=np.float64), "velocity": float(velocity), "found": res is not None,
+                "expansions": np.array(log, dtype=np.float64).reshape(-1, 8),
+                "visited_count": int(solver.visited_nodes.sum())})
+    if res is not None:
+        out["path_length"] = int(res["path length"])
+        out["path"] = np.array([[p.x, p.y, p.traj_time_stamp] for p in res["path"]], dtype=np.float64).reshape(-1, 3)
+        out["cost"] = float(res["cost"])
+        out["cost_list"] = np.array([float(c) for c in res["cost list"]], dtype=np.float64)
+        out["node_path"] = np.array([[n.position[0], n.position[1], n.g, n.h, n.f, n.cost, n.pathLen, n.time_stamp]
+                                     for n in res["node"]], dtype=np.float64).reshape(-1, 8)
+    return out
+
+
+def g1():
+    # config 1: 50x50 lattice, 10 obstacles, (0,0) -> (490,490)
+    w = synth.make_lattice_world(seed=0, n_obstacles=10)
+    save_npz("g1_astar_cfg1.npz", **run_astar_basic(w, (0, 0), (490, 490)))
+    for k, (seed, nobs, st, gl) in enumerate([(1, 25, (0, 0), (490, 490)), (2, 40, (0, 490), (490, 0)),
+                                              (3, 10, (250, 250), (250, 260)), (4, 60, (0, 0), (300, 470))]):
+        w = synth.make_lattice_world(seed=seed, n_obstacles=nobs, r_range=(10, 25))
+        out = run_astar_basic(w, st, gl)
+        save_npz("g1_astar_%d.npz" % k, **out)
+        print("g1", k, "found", out["found"], "path", len(out["path"]), "expansions", len(out["expansions"]))
+    # float-valued start (round(., 2) style) in a polygon world: astar_real
+    rect = [(-300.0, -100.0), (-100.0, -100.0), (-100.0, 100.0), (-300.0, 100.0)]
+    penta = [(-300.0, -100.0), (-120.0, -120.0), (-80.0, 20.0), (-180.0, 110.0), (-320.0, 60.0)]
+    for k, (seed, poly, st, gl) in enumerate([(5, rect, (-290.0, -90.0), (-110.0, 90.0)),
+                                              (6, penta, (-285.37, -82.11), (-125.37, 57.89)),
+                                              (7, rect, (-200.5, 0.25), (-120.5, -79.75))]):
+        w = synth.make_world(seed=seed, n_obstacles=24, obst_radius=(3.0, 9.0), start=st)
+        obs = [o for o in w["obstacles"].tolist() if (o[0] - gl[0]) ** 2 + (o[1] - gl[1]) ** 2 > (o[2] + 12) ** 2]
+        out = run_astar_real(obs, poly, st, gl)
+        save_npz("g1_real_%d.npz" % k, **out)
+        print("g1 real", k, "found", out["found"], "path", len(out["path"]), "expansions", len(out["expansions"]))
+
+
+def g6():
+    rect = [(-300.0, -100.0), (-100.0, -100.0), (-100.0, 100.0), (-300.0, 100.0)]
+    penta = [(-300.0, -100.0), (-120.0, -120.0), (-80.0, 20.0), (-180.0, 110.0), (-320.0, 60.0)]
+    specs = [(21, rect, (-290.0, -90.0), 200, (0, 10, 10), 12), (22, penta, (-280.0, -80.0), 400, (0, 10, 10), 12),
+             (23, rect, (-200.0, 0.0), 300, (0, 3.5, 1.25), 20), (24, rect, (-290.5, -90.25), 150, (0, 10, 10), 8)]
+    for k, (seed, poly, st, limit, wts, nobs) in enumerate(specs):
+        w = synth.make_world(seed=seed, n_obstacles=nobs, obst_radius=(3.0, 8.0), start=st, n_habitats=8,
+                             hab_radius=(10.0, 25.0))
+        out = run_astar_fixlen(w["obstacles"].tolist(), w["habitats"].tolist(), poly, st, limit, wts)
+        save_npz("g6_fixlen_%d.npz" % k, **out)
+        print("g6 fixlen", k, "found", out["found"], "path", len(out.get("path", [])), "expansions", len(out["expansions"]),
+              "habitats left", len(out["habitats_left"]))
+    sog = [(31, (-290.0, -90.0), 200, (0, 10, 10, 100), 16), (32, (-200.0, 0.0), 300, (0, 10, 10, 100), 16),
+           (33, (-290.0, 90.0), 100, (0, 2.5, 1.5, 40.5), 64)]
+    for k, (seed, st, limit, wts, nobs) in enumerate(sog):
+        w = synth.make_world(seed=seed, n_obstacles=nobs, obst_radius=(2.0, 6.0), start=st, n_habitats=8,
+                             hab_radius=(10.0, 25.0))
+        out = run_astar_sog(w, st, limit, wts)
+        save_npz("g6_sog_%d.npz" % k, **out)
+        print("g6 sog", k, "found", out["found"], "path", out.get("path_length"), "expansions", len(out["expansions"]))
+
+
+ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)
