@@ -1,0 +1,412 @@
+// astar_kernel.h -- the four runnable A* variants of path_planning/astar*.py on gfx950, one wavefront
+// per search instance (start / goal / length limit), E instances per launch over one shared world.
+//
+//   variant 0  astar.py           box bounds, squared-distance g/h, exact-goal stop        (:193-271)
+//   variant 1  astar_real.py      polygon-fan bounds, stop within 10 m of the goal        (:144-222)
+//   variant 2  astar_fixLen.py    fixed path length, habitat-coverage cost, visited bitmap (:286-418)
+//   variant 3  astar_fixLenSOG.py fixLen + shark-occupancy reward / top-n heuristic        (:551-657)
+//
+// The search itself is a serial chain (pop the first minimum f, expand 8 neighbours); the lanes
+// split the work inside one expansion:
+//   open-set scan       lane-strided min over every node created so far (open flag), first index wins
+//   bounds + collision  lane = (neighbour k, slice s): 8 x 8 lanes cover the 8 neighbours, each slice
+//                       takes every 8th fan triangle / obstacle
+//   SOG cell lookup     64 cells per pass in dict order, first match by ballot
+// Quirks kept: no dedup apart from the visited bitmap, fixLen's h with pathLen == 0,
+// update_habitat_coverage popping while it enumerates, get_cell_prob's rounded corners.
+#ifndef AUVP_ASTAR_KERNEL_H
+#define AUVP_ASTAR_KERNEL_H
+#include "auvp_math.h"
+#include "auvp_types.h"
+#include "auvp_wave.h"
+
+namespace auvp {
+
+struct AstarWorldDev {
+  int32_t n_obstacles, n_habitats, n_poly, n_bins, n_cells, _pad;
+  const double* ox;      // [O]
+  const double* oy;
+  const double* ot;      // [O] T(size_i): `d <= size` on the squared distance (plain, per obstacle)
+  const double* hab;     // [H,4] x, y, size, T(size)
+  const double* poly;    // [V,2]
+  const double* bins;    // [T,2]
+  const double* rcells;  // [C,4] cell corners rounded to 2 decimals (get_cell_prob, :500-501)
+  const double* prob;    // [T,C]
+  const double* topn;    // [T,C+1] prefix sums of the descending-sorted probabilities (get_top_n_prob)
+  double cx, cy;         // polygon centroid (fan apex)
+};
+
+struct AstarParamsDev {
+  int32_t variant, cap_nodes, cap_exp, flags;
+  double box[4];
+  double velocity;
+  double w[4];
+  int32_t vx, vy;  // visited bitmap dims
+};
+
+struct AstarSummary {  // must match auvp_astar_summary
+  int32_t status, found, n_nodes, n_expansions, n_children, path_len, smooth_len, n_hab_left, visited_count, leaf, _p0, _p1;
+};
+
+struct AstarBuffers {
+  const double* start;   // [E,2]
+  const double* goal;    // [E,2]   (variants 0,1)
+  const double* limit;   // [E]     (variants 2,3)
+  double* nodes;         // [E][7][cap_nodes] SoA x, y, g, h, f, cost, pathLen
+  int32_t* node_i;       // [E][3][cap_nodes] parent, time_stamp, open
+  uint8_t* visited;      // [E][vx*vy]
+  int32_t* hab_left;     // [E][H]
+  double* exp_log;       // optional [E][cap_exp][8]
+  AstarSummary* summary; // [E]
+};
+
+__device__ __forceinline__ double astar_sqdist(double ax, double ay, double bx, double by) {
+  double dx = auvp_fabs(ax - bx), dy = auvp_fabs(ay - by);
+  return dx * dx + dy * dy;
+}
+
+// same_side (astar_real.py:62-68): np.cross of 2-vectors = a0*b1 - a1*b0
+__device__ __forceinline__ bool astar_same_side(double p1x, double p1y, double p2x, double p2y, double ax, double ay,
+                                                double bx, double by) {
+  double ex = bx - ax, ey = by - ay;
+  double cp1 = ex * (p1y - ay) - ey * (p1x - ax);
+  double cp2 = ex * (p2y - ay) - ey * (p2x - ax);
+  return cp1 * cp2 >= 0;
+}
+
+__device__ __forceinline__ bool astar_in_triangle(double px, double py, double ax, double ay, double bx, double by,
+                                                  double cx, double cy) {
+  return astar_same_side(px, py, ax, ay, bx, by, cx, cy) & astar_same_side(px, py, bx, by, ax, ay, cx, cy) &
+         astar_same_side(px, py, cx, cy, ax, ay, bx, by);
+}
+
+// wave-cooperative collision_free(position) (:120-135): true when no obstacle covers the point
+__device__ __forceinline__ bool astar_point_free(const AstarWorldDev& W, double px, double py) {
+  bool hit = false;
+  for (int i = lane_id(); i < W.n_obstacles; i += 64) {
+    double dx = px - W.ox[i], dy = py - W.oy[i];
+    hit = hit | (dx * dx + dy * dy <= W.ot[i]);
+  }
+  return !__any(hit);
+}
+
+constexpr int ASTAR_WAVES = 4;
+constexpr int ASTAR_MAX_HAB = 64;
+
+__global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W, AstarParamsDev P, AstarBuffers B, int n_inst) {
+  __shared__ int32_t s_hopen[ASTAR_WAVES][ASTAR_MAX_HAB];
+  __shared__ int32_t s_hclosed[ASTAR_WAVES][ASTAR_MAX_HAB];
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  const int ep = (int)blockIdx.x * ASTAR_WAVES + wave;
+  if (ep >= n_inst) return;
+  const int V = P.variant;
+  const int cap = P.cap_nodes;
+  double* nd = B.nodes + (size_t)ep * 7 * cap;
+  double *nx = nd, *ny = nd + cap, *ng = nd + 2 * (size_t)cap, *nh = nd + 3 * (size_t)cap, *nf = nd + 4 * (size_t)cap,
+         *ncost = nd + 5 * (size_t)cap, *nlen = nd + 6 * (size_t)cap;
+  int32_t* ni = B.node_i + (size_t)ep * 3 * cap;
+  int32_t *npar = ni, *nts = ni + cap, *nopen = ni + 2 * (size_t)cap;
+  uint8_t* visited = B.visited ? B.visited + (size_t)ep * P.vx * P.vy : nullptr;
+  int32_t* hopen = s_hopen[wave];
+  int32_t* hclosed = s_hclosed[wave];
+  const int H = W.n_habitats, C = W.n_cells, T = W.n_bins;
+  const double sx = readfirst_f64(B.start[2 * (size_t)ep]), sy = readfirst_f64(B.start[2 * (size_t)ep + 1]);
+  double gx = 0.0, gy = 0.0, limit = 0.0;
+  if (V <= 1) { gx = readfirst_f64(B.goal[2 * (size_t)ep]); gy = readfirst_f64(B.goal[2 * (size_t)ep + 1]); }
+  else limit = readfirst_f64(B.limit[ep]);
+  const double w2 = P.w[1], w3 = P.w[2], w4 = P.w[3];
+  const bool logx = (P.flags & 1) != 0 && B.exp_log != nullptr;
+
+  for (int i = lane; i < H; i += 64) hopen[i] = i;
+  int n_hopen = H, n_hclosed = 0;
+  if (lane == 0) {
+    nx[0] = sx; ny[0] = sy; ng[0] = 0.0; nh[0] = 0.0; nf[0] = 0.0; ncost[0] = 0.0; nlen[0] = 0.0;
+    npar[0] = -1; nts[0] = 0; nopen[0] = 1;
+  }
+  wave_sync();
+  int n_nodes = 1, n_open = 1, n_exp = 0, n_children = 0, status = 0, found = -1, visited_count = 0;
+  int first_open = 0;  // every node below this index is closed
+
+  // neighbour offsets: lane k = lane >> 3 handles neighbour k, slice s = lane & 7
+  const int k8 = lane >> 3, s8 = lane & 7;
+  int offx, offy;
+  {
+    // astar.py:88 order vs the other variants' (astar_fixLen.py:146)
+    const int ax[8] = {0, 0, -10, 10, 10, 10, -10, -10}, ay[8] = {-10, 10, 0, 0, 10, -10, 10, -10};
+    const int bx[8] = {0, 0, -10, 10, -10, -10, 10, 10}, by[8] = {-10, 10, 0, 0, -10, 10, -10, 10};
+    offx = V == 0 ? ax[k8] : bx[k8];
+    offy = V == 0 ? ay[k8] : by[k8];
+  }
+
+  while (n_open > 0) {
+    // ------------------------------------------------------------ pop the first minimum f
+    double bf = __builtin_inf();
+    int bi = 0x7fffffff;
+    for (int i = first_open + lane; i < n_nodes; i += 64) {
+      if (nopen[i]) {
+        double f = nf[i];
+        if (bi == 0x7fffffff || f < bf) { bf = f; bi = i; }
+      }
+    }
+    // reduce: smaller f wins; on equal f the smaller index wins (list order)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      double of = __shfl_xor(bf, o, 64);
+      int oi = __shfl_xor(bi, o, 64);
+      bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || of < bf || (of == bf && oi < bi));
+      bf = take ? of : bf;
+      bi = take ? oi : bi;
+    }
+    const int cur = uni(bi);
+    if (lane == 0) nopen[cur] = 0;
+    n_open--;
+    if (cur == first_open) first_open++;
+    const double cxp = readfirst_f64(nx[cur]), cyp = readfirst_f64(ny[cur]);
+    const double cg = readfirst_f64(ng[cur]), ccost = readfirst_f64(ncost[cur]), clen = readfirst_f64(nlen[cur]);
+    bool stop;
+    if (V == 0) stop = (cxp == gx && cyp == gy);
+    else if (V == 1) stop = astar_sqdist(cxp, cyp, gx, gy) <= 100;
+    else stop = auvp_fabs(clen - limit) <= 10;
+    if (stop) { found = cur; break; }
+    if (logx && n_exp < P.cap_exp && lane == 0) {
+      double* e = B.exp_log + ((size_t)ep * P.cap_exp + n_exp) * 8;
+      e[0] = cxp; e[1] = cyp; e[2] = cg; e[3] = nh[cur]; e[4] = nf[cur]; e[5] = ccost; e[6] = clen; e[7] = (double)nts[cur];
+    }
+    n_exp++;
+    // ------------------------------------------------------------ neighbours: bounds, then collision
+    const double qx = cxp + (double)offx, qy = cyp + (double)offy;
+    bool inb;
+    if (V == 0) {
+      inb = (qx >= P.box[0] && qx <= P.box[2]) && (qy >= P.box[1] && qy <= P.box[3]);
+    } else {
+      bool any_tri = false;
+      for (int i = s8; i < W.n_poly; i += 8) {
+        int j = (i != W.n_poly - 1) ? i + 1 : 0;
+        any_tri = any_tri | astar_in_triangle(qx, qy, W.poly[2 * i], W.poly[2 * i + 1], W.poly[2 * j], W.poly[2 * j + 1],
+                                              W.cx, W.cy);
+      }
+      unsigned long long bm = __ballot(any_tri);
+      inb = ((bm >> (k8 * 8)) & 0xffull) != 0;
+    }
+    bool hit = false;
+    if (inb) {
+      for (int i = s8; i < W.n_obstacles; i += 8) {
+        double dx = qx - W.ox[i], dy = qy - W.oy[i];
+        hit = hit | (dx * dx + dy * dy <= W.ot[i]);
+      }
+    }
+    const unsigned long long hm = __ballot(hit);
+    const unsigned long long im = __ballot(inb && s8 == 0);
+    int childmask = 0;  // bit k: neighbour k becomes a child
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      bool in_k = (im >> (k * 8)) & 1ull;
+      bool hit_k = ((hm >> (k * 8)) & 0xffull) != 0;
+      n_children += in_k ? 1 : 0;
+      childmask |= (in_k && !hit_k) ? (1 << k) : 0;
+    }
+    const int nch = __popc(childmask);
+    if (n_nodes + nch > cap) { status = -2; break; }
+    // ------------------------------------------------------------ children, in neighbour order
+    if (V == 2) {
+      // first loop of :350-363: habitat coverage update per new node (mutates the lists)
+      for (int k = 0; k < 8; k++) {
+        if (!((childmask >> k) & 1)) continue;
+        const double px = __shfl(qx, k * 8, 64), py = __shfl(qy, k * 8, 64);
+        if (lane == 0) {
+          // update_habitat_coverage (:182-199): pop(index) while enumerating skips the next element
+          for (int idx = 0; idx < n_hopen; idx++) {
+            const double* hb = W.hab + 4 * (size_t)hopen[idx];
+            double ddx = px - hb[0], ddy = py - hb[1];
+            if (ddx * ddx + ddy * ddy <= hb[3]) {
+              hclosed[n_hclosed++] = hopen[idx];
+              for (int m = idx; m < n_hopen - 1; m++) hopen[m] = hopen[m + 1];
+              n_hopen--;
+            }
+          }
+        }
+        n_hopen = __shfl(n_hopen, 0, 64);
+        n_hclosed = __shfl(n_hclosed, 0, 64);
+        wave_sync();
+      }
+    }
+    int slot = 0;
+    for (int k = 0; k < 8 && status == 0; k++) {
+      if (!((childmask >> k) & 1)) continue;
+      const int c = n_nodes + slot;
+      slot++;
+      const double px = readfirst_f64(__shfl(qx, k * 8, 64)), py = readfirst_f64(__shfl(qy, k * 8, 64));
+      double g_, h_, f_, cost_ = 0.0, len_ = 0.0;
+      int ts_ = 0, open_ = 1;
+      if (V <= 1) {
+        g_ = cg + astar_sqdist(px, py, cxp, cyp);
+        h_ = astar_sqdist(px, py, gx, gy);
+        f_ = g_ + h_;
+      } else if (V == 2) {
+        // cost_of_edge with the lists as they stand after all children were created (:395-400, cost.py:66-101)
+        bool d2l = false, d3l = false;
+        for (int i = lane; i < n_hopen + n_hclosed; i += 64) {
+          const bool closed = i >= n_hopen;
+          const double* hb = W.hab + 4 * (size_t)(closed ? hclosed[i - n_hopen] : hopen[i]);
+          double ddx = px - hb[0], ddy = py - hb[1];
+          bool cov = ddx * ddx + ddy * ddy <= hb[3];
+          d2l = d2l | cov;
+          d3l = d3l | (cov && closed);
+        }
+        const double d2 = __any(d2l) ? 1.0 : 0.0, d3 = __any(d3l) ? 1.0 : 0.0;
+        g_ = ccost - w2 * d2 - w3 * d3;
+        cost_ = g_;
+        h_ = -w2 * auvp_fabs(limit - 0.0) - w3 * (double)n_hopen;  // child.pathLen is still 0 (:401-403)
+        f_ = g_ + h_;
+        len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
+      } else {
+        len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
+        const double dist_left = auvp_fabs(limit - len_);
+        ts_ = (int)(len_ / P.velocity);
+        int tb = -1;
+        for (int t = 0; t < T; t++) {
+          if ((double)ts_ <= W.bins[2 * t + 1] && (double)ts_ >= W.bins[2 * t]) { tb = t; break; }
+        }
+        if (tb < 0) { status = -1; break; }
+        // get_cell_prob (:485-514): first cell in dict order whose rounded corners bracket the point
+        int key = -1;
+        for (int c0 = 0; c0 < C && key < 0; c0 += 64) {
+          int ci = c0 + lane;
+          bool m = false;
+          if (ci < C) {
+            const double4 r = reinterpret_cast<const double4*>(W.rcells)[ci];
+            double ddx = auvp_fabs(r.x - r.z), ddy = auvp_fabs(r.y - r.w);
+            m = (auvp_fabs(px - r.x) <= ddx && auvp_fabs(px - r.z) <= ddx) && (auvp_fabs(py - r.y) <= ddy && auvp_fabs(py - r.w) <= ddy);
+          }
+          unsigned long long mm = __ballot(m);
+          if (mm) key = c0 + (__ffsll((long long)mm) - 1);
+        }
+        if (key < 0) { status = -1; break; }
+        const int ntop = (int)dist_left;
+        if (ntop > C) { status = -1; break; }
+        g_ = ccost - w4 * W.prob[(size_t)tb * C + key];
+        cost_ = g_;
+        h_ = -w2 * dist_left - w3 * (double)H - w4 * W.topn[(size_t)tb * (C + 1) + ntop];
+        f_ = g_ + h_;
+      }
+      if (V >= 2) {
+        // visited bitmap (:414-416 / :653-657), numpy index semantics (negative wraps)
+        int xi = (int)(px + 500), yi = (int)(py + 200);
+        if (xi < 0) xi += P.vx;
+        if (yi < 0) yi += P.vy;
+        if (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy) { status = -1; break; }
+        const size_t vi = (size_t)xi * P.vy + yi;
+        const int was = uni((int)visited[vi]);
+        if (was) open_ = 0;
+        else {
+          if (lane == 0) visited[vi] = 1;
+          visited_count++;
+        }
+      }
+      if (lane == 0) {
+        nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = cost_; nlen[c] = len_;
+        npar[c] = cur; nts[c] = ts_; nopen[c] = open_;
+      }
+      n_open += open_;
+      wave_sync();
+    }
+    if (status) break;
+    n_nodes += nch;
+  }
+
+  for (int i = lane; i < n_hopen; i += 64) B.hab_left[(size_t)ep * (H > 0 ? H : 1) + i] = hopen[i];
+  if (lane == 0) {
+    AstarSummary& s = B.summary[ep];
+    s.status = status; s.found = found >= 0 ? 1 : 0; s.n_nodes = n_nodes; s.n_expansions = n_exp; s.n_children = n_children;
+    int L = 0;
+    for (int m = found; m >= 0; m = npar[m]) L++;
+    s.path_len = L; s.smooth_len = 0; s.n_hab_left = n_hopen; s.visited_count = visited_count; s.leaf = found;
+    s._p0 = 0; s._p1 = 0;
+  }
+}
+
+// Backtrack of the popped goal node (:231-243 / :319-333 / :593-618) and, for variant 3, smoothPath
+// (:404-440).  out per instance: path [L,3] root->leaf x,y,round(time_stamp,2); cost_list [L] leaf->root;
+// node_path [L,8] root->leaf; smooth [<=L,3].  One wave per instance.
+__global__ __launch_bounds__(64) void astar_path_kernel(AstarWorldDev W, AstarParamsDev P, AstarBuffers B,
+                                                        const int64_t* __restrict__ offsets, double* __restrict__ path,
+                                                        double* __restrict__ cost_list, double* __restrict__ node_path,
+                                                        double* __restrict__ smooth, int n_inst) {
+  const int ep = blockIdx.x;
+  if (ep >= n_inst) return;
+  const int lane = lane_id();
+  AstarSummary& s = B.summary[ep];
+  if (!s.found || s.path_len <= 0) return;
+  const int cap = P.cap_nodes, L = s.path_len;
+  const double* nd = B.nodes + (size_t)ep * 7 * cap;
+  const int32_t* ni = B.node_i + (size_t)ep * 3 * cap;
+  const size_t o = (size_t)offsets[ep];
+  double* pth = path + 3 * o;
+  if (lane == 0) {
+    int k = 0;
+    for (int m = s.leaf; m >= 0; m = ni[m], k++) {
+      cost_list[o + k] = nd[5 * (size_t)cap + m];
+      double* e = pth + 3 * (size_t)(L - 1 - k);
+      e[0] = nd[m]; e[1] = nd[cap + m]; e[2] = (double)ni[cap + m];  // round(int, 2) == int
+      double* q = node_path + 8 * (o + (size_t)(L - 1 - k));
+      q[0] = nd[m]; q[1] = nd[cap + m]; q[2] = nd[2 * (size_t)cap + m]; q[3] = nd[3 * (size_t)cap + m];
+      q[4] = nd[4 * (size_t)cap + m]; q[5] = nd[5 * (size_t)cap + m]; q[6] = nd[6 * (size_t)cap + m];
+      q[7] = (double)ni[cap + m];
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (P.variant != 3) return;
+  // smoothPath: keep[] lives in the smooth buffer's tail until compaction (L doubles are enough)
+  int status = 0;
+  unsigned long long keepm[8];  // L <= 512 path nodes as bit masks
+  for (int i = 0; i < 8; i++) keepm[i] = ~0ull;
+  if (L > 512) { if (lane == 0) s.status = -2; return; }
+  if (L >= 2) {
+    int index = 1, check = 0, curp = 1;
+    while (index < L - 1) {
+      const double ax = pth[3 * (size_t)check], ay = pth[3 * (size_t)check + 1];
+      const double bx = pth[3 * (size_t)curp], by = pth[3 * (size_t)curp + 1];
+      // Walkable (:218-242)
+      double wx = ax, wy = ay;
+      const int step_x = (int)(auvp_fabs(bx - ax) / 5), step_y = (int)(auvp_fabs(by - ay) / 5);
+      bool walk = true;
+      int guard = 0;
+      while (wx <= bx && wy <= by) {
+        const double ix = wx, iy = wy;
+        wx += step_x; wy += step_y;
+        if (!astar_point_free(W, ix, iy)) { walk = false; break; }
+        if (++guard > 1000000) { status = -1; break; }  // both steps 0: the reference never returns
+      }
+      if (status) break;
+      if (walk) {
+        // inside_habitats (:304-320): module-level euclidean_dist = sqrt(|dx|^2 + |dy|^2)
+        bool inside = false;
+        for (int h = lane; h < W.n_habitats; h += 64) {
+          double d = auvp_sqrt(astar_sqdist(W.hab[4 * h], W.hab[4 * h + 1], bx, by));
+          inside = inside | (d <= W.hab[4 * h + 2]);
+        }
+        if (!__any(inside)) keepm[curp >> 6] &= ~(1ull << (curp & 63));
+        index += 1; curp = index;
+      } else {
+        check = curp; index += 1; curp = index;
+      }
+    }
+  }
+  if (lane == 0) {
+    int n = 0;
+    for (int i = 0; i < L; i++) {
+      if ((keepm[i >> 6] >> (i & 63)) & 1ull) {
+        smooth[3 * (o + n)] = pth[3 * (size_t)i]; smooth[3 * (o + n) + 1] = pth[3 * (size_t)i + 1];
+        smooth[3 * (o + n) + 2] = pth[3 * (size_t)i + 2];
+        n++;
+      }
+    }
+    s.smooth_len = n;
+    if (status) s.status = status;
+  }
+}
+
+}  // namespace auvp
+#endif

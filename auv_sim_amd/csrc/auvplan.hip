@@ -62,6 +62,8 @@ struct auvp_handle {
   // planner families that live in their own headers keep their state behind an opaque pointer
   void* prrt = nullptr;
   void (*prrt_free)(void*) = nullptr;
+  std::vector<double> w_obst, w_hab, w_poly, w_bins, w_cells, w_prob;  // host copy of the world
+  unsigned world_version = 0;
   void* astar = nullptr;
   void (*astar_free)(void*) = nullptr;
 };
@@ -264,6 +266,14 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
     bb[2] = std::max(bb[2], polygon[2 * i]); bb[3] = std::max(bb[3], polygon[2 * i + 1]);
   }
   memcpy(W.bb, bb, sizeof bb);
+  // host copies: the A* family derives its own device tables from the same world (astar_host.h)
+  h->w_obst.assign(obstacles, obstacles + (size_t)O * 3);
+  h->w_hab.assign(habitats, habitats + (size_t)H * 3);
+  h->w_poly.assign(polygon, polygon + (size_t)V * 2);
+  h->w_bins.assign(bins, bins + (size_t)T * 2);
+  h->w_cells.assign(cells, cells + (size_t)C * 4);
+  h->w_prob.assign(prob, prob + (size_t)T * C);
+  h->world_version++;
   h->have_world = true;
   return AUVP_OK;
 }
@@ -282,6 +292,8 @@ int auvp_world_set_habitats(auvp_handle* h, const double* habitats, int32_t H) {
   h->W.n_habitats = H;
   h->W.hab = h->d_hab.as<double>();
   h->W.hab_t = h->d_habt.as<double>();
+  h->w_hab.assign(habitats, habitats + (size_t)H * 3);
+  h->world_version++;
   return AUVP_OK;
 }
 
@@ -583,3 +595,6 @@ PrrtState* prrt_of(auvp_handle* h) {
   return static_cast<PrrtState*>(h->prrt);
 }
 }  // namespace
+
+#include "astar_kernel.h"
+#include "astar_host.h"

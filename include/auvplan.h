@@ -155,6 +155,41 @@ int auvp_prrt_grid(auvp_handle* h, int32_t episode, int32_t* occupied, int32_t* 
 int auvp_prrt_step_log(auvp_handle* h, int32_t episode, int32_t* log8);
 void* auvp_prrt_summaries_dev(auvp_handle* h);
 
+/* ---------------------------------------------------------------------------------------------
+ * A* variants (path_planning/astar.py, astar_real.py, astar_fixLen.py, astar_fixLenSOG.py), one
+ * wavefront per search instance, E instances over the world of auvp_world_set (obstacles = obs_lst,
+ * habitats = habitat_list, polygon = boundary_list corners, bins/cells/prob = sharkGrid).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t variant;   /* 0 astar.astar (astar.py:193), 1 astar_real (:144), 2 astar_fixLen (:286), 3 astar_fixLenSOG (:551) */
+  int32_t cap_nodes; /* Node capacity per instance; overflow -> AUVP_ERR_CAPACITY in the instance's status */
+  double box[4];     /* variant 0: boundary[0].x, boundary[0].y, boundary[1].x, boundary[1].y (astar.py:26-27) */
+  double velocity;   /* variant 3: AUV_velocity (astar_fixLenSOG.py:111) */
+  double w[4];       /* weights (w1 unused by the searches, as in the reference) */
+} auvp_astar_params;
+
+typedef struct {
+  int32_t status;        /* 0 ok; <0: capacity, or a state in which the reference raises (IndexError / TypeError) */
+  int32_t found;         /* 0: open list ran empty -> the reference returns None */
+  int32_t n_nodes, n_expansions;
+  int32_t n_children;    /* neighbour cells that passed the bounds test (the "cells/s" unit) */
+  int32_t path_len, smooth_len, n_hab_left, visited_count, leaf, _p0, _p1;
+} auvp_astar_summary;
+
+/* starts [E,2]; goals [E,2] (variants 0,1) or limits [E] = pathLenLimit (variants 2,3) */
+int auvp_astar_batch(auvp_handle* h, int32_t n_instances, const double* starts, const double* goals,
+                     const double* limits, const auvp_astar_params* params, int32_t flags);
+int auvp_astar_summaries(auvp_handle* h, auvp_astar_summary* out /* [E] */);
+/* offsets [E+1] prefix sums of path_len.  path3 [n,3] root->leaf x,y,round(time_stamp,2); cost_list [n]
+ * leaf->root ("cost list"); node_path8 [n,8] root->leaf x,y,g,h,f,cost,pathLen,time_stamp ("node");
+ * smooth3 [n,3] smoothPath output (variant 3; smooth_len rows per instance, re-read the summaries) */
+int auvp_astar_paths(auvp_handle* h, const int64_t* offsets, double* path3, double* cost_list, double* node_path8,
+                     double* smooth3);
+/* AUVP_FLAG_ITER_LOG: the popped node of every expansion, [n_expansions,8] like node_path8 */
+int auvp_astar_exp_log(auvp_handle* h, int32_t instance, double* out8);
+/* variant 2: indices of the habitats still in the caller's habitat_list after the call (:310,:193-197) */
+int auvp_astar_hab_left(auvp_handle* h, int32_t instance, int32_t* out);
+
 /* standalone evaluations on the device (parity probes for the building blocks) */
 /* RRT.check_collision (:530-549) of n_paths paths; pts [sum(npts),2], path i = pts[off[i]:off[i+1]] */
 int auvp_check_collision_batch(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xy,
