@@ -1,0 +1,58 @@
+"""Drop-in for path_planning/astar_fixLenSOG.py: `astar(start, obstacleList, boundaryList, habitatList,
+sharkGrid, shark_dict, AUV_velocity).astar(pathLenLimit, weights, shark_traj)` -> dict with
+"path length", "path" (smoothed), "cost", "cost list", "node" -- or None when the open list runs empty
+(astar_fixLenSOG.py:111,551,618).  `sharkGrid` must be given ({(t0,t1): {cell.bounds: prob}}); the
+reference's fallback for `{}` (splitCell + a CSV path relative to its repo root, :127-132) needs shapely
+and is not reproduced.  Deviation: visited bitmap starts clean on every call (see astar_fixLen)."""
+import numpy as np
+
+from . import _astar_common as ac
+from ._astar_common import Node
+from .motion_plan_state import Motion_plan_state
+from .rrt_dubins import pack_shark_grid
+
+
+class astar:
+    def __init__(self, start, obstacleList, boundaryList, habitatList, sharkGrid, shark_dict, AUV_velocity,
+                 cap_nodes=200000, device=0):
+        if not sharkGrid:
+            raise ValueError("sharkGrid is required (the reference's CSV/splitCell fallback is not reproduced)")
+        self.start = start
+        self.velocity = AUV_velocity
+        self.obstacle_list = obstacleList
+        self.boundary_list = boundaryList
+        self.habitat_list = habitatList
+        self.visited_nodes = np.zeros([600, 600])
+        self.sharkGrid = sharkGrid
+        self.sharkDict = shark_dict
+        self.cap_nodes = cap_nodes
+        self._ctx = ac.context(device)
+        self._bins, self._cells, self._prob = pack_shark_grid(sharkGrid)
+
+    def _result(self, r, start):
+        if not r["found"]:
+            return None
+        like = start
+        nodes = []
+        prev = None
+        for q in r["node_path"]:  # root -> leaf
+            n = Node(prev, ac.position_of((q[0], q[1]), like))
+            n.g, n.h, n.f, n.cost, n.pathLen, n.time_stamp = float(q[2]), float(q[3]), float(q[4]), float(q[5]), float(q[6]), int(q[7])
+            nodes.append(n)
+            prev = n
+        smooth = []
+        for s in r["smooth_path"]:
+            p = ac.position_of((s[0], s[1]), like)
+            smooth.append(Motion_plan_state(p[0], p[1], traj_time_stamp=int(s[2])))
+        cost = [float(c) for c in r["cost_list"]]
+        return {"path length": len(smooth), "path": smooth, "cost": cost[0], "cost list": cost, "node": nodes}
+
+    def astar(self, pathLenLimit, weights, shark_traj):
+        return self.astar_batch([self.start], [pathLenLimit], weights)[0]
+
+    def astar_batch(self, starts, limits, weights):
+        self._ctx.set_world(obstacles=ac.circles(self.obstacle_list), habitats=ac.circles(self.habitat_list),
+                            polygon=ac.corners(self.boundary_list), bins=self._bins, cells=self._cells, prob=self._prob)
+        res = ac.run(self._ctx, "astar_fixLenSOG", [tuple(map(float, s)) for s in starts], limits=[float(v) for v in limits],
+                     weights=[float(w) for w in weights], velocity=float(self.velocity), cap_nodes=self.cap_nodes)
+        return [self._result(r, starts[i]) for i, r in enumerate(res)]

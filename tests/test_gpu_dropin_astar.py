@@ -1,0 +1,69 @@
+"""The A* drop-in modules used like their reference counterparts (same constructor / method
+signatures, Motion_plan_state lists in and out), compared with the goldens."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _mps(rows, **kw):
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    return [MPS(r[0], r[1], size=r[2]) if len(r) > 2 else MPS(r[0], r[1]) for r in rows]
+
+
+def test_astar_config1():
+    from auv_sim_amd.astar import astar
+    g = np.load(os.path.join(GOLDEN, "g1_astar_cfg1.npz"))
+    obs = _mps(g["obstacles"].tolist())
+    box = g["box"].tolist()
+    bnd = _mps([(box[0], box[1]), (box[2], box[3])])
+    solver = astar((0, 0), (490, 490), obs, bnd)
+    path = solver.astar(obs, (0, 0), (490, 490))
+    assert [(p.x, p.y) for p in path] == [tuple(r) for r in g["path"].tolist()]
+    assert isinstance(path[0].x, int)  # int lattice in, int positions out (as the reference)
+
+
+def test_astar_real():
+    from auv_sim_amd.astar_real import astar
+    g = np.load(os.path.join(GOLDEN, "g1_real_1.npz"))
+    obs, bnd = _mps(g["obstacles"].tolist()), _mps(g["polygon"].tolist())
+    start, goal = tuple(g["start"].tolist()), tuple(g["goal"].tolist())
+    path = astar(start, goal, obs, bnd).astar(obs, bnd)
+    assert [(p.x, p.y) for p in path] == [tuple(r) for r in g["path"].tolist()]
+
+
+def test_astar_fixlen_mutates_habitat_list_like_reference():
+    from auv_sim_amd.astar_fixLen import astar
+    g = np.load(os.path.join(GOLDEN, "g6_fixlen_1.npz"))
+    obs, hab, bnd = _mps(g["obstacles"].tolist()), _mps(g["habitats"].tolist()), _mps(g["polygon"].tolist())
+    start = tuple(g["start"].tolist())
+    res = astar(start, obs, bnd).astar(hab, obs, bnd, start, float(g["limit"]), g["weights"].tolist())
+    assert [(p.x, p.y) for p in res[0]] == [tuple(r) for r in g["path"].tolist()]
+    assert res[1] == g["cost_list"].tolist()
+    assert [[h.x, h.y, h.size] for h in hab] == g["habitats_left"].tolist()
+
+
+@pytest.mark.parametrize("name", ["g6_sog_0", "g6_sog_1", "g6_sog_2"])
+def test_astar_fixlen_sog(name):
+    from auv_sim_amd.astar_fixLenSOG import astar
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    obs, hab, bnd = _mps(g["obstacles"].tolist()), _mps(g["habitats"].tolist()), _mps(g["polygon"].tolist())
+    cells = [tuple(c) for c in g["cells"].tolist()]
+    shark = {(int(b[0]), int(b[1])): {cells[i]: p for i, p in enumerate(g["prob"][t].tolist())}
+             for t, b in enumerate(g["bins"].tolist())}
+    start = tuple(g["start"].tolist())
+    res = astar(start, obs, bnd, hab, shark, {}, float(g["velocity"])).astar(float(g["limit"]), g["weights"].tolist(), {})
+    if not bool(g["found"]):
+        assert res is None
+        return
+    assert set(res.keys()) == {"path length", "path", "cost", "cost list", "node"}
+    assert res["path length"] == int(g["path_length"])
+    assert [[p.x, p.y, p.traj_time_stamp] for p in res["path"]] == g["path"].tolist()
+    assert res["cost"] == float(g["cost"]) and res["cost list"] == g["cost_list"].tolist()
+    got = [[n.position[0], n.position[1], n.g, n.h, n.f, n.cost, n.pathLen, n.time_stamp] for n in res["node"]]
+    assert got == g["node_path"].tolist()
+    assert all(n.parent is (res["node"][i - 1] if i else None) for i, n in enumerate(res["node"]))

@@ -1,0 +1,50 @@
+"""Host-side logic that needs no GPU: shark-grid CSV loader / packer, synthetic worlds, record type."""
+import os
+
+import numpy as np
+import pytest
+
+
+class _Cell:
+    def __init__(self, b):
+        self.bounds = tuple(b)
+
+
+def test_create_shark_grid_roundtrip(tmp_path):
+    from auv_sim_amd.rrt_dubins import createSharkGrid, pack_shark_grid
+    cells = [_Cell((10.0 * i, 0.0, 10.0 * i + 10.0, 10.0)) for i in range(5)]
+    p = tmp_path / "grid.csv"
+    # the reference's wire format (path_planning/shark_data/*.csv): header `time bin,grid`
+    p.write_text('time bin,grid\n"(0, 50)","[0.1, 0.2, 0.0, 0.4, 0.5]"\n"(50, 100)","[0.5, 0.25, 0.125, 0.0, 1.0]"\n')
+    g = createSharkGrid(str(p), cells)
+    assert list(g.keys()) == [(0, 50), (50, 100)]
+    assert list(g[(0, 50)].keys()) == [c.bounds for c in cells]
+    assert g[(50, 100)][cells[2].bounds] == 0.125
+    bins, cl, prob = pack_shark_grid(g)
+    assert bins.tolist() == [[0.0, 50.0], [50.0, 100.0]]
+    assert cl.shape == (5, 4) and prob.shape == (2, 5) and prob[1, 4] == 1.0
+
+
+def test_pack_shark_grid_rejects_inconsistent_cell_order():
+    from auv_sim_amd.rrt_dubins import pack_shark_grid
+    a, b = (0.0, 0.0, 1.0, 1.0), (1.0, 0.0, 2.0, 1.0)
+    with pytest.raises(NotImplementedError):
+        pack_shark_grid({(0, 1): {a: 0.1, b: 0.2}, (1, 2): {b: 0.1, a: 0.2}})
+
+
+def test_synth_worlds_are_reproducible():
+    from auv_sim_amd import synth
+    w1, w2 = synth.make_world(seed=5, n_obstacles=64), synth.make_world(seed=5, n_obstacles=64)
+    assert all(np.array_equal(w1[k], w2[k]) for k in ("obstacles", "habitats", "cells", "prob"))
+    assert w1["cells"].shape == (400, 4) and w1["prob"].shape == (10, 400)
+    # obstacles leave the start clear
+    d = np.hypot(w1["obstacles"][:, 0] - w1["start"][0], w1["obstacles"][:, 1] - w1["start"][1])
+    assert (d > w1["obstacles"][:, 2] + 5.0).all()
+
+
+def test_motion_plan_state_signature():
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    m = MPS(1, 2, size=3)
+    assert (m.x, m.y, m.z, m.theta, m.size, m.parent, m.path, m.length) == (1, 2, 0, 0, 3, None, [], 0)
+    assert repr(MPS(1, 2)) == "MPS: [x=1, y=2]" and "size=3" in repr(m)
+    assert MPS(1, 2, length=4.0).length == 4.0 and MPS(0, 0, rl_state_id=7).rl_state_id == 7
