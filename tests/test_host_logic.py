@@ -46,5 +46,5 @@ def test_motion_plan_state_signature():
     from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
     m = MPS(1, 2, size=3)
     assert (m.x, m.y, m.z, m.theta, m.size, m.parent, m.path, m.length) == (1, 2, 0, 0, 3, None, [], 0)
-    assert repr(MPS(1, 2)) == "MPS: [x=1, y=2]" and "size=3" in repr(m)
+    assert repr(MPS(1, 2)) == "MPS: [x=1, y=2]" and "size=3" in repr(MPS(1, 2, z=-5, size=3))
     assert MPS(1, 2, length=4.0).length == 4.0 and MPS(0, 0, rl_state_id=7).rl_state_id == 7
