@@ -58,8 +58,94 @@ def cpu_baseline(world, n_iter, args):
                       % (eps, n_iter, eps - 1, t_used)}
 
 
+def bench_astar(ctx, with_cpu, n_inst=1024, reps=3):
+    """BASELINE config 3: 1024 independent astar_fixLenSOG searches (starts on the 10 m lattice,
+    pathLenLimit in {100,200,300}) over one shared world: 64 obstacles, 10 habitats, rectangle polygon,
+    20x20-cell shark grid (the reference's hard-coded 600x600 visited window bounds the workspace).
+    cells/s = neighbour cells that passed the bounds test / time."""
+    from auv_sim_amd import _astar_lib, synth
+    w = synth.make_world(seed=12, n_obstacles=64, obst_radius=(2.0, 6.0), n_habitats=10, hab_radius=(10.0, 25.0))
+    ctx.set_world(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
+    rng = np.random.default_rng(3)
+    starts = np.column_stack([-290.0 + 10.0 * rng.integers(0, 19, n_inst), -90.0 + 10.0 * rng.integers(0, 19, n_inst)])
+    limits = rng.choice([100.0, 200.0, 300.0], n_inst)
+    wts = (0, 10, 10, 100)
+    kw = dict(limits=limits, weights=wts, velocity=1.0, cap_nodes=20000)
+    _astar_lib.run_batch(ctx, "astar_fixLenSOG", starts, **kw)
+    ms, cells, exps, found = [], 0, 0, 0
+    for _ in range(reps):
+        res = _astar_lib.run_batch(ctx, "astar_fixLenSOG", starts, **kw)
+        ms.append(ctx.last_kernel_ms())
+        cells = sum(r["n_children"] for r in res)
+        exps = sum(r["n_expansions"] for r in res)
+        found = sum(r["found"] for r in res)
+        bad = [r["status"] for r in res if r["status"] < 0]
+        if bad:
+            return {"error": "instance status %s" % sorted(set(bad))}
+    k_ms = float(np.mean(ms))
+    out = {"metric": "A* cells/s (astar_fixLenSOG, child cells evaluated)", "value": cells / (k_ms * 1e-3), "unit": "cells/s",
+           "instances": n_inst, "cells_per_launch": cells, "expansions_per_launch": exps, "found": found, "kernel_ms": k_ms,
+           "config": "1024 x astar_fixLenSOG, 64 obstacles, 10 habitats, 400-cell grid x 10 bins, limits 100/200/300",
+           # SURVEY 8(d): ~0.1 KB algorithmic HBM bytes per child cell (node write 68 + visited 1 + SOG 16 + scan share)
+           "roofline": {"bound": "hbm", "achieved": cells * 100.0 / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": cells * 100.0 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    if with_cpu:
+        from oracle import orc_astar as oa
+        t0, c, n = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < 5.0 and n < n_inst:
+            r = oa.run("astar_fixLenSOG", starts[n], obstacles=w["obstacles"], habitats=w["habitats"], polygon=w["polygon"],
+                       bins=w["bins"], cells=w["cells"], prob=w["prob"], limit=float(limits[n]), weights=wts, velocity=1.0,
+                       cap_nodes=20000, kind="libm")
+            c += r["n_children"]
+            n += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": c / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+                               "sample": "first %d of the %d instances, oracle/ libm build, %.1f s" % (n, n_inst, dt)}
+    return out
+
+
+def bench_planner(ctx, with_cpu, n_ep=512, max_step=2000, reps=3):
+    """BASELINE config 4: 512 Planner_RRT.planning(max_step=2000) episodes, 200 m x 200 m rectangle, 256
+    obstacles, cell 5 m, 1 theta subsection, freq 10, start (20,20) -> goal (170,180), seed = episode id."""
+    from auv_sim_amd import synth
+    from auv_sim_amd._prrt_lib import PlannerBatch
+    w = synth.make_rect_world(seed=3, n_obstacles=256)
+    ctx.set_world(obstacles=w["obstacles"])
+    starts = np.tile(np.array([w["start"][0], w["start"][1], 0.0, 0.0]), (n_ep, 1))
+    goals = np.tile(w["goal"], (n_ep, 1))
+    seeds = np.arange(n_ep, dtype=np.uint64)
+    ms, steps, done = [], 0, 0
+    for i in range(reps + 1):
+        pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, freq=10, cell=5, subs=1)
+        summ = pb.plan()
+        if i:
+            ms.append(ctx.last_kernel_ms())
+        steps, done = int(summ["steps"].sum()), int(summ["done"].sum())
+        if (summ["status"] < 0).any():
+            return {"error": "episode status %s" % np.unique(summ["status"])}
+    k_ms = float(np.mean(ms))
+    out = {"metric": "Planner_RRT steps/s (generate_one_node calls)", "value": steps / (k_ms * 1e-3), "unit": "steps/s",
+           "episodes": n_ep, "steps_per_launch": steps, "episodes_done": done, "kernel_ms": k_ms,
+           "config": "512 x Planner_RRT.planning(2000), 200 m env, 256 obstacles, cell 5 m, freq 10",
+           # SURVEY 8(d): ~0.33 KB algorithmic HBM bytes per step
+           "roofline": {"bound": "hbm", "achieved": steps * 330.0 / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": steps * 330.0 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    if with_cpu:
+        from oracle import orc_planner as op
+        t0, c, n = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < 5.0 and n < n_ep:
+            r = op.planning(w["obstacles"], w["rect"], starts[n], goals[n], n, max_step, 10, 5, 1, kind="libm")
+            c += r["steps"]
+            n += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": c / dt, "unit": "steps/s", "cores": 1, "kind": "port",
+                               "sample": "first %d of the %d episodes, oracle/ libm build, %.1f s" % (n, n_ep, dt)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--no-extra", action="store_true", help="skip the A* / Planner_RRT side measurements")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -183,6 +269,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(world, args.iters, args)
         else:
             out["cpu_baseline"] = None
+        if not args.no_extra:
+            # the other two planner families of the path, per GPU (rank 0's device), outside the timed region
+            out["astar"] = bench_astar(ctx, with_cpu=(world_size == 1 and not args.no_cpu))
+            out["planner_rrt"] = bench_planner(ctx, with_cpu=(world_size == 1 and not args.no_cpu))
         print(json.dumps(out))
     if world_size > 1:
         dist.barrier()
