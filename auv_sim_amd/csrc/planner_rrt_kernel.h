@@ -116,7 +116,7 @@ __device__ __forceinline__ bool prrt_hits(const double (&ox)[J], const double (&
 }
 
 template <int J>
-__global__ __launch_bounds__(RRT_WAVES * 64) void prrt_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
+__global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) void prrt_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();

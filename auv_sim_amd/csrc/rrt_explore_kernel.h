@@ -53,8 +53,8 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
   RrtLdsPlan p;
   p.chunk = nfreq < 1 ? 1 : (nfreq > RRT_MAX_CHUNK ? RRT_MAX_CHUNK : nfreq);
   const int C = p.chunk;
-  int steer_u = (3 * C + 3) * 8;
-  int steer_s = ((C + 1) * 7) * 8;
+  int steer_u = (64 + 3 * C + 3) * 8;  // 64 leading random() values + the steer window
+  int steer_s = ((C + 1) * 7 + 4) * 8;  // + path bounding box (4 doubles)
   int cost = RRT_ELIST * 4 + 64 * 8;
   int s = steer_u > steer_s ? steer_u : steer_s;
   s = s > cost ? s : cost;
@@ -179,6 +179,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
   double* inc = scratch;                           // [(C+1)*4]   (steer, phase 2: aliases u_win)
   double* sc = scratch + (size_t)(C + 1) * 4;      // [(C+1)*2]
   double* phi_l = scratch + (size_t)(C + 1) * 6;   // [C+1]
+  double* bbox_l = scratch + (size_t)(C + 1) * 7;  // [4] xmin, ymin, xmax, ymax of the steer
   int32_t* elist = reinterpret_cast<int32_t*>(wbase);                  // [192]  (cost walk)
   double* term = reinterpret_cast<double*>(wbase + RRT_ELIST * 4);     // [64]
   uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + plan.scratch);
@@ -260,19 +261,37 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
     // ------------------------------------------------------------ parent selection (:121-139)
     if (clk) t_prev = __builtin_amdgcn_s_memtime();
     int par;
+    // The next 64 random() values of the stream are tempered in one pass (lane j holds number j);
+    // the iteration's scalar draws are read out of that window and `base` counts how many of them
+    // the selection + n_expand draws consumed.  The steer window continues in the same buffer.
+    int base = 0;
+    double u_me;
     if (MODE == 0) {
-      int rb, cnt;
+      int rb = 0, cnt = 0, f = -1;
       for (;;) {
-        double u = rng_next_random(rng);
-        rb = uni((int)py_uniform(1.0, (double)(K + 1), u));
-        if (rb > K) { status = -5; break; }
-        cnt = uni(bin_count[rb]);
-        if (cnt != 0) break;
+        rng_ensure(rng, 128u);
+        u_me = rng_random_at(rng, (uint32_t)lane);
+        // ran_bin = int(uniform(1, K+1)) until that bin is non-empty (:123-125): every lane tries its
+        // own draw, the first success in stream order wins; a key beyond K before it is a KeyError
+        const int rbj = (int)py_uniform(1.0, (double)(K + 1), u_me);
+        const bool cand = lane < 60;  // leave room for the two draws that follow the successful one
+        const bool badkey = cand && rbj > K;
+        const int cj = (cand && !badkey) ? bin_count[rbj] : 0;
+        const unsigned long long okm = __ballot(cj != 0), badm = __ballot(badkey);
+        const int fo = okm ? (__ffsll((long long)okm) - 1) : 64, fb = badm ? (__ffsll((long long)badm) - 1) : 64;
+        if (fb < fo) { status = -5; break; }
+        if (fo < 64) {
+          f = fo;
+          rb = __builtin_amdgcn_readlane(rbj, fo);
+          cnt = __builtin_amdgcn_readlane(cj, fo);
+          break;
+        }
+        rng_advance_words(rng, 120u);  // 60 unsuccessful draws (only while most bins are still empty)
       }
       if (status) break;
-      double u = rng_next_random(rng);
-      int ri = uni((int)py_uniform(0.0, (double)cnt, u));
+      const int ri = uni((int)py_uniform(0.0, (double)cnt, readlane_f64(u_me, f + 1)));
       par = uni(bin_items[(size_t)rb * bcap + ri]);
+      base = f + 2;
     } else if (MODE == 1) {
       double u = rng_next_random(rng);
       double ran_time = py_uniform(0.0, P.max_plan_time * P.freq, u);
@@ -321,32 +340,47 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
       cx = readfirst_f64(a.x); cy = readfirst_f64(a.y); cth = readfirst_f64(b.x); ctt = readfirst_f64(b.y);
       clen = readfirst_f64(nodeF[(size_t)par * 8 + 4]);
     }
-    int n_total;
-    {
-      double u = rng_next_random(rng);
-      n_total = uni((int)auvp_floor(py_uniform(0.0, P.freq, u) / 1));
+    if (MODE != 0) {  // modes 1/2 consumed their selection draws one by one; open the window here
+      rng_ensure(rng, 128u);
+      u_me = rng_random_at(rng, (uint32_t)lane);
+      base = 0;
     }
+    const int n_total = uni((int)auvp_floor(py_uniform(0.0, P.freq, readlane_f64(u_me, base)) / 1));
+    base += 1;
     int cnt = 0;  // appended path points
     if (lane == 0) { pts[0][0] = cx; pts[0][1] = cy; }
     bool cap_err = false;
     for (int c0 = 0; c0 < n_total; c0 += C) {
       const int n = (n_total - c0) < C ? (n_total - c0) : C;
       const int nwin = 3 * n;
-      rng_ensure(rng, (uint32_t)(2 * nwin));
-      for (int jj = lane; jj < nwin; jj += 64) u_win[jj] = rng_random_at(rng, (uint32_t)jj);
+      // window entry j of this chunk = random() number base + j of the stream
+      if (c0 == 0) {
+        u_win[lane] = u_me;
+        if (base + nwin > 64) {
+          rng_ensure(rng, (uint32_t)(2 * (base + nwin)));
+          for (int jj = 64 + lane; jj < base + nwin; jj += 64) u_win[jj] = rng_random_at(rng, (uint32_t)jj);
+        }
+      } else {
+        base = 0;
+        rng_ensure(rng, (uint32_t)(2 * nwin));
+        for (int jj = lane; jj < nwin; jj += 64) u_win[jj] = rng_random_at(rng, (uint32_t)jj);
+      }
       wave_sync();
+      const double* uw = u_win + base;
       // "taken" predicate for every possible start offset
-      unsigned long long msk[3];
+      unsigned long long msk[3] = {0ull, 0ull, 0ull};
 #pragma unroll
       for (int t = 0; t < 3; t++) {
-        int jj = lane + 64 * t;
-        bool f = false;
-        if (jj + 1 < nwin) {
-          double dist = py_uniform(0.0, P.dist_to_end, u_win[jj]);
-          double diff = py_uniform(-P.diff_max, P.diff_max, u_win[jj + 1]);
-          f = auvp_fabs(dist) > auvp_fabs(diff);
+        if (64 * t + 1 < nwin) {  // wave-uniform: short steers need one pass only
+          int jj = lane + 64 * t;
+          bool f = false;
+          if (jj + 1 < nwin) {
+            double dist = py_uniform(0.0, P.dist_to_end, uw[jj]);
+            double diff = py_uniform(-P.diff_max, P.diff_max, uw[jj + 1]);
+            f = auvp_fabs(dist) > auvp_fabs(diff);
+          }
+          msk[t] = __ballot(f);
         }
-        msk[t] = __ballot(f);
       }
       // Where does sub-arc s start?  pos_s = 2s + (#taken among sub-arcs < s).  Fixed point of
       //   taken_s = T[2s + c_s],  c_s = popcount(taken below s)
@@ -370,12 +404,12 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
       const bool taken = (tmask >> lane) & 1ull;
       double radius = 0.0, phi = 0.0, vt = 1.0;
       if (taken) {
-        double dist = py_uniform(0.0, P.dist_to_end, u_win[mypos]);
-        double diff = py_uniform(-P.diff_max, P.diff_max, u_win[mypos + 1]);
+        double dist = py_uniform(0.0, P.dist_to_end, uw[mypos]);
+        double diff = py_uniform(-P.diff_max, P.diff_max, uw[mypos + 1]);
         double s1 = dist + diff, s2 = dist - diff;
         radius = (s1 + s2) / (-s1 + s2);
         phi = (s1 + s2) / (2 * radius);
-        vt = py_uniform(0.0, 2 * P.v, u_win[mypos + 2]);
+        vt = py_uniform(0.0, 2 * P.v, uw[mypos + 2]);
       }
       wave_sync();  // the window is dead: its LDS becomes the steer scratch
       if (lane <= C) phi_l[lane] = phi;  // untaken / idle lanes add an exact 0.0
@@ -407,8 +441,18 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
       // x += dx; y += dy; t += dt; length += movement: four serial chains, one lane each
       if (lane < 4) {
         double acc = lane == 0 ? cx : (lane == 1 ? cy : (lane == 2 ? ctt : clen));
+        // lanes 0/1 also track the extent of x / y over every prefix position (a superset of the
+        // appended path points; the parent point is part of the path); kept in LDS between chunks
+        double bmin = acc, bmax = acc;
+        if (c0 != 0 && lane < 2) { bmin = bbox_l[lane]; bmax = bbox_l[2 + lane]; }
 #pragma unroll 4
-        for (int s = 0; s < n; s++) { acc = acc + inc[4 * s + lane]; inc[4 * s + lane] = acc; }
+        for (int s = 0; s < n; s++) {
+          acc = acc + inc[4 * s + lane];
+          inc[4 * s + lane] = acc;
+          bmin = acc < bmin ? acc : bmin;
+          bmax = acc > bmax ? acc : bmax;
+        }
+        if (lane < 2) { bbox_l[lane] = bmin; bbox_l[2 + lane] = bmax; }
       }
       wave_sync();
       double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
@@ -431,8 +475,12 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
         ctt = readlane_f64(mt_, n - 1); clen = readlane_f64(ml, n - 1);
         cth = readlane_f64(myth, n - 1);
       }
-      rng_advance_words(rng, (uint32_t)(2 * used));
+      rng_advance_words(rng, (uint32_t)(2 * (base + used)));
       wave_sync();
+    }
+    if (n_total == 0) {
+      rng_advance_words(rng, (uint32_t)(2 * base));  // selection + n_expand draws only
+      if (lane < 2) { bbox_l[lane] = lane == 0 ? cx : cy; bbox_l[2 + lane] = lane == 0 ? cx : cy; }
     }
     if (cap_err) { status = -2; break; }
     wave_sync();
@@ -440,19 +488,26 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
 
     AUVP_PHASE(1);
     // ------------------------------------------------------------ check_collision (:530-549)
+    // Exact cull first: an obstacle whose effective disc does not reach the bounding box of the
+    // path cannot be within T_i of any path point (a point in the box is at least as far from the
+    // centre as the box is), so a slot of 64 obstacles with no candidate is skipped as a whole.
+    const double bx0 = bbox_l[0], by0 = bbox_l[1], bx1 = bbox_l[2], by1 = bbox_l[3];
     int hit = 0;
-    {
-      double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
-      for (int p = 0; p < P_n; p++) {
-        // next point's LDS read is in flight while this one is tested (pts has room for P_n + 1)
-        const double2 qn = *reinterpret_cast<const double2*>(&pts[p + 1][0]);
 #pragma unroll
-        for (int j = 0; j < J; j++) {
+    for (int j = 0; j < J; j++) {
+      const double ex = ox[j] < bx0 ? bx0 - ox[j] : (ox[j] > bx1 ? ox[j] - bx1 : 0.0);
+      const double ey = oy[j] < by0 ? by0 - oy[j] : (oy[j] > by1 ? oy[j] - by1 : 0.0);
+      const bool cand = ex * ex + ey * ey <= ot[j] * (1.0 + 0x1p-40);
+      if (__any(cand)) {
+        double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
+        for (int p = 0; p < P_n; p++) {
+          // next point's LDS read is in flight while this one is tested (pts has room for P_n + 1)
+          const double2 qn = *reinterpret_cast<const double2*>(&pts[p + 1][0]);
           double ddx = q.x - ox[j], ddy = q.y - oy[j];
           double d2 = ddx * ddx + ddy * ddy;
           hit |= (d2 <= ot[j]) ? 1 : 0;  // no short-circuit: straight-line code
+          q = qn;
         }
-        q = qn;
       }
     }
     const bool ok = !__any(hit != 0) && !any_point_outside(S.poly, W.n_poly, pts, P_n);
