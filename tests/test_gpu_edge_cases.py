@@ -1,0 +1,88 @@
+"""Edge cases the goldens do not reach, HIP vs the CPU checker (portable build), bit-for-bit:
+large obstacle lists (the J = 8 / 16 register layouts), steer chunking (freq > 63) in Planner_RRT,
+empty worlds, single-iteration budgets, A* with no obstacles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from auv_sim_amd import _lib
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("O,mode", [(400, "timebin"), (900, "timebin"), (130, "nn"), (1, "plantime")])
+def test_exploring_many_obstacles(ctx, orc, O, mode):
+    from auv_sim_amd import synth
+    world = synth.make_world(seed=40 + O, n_obstacles=O, obst_radius=(0.5, 2.5))
+    ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    E, n_iter = 5, 500
+    init = np.zeros((E, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    seeds = np.arange(70, 70 + E, dtype=np.uint64)
+    summ = ctx.rrt_explore_batch(init, seeds, n_iter, mode=mode)
+    for e in range(E):
+        r = orc.rrt_explore(w, int(seeds[e]), n_iter, mode=mode, init=init[e], kind="portable")
+        s = summ[e]
+        assert s["status"] == r["status"] and s["n_nodes"] == r["n_nodes"] and s["rng_after"] == r["rng_after"]
+        t = ctx.tree(e, s)
+        assert np.array_equal(t["parent"], r["parent"]) and np.array_equal(t["nodes"], r["nodes"])
+        if r["status"] == 0:
+            assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])
+
+
+def test_exploring_empty_world_and_tiny_budget(ctx, orc):
+    poly = [[-50.0, -50.0], [50.0, -50.0], [50.0, 50.0], [-50.0, 50.0]]
+    ctx.set_world(polygon=poly)
+    w = orc.WorldArrays(polygon=poly)
+    init = np.zeros((3, 6))
+    for n_iter in (1, 2, 40):
+        summ = ctx.rrt_explore_batch(init, [5, 6, 7], n_iter, max_traj_time=20.0, bin_interval=5)
+        for e in range(3):
+            r = orc.rrt_explore(w, 5 + e, n_iter, init=init[e], max_traj_time=20.0, bin_interval=5, kind="portable")
+            s = summ[e]
+            assert s["status"] == r["status"] and s["n_nodes"] == r["n_nodes"] and s["rng_after"] == r["rng_after"]
+            if r["status"] == 0:
+                assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])  # no grid, no habitats: all zeros
+
+
+def test_planner_chunked_steer_and_many_subsections(ctx, orc):
+    from auv_sim_amd import synth
+    from auv_sim_amd._prrt_lib import PlannerBatch
+    from oracle import orc_planner as op
+    w = synth.make_rect_world(seed=2, n_obstacles=600, size=150.0, start=(12.0, 12.0), goal=(130.0, 120.0), obst_radius=(0.5, 1.5))
+    ctx.set_world(obstacles=w["obstacles"])
+    E = 6
+    starts = np.tile(np.array([12.0, 12.0, 2.9, 0.0]), (E, 1))
+    goals = np.tile(w["goal"], (E, 1))
+    seeds = np.arange(900, 900 + E, dtype=np.uint64)
+    pb = PlannerBatch(ctx, starts, goals, w["rect"], 400, seeds=seeds, freq=80, cell=3, subs=16)
+    summ = pb.plan()
+    paths = pb.paths(summ)
+    for e in range(E):
+        r = op.planning(w["obstacles"], w["rect"], starts[e], goals[e], int(seeds[e]), 400, 80, 3, 16, kind="portable")
+        s = summ[e]
+        assert s["status"] == r["status"] == 0 and s["steps"] == r["steps"] and bool(s["done"]) == r["done"]
+        t = pb.tree(e, s)
+        assert np.array_equal(t["parent"], r["parent"]) and np.array_equal(t["nodes"], r["nodes"][:, :4])
+        assert np.array_equal(t["node_bucket"], r["node_bucket"]) and s["rng_after"] == r["rng_after"]
+        if r["done"]:
+            assert np.array_equal(paths[e], r["path"])
+
+
+def test_astar_without_obstacles(ctx, orc):
+    from auv_sim_amd import _astar_lib as al
+    from oracle import orc_astar as oa
+    ctx.set_world()
+    res = al.run_batch(ctx, "astar", [(0.0, 0.0), (30.0, 10.0)], goals=[(90.0, 40.0), (30.0, 10.0)], box=(0, 0, 100, 100),
+                       exp_log=True)
+    for e, (s, g) in enumerate([((0.0, 0.0), (90.0, 40.0)), ((30.0, 10.0), (30.0, 10.0))]):
+        o = oa.run("astar", s, goal=g, box=(0, 0, 100, 100), kind="portable")
+        assert res[e]["found"] and o["found"]
+        assert np.array_equal(res[e]["path"], o["path"]) and np.array_equal(res[e]["expansions"], o["expansions"])
+    assert len(res[1]["path"]) == 1  # start == goal: popped immediately
