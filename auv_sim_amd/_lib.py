@@ -48,6 +48,28 @@ OK, NO_QUALIFYING_LEAF = 0, 1
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """A process must hold ONE HIP/HSA runtime.  PyTorch-ROCm bundles its own libamdhip64.so.7 /
+    libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm's); whichever copy is loaded first serves both
+    torch and libauvplan.so.  torch does not find its GPU on the system copy, so when torch is
+    installed its copies are mapped first (without importing torch).  AUVP_SYSTEM_HIP=1 opts out."""
+    import sys
+    if os.environ.get("AUVP_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            p = os.path.join(libdir, name)
+            if os.path.exists(p):
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass  # fall back to the system runtime; torch (if imported later) may then not see the GPU
+
+
 def load():
     """Load libauvplan.so; raises if it has not been built (no fallback)."""
     global _lib
@@ -56,6 +78,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build the HIP extension first "
                           "(python -c 'import __graft_entry__ as g; g.build()')" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.auvp_version.restype = C.c_char_p
@@ -110,8 +133,10 @@ class Context:
         rc = self.L.auvp_create(int(device), C.byref(self.h))
         if rc != 0:
             raise AuvpError(rc, "auvp_create(device=%d) failed: no usable HIP device (no CPU fallback)" % device)
+        self.device = int(device)
         self.n_episodes = 0
         self.max_iter = 0
+        self.world_sizes = {}
 
     def close(self):
         if getattr(self, "h", None):

@@ -270,5 +270,55 @@ void* auvp_prrt_summaries_dev(auvp_handle* h) {
   return S.ready ? (void*)S.B.summary : nullptr;
 }
 
+// RRTEnv observation arrays (gym_rrt/envs/rrt_env.py:250-295) for every episode, written to
+// caller-owned DEVICE buffers: rrt_grid [E,n_buckets,4] f64 = cell.x, cell.y, subsection.theta,
+// len(node_array); has_node [E,n_buckets] i64; num_nodes [E,n_buckets] i64.
+int auvp_prrt_observation_dev(auvp_handle* h, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev) {
+  if (!h || !rrt_grid_dev) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  // subsection thetas exactly as Grid_cell_RRT builds them (grid_cell_rrt.py:49-55)
+  std::vector<double> th(S.P.S);
+  {
+    const double pi = M_PI;
+    double theta = 0.0;
+    for (int i = 0; i < S.P.S; i++) {
+      th[i] = theta;
+      theta = theta + S.P.delta_theta;
+      while (!(-pi <= theta && theta <= pi)) theta += theta > pi ? (-2 * pi) : (2 * pi);
+    }
+  }
+  int rc;
+  if ((rc = upload(h, S.tmp_out, th.data(), th.size()))) return rc;
+  const long long total = (long long)S.E * S.P.n_buckets;
+  const int grid = (int)std::min<long long>((total + 255) / 256, 65535LL * 16);
+  hipLaunchKernelGGL(auvp::prrt_observation_kernel, dim3(grid), dim3(256), 0, h->stream, S.P, S.B, S.tmp_out.as<double>(), S.E,
+                     reinterpret_cast<double*>(rrt_grid_dev), reinterpret_cast<long long*>(has_node_dev),
+                     reinterpret_cast<long long*>(num_nodes_dev));
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+// the same for one episode, copied to host arrays
+int auvp_prrt_observation(auvp_handle* h, int32_t ep, double* rrt_grid, int64_t* has_node, int64_t* num_nodes) {
+  if (!h || !rrt_grid) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready || ep < 0 || ep >= S.E) return fail(h, AUVP_ERR_STATE, "bad episode");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t nb = (size_t)S.P.n_buckets, tot = (size_t)S.E * nb;
+  DevBuf g, hn, nn;
+  HIPCHK(h, g.reserve(tot * 4 * sizeof(double)));
+  HIPCHK(h, hn.reserve(tot * sizeof(int64_t)));
+  HIPCHK(h, nn.reserve(tot * sizeof(int64_t)));
+  int rc = auvp_prrt_observation_dev(h, g.p, hn.p, nn.p);
+  if (rc != AUVP_OK) return rc;
+  HIPCHK(h, hipMemcpy(rrt_grid, g.as<double>() + (size_t)ep * nb * 4, nb * 4 * sizeof(double), hipMemcpyDeviceToHost));
+  if (has_node) HIPCHK(h, hipMemcpy(has_node, hn.as<int64_t>() + (size_t)ep * nb, nb * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (num_nodes) HIPCHK(h, hipMemcpy(num_nodes, nn.as<int64_t>() + (size_t)ep * nb, nb * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
 }  // extern "C"
 #endif

@@ -519,5 +519,27 @@ __global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, co
   }
 }
 
+// RRTEnv's per-step observation arrays (gym_rrt/envs/rrt_env.py:250-295), elementwise over
+// (episode, bucket): [cell.x, cell.y, subsection.theta, len(node_array)], has_node, node counts.
+// The reference rebuilds these three O(#buckets) Python lists after every node.
+__global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, PrrtBuffers B, const double* __restrict__ thetas,
+                                                               int n_episodes, double* __restrict__ rrt_grid,
+                                                               long long* __restrict__ has_node, long long* __restrict__ num_nodes) {
+  const long long total = (long long)n_episodes * P.n_buckets;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int b = (int)(i % P.n_buckets);
+    const int k = b % P.S, cell = b / P.S, col = cell % P.cols, row = cell / P.cols;
+    const int c = B.bucket_counts[i];
+    double4 v;
+    v.x = P.rect[0] + col * P.cell;  // env_btm_left_corner.x + col * cell_side_length (rrt_dubins.py:91)
+    v.y = P.rect[1] + row * P.cell;
+    v.z = thetas[k];
+    v.w = (double)c;
+    reinterpret_cast<double4*>(rrt_grid)[i] = v;
+    if (has_node) has_node[i] = c != 0 ? 1 : 0;
+    if (num_nodes) num_nodes[i] = c;
+  }
+}
+
 }  // namespace auvp
 #endif

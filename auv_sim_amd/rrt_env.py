@@ -1,0 +1,124 @@
+"""Batched counterpart of gym_rrt/envs/rrt_env.py::RRTEnv for E planning episodes at once.
+
+The reference env runs one Planner_RRT and, after every node, rebuilds three O(#buckets) Python lists
+(`convert_rrt_grid_to_1D`, `generate_rrt_grid_has_node_array`, `convert_rrt_grid_to_1D_num_of_nodes_only`,
+rrt_env.py:227-231,250-295).  Here the E planners, their bucket grids and the observation arrays live on
+the MI355X; `step(cells, step_num)` is one `auvp_prrt_step` launch + one elementwise observation kernel
+and hands the observations back as numpy arrays (or leaves them in caller-owned device memory).
+
+step() contract per episode (rrt_env.py:182-247): chosen_grid_cell_idx -> (cell, subsection)
+= divmod(idx, num_of_subsections); reward R_FOUND_PATH (300) when the goal arc is free, R_CREATE_NODE (0)
+when a node was added, R_INVALID_NODE (-1) otherwise.  Episodes that are done are skipped.
+RNG: seeded per episode (`seeds[e]` plays random.seed), drawn on the device.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._prrt_lib import PlannerBatch, _bind
+
+R_FOUND_PATH = 300
+R_CREATE_NODE = 0
+R_INVALID_NODE = -1
+RRT_PLANNER_FREQ = 10
+
+
+class RRTEnvBatch:
+    def __init__(self, auv_init_pos, shark_init_pos, boundary_array, grid_cell_side_length, num_of_subsections,
+                 obstacle_array=(), seeds=(0,), max_nodes=2048, freq=RRT_PLANNER_FREQ, device=0):
+        """auv_init_pos / shark_init_pos: one Motion_plan_state (shared) or a list of E of them"""
+        self.E = len(seeds)
+        self.seeds = np.asarray(seeds, dtype=np.uint64)
+        self._ctx = _lib.Context(device)
+        self._obst = np.array([(float(o.x), float(o.y), float(o.size)) for o in obstacle_array], dtype=np.float64).reshape(-1, 3)
+        self.obstacle_array = np.array([[o.x, o.y, o.z, o.size] for o in obstacle_array])
+        self._rect = (float(boundary_array[0].x), float(boundary_array[0].y), float(boundary_array[1].x), float(boundary_array[1].y))
+        self.cell_side_length = grid_cell_side_length
+        self.num_of_subsections = num_of_subsections
+        self.max_nodes = int(max_nodes)
+        self.freq = freq
+
+        def _many(m):
+            return list(m) if isinstance(m, (list, tuple)) else [m] * self.E
+
+        self._auv, self._shark = _many(auv_init_pos), _many(shark_init_pos)
+        self._L = _bind()
+        self._L.auvp_prrt_observation.argtypes = [C.c_void_p, C.c_int32, _lib._dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        self._L.auvp_prrt_observation_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._pb = None
+        self.state = None
+
+    @property
+    def n_buckets(self):
+        return self._pb.rows * self._pb.cols * self._pb.subs
+
+    def reset(self):
+        """rrt_env.py:410-449 for every episode"""
+        self._ctx.set_world(obstacles=self._obst)
+        starts = [[float(a.x), float(a.y), float(a.theta), float(a.traj_time_stamp)] for a in self._auv]
+        goals = [[float(s.x), float(s.y)] for s in self._shark]
+        self._pb = PlannerBatch(self._ctx, starts, goals, self._rect, self.max_nodes, seeds=self.seeds, freq=self.freq,
+                                cell=self.cell_side_length, subs=self.num_of_subsections)
+        self._done = np.zeros(self.E, dtype=bool)
+        self.state = self._observe(None)
+        return self.state
+
+    def _observe(self, summ):
+        nb = self.n_buckets
+        # device tensors are torch's job (allocation only); one elementwise pass fills all episodes
+        import torch
+        dev = torch.device("cuda", self._ctx.device)
+        if getattr(self, "_obs_dev", None) is None:
+            self._obs_dev = (torch.empty((self.E, nb, 4), dtype=torch.float64, device=dev),
+                             torch.empty((self.E, nb), dtype=torch.int64, device=dev),
+                             torch.empty((self.E, nb), dtype=torch.int64, device=dev))
+        g, h, n = self._obs_dev
+        self.observation_to_device(g.data_ptr(), h.data_ptr(), n.data_ptr())
+        grid, has, num = g.cpu().numpy(), h.cpu().numpy(), n.cpu().numpy()
+        st = {
+            "auv_pos": np.array([[a.x, a.y, a.z, a.theta] for a in self._auv], dtype=np.float64),
+            "shark_pos": np.array([[s.x, s.y, s.z, s.theta] for s in self._shark], dtype=np.float64),
+            "obstacles_pos": self.obstacle_array,
+            "rrt_grid": grid, "has_node": has, "rrt_grid_num_of_nodes_only": num,
+            "path": [None] * self.E if self.state is None else self.state["path"],
+        }
+        return st
+
+    def observation_to_device(self, rrt_grid_ptr, has_node_ptr=None, num_nodes_ptr=None):
+        """write the observation arrays of all episodes into caller-owned device memory (e.g. torch
+        tensors' data_ptr()): rrt_grid [E,n_buckets,4] f64, has_node / num_nodes [E,n_buckets] i64"""
+        self._ctx._chk(self._L.auvp_prrt_observation_dev(self._ctx.h, C.c_void_p(rrt_grid_ptr),
+                                                         C.c_void_p(has_node_ptr) if has_node_ptr else None,
+                                                         C.c_void_p(num_nodes_ptr) if num_nodes_ptr else None))
+
+    def step(self, chosen_grid_cell_idx, step_num=None):
+        """chosen_grid_cell_idx [E] (RRTEnv.step's flat index over cells x subsections).
+        Returns (state, reward [E], done [E], {})"""
+        idx = np.asarray(chosen_grid_cell_idx, dtype=np.int64).reshape(self.E)
+        # flat index -> bucket id: (row*cols + col)*S + k is the same flattening RRTEnv uses (:203-213)
+        buckets = np.where(self._done, -1, idx).astype(np.int32)
+        before = self._pb.summaries()
+        summ = self._pb.step(buckets)
+        bad = summ["status"] < 0
+        if bad.any():
+            raise _lib.AuvpError(int(summ["status"][bad][0]), "planner episode failed on the device")
+        active = ~self._done
+        done_now = (summ["done"] != 0) & active
+        created = (summ["n_nodes"] > before["n_nodes"]) & active
+        reward = np.where(done_now, R_FOUND_PATH, np.where(created, R_CREATE_NODE, R_INVALID_NODE)).astype(np.int64)
+        reward[~active] = 0
+        paths = self._pb.paths(summ) if done_now.any() else None
+        self.state = self._observe(summ)
+        for e in range(self.E):
+            if done_now[e]:
+                self.state["path"][e] = paths[e]
+            elif created[e]:
+                t = int(summ[e]["last_new_node"])
+                self.state["path"][e] = t  # id of the node added this step (tree stays on the device)
+        self._done |= done_now
+        return self.state, reward, self._done.copy(), {}
+
+    def tree(self, e):
+        s = self._pb.summaries()[e]
+        return self._pb.tree(e, s)

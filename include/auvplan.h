@@ -154,6 +154,13 @@ int auvp_prrt_grid(auvp_handle* h, int32_t episode, int32_t* occupied, int32_t* 
 /* per-step log (AUVP_FLAG_ITER_LOG): [max_step,8] bucket, picked, accepted, done, npath, arc_n, arc_free, new_node */
 int auvp_prrt_step_log(auvp_handle* h, int32_t episode, int32_t* log8);
 void* auvp_prrt_summaries_dev(auvp_handle* h);
+/* RRTEnv observation arrays (gym_rrt/envs/rrt_env.py:250-295: convert_rrt_grid_to_1D,
+ * generate_rrt_grid_has_node_array, convert_rrt_grid_to_1D_num_of_nodes_only) for all episodes into
+ * caller-owned DEVICE buffers: rrt_grid [E,n_buckets,4] f64 = cell.x, cell.y, subsection.theta,
+ * len(node_array); has_node [E,n_buckets] i64; num_nodes [E,n_buckets] i64 (either may be NULL) */
+int auvp_prrt_observation_dev(auvp_handle* h, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev);
+/* the same for one episode, copied to host arrays */
+int auvp_prrt_observation(auvp_handle* h, int32_t episode, double* rrt_grid, int64_t* has_node, int64_t* num_nodes);
 
 /* ---------------------------------------------------------------------------------------------
  * A* variants (path_planning/astar.py, astar_real.py, astar_fixLen.py, astar_fixLenSOG.py), one
