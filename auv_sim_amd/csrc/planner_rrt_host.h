@@ -126,40 +126,9 @@ int auvp_prrt_create_batch(auvp_handle* h, int32_t E, const double* starts, cons
   if ((rc = upload(h, S.rng_state, rs.data(), rs.size()))) return rc;
   // mps_list = [start]; add_node_to_grid(start)  (:53,:108-159) -- done on the host, same arithmetic
   HIPCHK(h, hipMemsetAsync(S.bcount.p, 0, (size_t)E * P.n_buckets * sizeof(int32_t), h->stream));
-  std::vector<auvp::PrrtSummary> sums(E);
-  std::vector<double> nf0(4);
-  for (int e = 0; e < E; e++) {
-    const double* st = starts + 4 * (size_t)e;
-    auvp::PrrtSummary& s = sums[e];
-    memset(&s, 0, sizeof s);
-    s.n_nodes = 1; s.last_new_node = -1;
-    int row = (int)(st[1] / P.cell), col = (int)(st[0] / P.cell);
-    bool err = false;
-    if (row < 0) { row += P.rows; err |= row < 0; }
-    if (col < 0) { col += P.cols; err |= col < 0; }
-    int bk = -1;
-    if (!err && row < P.rows && col < P.cols) {
-      int sub = (int)std::floor(st[2] / P.delta_theta);
-      if (sub < 0) sub = (int)(P.S + sub);
-      if (sub == P.S) sub -= 1;
-      if (sub < 0) { sub += P.S; err |= sub < 0; }
-      err |= sub >= P.S;
-      bk = (row * P.cols + col) * P.S + sub;
-    }
-    if (err) { s.status = AUVP_ERR_ARG; bk = -1; }
-    int32_t ni[4] = {0, -1, 0, 0};
-    HIPCHK(h, hipMemcpyAsync(B.node_f + (size_t)e * B.cap_nodes * 4, st, 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(B.node_i + (size_t)e * B.cap_nodes * 4, ni, sizeof ni, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(B.node_bucket + (size_t)e * B.cap_nodes, &bk, sizeof bk, hipMemcpyHostToDevice, h->stream));
-    if (bk >= 0) {
-      const int32_t one = 1;
-      HIPCHK(h, hipMemcpyAsync(B.bucket_counts + (size_t)e * P.n_buckets + bk, &one, sizeof one, hipMemcpyHostToDevice, h->stream));
-      HIPCHK(h, hipMemcpyAsync(B.occupied + (size_t)e * B.cap_nodes, &bk, sizeof bk, hipMemcpyHostToDevice, h->stream));
-      s.n_occ = 1;
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // the small host temporaries above are reused per episode
-  }
-  if ((rc = upload(h, S.summary, sums.data(), sums.size()))) return rc;
+  // one thread per episode places the start node with the kernel's own add_node_to_grid arithmetic
+  hipLaunchKernelGGL(auvp::prrt_init_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, P, B, (int)E);
+  HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   S.E = E;
   S.ready = true;

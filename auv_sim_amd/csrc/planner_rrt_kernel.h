@@ -519,6 +519,43 @@ __global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, co
   }
 }
 
+// Planner_RRT.__init__ (:34-75): mps_list = [start]; add_node_to_grid(start).  One thread per episode.
+__global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_episodes) return;
+  const double* st = B.start + 4 * (size_t)e;
+  const double sx = st[0], sy = st[1], sth = st[2], stt = st[3];
+  double* nf = B.node_f + (size_t)e * B.cap_nodes * 4;
+  nf[0] = sx; nf[1] = sy; nf[2] = sth; nf[3] = stt;
+  reinterpret_cast<int4*>(B.node_i)[(size_t)e * B.cap_nodes] = make_int4(0, -1, 0, 0);
+  // same index arithmetic as the step kernel (int(y / cs), int(x / cs), floor(theta / delta_theta))
+  int row = (int)(sy / P.cell), col = (int)(sx / P.cell);
+  bool err = false;
+  if (row < 0) { row += P.rows; err |= row < 0; }
+  if (col < 0) { col += P.cols; err |= col < 0; }
+  int bk = -1;
+  if (!err && row < P.rows && col < P.cols) {
+    int sub = (int)auvp_floor(sth / P.delta_theta);
+    if (sub < 0) sub = (int)(P.S + sub);
+    if (sub == P.S) sub -= 1;
+    if (sub < 0) { sub += P.S; err |= sub < 0; }
+    err |= sub >= P.S;
+    bk = (row * P.cols + col) * P.S + sub;
+  }
+  if (err) bk = -1;
+  B.node_bucket[(size_t)e * B.cap_nodes] = bk;
+  if (bk >= 0) {
+    B.bucket_counts[(size_t)e * P.n_buckets + bk] = 1;
+    B.occupied[(size_t)e * B.cap_nodes] = bk;
+  }
+  PrrtSummary s;
+  s.status = err ? -1 : 0; s.n_nodes = 1; s.n_points = 0; s.n_occ = bk >= 0 ? 1 : 0; s.steps = 0; s.done = 0;
+  s.path_len = 0; s.last_node = 0; s.last_accepted = 0; s.last_new_node = -1; s.n_arc = 0; s._pad = 0;
+  for (int i = 0; i < 6; i++) s.arc[i] = 0.0;
+  s.rng_after = 0.0; s.n_draw32 = 0ull;
+  B.summary[e] = s;
+}
+
 // RRTEnv's per-step observation arrays (gym_rrt/envs/rrt_env.py:250-295), elementwise over
 // (episode, bucket): [cell.x, cell.y, subsection.theta, len(node_array)], has_node, node counts.
 // The reference rebuilds these three O(#buckets) Python lists after every node.
