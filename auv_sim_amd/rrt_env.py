@@ -9,8 +9,11 @@ and hands the observations back as numpy arrays (or leaves them in caller-owned 
 step() contract per episode (rrt_env.py:182-247): chosen_grid_cell_idx -> (cell, subsection)
 = divmod(idx, num_of_subsections); reward R_FOUND_PATH (300) when the goal arc is free, R_CREATE_NODE (0)
 when a node was added, R_INVALID_NODE (-1) otherwise.  Episodes that are done are skipped.
-RNG: seeded per episode (`seeds[e]` plays random.seed), drawn on the device.
+RNG: seeded per episode (`seeds[e]` plays random.seed), drawn on the device; `seeds=None` runs ONE
+episode on Python's global `random` stream exactly like the reference env (the stream is handed to the
+device for each step and advanced by what the step consumed).
 """
+import random
 import ctypes as C
 
 import numpy as np
@@ -28,8 +31,9 @@ class RRTEnvBatch:
     def __init__(self, auv_init_pos, shark_init_pos, boundary_array, grid_cell_side_length, num_of_subsections,
                  obstacle_array=(), seeds=(0,), max_nodes=2048, freq=RRT_PLANNER_FREQ, device=0):
         """auv_init_pos / shark_init_pos: one Motion_plan_state (shared) or a list of E of them"""
-        self.E = len(seeds)
-        self.seeds = np.asarray(seeds, dtype=np.uint64)
+        self.global_stream = seeds is None
+        self.E = 1 if seeds is None else len(seeds)
+        self.seeds = None if seeds is None else np.asarray(seeds, dtype=np.uint64)
         self._ctx = _lib.Context(device)
         self._obst = np.array([(float(o.x), float(o.y), float(o.size)) for o in obstacle_array], dtype=np.float64).reshape(-1, 3)
         self.obstacle_array = np.array([[o.x, o.y, o.z, o.size] for o in obstacle_array])
@@ -58,11 +62,19 @@ class RRTEnvBatch:
         self._ctx.set_world(obstacles=self._obst)
         starts = [[float(a.x), float(a.y), float(a.theta), float(a.traj_time_stamp)] for a in self._auv]
         goals = [[float(s.x), float(s.y)] for s in self._shark]
-        self._pb = PlannerBatch(self._ctx, starts, goals, self._rect, self.max_nodes, seeds=self.seeds, freq=self.freq,
-                                cell=self.cell_side_length, subs=self.num_of_subsections)
+        kw = dict(freq=self.freq, cell=self.cell_side_length, subs=self.num_of_subsections)
+        if self.global_stream:
+            self._pb = PlannerBatch(self._ctx, starts, goals, self._rect, self.max_nodes, mt_states=self._mt_state(), **kw)
+        else:
+            self._pb = PlannerBatch(self._ctx, starts, goals, self._rect, self.max_nodes, seeds=self.seeds, **kw)
         self._done = np.zeros(self.E, dtype=bool)
         self.state = self._observe(None)
         return self.state
+
+    @staticmethod
+    def _mt_state():
+        ver, internal, _ = random.getstate()
+        return np.array(internal[:624], dtype=np.uint32).reshape(1, 624), np.array([internal[624]], dtype=np.int32)
 
     def _observe(self, summ):
         nb = self.n_buckets
@@ -99,7 +111,13 @@ class RRTEnvBatch:
         # flat index -> bucket id: (row*cols + col)*S + k is the same flattening RRTEnv uses (:203-213)
         buckets = np.where(self._done, -1, idx).astype(np.int32)
         before = self._pb.summaries()
-        summ = self._pb.step(buckets)
+        if self.global_stream:
+            summ = self._pb.step(buckets, mt_states=self._mt_state())
+            n = int(summ[0]["n_draw32"]) if buckets[0] >= 0 else 0
+            if n:
+                random.getrandbits(32 * n)
+        else:
+            summ = self._pb.step(buckets)
         bad = summ["status"] < 0
         if bad.any():
             raise _lib.AuvpError(int(summ["status"][bad][0]), "planner episode failed on the device")

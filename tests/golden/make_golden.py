@@ -677,7 +677,71 @@ def g6():
         print("g6 sog", k, "found", out["found"], "path", out.get("path_length"), "expansions", len(out["expansions"]))
 
 
-ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6}
+# --------------------------------------------------------------------------------------------
+# G8: the caller of Planner_RRT -- gym_rrt/envs/rrt_env.py RRTEnv.reset / step
+# --------------------------------------------------------------------------------------------
+def g8():
+    refstubs.install()
+    _purge({"gym_rrt"})
+    saved = list(sys.path)
+    sys.path[:0] = [REF]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            envmod = importlib.import_module("gym_rrt.envs.rrt_env")
+            mpsm = importlib.import_module("gym_rrt.envs.motion_plan_state_rrt")
+            planmod = importlib.import_module("gym_rrt.envs.rrt_dubins")
+    finally:
+        sys.path[:] = saved
+    MPS = mpsm.Motion_plan_state
+    planmod.time = refstubs.VirtualClock()
+    lay = main_layout_obstacles()
+    for name, seed, cell, subs, n_steps in (("g8_env_s1", 5, 5, 1, 700), ("g8_env_s8", 6, 5, 4, 400)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            env = envmod.RRTEnv()
+            auv = MPS(x=10.0, y=10.0, z=-5.0, theta=0.0)
+            shark = MPS(x=35.0, y=45.0, z=-5.0, theta=0.0)
+            obs = [MPS(x=o[0], y=o[1], size=o[2]) for o in lay]
+            bnd = [MPS(x=0.0, y=0.0), MPS(x=50.0, y=50.0)]
+            random.seed(seed)
+            st = env.init_env(auv, shark, bnd, cell, subs, obs)
+        grid0 = np.array(st["rrt_grid"], dtype=np.float64)
+        choices, rewards, dones, counts = [], [], [], []
+        done = False
+        for i in range(n_steps):
+            has = np.flatnonzero(np.asarray(env.state["has_node"]))
+            # deterministic policy: cycle through the occupied flat indices, every 7th step an empty one
+            idx = int(has[i % len(has)])
+            if i % 7 == 3:
+                empt = np.flatnonzero(np.asarray(env.state["has_node"]) == 0)
+                idx = int(empt[(i * 13) % len(empt)])
+                # the reference blocks on input() for an empty cell (rrt_dubins.py:219): answer it
+                import builtins
+                old_input = builtins.input
+                builtins.input = lambda *a: ""
+            with contextlib.redirect_stdout(io.StringIO()):
+                s, r, done, _ = env.step(idx, i)
+            if i % 7 == 3:
+                builtins.input = old_input
+            choices.append(idx); rewards.append(r); dones.append(bool(done))
+            counts.append(np.asarray(s["rrt_grid_num_of_nodes_only"], dtype=np.int64).copy())
+            if done:
+                break
+        last = env.state
+        path = last["path"]
+        out = {"seed": seed, "cell": cell, "subs": subs, "obstacles": np.array(lay, dtype=np.float64),
+               "rect": np.array([0.0, 0.0, 50.0, 50.0]), "start": np.array([10.0, 10.0]), "goal": np.array([35.0, 45.0]),
+               "freq": envmod.RRT_PLANNER_FREQ, "rrt_grid0": grid0, "choices": np.array(choices, dtype=np.int64),
+               "rewards": np.array(rewards, dtype=np.int64), "dones": np.array(dones, dtype=np.int8),
+               "counts": np.array(counts, dtype=np.int64), "final_rrt_grid": np.array(last["rrt_grid"], dtype=np.float64),
+               "final_has_node": np.array(last["has_node"], dtype=np.int64), "rng_after": random.random(),
+               "done": bool(done)}
+        if done and isinstance(path, list):
+            out["path"] = np.array([[p.x, p.y, p.theta, p.traj_time_stamp] for p in path], dtype=np.float64)
+        save_npz(name + ".npz", **out)
+        print(name, "steps", len(choices), "done", done, "rewards", {int(k): int((np.array(rewards) == k).sum()) for k in set(rewards)})
+
+
+ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g8": g8}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -58,3 +58,27 @@ def test_env_batch_replays_golden_buckets():
             break
     t0, t1 = env.tree(0), env.tree(1)
     assert np.array_equal(t0["nodes"], t1["nodes"]) and len(t0["nodes"]) == st["rrt_grid_num_of_nodes_only"][0].sum()
+
+
+@pytest.mark.parametrize("name", ["g8_env_s1", "g8_env_s8"])
+def test_env_matches_reference_rrtenv(name):
+    """golden = the reference's own RRTEnv.init_env/step run (tests/golden/make_golden.py g8): same
+    flat cell indices in, same rewards / node-count observations / RNG position out"""
+    import random
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    from auv_sim_amd.rrt_env import RRTEnvBatch
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    obstacles = [MPS(o[0], o[1], size=o[2]) for o in g["obstacles"].tolist()]
+    bnd = [MPS(0.0, 0.0), MPS(50.0, 50.0)]
+    auv, shark = MPS(10.0, 10.0, z=-5.0), MPS(35.0, 45.0, z=-5.0)
+    random.seed(int(g["seed"]))
+    env = RRTEnvBatch(auv, shark, bnd, int(g["cell"]), int(g["subs"]), obstacles, seeds=None, max_nodes=1200, freq=int(g["freq"]))
+    st = env.reset()
+    assert np.array_equal(st["rrt_grid"][0], g["rrt_grid0"])  # cell.x, cell.y, subsection.theta, count
+    for i, idx in enumerate(g["choices"].tolist()):
+        st, reward, done, _ = env.step([idx], step_num=i)
+        assert reward[0] == g["rewards"][i], i
+        assert bool(done[0]) == bool(g["dones"][i])
+        assert np.array_equal(st["rrt_grid_num_of_nodes_only"][0], g["counts"][i]), i
+    assert np.array_equal(st["rrt_grid"][0], g["final_rrt_grid"]) and np.array_equal(st["has_node"][0], g["final_has_node"])
+    assert random.random() == float(g["rng_after"])
