@@ -32,6 +32,8 @@ struct WorldDev {
   const double* xb_data;    // [xb_off[NB]][4]
   double xb_x0, xb_inv_w;
   double bb[4];  // polygon bounds xmin,ymin,xmax,ymax (get_random_mps, :334)
+  double safe_box[4];    // when the polygon is an axis-aligned rectangle: its corners (strict interior test)
+  int32_t has_safe_box, _pad1;
 };
 
 struct RrtParamsDev {

@@ -266,6 +266,19 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
     bb[2] = std::max(bb[2], polygon[2 * i]); bb[3] = std::max(bb[3], polygon[2 * i + 1]);
   }
   memcpy(W.bb, bb, sizeof bb);
+  // axis-aligned rectangle given by its 4 corners: strict containment in it implies Point.within
+  W.has_safe_box = 0;
+  if (V == 4) {
+    bool rect = true;
+    for (int i = 0; i < 4 && rect; i++) {
+      const double x0 = polygon[2 * i], y0 = polygon[2 * i + 1], x1 = polygon[2 * ((i + 1) % 4)], y1 = polygon[2 * ((i + 1) % 4) + 1];
+      const bool horiz = (y0 == y1) && (x0 != x1), vert = (x0 == x1) && (y0 != y1);
+      const double x2 = polygon[2 * ((i + 2) % 4)], y2 = polygon[2 * ((i + 2) % 4) + 1];
+      const bool next_vert = (x1 == x2) && (y1 != y2), next_horiz = (y1 == y2) && (x1 != x2);
+      rect = (horiz && next_vert) || (vert && next_horiz);
+    }
+    if (rect) { W.has_safe_box = 1; memcpy(W.safe_box, bb, sizeof bb); }
+  }
   // host copies: the A* family derives its own device tables from the same world (astar_host.h)
   h->w_obst.assign(obstacles, obstacles + (size_t)O * 3);
   h->w_hab.assign(habitats, habitats + (size_t)H * 3);
@@ -410,7 +423,9 @@ int auvp_rrt_run(auvp_handle* h) {
   const RrtBuffers& B = h->B;
   const int E = h->E;
   const int nfreq = (int)std::floor(P.freq);
-  const size_t lds = (size_t)rrt_lds_plan(P.K, h->max_pts, nfreq).total;
+  const int O_ = h->W.n_obstacles;
+  const int jslots = (O_ <= 64 ? 1 : (O_ <= 128 ? 2 : (O_ <= 256 ? 4 : (O_ <= 512 ? 8 : 16)))) * 64;
+  const size_t lds = (size_t)rrt_lds_plan(P.K, h->max_pts, nfreq, jslots).total;
   if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB (K=%d, freq=%d)", lds, P.K, nfreq);
   const int grid = (E + RRT_WAVES - 1) / RRT_WAVES;
   const int O = h->W.n_obstacles;

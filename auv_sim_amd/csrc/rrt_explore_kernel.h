@@ -44,12 +44,13 @@ struct RrtSharedLds {
 //   [mt]       624 u32
 //   [pts]      max_pts * 2 f64
 //   [bins]     (K+2) i32
+// after the 4 per-wave blocks: obstacle tile [3][J*64] f64 shared by the workgroup
 struct RrtLdsPlan {
   int chunk;  // C
   int scratch, mt, pts, bins, per_wave, total;
 };
 
-__host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq) {
+__host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq, int obst_slots) {
   RrtLdsPlan p;
   p.chunk = nfreq < 1 ? 1 : (nfreq > RRT_MAX_CHUNK ? RRT_MAX_CHUNK : nfreq);
   const int C = p.chunk;
@@ -63,7 +64,7 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
   p.pts = ((max_pts * 16) + 15) & ~15;
   p.bins = (((K + 2) * 4) + 15) & ~15;
   p.per_wave = p.scratch + p.mt + p.pts + p.bins;
-  p.total = (int)sizeof(RrtSharedLds) + RRT_WAVES * p.per_wave;
+  p.total = (int)sizeof(RrtSharedLds) + RRT_WAVES * p.per_wave + obst_slots * 3 * 8;  // + obstacle tile x,y,T
   return p;
 }
 
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
   const int wave = uni((int)(threadIdx.x >> 6));  // wave-uniform: keeps every per-episode address scalar
   const int lane = lane_id();
   const int nfreq = (int)P.freq;
-  const RrtLdsPlan plan = rrt_lds_plan(P.K, max_pts, nfreq);
+  const RrtLdsPlan plan = rrt_lds_plan(P.K, max_pts, nfreq, J * 64);
   const int C = plan.chunk;
   unsigned char* wbase = smem + sizeof(RrtSharedLds) + (size_t)wave * plan.per_wave;
   double* scratch = reinterpret_cast<double*>(wbase);
@@ -193,21 +194,21 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
   }
   for (int i = threadIdx.x; i < W.n_poly * 2; i += blockDim.x) (&S.poly[0][0])[i] = W.poly[i];
   for (int i = threadIdx.x; i < W.n_bins * 2; i += blockDim.x) (&S.bins[0][0])[i] = W.bins[i];
+  // obstacles: SoA tile shared by the 4 episodes of the workgroup, padded to J*64 (slot j, lane l =
+  // obstacle j*64 + l); with the bounding-box cull most slots are only touched by 3 reads per expansion
+  double* olx = reinterpret_cast<double*>(smem + sizeof(RrtSharedLds) + (size_t)RRT_WAVES * plan.per_wave);
+  double* oly = olx + J * 64;
+  double* olt = oly + J * 64;
+  for (int i = threadIdx.x; i < J * 64; i += blockDim.x) {
+    const bool ok = i < W.n_obstacles;
+    olx[i] = ok ? W.ox[i] : 0.0;
+    oly[i] = ok ? W.oy[i] : 0.0;
+    olt[i] = ok ? W.ot[i] : -1.0;  // d2 >= 0 > -1: padding never collides
+  }
   __syncthreads();
 
   const int ep = (int)blockIdx.x * RRT_WAVES + wave;
   if (ep >= n_episodes) return;  // no workgroup barrier after this point
-
-  // ---- obstacles into registers: obstacle i = j*64 + lane ----
-  double ox[J], oy[J], ot[J];
-#pragma unroll
-  for (int j = 0; j < J; j++) {
-    int i = j * 64 + lane;
-    bool ok = i < W.n_obstacles;
-    ox[j] = ok ? W.ox[i] : 0.0;
-    oy[j] = ok ? W.oy[i] : 0.0;
-    ot[j] = ok ? W.ot[i] : -1.0;  // d2 >= 0 > -1: padding never collides
-  }
 
   // ---- per-episode views (scalar bases) ----
   const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
@@ -495,22 +496,27 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
     int hit = 0;
 #pragma unroll
     for (int j = 0; j < J; j++) {
-      const double ex = ox[j] < bx0 ? bx0 - ox[j] : (ox[j] > bx1 ? ox[j] - bx1 : 0.0);
-      const double ey = oy[j] < by0 ? by0 - oy[j] : (oy[j] > by1 ? oy[j] - by1 : 0.0);
-      const bool cand = ex * ex + ey * ey <= ot[j] * (1.0 + 0x1p-40);
+      const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], otj = olt[j * 64 + lane];
+      const double ex = oxj < bx0 ? bx0 - oxj : (oxj > bx1 ? oxj - bx1 : 0.0);
+      const double ey = oyj < by0 ? by0 - oyj : (oyj > by1 ? oyj - by1 : 0.0);
+      const bool cand = ex * ex + ey * ey <= otj * (1.0 + 0x1p-40);
       if (__any(cand)) {
         double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
         for (int p = 0; p < P_n; p++) {
           // next point's LDS read is in flight while this one is tested (pts has room for P_n + 1)
           const double2 qn = *reinterpret_cast<const double2*>(&pts[p + 1][0]);
-          double ddx = q.x - ox[j], ddy = q.y - oy[j];
+          double ddx = q.x - oxj, ddy = q.y - oyj;
           double d2 = ddx * ddx + ddy * ddy;
-          hit |= (d2 <= ot[j]) ? 1 : 0;  // no short-circuit: straight-line code
+          hit |= (d2 <= otj) ? 1 : 0;  // no short-circuit: straight-line code
           q = qn;
         }
       }
     }
-    const bool ok = !__any(hit != 0) && !any_point_outside(S.poly, W.n_poly, pts, P_n);
+    // polygon: when the path's bounding box lies strictly inside an axis-aligned rectangular boundary
+    // every point is strictly inside it and the crossing test would say so too; skip it then
+    const bool box_inside = W.has_safe_box && bx0 > W.safe_box[0] && by0 > W.safe_box[1] && bx1 < W.safe_box[2] &&
+                            by1 < W.safe_box[3];
+    const bool ok = !__any(hit != 0) && (box_inside || !any_point_outside(S.poly, W.n_poly, pts, P_n));
     if (log_it && lane == 0) {
       B.it_parent[logb + it] = par;
       B.it_accepted[logb + it] = ok ? 1 : 0;
