@@ -30,12 +30,14 @@ def _bind():
     L.auvp_astar_paths.argtypes = [vp, C.POINTER(C.c_int64), _dp, _dp, _dp, _dp]
     L.auvp_astar_exp_log.argtypes = [vp, C.c_int32, _dp]
     L.auvp_astar_hab_left.argtypes = [vp, C.c_int32, _ip]
+    L.auvp_astar_set_visited.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
+    L.auvp_astar_get_visited.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint8)]
     _bound = True
     return L
 
 
 def run_batch(ctx, variant, starts, goals=None, limits=None, box=(0, 0, 0, 0), velocity=1.0, weights=(0, 0, 0, 0),
-              cap_nodes=20000, exp_log=False):
+              cap_nodes=20000, exp_log=False, visited=None):
     """E searches over ctx's world in one launch.  Returns a list of per-instance dicts."""
     L = _bind()
     starts = _lib._f64(starts, (-1, 2))
@@ -48,8 +50,13 @@ def run_batch(ctx, variant, starts, goals=None, limits=None, box=(0, 0, 0, 0), v
         p.w[i] = float(wts[i])
     g = _lib._f64(goals, (-1, 2)) if goals is not None else None
     lim = _lib._f64(limits).reshape(E) if limits is not None else None
+    flags = 1 if exp_log else 0
+    if visited is not None:  # [E, vx, 600] uint8: the solver's visited_nodes carried over from earlier calls
+        vis = np.ascontiguousarray(visited, dtype=np.uint8)
+        ctx._chk(L.auvp_astar_set_visited(ctx.h, E, p.variant, vis.ctypes.data_as(C.POINTER(C.c_uint8))))
+        flags |= 8
     ctx._chk(L.auvp_astar_batch(ctx.h, E, _lib._p(starts), _lib._p(g) if g is not None else None,
-                                _lib._p(lim) if lim is not None else None, C.byref(p), 1 if exp_log else 0))
+                                _lib._p(lim) if lim is not None else None, C.byref(p), flags))
     summ = np.zeros(E, dtype=ASTAR_SUMMARY_DTYPE)
     ctx._chk(L.auvp_astar_summaries(ctx.h, summ.ctypes.data_as(C.c_void_p)))
     lens = np.where(summ["found"] != 0, summ["path_len"], 0).astype(np.int64)
@@ -73,6 +80,10 @@ def run_batch(ctx, variant, starts, goals=None, limits=None, box=(0, 0, 0, 0), v
         if H:
             ctx._chk(L.auvp_astar_hab_left(ctx.h, e, _lib._p(hl, _ip)))
         r["hab_left"] = hl[:int(s["n_hab_left"])]
+        if p.variant >= 2 and visited is not None:
+            vb = np.zeros((550 if p.variant == 2 else 600, 600), dtype=np.uint8)
+            ctx._chk(L.auvp_astar_get_visited(ctx.h, e, vb.ctypes.data_as(C.POINTER(C.c_uint8))))
+            r["visited"] = vb
         if exp_log:
             ex = np.zeros((max(int(s["n_expansions"]), 1), 8))
             ctx._chk(L.auvp_astar_exp_log(ctx.h, e, _lib._p(ex)))

@@ -2,8 +2,7 @@
 boundary_list, start, pathLenLimit, weights)` -> [path (Motion_plan_state list), cost list] or None
 (astar_fixLen.py:45,286).  Like the reference it REMOVES the habitats the search covered from the
 caller's `habitat_list` (the reference aliases and pops it, :310,:193-197).
-Known deviation: a second call on the same solver starts from a clean visited bitmap (the reference's
-`self.visited_nodes` keeps the marks of earlier calls)."""
+`self.visited_nodes` persists across calls on one solver object, as in the reference."""
 import numpy as np
 
 from . import _astar_common as ac
@@ -23,7 +22,9 @@ class astar:
     def astar(self, habitat_list, obs_lst, boundary_list, start, pathLenLimit, weights):
         self._ctx.set_world(obstacles=ac.circles(obs_lst), habitats=ac.circles(habitat_list), polygon=ac.corners(boundary_list))
         r = ac.run(self._ctx, "astar_fixLen", [tuple(map(float, start))], limits=[float(pathLenLimit)],
-                   weights=[float(w) for w in weights], cap_nodes=self.cap_nodes)[0]
+                   weights=[float(w) for w in weights], cap_nodes=self.cap_nodes,
+                   visited=(self.visited_nodes != 0).astype(np.uint8)[None])[0]
+        self.visited_nodes = r["visited"].astype(np.float64)
         keep = set(int(i) for i in r["hab_left"])
         survivors = [h for i, h in enumerate(list(habitat_list)) if i in keep]
         habitat_list[:] = survivors  # same objects, same order as the reference leaves them

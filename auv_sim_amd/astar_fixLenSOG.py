@@ -3,7 +3,7 @@ sharkGrid, shark_dict, AUV_velocity).astar(pathLenLimit, weights, shark_traj)` -
 "path length", "path" (smoothed), "cost", "cost list", "node" -- or None when the open list runs empty
 (astar_fixLenSOG.py:111,551,618).  `sharkGrid` must be given ({(t0,t1): {cell.bounds: prob}}); the
 reference's fallback for `{}` (splitCell + a CSV path relative to its repo root, :127-132) needs shapely
-and is not reproduced.  Deviation: visited bitmap starts clean on every call (see astar_fixLen)."""
+and is not reproduced.  `self.visited_nodes` persists across calls, as in the reference."""
 import numpy as np
 
 from . import _astar_common as ac
@@ -48,7 +48,13 @@ class astar:
         return {"path length": len(smooth), "path": smooth, "cost": cost[0], "cost list": cost, "node": nodes}
 
     def astar(self, pathLenLimit, weights, shark_traj):
-        return self.astar_batch([self.start], [pathLenLimit], weights)[0]
+        self._ctx.set_world(obstacles=ac.circles(self.obstacle_list), habitats=ac.circles(self.habitat_list),
+                            polygon=ac.corners(self.boundary_list), bins=self._bins, cells=self._cells, prob=self._prob)
+        r = ac.run(self._ctx, "astar_fixLenSOG", [tuple(map(float, self.start))], limits=[float(pathLenLimit)],
+                   weights=[float(w) for w in weights], velocity=float(self.velocity), cap_nodes=self.cap_nodes,
+                   visited=(self.visited_nodes != 0).astype(np.uint8)[None])[0]
+        self.visited_nodes = r["visited"].astype(np.float64)
+        return self._result(r, self.start)
 
     def astar_batch(self, starts, limits, weights):
         self._ctx.set_world(obstacles=ac.circles(self.obstacle_list), habitats=ac.circles(self.habitat_list),

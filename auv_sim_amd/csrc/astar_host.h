@@ -16,6 +16,7 @@ struct AstarState {
   auvp::AstarBuffers B{};
   DevBuf ox, oy, ot, hab, poly, bins, rcells, prob, topn;
   DevBuf start, goal, limit, nodes, node_i, visited, hab_left, exp_log, summary, off, path, cost, npath, smooth;
+  long long visited_set_for = -1;  // byte size of a bitmap uploaded by auvp_astar_set_visited, -1 none
 };
 
 AstarState* astar_of(auvp_handle* h) {
@@ -130,7 +131,14 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
   if (p->variant >= 2) {
     const size_t vb = (size_t)E * P.vx * P.vy;
     HIPCHK(h, S.visited.reserve(vb));
-    HIPCHK(h, hipMemsetAsync(S.visited.p, 0, vb, h->stream));
+    if (flags & AUVP_FLAG_KEEP_VISITED) {
+      // the reference keeps self.visited_nodes across astar() calls on one solver object
+      // (astar_fixLen.py:51, astar_fixLenSOG.py:117): the caller uploaded it with auvp_astar_set_visited
+      if (S.visited_set_for != (long long)vb) return fail(h, AUVP_ERR_STATE, "auvp_astar_set_visited not called for this batch shape");
+    } else {
+      HIPCHK(h, hipMemsetAsync(S.visited.p, 0, vb, h->stream));
+    }
+    S.visited_set_for = -1;
     B.visited = S.visited.as<uint8_t>();
   }
   B.exp_log = nullptr;
@@ -198,6 +206,30 @@ int auvp_astar_exp_log(auvp_handle* h, int32_t ep, double* out8) {
   HIPCHK(h, hipMemcpy(&s, S.B.summary + ep, sizeof s, hipMemcpyDeviceToHost));
   const size_t n = (size_t)std::min(s.n_expansions, S.P.cap_exp);
   if (n) HIPCHK(h, hipMemcpy(out8, S.B.exp_log + (size_t)ep * S.P.cap_exp * 8, n * 8 * sizeof(double), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+// visited bitmap in / out (variants 2,3): [E][vx*vy] bytes, vx = 550 (fixLen) or 600 (SOG), vy = 600;
+// set before auvp_astar_batch(..., AUVP_FLAG_KEEP_VISITED), get after any batch
+int auvp_astar_set_visited(auvp_handle* h, int32_t E, int32_t variant, const uint8_t* bitmap) {
+  if (!h || !bitmap || E <= 0 || variant < 2 || variant > 3) return AUVP_ERR_ARG;
+  AstarState& S = *astar_of(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t vb = (size_t)E * (variant == 2 ? 550 : 600) * 600;
+  int rc;
+  if ((rc = upload(h, S.visited, bitmap, vb))) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  S.visited_set_for = (long long)vb;
+  return AUVP_OK;
+}
+
+int auvp_astar_get_visited(auvp_handle* h, int32_t ep, uint8_t* bitmap) {
+  if (!h || !bitmap) return AUVP_ERR_ARG;
+  AstarState& S = *astar_of(h);
+  if (!S.ready || ep < 0 || ep >= S.E || !S.B.visited) return fail(h, AUVP_ERR_STATE, "no visited bitmap");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t one = (size_t)S.P.vx * S.P.vy;
+  HIPCHK(h, hipMemcpy(bitmap, S.B.visited + (size_t)ep * one, one, hipMemcpyDeviceToHost));
   return AUVP_OK;
 }
 

@@ -31,7 +31,7 @@ enum {
 };
 
 enum { AUVP_MODE_TIMEBIN = 0, AUVP_MODE_PLANTIME = 1, AUVP_MODE_NN = 2 };
-enum { AUVP_FLAG_ITER_LOG = 1, AUVP_FLAG_LEAF_LOG = 2, AUVP_FLAG_PHASE_CLOCKS = 4 };
+enum { AUVP_FLAG_ITER_LOG = 1, AUVP_FLAG_LEAF_LOG = 2, AUVP_FLAG_PHASE_CLOCKS = 4, AUVP_FLAG_KEEP_VISITED = 8 };
 
 const char* auvp_version(void);
 /* create a planner context on HIP device `device`; fails (AUVP_ERR_HIP) when no gfx950 GPU is
@@ -196,6 +196,11 @@ int auvp_astar_paths(auvp_handle* h, const int64_t* offsets, double* path3, doub
 int auvp_astar_exp_log(auvp_handle* h, int32_t instance, double* out8);
 /* variant 2: indices of the habitats still in the caller's habitat_list after the call (:310,:193-197) */
 int auvp_astar_hab_left(auvp_handle* h, int32_t instance, int32_t* out);
+/* self.visited_nodes (astar_fixLen.py:51 [550,600]; astar_fixLenSOG.py:117 [600,600]) persists across
+ * astar() calls on one solver object in the reference: upload it before a batch launched with
+ * AUVP_FLAG_KEEP_VISITED ([E][vx*600] bytes, row-major [x_pos][y_pos]) and read it back afterwards */
+int auvp_astar_set_visited(auvp_handle* h, int32_t n_instances, int32_t variant, const uint8_t* bitmap);
+int auvp_astar_get_visited(auvp_handle* h, int32_t instance, uint8_t* bitmap);
 
 /* standalone evaluations on the device (parity probes for the building blocks) */
 /* RRT.check_collision (:530-549) of n_paths paths; pts [sum(npts),2], path i = pts[off[i]:off[i+1]] */

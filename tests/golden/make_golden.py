@@ -677,6 +677,35 @@ def g6():
         print("g6 sog", k, "found", out["found"], "path", out.get("path_length"), "expansions", len(out["expansions"]))
 
 
+def g6b():
+    """two astar() calls on ONE astar_fixLen solver: self.visited_nodes carries over (:51,:414-416)"""
+    mod, mpsm = import_astar("astar_fixLen")
+    MPS = mpsm.Motion_plan_state
+    rect = [(-300.0, -100.0), (-100.0, -100.0), (-100.0, 100.0), (-300.0, 100.0)]
+    w = synth.make_world(seed=26, n_obstacles=10, obst_radius=(3.0, 8.0), n_habitats=8, hab_radius=(10.0, 25.0))
+    obs = [MPS(o[0], o[1], size=o[2]) for o in w["obstacles"].tolist()]
+    bnd = [MPS(p[0], p[1]) for p in rect]
+    solver = mod.astar((-290.0, -90.0), obs, bnd)
+    outs = {}
+    for k, (st, limit) in enumerate([((-290.0, -90.0), 150), ((-250.0, -60.0), 120)]):
+        hab = [MPS(h[0], h[1], size=h[2]) for h in w["habitats"].tolist()]
+        log = []
+        solver.curr_neighbors = mod.astar.curr_neighbors.__get__(solver)
+        _log_expansions(solver, log)
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = solver.astar(hab, obs, bnd, st, limit, [0, 10, 10])
+        outs["found%d" % k] = res is not None
+        outs["start%d" % k] = np.array(st)
+        outs["limit%d" % k] = float(limit)
+        outs["expansions%d" % k] = np.array(log, dtype=np.float64).reshape(-1, 8)
+        outs["path%d" % k] = np.array([[p.x, p.y] for p in (res[0] if res else [])], dtype=np.float64).reshape(-1, 2)
+        outs["visited_count%d" % k] = int(solver.visited_nodes.sum())
+    save_npz("h6_fixlen_twice.npz", obstacles=w["obstacles"], habitats=w["habitats"], polygon=np.array(rect),
+             weights=np.array([0.0, 10.0, 10.0]), **outs)
+    print("g6b", outs["found0"], outs["found1"], len(outs["expansions0"]), len(outs["expansions1"]), outs["visited_count0"],
+          outs["visited_count1"])
+
+
 # --------------------------------------------------------------------------------------------
 # G8: the caller of Planner_RRT -- gym_rrt/envs/rrt_env.py RRTEnv.reset / step (SURVEY 8(f) f1)
 # --------------------------------------------------------------------------------------------
@@ -741,7 +770,7 @@ def g8():
         print(name, "steps", len(choices), "done", done, "rewards", {int(k): int((np.array(rewards) == k).sum()) for k in set(rewards)})
 
 
-ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g8": g8}
+ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

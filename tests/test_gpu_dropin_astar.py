@@ -67,3 +67,19 @@ def test_astar_fixlen_sog(name):
     got = [[n.position[0], n.position[1], n.g, n.h, n.f, n.cost, n.pathLen, n.time_stamp] for n in res["node"]]
     assert got == g["node_path"].tolist()
     assert all(n.parent is (res["node"][i - 1] if i else None) for i, n in enumerate(res["node"]))
+
+
+def test_astar_fixlen_solver_reuse_keeps_visited_bitmap():
+    """the reference's self.visited_nodes persists across astar() calls on one solver object"""
+    from auv_sim_amd.astar_fixLen import astar
+    g = np.load(os.path.join(GOLDEN, "h6_fixlen_twice.npz"))
+    obs, bnd = _mps(g["obstacles"].tolist()), _mps(g["polygon"].tolist())
+    solver = astar(tuple(g["start0"].tolist()), obs, bnd)
+    for k in (0, 1):
+        hab = _mps(g["habitats"].tolist())
+        start = tuple(g["start%d" % k].tolist())
+        res = solver.astar(hab, obs, bnd, start, float(g["limit%d" % k]), g["weights"].tolist())
+        assert (res is not None) == bool(g["found%d" % k])
+        if res is not None:
+            assert [(p.x, p.y) for p in res[0]] == [tuple(r) for r in g["path%d" % k].tolist()]
+        assert int(solver.visited_nodes.sum()) == int(g["visited_count%d" % k])
