@@ -613,3 +613,4 @@ PrrtState* prrt_of(auvp_handle* h) {
 
 #include "astar_kernel.h"
 #include "astar_host.h"
+#include "sog_kernels.h"

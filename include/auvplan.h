@@ -202,6 +202,20 @@ int auvp_astar_hab_left(auvp_handle* h, int32_t instance, int32_t* out);
 int auvp_astar_set_visited(auvp_handle* h, int32_t n_instances, int32_t variant, const uint8_t* bitmap);
 int auvp_astar_get_visited(auvp_handle* h, int32_t instance, uint8_t* bitmap);
 
+/* ---- shark occupancy / AUV detection grids ------------------------------------------------------
+ * SharkOccupancyGrid.convert (path_planning/sharkOccupancyGrid.py:47-74): the producer of the
+ * `sharkGrid` dict the A* SOG variant and createSharkGrid consume.  cells [C,4] = bounds of
+ * cell_list (splitCell output, :376-393) in list order; box = boundary.bounds; traj_len [S] points
+ * per shark in dict order; pts [sum(traj_len),3] = x, y, traj_time_stamp.  Outputs: n_bins
+ * (createBinList :306-319), rows/cols (:134), bins [n_bins,2], grids [n_bins,rows,cols] = resultArr.
+ * A cell whose index falls outside the grid is the reference's IndexError -> AUVP_ERR_ARG.
+ * Call once with grids == NULL (or cap_bins == 0 -> AUVP_ERR_CAPACITY with the sizes filled in) to size
+ * the output. */
+int auvp_sog_convert(auvp_handle* h, const double* cells, int32_t n_cells, const double* box4, double cell_size,
+                     double bin_interval, double detect_range, int32_t n_sharks, const int32_t* traj_len,
+                     const double* pts_xyt, int32_t cap_bins, int32_t* n_bins, int32_t* rows, int32_t* cols,
+                     double* bins, double* grids);
+
 /* standalone evaluations on the device (parity probes for the building blocks) */
 /* RRT.check_collision (:530-549) of n_paths paths; pts [sum(npts),2], path i = pts[off[i]:off[i+1]] */
 int auvp_check_collision_batch(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xy,

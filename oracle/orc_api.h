@@ -108,9 +108,28 @@ typedef struct {
   int32_t* hab_left;   /* [H] indices of the habitats still in habitat_open_list (variant 2) */
 } orc_astar_out;
 
+/* SharkOccupancyGrid.convert (path_planning/sharkOccupancyGrid.py:47) */
+typedef struct {
+  int32_t n_cells, n_sharks;
+  double box[4];            /* boundary.bounds */
+  double cell_size, bin_interval, detect_range;
+  const double* cells;      /* [C,4] bounds, cell_list order */
+  const int32_t* traj_len;  /* [S] points per shark (dict order) */
+  const double* pts;        /* [sum,3] x, y, traj_time_stamp */
+} orc_sog_in;
+
+typedef struct {
+  int32_t cap_bins, n_bins, rows, cols;
+  double* bins;     /* [cap_bins,2] */
+  double* grids;    /* [cap_bins,rows,cols] AUV detection grid per bin (resultArr) */
+  double* occ_dbg;  /* [rows,cols] constructSharkOccupancyGrid of (bin 0, shark 0), optional */
+  double* auv_dbg;  /* [rows,cols] constructAUVGrid of the same, optional */
+} orc_sog_out;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int orc_sog_convert(const orc_sog_in* in, orc_sog_out* out);
 int orc_astar_run(const orc_world* w, const orc_astar_params* p, orc_astar_out* o);
 const char* orc_math_name(void);
 double orc_sin(double x);

@@ -98,6 +98,14 @@ class CellStub:
     def exterior(self):
         return _Coords(self._pts + [self._pts[0]])
 
+    def touches(self, pt):
+        """shapely: the point lies on the cell's boundary (sharkOccupancyGrid.py:264 uses
+        `point.within(cell) or cell.touches(point)` = closed containment)"""
+        minx, miny, maxx, maxy = self.bounds
+        on_x = (pt.x == minx or pt.x == maxx) and miny <= pt.y <= maxy
+        on_y = (pt.y == miny or pt.y == maxy) and minx <= pt.x <= maxx
+        return on_x or on_y
+
 
 def _mod(name, **attrs):
     m = types.ModuleType(name)

@@ -770,7 +770,69 @@ def g8():
         print(name, "steps", len(choices), "done", done, "rewards", {int(k): int((np.array(rewards) == k).sum()) for k in set(rewards)})
 
 
-ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8}
+# --------------------------------------------------------------------------------------------
+# G9: SharkOccupancyGrid.convert (path_planning/sharkOccupancyGrid.py:47-74) -- SURVEY 8(f) f2
+# --------------------------------------------------------------------------------------------
+def g9():
+    refstubs.install()
+    _purge(_SHARED)
+    saved = list(sys.path)
+    sys.path[:0] = [os.path.join(REF, "path_planning"), REF]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            sog = importlib.import_module("sharkOccupancyGrid")
+            mpsm = importlib.import_module("motion_plan_state")
+    finally:
+        sys.path[:] = saved
+    MPS = mpsm.Motion_plan_state
+    rng = random.Random(91)
+    specs = [("g9_sog_small", (0.0, 0.0, 10.0, 10.0), 2.0, 2.0, 4.0, 1, 50, 0.1),
+             ("g9_sog_catalina", (-300.0, -100.0, -100.0, 100.0), 10.0, 50.0, 50.0, 6, 240, 1.0),
+             ("g9_sog_fine", (-40.0, -30.0, 35.0, 42.0), 5.0, 20.0, 12.0, 4, 150, 0.5)]
+    for name, box, cs, bin_interval, detect, n_sharks, n_pts, dt in specs:
+        x0, y0, x1, y1 = box
+        ncol, nrow = int(round((x1 - x0) / cs)), int(round((y1 - y0) / cs))
+        cells = [refstubs.CellStub(x0 + c * cs, y0 + r * cs, x0 + (c + 1) * cs, y0 + (r + 1) * cs)
+                 for r in range(nrow) for c in range(ncol)]
+        boundary = refstubs.Polygon([(x0, y0), (x1, y0), (x1, y1), (x0, y1)])
+        sharks = {}
+        for s in range(1, n_sharks + 1):
+            px, py = rng.uniform(x0 + 1, x1 - 1), rng.uniform(y0 + 1, y1 - 1)
+            vx, vy = rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6)
+            traj = []
+            for i in range(1, n_pts + 1):
+                px = min(max(px + vx, x0), x1)
+                py = min(max(py + vy, y0), y1)
+                if rng.random() < 0.05:
+                    vx, vy = rng.uniform(-0.6, 0.6), rng.uniform(-0.6, 0.6)
+                if rng.random() < 0.03:  # exactly on a cell edge / corner
+                    px = x0 + cs * round((px - x0) / cs)
+                traj.append(MPS(px, py, traj_time_stamp=dt * i))
+            sharks[s] = traj
+        grid = sog.SharkOccupancyGrid(cs, boundary, bin_interval, detect, cells)
+        with contextlib.redirect_stdout(io.StringIO()):
+            arr, celld = grid.convert(sharks)
+        keys = list(arr.keys())
+        occ0 = np.array(grid.constructSharkOccupancyGrid(grid.timeBinDict[keys[0]][1]), dtype=np.float64)
+        with contextlib.redirect_stdout(io.StringIO()):
+            auv0 = np.array(grid.constructAUVGrid(occ0.tolist()), dtype=np.float64)
+        flat = []
+        for s in range(1, n_sharks + 1):
+            for p in sharks[s]:
+                flat.append([p.x, p.y, p.traj_time_stamp])
+        cell_bounds = np.array([c.bounds for c in cells], dtype=np.float64)
+        save_npz(name + ".npz", box=np.array(box), cell_size=cs, bin_interval=bin_interval, detect_range=detect,
+                 cells=cell_bounds, points=np.array(flat, dtype=np.float64),
+                 traj_len=np.array([len(sharks[s]) for s in range(1, n_sharks + 1)], dtype=np.int32),
+                 bins=np.array([[k[0], k[1]] for k in keys], dtype=np.float64),
+                 grids=np.array([arr[k] for k in keys], dtype=np.float64), occ_bin0_shark1=occ0, auv_bin0_shark1=auv0,
+                 cell_keys=np.array([[list(b) for b in celld[k].keys()] for k in keys], dtype=np.float64),
+                 cell_vals=np.array([list(celld[k].values()) for k in keys], dtype=np.float64))
+        print(name, "bins", len(keys), "grid", np.array(arr[keys[0]]).shape, "cells", len(cells),
+              "nonzero per bin", [len(celld[k]) for k in keys][:4])
+
+
+ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8, "g9": g9}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)
