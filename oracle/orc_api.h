@@ -126,9 +126,38 @@ typedef struct {
   double* auv_dbg;  /* [rows,cols] constructAUVGrid of the same, optional */
 } orc_sog_out;
 
+/* ParticleFilter (particleFilter.py) driven like robotSim.py:665-701: create(), then per step
+ * create_and_update, update_weights (normalize, correct), particleMean, meanError; numpy legacy
+ * RandomState stream (MT19937 key + pos in/out) */
+typedef struct {
+  int32_t n_particles, n_steps, n_auv, do_create;
+  double shark0[2];        /* ParticleFilter(init_x_shark, init_y_shark, ...) */
+  const double* meas;      /* [n_steps,n_auv,5] list_of_range_bearing rows: x, y, theta, [3], [4] */
+  const double* shark_xy;  /* [n_steps,2] self.x_shark / self.y_shark when meanError runs */
+  const double* init;      /* [N,5] x, y, v, theta, weight when !do_create */
+  const int32_t* init_obj; /* [N] object id of each list entry when !do_create (aliases share an id), or NULL */
+  uint32_t* mt;            /* [624] in/out */
+  int32_t* mt_pos;         /* in/out */
+} orc_pf_in;
+
+typedef struct {
+  double* created;      /* [N,5] (do_create) */
+  double* updated;      /* [n_steps,N,5] after create_and_update */
+  double* resampled;    /* [n_steps,N,5] the list update_weights returns */
+  int32_t* choice;      /* [n_steps,N] index drawn by random.choice(len(list_of_new_particles)) */
+  int32_t* alias_first; /* [n_steps,N] first list position holding the same object */
+  int32_t* list_len;    /* [n_steps] len(list_of_new_particles) */
+  double* mean;         /* [n_steps,2] */
+  double* range_error;  /* [n_steps] */
+  uint64_t n_draw32;
+} orc_pf_out;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int orc_pf_run(const orc_pf_in* in, orc_pf_out* out);
+void orc_np_kat(uint32_t seed, int n, double* out_uniform, int32_t* out_choice, int32_t choice_n);
+double orc_pow_e(double z);
 int orc_sog_convert(const orc_sog_in* in, orc_sog_out* out);
 int orc_astar_run(const orc_world* w, const orc_astar_params* p, orc_astar_out* o);
 const char* orc_math_name(void);

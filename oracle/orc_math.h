@@ -18,12 +18,14 @@
 
 #ifdef ORC_PORTABLE_MATH
 #include "../auv_sim_amd/csrc/auvp_math.h"
+#include "../auv_sim_amd/csrc/auvp_exp.h"
 #define ORC_SIN(x) auvp_sin(x)
 #define ORC_COS(x) auvp_cos(x)
 #define ORC_POW2(x) ((x) * (x))
 #define ORC_SQRT(x) auvp_sqrt(x)
 #define ORC_ATAN2(y, x) auvp_atan2(y, x)
 #define ORC_HYPOT(x, y) auvp_hypot(x, y)
+#define ORC_POW_E(z) auvp_pow_e(z)
 #define ORC_MATH_NAME "portable"
 #else
 #define ORC_SIN(x) sin(x)
@@ -32,6 +34,7 @@
 #define ORC_SQRT(x) sqrt(x)
 #define ORC_ATAN2(y, x) atan2(y, x)
 #define ORC_HYPOT(x, y) hypot(x, y)
+#define ORC_POW_E(z) pow(2.718281828459045, (z)) /* math.e ** z */
 #define ORC_MATH_NAME "libm"
 #endif
 

@@ -832,7 +832,127 @@ def g9():
               "nonzero per bin", [len(celld[k]) for k in keys][:4])
 
 
-ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8, "g9": g9}
+# --------------------------------------------------------------------------------------------
+# G10: particleFilter.py (ParticleFilter.create / create_and_update / update_weights / particleMean /
+# meanError) driven the way robotSim.py:665-701 drives it, numpy's global legacy RandomState seeded
+# --------------------------------------------------------------------------------------------
+def g10():
+    import types
+    refstubs.install()
+    _purge(_SHARED | {"particleFilter", "live3DGraph", "twoDfigure"})
+    # plotting-only imports of particleFilter.py:14-15
+    sys.modules["live3DGraph"] = types.ModuleType("live3DGraph")
+    sys.modules["live3DGraph"].Live3DGraph = object
+    sys.modules["twoDfigure"] = types.ModuleType("twoDfigure")
+    sys.modules["twoDfigure"].Figure = object
+    saved = list(sys.path)
+    sys.path[:0] = [REF]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            pfm = importlib.import_module("particleFilter")
+    finally:
+        sys.path[:] = saved
+    orig_choice = np.random.choice
+    specs = [("g10_pf_one_auv", 11, 1, 14, (40.0, -25.0)), ("g10_pf_two_auvs", 12, 2, 14, (-310.0, 120.0)),
+             ("g10_pf_three_auvs_far", 4000000123, 3, 10, (900.0, 650.0))]
+    for name, seed, n_auv, n_steps, shark0 in specs:
+        rng = random.Random(seed * 7 + 1)
+        np.random.seed(seed)
+        choice_log = []
+
+        def logged_choice(a, *args, **kw):
+            x = orig_choice(a, *args, **kw)
+            choice_log[-1][1].append(int(x))
+            return x
+        pfm.random.choice = logged_choice  # numpy.random module attribute, restored below
+        try:
+            pf = pfm.ParticleFilter(shark0[0], shark0[1], [])
+            particles = pf.create()
+
+            def snap(ps):
+                return np.array([[p.x_p, p.y_p, p.v_p, p.theta_p, p.weight_p] for p in ps], dtype=np.float64)
+            created = snap(particles)
+            sx, sy, sth = shark0[0], shark0[1], rng.uniform(-math.pi, math.pi)
+            auv = [[shark0[0] + rng.uniform(-120, 120), shark0[1] + rng.uniform(-120, 120), rng.uniform(-math.pi, math.pi)]
+                   for _ in range(n_auv)]
+            upd, new, meas_all, means, errs, alias, ells = [], [], [], [], [], [], []
+            for step in range(n_steps):
+                with contextlib.redirect_stdout(io.StringIO()):
+                    particles = pf.create_and_update(particles)
+                upd.append(snap(particles))
+                sth += rng.uniform(-0.3, 0.3)
+                sx += 1.2 * math.cos(sth)
+                sy += 1.2 * math.sin(sth)
+                meas = []
+                for a in auv:
+                    a[2] += rng.uniform(-0.2, 0.2)
+                    a[0] += 1.0 * math.cos(a[2])
+                    a[1] += 1.0 * math.sin(a[2])
+                    z_range = math.hypot(sx - a[0], sy - a[1]) + rng.gauss(0, 5)
+                    z_bearing = pfm.angle_wrap(math.atan2(sy - a[1], sx - a[0]) - a[2]) + rng.gauss(0, 0.1)
+                    # robotSim.py:get_all_sharks_sensor_measurements row: x, y, theta, range, bearing, id
+                    meas.append([a[0], a[1], a[2], z_range, z_bearing, 1])
+                pf.x_shark, pf.y_shark = sx, sy
+                choice_log.append((step, []))
+                with contextlib.redirect_stdout(io.StringIO()):
+                    particles = pf.update_weights(particles, meas)
+                    m = pf.particleMean(particles)
+                    e = pf.meanError(m[0], m[1])
+                new.append(snap(particles))
+                first = {}
+                alias.append([first.setdefault(id(p), i) for i, p in enumerate(particles)])
+                meas_all.append([r[:5] for r in meas])
+                means.append(m)
+                errs.append(e)
+                ells.append([sx, sy])
+            st = np.random.get_state()
+        finally:
+            pfm.random.choice = orig_choice
+        save_npz(name + ".npz", seed=np.uint64(seed), shark0=np.array(shark0), created=created,
+                 updated=np.array(upd), resampled=np.array(new), measurements=np.array(meas_all, dtype=np.float64),
+                 shark_xy=np.array(ells), mean=np.array(means), range_error=np.array(errs),
+                 alias_first=np.array(alias, dtype=np.int32),
+                 choice=np.array([c[1] for c in choice_log], dtype=np.int32),
+                 mt_key=np.asarray(st[1], dtype=np.uint32), mt_pos=np.int32(st[2]))
+        print(name, "steps", n_steps, "err", [round(x, 2) for x in errs[:3]], "...", round(errs[-1], 2),
+              "max multiplicity", max(np.bincount(a).max() for a in alias))
+
+
+# --------------------------------------------------------------------------------------------
+# G11: habitatGrid.py HabitatGrid (habitat-id layout of the cell grid, inside_habitat, within_habitat_env)
+# --------------------------------------------------------------------------------------------
+def g11():
+    saved = list(sys.path)
+    sys.path[:0] = [REF]
+    try:
+        _purge({"habitatGrid", "habitatCell", "habitat"})
+        hg = importlib.import_module("habitatGrid")
+    finally:
+        sys.path[:] = saved
+    rng = random.Random(5)
+    out = {}
+    for k, (ex, ey, sx, sy, hs, cs) in enumerate([(0, 0, 50, 40, 10, 1), (0.0, 0.0, 60.0, 60.0, 20, 5), (5, 3, 35, 25, 10, 2),
+                                                   (0, 0, 500, 500, 50, 10)]):
+        g = hg.HabitatGrid(ex, ey, sx, sy, habitat_side_length=hs, cell_side_length=cs)
+        ids = np.array([[c.habitat_id for c in row] for row in g.habitat_cell_grid], dtype=np.int32)
+        cell_xy = np.array([[[c.x, c.y] for c in row] for row in g.habitat_cell_grid], dtype=np.float64)
+        habs = np.array([[h.x, h.y, h.id, h.side_length] for h in g.habitat_array], dtype=np.float64)
+        q = np.array([[rng.uniform(0, ex + sx + 8), rng.uniform(0, ey + sy + 8)] for _ in range(200)])
+        with contextlib.redirect_stdout(io.StringIO()):
+            inside = [g.inside_habitat(p) for p in q]
+            within = [g.within_habitat_env(p) for p in q]
+        out[f"c{k}_args"] = np.array([ex, ey, sx, sy, hs, cs], dtype=np.float64)
+        out[f"c{k}_ids"] = ids
+        out[f"c{k}_cell_xy"] = cell_xy
+        out[f"c{k}_habitats"] = habs
+        out[f"c{k}_query"] = q
+        out[f"c{k}_inside_id"] = np.array([(-1 if c is False else c.habitat_id) for c in inside], dtype=np.int32)
+        out[f"c{k}_within"] = np.array(within, dtype=np.int8)
+    save_npz("g11_habitat_grid.npz", **out)
+
+
+ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8, "g9": g9,
+       "g10": g10, "g11": g11}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

@@ -37,3 +37,26 @@ def test_sincos_mostly_equal_to_libm(orc):
     assert ds.max() <= 1.0 and dc.max() <= 1.0
     # informational bound: the two agree bit-for-bit on the vast majority of inputs
     assert (ds == 0).mean() > 0.9 and (dc == 0).mean() > 0.9
+
+
+def test_pow_e_half_ulp_and_equal_to_libm(orc):
+    """auvp_exp.h pow(math.e, z): the particle-filter weights (particleFilter.py:103-116)"""
+    import mpmath as mp
+    from oracle import orc_pf
+    mp.mp.prec = 200
+    rng = np.random.default_rng(2)
+    zs = np.concatenate([-rng.uniform(0, 20, 3000) ** 2 / 0.5, -rng.uniform(0, 800, 3000) ** 2 / 20000,
+                         -rng.uniform(0, 1e-3, 200), rng.uniform(-740, 700, 500), [0.0, -0.0, -1.0, 1.0, -745.0, -800.0]])
+    got = orc_pf.pow_e(zs, kind="portable")
+    libm = orc_pf.pow_e(zs, kind="libm")
+    E = mp.mpf(math.e)
+    worst = 0.0
+    for z, g in zip(zs[::7], got[::7]):
+        want = mp.power(E, mp.mpf(float(z)))
+        if want > mp.mpf(2) ** -1020:
+            worst = max(worst, _ulp_err(float(g), want, mp))
+    assert worst < 0.52, worst
+    assert np.array_equal(libm, np.array([math.e ** float(z) for z in zs]))
+    assert (got == libm).mean() > 0.98
+    big = np.abs(libm) > 1e-300
+    assert (np.abs(got - libm)[big] <= np.spacing(np.abs(libm))[big]).all()
