@@ -66,6 +66,8 @@ struct auvp_handle {
   unsigned world_version = 0;
   void* astar = nullptr;
   void (*astar_free)(void*) = nullptr;
+  void* pf = nullptr;
+  void (*pf_free)(void*) = nullptr;
 };
 
 namespace {
@@ -157,6 +159,7 @@ void auvp_destroy(auvp_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->prrt && h->prrt_free) h->prrt_free(h->prrt);
   if (h->astar && h->astar_free) h->astar_free(h->astar);
+  if (h->pf && h->pf_free) h->pf_free(h->pf);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -614,3 +617,5 @@ PrrtState* prrt_of(auvp_handle* h) {
 #include "astar_kernel.h"
 #include "astar_host.h"
 #include "sog_kernels.h"
+#include "pf_kernel.h"
+#include "pf_host.h"

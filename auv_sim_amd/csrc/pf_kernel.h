@@ -1,0 +1,430 @@
+// pf_kernel.h -- the shark particle filter (particleFilter.py) on gfx950: one 256-thread workgroup = one
+// filter (N particles, PPT consecutive list positions per thread), F filters per launch, S steps per launch.
+//
+//   pf_create_kernel   Particle.__init__ x N                       particleFilter.py:44-53, 311-317
+//   pf_step_kernel     create_and_update                           :277-282  (Particle.update_particle :55-75)
+//                      update_weights (weight, normalize, correct) :285-310, 92-116, 127-151, 179-252
+//                      particleMean, meanError                     :153-177
+//
+// The reference draws from numpy's global legacy RandomState (its `random` is numpy.random, :8):
+// MT19937 state lives in LDS and is refilled by the workgroup in three data-parallel phases (the
+// recurrence reads 397 words ahead: [0,227) [227,454) [454,624) are independent inside a phase).  Draws
+// whose count is data dependent (randint's masked rejection in random.choice) are taken a state block
+// at a time: temper, flag `word & mask <= rng`, block scan, the r-th accepted word is the r-th choice.
+//
+// Object identity: `correct` deep-copies and then picks list indices with replacement, so one Particle
+// object can sit at several list positions and create_and_update moves it once per position, each time
+// with that position's two uniforms.  Positions that share an object are applied in list order by
+// rounds of atomicMin over the pending positions (#rounds = largest multiplicity, ~5 at N = 1000).
+//
+// Ordered sums (particleMean, the per-AUV weight sum) keep the reference's left-to-right order; max()
+// is order free.  Math through auvp_math.h / auvp_exp.h: bit-identical to the portable checker build.
+#ifndef AUVP_PF_KERNEL_H
+#define AUVP_PF_KERNEL_H
+#include "auvp_exp.h"
+
+namespace auvp {
+
+enum { PF_PHASE_UPDATE = 1, PF_PHASE_WEIGHTS = 2, PF_PHASE_MEAN = 4 };
+enum { PF_OK = 0, PF_ERR_ANGLE = 1, PF_ERR_EMPTY = 2 };
+
+struct PfDev {
+  int32_t F, N, A, S, phases, _pad;
+  double* st;              // [F][5][N]  x, y, v, theta, weight per list position
+  int32_t* ent;            // [F][N]     object id of the list position (index drawn by the last correct)
+  int32_t* llen;           // [F]        bound of the object ids (len(list_of_new_particles) of the last correct)
+  uint32_t* mt;            // [F][624]
+  int32_t* mtpos;          // [F]
+  const double* shark0;    // [F][2]     (create)
+  const double* meas;      // [S][F][A][5]
+  const double* shark;     // [S][F][2]
+  double* wl;              // [F][A][N]  scratch: per-AUV weights
+  double* mean;            // [S][F][2]
+  double* err;             // [S][F]
+  int32_t* out_len;        // [S][F]
+  int32_t* status;         // [F]
+  unsigned long long* ndraw;  // [F]
+  double* updated;         // [S][F][N][5] or null (diagnostic)
+  int32_t* choice;         // [S][F][N] or null (diagnostic)
+};
+
+#define PF_T 256
+#define PF_UPPER 0x80000000u
+#define PF_LOWER 0x7fffffffu
+#define PF_MAG 0x9908b0dfu
+#define PF_PI 3.141592653589793
+
+struct PfRng {
+  uint32_t* mt;  // LDS [624]
+  int pos;       // uniform
+  unsigned long long drawn;
+};
+
+__device__ __forceinline__ uint32_t pf_twist(uint32_t a, uint32_t b, uint32_t c) {
+  const uint32_t y = (a & PF_UPPER) | (b & PF_LOWER);
+  return c ^ (y >> 1) ^ ((y & 1u) ? PF_MAG : 0u);
+}
+
+// one MT19937 state regeneration by the whole workgroup; ends with a barrier
+__device__ __forceinline__ void pf_refill(uint32_t* mt, int tid) {
+  uint32_t v = 0;
+  if (tid < 227) v = pf_twist(mt[tid], mt[tid + 1], mt[tid + 397]);
+  __syncthreads();
+  if (tid < 227) mt[tid] = v;
+  __syncthreads();
+  if (tid < 227) v = pf_twist(mt[227 + tid], mt[228 + tid], mt[tid]);
+  __syncthreads();
+  if (tid < 227) mt[227 + tid] = v;
+  __syncthreads();
+  if (tid < 170) v = pf_twist(mt[454 + tid], mt[tid == 169 ? 0 : 455 + tid], mt[227 + tid]);
+  __syncthreads();
+  if (tid < 170) mt[454 + tid] = v;
+  __syncthreads();
+}
+
+// the next `count` tempered outputs -> dst[0..count) (LDS); ends with a barrier
+__device__ __forceinline__ void pf_gen_words(PfRng& r, uint32_t* dst, int count, int tid) {
+  int done = 0;
+  while (done < count) {
+    if (r.pos >= 624) { pf_refill(r.mt, tid); r.pos = 0; }
+    const int take = min(624 - r.pos, count - done);
+    for (int i = tid; i < take; i += PF_T) dst[done + i] = mt_temper(r.mt[r.pos + i]);
+    r.pos += take;
+    done += take;
+    __syncthreads();
+  }
+  r.drawn += (unsigned long long)count;
+}
+
+__device__ __forceinline__ double pf_double(uint32_t w0, uint32_t w1) {
+  return ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
+}
+
+// angle_wrap (:18-33): one rounded add per recursion level; false = nan / deeper than CPython recurses
+__device__ __forceinline__ bool pf_angle_wrap(double& a) {
+  double ang = a;
+  for (int depth = 0; depth < 900; depth++) {
+    if (-PF_PI <= ang && ang <= PF_PI) { a = ang; return true; }
+    else if (ang > PF_PI) ang += (-2 * PF_PI);
+    else if (ang < -PF_PI) ang += (2 * PF_PI);
+    else return false;
+  }
+  return false;
+}
+
+__device__ __forceinline__ double pf_block_max(double v, double* red, int tid) {
+  for (int o = 32; o; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double m = red[0];
+  for (int w = 1; w < PF_T / 64; w++) m = red[w] > m ? red[w] : m;
+  return m;
+}
+
+// exclusive scan of one int per thread over the workgroup; *total = sum
+__device__ __forceinline__ int pf_block_scan(int v, int* red, int tid, int* total) {
+  int inc = v;
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
+  __syncthreads();
+  if ((tid & 63) == 63) red[tid >> 6] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int w = 0; w < PF_T / 64; w++) { if (w < (tid >> 6)) base += red[w]; tot += red[w]; }
+  *total = tot;
+  return base + inc - v;
+}
+
+struct PfLds {
+  uint32_t* mt; int* red_i; double* red_d; double *sx, *sy, *sv, *sth, *sw; int* off; uint32_t* wbuf; int* slot;
+};
+__host__ __device__ inline size_t pf_lds_bytes(int N) {
+  const size_t n2 = (size_t)(N + 2) & ~(size_t)1;
+  return 624 * 4 + 8 * 4 + 16 * 8 + 5 * n2 * 8 + n2 * 4 + (size_t)5 * n2 * 4;
+}
+__device__ __forceinline__ PfLds pf_carve(unsigned char* smem, int N) {
+  const size_t n2 = (size_t)(N + 2) & ~(size_t)1;
+  PfLds L;
+  L.mt = (uint32_t*)smem;
+  L.red_i = (int*)(L.mt + 624);
+  L.red_d = (double*)(L.red_i + 8);
+  L.sx = L.red_d + 16; L.sy = L.sx + n2; L.sv = L.sy + n2; L.sth = L.sv + n2; L.sw = L.sth + n2;
+  L.off = (int*)(L.sw + n2);
+  L.wbuf = (uint32_t*)(L.off + n2);  // 5*n2 words: the RNG window, then the alias slots, then the drawn indices
+  L.slot = (int*)L.wbuf;
+  return L;
+}
+
+__global__ __launch_bounds__(PF_T) void pf_create_kernel(PfDev D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int f = blockIdx.x, tid = threadIdx.x, N = D.N;
+  PfLds L = pf_carve(smem, N);
+  PfRng r{L.mt, D.mtpos[f], 0ull};
+  for (int i = tid; i < 624; i += PF_T) L.mt[i] = D.mt[(size_t)f * 624 + i];
+  __syncthreads();
+  const double x0 = D.shark0[2 * f], y0 = D.shark0[2 * f + 1];
+  double* st = D.st + (size_t)f * 5 * N;
+  const int chunk = (5 * ((N + 2) & ~1)) / 8;  // particles per RNG window (8 words each)
+  for (int base = 0; base < N; base += chunk) {
+    const int cnt = min(chunk, N - base);
+    pf_gen_words(r, L.wbuf, 8 * cnt, tid);
+    for (int i = tid; i < cnt; i += PF_T) {
+      const uint32_t* w = L.wbuf + 8 * i;
+      const int p = base + i;
+      st[p] = x0 + (-150.0 + 300.0 * pf_double(w[0], w[1]));
+      st[N + p] = y0 + (-150.0 + 300.0 * pf_double(w[2], w[3]));
+      st[2 * N + p] = 0.0 + 5.0 * pf_double(w[4], w[5]);
+      st[3 * N + p] = -PF_PI + (PF_PI - -PF_PI) * pf_double(w[6], w[7]);
+      st[4 * N + p] = 1.0 / 1000;  // NUMBER_OF_PARTICLES is the literal 1000 in Particle.__init__ (:47,53)
+      D.ent[(size_t)f * N + p] = p;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < 624; i += PF_T) D.mt[(size_t)f * 624 + i] = L.mt[i];
+  if (tid == 0) { D.mtpos[f] = r.pos; D.llen[f] = N; D.ndraw[f] += r.drawn; D.status[f] = PF_OK; }
+}
+
+template <int PPT>
+__global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int f = blockIdx.x, tid = threadIdx.x, N = D.N, A = D.A;
+  PfLds L = pf_carve(smem, N);
+  PfRng r{L.mt, D.mtpos[f], 0ull};
+  double* st = D.st + (size_t)f * 5 * N;
+  for (int i = tid; i < 624; i += PF_T) L.mt[i] = D.mt[(size_t)f * 624 + i];
+  for (int i = tid; i < N; i += PF_T) {
+    L.sx[i] = st[i]; L.sy[i] = st[N + i]; L.sv[i] = st[2 * N + i]; L.sth[i] = st[3 * N + i]; L.sw[i] = st[4 * N + i];
+  }
+  int e[PPT];
+  const int p0 = tid * PPT;
+#pragma unroll
+  for (int j = 0; j < PPT; j++) e[j] = (p0 + j < N) ? D.ent[(size_t)f * N + p0 + j] : 0;
+  int llen = D.llen[f];
+  int status = D.status[f];
+  __syncthreads();
+
+  for (int s = 0; s < D.S; s++) {
+    if (D.phases & PF_PHASE_UPDATE) {
+      // ---- create_and_update: list position p consumes uniforms 2p, 2p+1 of this step
+      pf_gen_words(r, L.wbuf, 4 * N, tid);
+      double u0[PPT], u1[PPT];
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        const int p = p0 + j;
+        if (p < N) { u0[j] = pf_double(L.wbuf[4 * p], L.wbuf[4 * p + 1]); u1[j] = pf_double(L.wbuf[4 * p + 2], L.wbuf[4 * p + 3]); }
+      }
+      __syncthreads();
+      for (int i = tid; i < llen; i += PF_T) L.slot[i] = 0x7fffffff;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PPT; j++) if (p0 + j < N) atomicMin(&L.slot[e[j]], p0 + j);
+      __syncthreads();
+      int lead[PPT];
+      unsigned pending = 0;
+#pragma unroll
+      for (int j = 0; j < PPT; j++) if (p0 + j < N) { lead[j] = L.slot[e[j]]; pending |= 1u << j; }
+      __syncthreads();
+      for (;;) {
+        unsigned applied = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+          if ((pending >> j & 1u) && L.slot[e[j]] == p0 + j) {
+            const int q = lead[j];
+            double v = L.sv[q], th = L.sth[q];
+            v += 0.0 + 5.0 * u0[j];                                   // uniform(0, RANDOM_VELOCITY)
+            for (int d = 0; d < 900 && v > 5; d++) v += -5;           // velocity_wrap
+            th += -(PF_PI / 2) + (PF_PI / 2 - -(PF_PI / 2)) * u1[j];  // uniform(-RANDOM_THETA, RANDOM_THETA)
+            if (!pf_angle_wrap(th)) status = PF_ERR_ANGLE;
+            double sn, cs;
+            auvp_sincos(th, &sn, &cs);
+            L.sv[q] = v; L.sth[q] = th;
+            L.sx[q] += v * cs * .1;
+            L.sy[q] += v * sn * .1;
+            applied |= 1u << j;
+          }
+        }
+        pending &= ~applied;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PPT; j++) if (applied >> j & 1u) L.slot[e[j]] = 0x7fffffff;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PPT; j++) if (pending >> j & 1u) atomicMin(&L.slot[e[j]], p0 + j);
+        if (!__syncthreads_or(pending != 0)) break;
+      }
+      // every position reads its object's state (leaders' slots are only read here)
+      double cx[PPT], cy[PPT], cv[PPT], ct[PPT];
+#pragma unroll
+      for (int j = 0; j < PPT; j++) if (p0 + j < N) { const int q = lead[j]; cx[j] = L.sx[q]; cy[j] = L.sy[q]; cv[j] = L.sv[q]; ct[j] = L.sth[q]; }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PPT; j++) if (p0 + j < N) { const int p = p0 + j; L.sx[p] = cx[j]; L.sy[p] = cy[j]; L.sv[p] = cv[j]; L.sth[p] = ct[j]; }
+      __syncthreads();
+      if (D.updated) {
+        double* u = D.updated + ((size_t)s * D.F + f) * N * 5;
+        for (int i = tid; i < N; i += PF_T) { u[5 * i] = L.sx[i]; u[5 * i + 1] = L.sy[i]; u[5 * i + 2] = L.sv[i]; u[5 * i + 3] = L.sth[i]; u[5 * i + 4] = L.sw[i]; }
+      }
+      // positions are independent copies again after correct; until then the shared object id stays
+    }
+
+    if (D.phases & PF_PHASE_WEIGHTS) {
+      // ---- update_weights: per AUV measurement, weight of every particle (:285-300)
+      double* wl = D.wl + (size_t)f * A * N;
+      for (int a = 0; a < A; a++) {
+        const double* m = D.meas + (((size_t)s * D.F + f) * A + a) * 5;
+        const double mx = m[0], my = m[1], mth = m[2], auv_alpha = m[3], auv_range = m[4];
+        double lmax = -__builtin_inf();
+#pragma unroll
+        for (int j = 0; j < PPT; j++) {
+          const int p = p0 + j;
+          if (p < N) {
+            const double px = L.sx[p], py = L.sy[p];
+            double pa = auvp_atan2((-my + py), (px + -mx)) - mth;     // calc_particle_alpha
+            if (!pf_angle_wrap(pa)) status = PF_ERR_ANGLE;
+            const double dy = my - py, dx = mx - px;
+            const double pr = auvp_sqrt(dy * dy + dx * dx);           // calc_particle_range
+            double d = pa - auv_alpha;
+            if (!pf_angle_wrap(d)) status = PF_ERR_ANGLE;
+            const double constant = 1.2533141375;
+            const double fa = .001 + (1 / (constant) * (auvp_pow_e((-(d * d)) / (0.5))));
+            const double dr = pr - auv_range;
+            const double fw = .001 + (1 / (100 * constant) * (auvp_pow_e((-(dr * dr)) / (20000))));
+            const double w = fw * fa;
+            wl[(size_t)a * N + p] = w;
+            lmax = w > lmax ? w : lmax;
+          }
+        }
+        const double den = pf_block_max(lmax, L.red_d, tid);
+        // normalize (:133-139) in place
+#pragma unroll
+        for (int j = 0; j < PPT; j++) { const int p = p0 + j; if (p < N) wl[(size_t)a * N + p] = (1 / den) * wl[(size_t)a * N + p]; }
+      }
+      double nw[PPT], lmax = -__builtin_inf();
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        const int p = p0 + j;
+        nw[j] = 0;
+        if (p < N) { for (int a = 0; a < A; a++) nw[j] += wl[(size_t)a * N + p]; lmax = nw[j] > lmax ? nw[j] : lmax; }
+      }
+      const double fden = pf_block_max(lmax, L.red_d, tid);
+      // ---- correct (:179-252): 1..5 deep copies by weight class, then N index draws
+      int k[PPT], ksum = 0;
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        const int p = p0 + j;
+        k[j] = 0;
+        if (p < N) {
+          const double w = (1 / fden) * nw[j];
+          L.sw[p] = w;
+          k[j] = w < 0.2 ? 1 : (w < 0.4 ? 2 : (w < 0.6 ? 3 : (w < .8 ? 4 : (w <= 1.0 ? 5 : 0))));
+          ksum += k[j];
+        }
+      }
+      int total = 0;
+      int run = pf_block_scan(ksum, L.red_i, tid, &total);
+#pragma unroll
+      for (int j = 0; j < PPT; j++) if (p0 + j < N) { L.off[p0 + j] = run; run += k[j]; }
+      if (tid == 0) L.off[N] = total;
+      const int len = total;
+      __syncthreads();
+      if (len == 0) { status = PF_ERR_EMPTY; break; }  // numpy raises ValueError
+      int* cho = L.slot;
+      if (len == 1) {
+        for (int i = tid; i < N; i += PF_T) cho[i] = 0;  // randint(0, 1): no draw
+        __syncthreads();
+      } else {
+        const uint32_t rng = (uint32_t)len - 1u;
+        uint32_t mask = rng;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        int got = 0;
+        while (got < N) {
+          if (r.pos >= 624) { pf_refill(r.mt, tid); r.pos = 0; }
+          const int avail = 624 - r.pos;
+          // thread t looks at words [3t, 3t+3) of the block (768 >= 624)
+          uint32_t val[3];
+          int cnt = 0;
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            const int i = 3 * tid + c;
+            val[c] = 0xffffffffu;
+            if (i < avail) { const uint32_t v = mt_temper(r.mt[r.pos + i]) & mask; if (v <= rng) { val[c] = v; cnt++; } }
+          }
+          int tot = 0;
+          int rank = got + pf_block_scan(cnt, L.red_i, tid, &tot);
+          if (tid == 0) L.red_i[4] = avail - 1;
+          __syncthreads();
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            if (val[c] != 0xffffffffu) {
+              if (rank < N) cho[rank] = (int)val[c];
+              if (rank == N - 1) L.red_i[4] = 3 * tid + c;  // the word that completes the N draws
+              rank++;
+            }
+          }
+          __syncthreads();
+          const int used = L.red_i[4] + 1;
+          r.pos += used;
+          r.drawn += (unsigned long long)used;
+          got = min(N, got + tot);
+          __syncthreads();
+        }
+      }
+      if (D.choice) for (int i = tid; i < N; i += PF_T) D.choice[((size_t)s * D.F + f) * N + i] = cho[i];
+      // ---- the new list: position n = copy of the source of list_of_new_particles[cho[n]]
+      double gx[PPT], gy[PPT], gv[PPT], gt[PPT], gw[PPT];
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        const int n = p0 + j;
+        if (n < N) {
+          const int x = cho[n];
+          int lo = 0, hi = N;  // largest p with off[p] <= x  (off[p] < off[p+1] for every p that made copies)
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.off[mid] <= x) lo = mid; else hi = mid; }
+          gx[j] = L.sx[lo]; gy[j] = L.sy[lo]; gv[j] = L.sv[lo]; gt[j] = L.sth[lo]; gw[j] = L.sw[lo];
+          e[j] = x;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < PPT; j++) {
+        const int n = p0 + j;
+        if (n < N) { L.sx[n] = gx[j]; L.sy[n] = gy[j]; L.sv[n] = gv[j]; L.sth[n] = gt[j]; L.sw[n] = gw[j]; }
+      }
+      llen = len;
+      if (tid == 0) D.out_len[(size_t)s * D.F + f] = len;
+      __syncthreads();
+    }
+
+    if (D.phases & PF_PHASE_MEAN) {
+      // ---- particleMean (:153-167): left-to-right sums, x on wave 0 and y on wave 1
+      if (tid == 0 || tid == 64) {
+        const double* src = tid == 0 ? L.sx : L.sy;
+        double sum = 0;
+        for (int i = 0; i < N; i++) sum += src[i];
+        L.red_d[8 + (tid >> 6)] = sum / N;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const double xm = L.red_d[8], ym = L.red_d[9];
+        const double* sh = D.shark + ((size_t)s * D.F + f) * 2;
+        const double xd = xm - sh[0], yd = ym - sh[1];
+        D.mean[((size_t)s * D.F + f) * 2] = xm;
+        D.mean[((size_t)s * D.F + f) * 2 + 1] = ym;
+        D.err[(size_t)s * D.F + f] = auvp_sqrt((xd * xd) + (yd * yd));  // meanError (:169-177)
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- persist
+  for (int i = tid; i < 624; i += PF_T) D.mt[(size_t)f * 624 + i] = L.mt[i];
+  for (int i = tid; i < N; i += PF_T) {
+    st[i] = L.sx[i]; st[N + i] = L.sy[i]; st[2 * N + i] = L.sv[i]; st[3 * N + i] = L.sth[i]; st[4 * N + i] = L.sw[i];
+  }
+#pragma unroll
+  for (int j = 0; j < PPT; j++) if (p0 + j < N) D.ent[(size_t)f * N + p0 + j] = e[j];
+  if (__syncthreads_or(status != PF_OK) && tid == 0 && D.status[f] == PF_OK) D.status[f] = status != PF_OK ? status : PF_ERR_ANGLE;
+  if (tid == 0) { D.mtpos[f] = r.pos; D.llen[f] = llen; D.ndraw[f] += r.drawn; }
+}
+
+}  // namespace auvp
+#endif

@@ -216,6 +216,44 @@ int auvp_sog_convert(auvp_handle* h, const double* cells, int32_t n_cells, const
                      const double* pts_xyt, int32_t cap_bins, int32_t* n_bins, int32_t* rows, int32_t* cols,
                      double* bins, double* grids);
 
+/* ---- shark particle filters ------------------------------------------------------------------------
+ * particleFilter.py driven like robotSim.py:665-701, F independent filters x N particles (N <= 2048),
+ * one workgroup per filter.  The reference draws from numpy's global legacy RandomState (its `random`
+ * is numpy.random, particleFilter.py:8): each filter carries an MT19937 key [624] + position, handed
+ * in and read back so a caller can continue numpy's own stream (np.random.get_state / set_state).
+ * Particles are rows {x_p, y_p, v_p, theta_p, weight_p}; `obj` is the object id of a list position
+ * (positions that hold the same Particle object after `correct` share an id and are moved once per
+ * position by create_and_update, like the reference). */
+enum { AUVP_PF_UPDATE = 1,  /* ParticleFilter.create_and_update (:277-282) */
+       AUVP_PF_WEIGHTS = 2, /* ParticleFilter.update_weights (:285-310): weight, normalize, correct */
+       AUVP_PF_MEAN = 4 };  /* particleMean + meanError (:153-177) */
+/* ParticleFilter(x, y, ...).create() for F filters (:311-317, Particle.__init__ :44-53) */
+int auvp_pf_create_batch(auvp_handle* h, int32_t n_filters, int32_t n_particles, const double* shark_xy0,
+                         const uint32_t* mt_key, const int32_t* mt_pos);
+/* start from caller-supplied lists instead: particles [F,N,5], obj [F,N] or NULL (all distinct),
+ * list_len [F] or NULL */
+int auvp_pf_set_particles(auvp_handle* h, int32_t n_filters, int32_t n_particles, const double* particles,
+                          const int32_t* obj, const int32_t* list_len, const uint32_t* mt_key, const int32_t* mt_pos);
+int auvp_pf_set_rng(auvp_handle* h, const uint32_t* mt_key, const int32_t* mt_pos);
+/* n_steps x the phases selected (AUVP_PF_* mask, in the order update, weights, mean) in ONE launch.
+ * meas [S,F,n_auv,5] = list_of_range_bearing rows {x, y, theta, [3], [4]} (update_weights passes [3] as
+ * the bearing and [4] as the range argument of Particle.weight, :293-295); shark_xy [S,F,2] =
+ * self.x_shark / y_shark for meanError.  AUVP_FLAG_ITER_LOG records the per-step log below.
+ * Per-filter status: 1 = an angle_wrap recursion deeper than CPython allows / nan, 2 = empty
+ * list_of_new_particles (numpy raises ValueError). */
+int auvp_pf_run(auvp_handle* h, int32_t n_steps, int32_t n_auv, int32_t phases, const double* meas,
+                const double* shark_xy, int32_t flags);
+int auvp_pf_particles(auvp_handle* h, double* particles, int32_t* obj);
+/* device-resident state for a caller that keeps working on the GPU: SoA [F][5][N] doubles, ids [F][N] */
+int auvp_pf_particles_dev(auvp_handle* h, double** particles_soa, int32_t** obj);
+/* of the last auvp_pf_run: mean [S,F,2], range_error [S,F], len(list_of_new_particles) [S,F] */
+int auvp_pf_estimates(auvp_handle* h, double* mean, double* range_error, int32_t* list_len);
+int auvp_pf_status(auvp_handle* h, int32_t* status, uint64_t* n_draw32);
+int auvp_pf_rng_state(auvp_handle* h, uint32_t* mt_key, int32_t* mt_pos);
+/* AUVP_FLAG_ITER_LOG: updated [S,F,N,5] (the list after create_and_update), choice [S,F,N] (the indices
+ * random.choice drew in correct, :248-250) */
+int auvp_pf_step_log(auvp_handle* h, double* updated, int32_t* choice);
+
 /* standalone evaluations on the device (parity probes for the building blocks) */
 /* RRT.check_collision (:530-549) of n_paths paths; pts [sum(npts),2], path i = pts[off[i]:off[i+1]] */
 int auvp_check_collision_batch(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xy,
