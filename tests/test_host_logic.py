@@ -48,3 +48,29 @@ def test_motion_plan_state_signature():
     assert (m.x, m.y, m.z, m.theta, m.size, m.parent, m.path, m.length) == (1, 2, 0, 0, 3, None, [], 0)
     assert repr(MPS(1, 2)) == "MPS: [x=1, y=2]" and "size=3" in repr(MPS(1, 2, z=-5, size=3))
     assert MPS(1, 2, length=4.0).length == 4.0 and MPS(0, 0, rl_state_id=7).rl_state_id == 7
+
+
+def test_habitat_grid_matches_reference_layout():
+    """auv_sim_amd.habitatGrid vs G11 (captured from habitatGrid.py): id layout, habitat list, lookups"""
+    import contextlib
+    import io
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from auv_sim_amd.habitatGrid import HabitatGrid
+    g = np.load(os.path.join(GOLDEN, "g11_habitat_grid.npz"))
+    k = 0
+    while f"c{k}_args" in g:
+        ex, ey, sx, sy, hs, cs = g[f"c{k}_args"].tolist()
+        grid = HabitatGrid(ex, ey, sx, sy, habitat_side_length=hs, cell_side_length=cs)
+        assert np.array_equal(grid.habitat_id_grid, g[f"c{k}_ids"])
+        xy = np.array([[[c.x, c.y] for c in row] for row in grid.habitat_cell_grid])
+        assert np.array_equal(xy, g[f"c{k}_cell_xy"])
+        habs = np.array([[h.x, h.y, h.id, h.side_length] for h in grid.habitat_array], dtype=np.float64)
+        assert np.array_equal(habs, g[f"c{k}_habitats"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            inside = [grid.inside_habitat(p) for p in g[f"c{k}_query"]]
+        assert [(-1 if c is False else c.habitat_id) for c in inside] == g[f"c{k}_inside_id"].tolist()
+        assert [int(grid.within_habitat_env(p)) for p in g[f"c{k}_query"]] == g[f"c{k}_within"].tolist()
+        k += 1
+    assert k == 4
