@@ -951,8 +951,160 @@ def g11():
     save_npz("g11_habitat_grid.npz", **out)
 
 
+# --------------------------------------------------------------------------------------------
+# G12: the other cost entry points of SURVEY 8(b): root cost.py Cost.habitat_shark_cost_func (4 weights,
+# stale-bin behaviour) and Cost.cost_of_edge; path_planning/cost.py habitat_shark_cost_point
+# --------------------------------------------------------------------------------------------
+def g12():
+    import types
+    refstubs.install()
+    _purge(_SHARED)
+    saved = list(sys.path)
+    sys.path[:0] = [REF]
+    try:
+        root_cost = importlib.import_module("cost")
+        root_mps = importlib.import_module("motion_plan_state")
+    finally:
+        sys.path[:] = saved
+    _purge(_SHARED)
+    _, mpsm, pp_cost = import_rrt()
+    MPS = root_mps.Motion_plan_state
+    rng = random.Random(1212)
+    cal = root_cost.Cost()
+    twin, edges, points = [], [], []
+    for k in range(16):
+        world = synth.make_world(seed=300 + k, n_obstacles=3, n_habitats=(0 if k == 3 else 5 + k % 4),
+                                 cell=10.0 if k % 2 else 20.0, n_bins=3 + k % 4)
+        _, habitats, _, _, shark = ref_world(world, MPS)
+        x0, y0, x1, y1 = world["box"].tolist()
+        T = len(world["bins"])
+        pts = []
+        for i in range(rng.randint(2, 90)):
+            x = rng.uniform(x0 - 10, x1 + 10)
+            y = rng.uniform(y0 - 10, y1 + 10)
+            if rng.random() < 0.15:
+                x = float(round(x / 10.0) * 10.0)
+            # the first point must fall into a bin (the reference reads an unbound local otherwise);
+            # later ones may fall outside every bin and then reuse the previous point's bin
+            t = rng.uniform(0.0, 50.0 * T) if (i == 0 or rng.random() < 0.7) else rng.uniform(50.0 * T + 1, 50.0 * T + 90)
+            if rng.random() < 0.1:
+                t = float(50 * rng.randint(0, T))
+            pts.append((x, y, t))
+        weights = rng.choice([[1, -3, -3, -4], [0.5, -1, -1, -1], [2, -0.5, -2.25, -1.75]])
+        length, peri, total = rng.uniform(10, 900), rng.uniform(400, 3000), rng.uniform(1.0, 500.0)
+        path = [MPS(p[0], p[1], traj_time_stamp=p[2]) for p in pts]
+        res = cal.habitat_shark_cost_func(path, length, peri, total, habitats, shark, weights)
+        twin.append({"world_seed": 300 + k, "n_habitats": len(habitats), "cell": 10.0 if k % 2 else 20.0, "n_bins": T,
+                     "pts": pts, "length": length, "peri": peri, "total": total, "weights": weights,
+                     "out": [float(res[0])] + [float(c) for c in res[1]]})
+        # cost_of_edge: nodes around the habitats, a split of the habitat list into open / closed
+        cut = rng.randint(0, len(habitats))
+        open_l, closed_l = habitats[:cut], habitats[cut:]
+        for _ in range(12):
+            if habitats and rng.random() < 0.6:
+                h = rng.choice(habitats)
+                pos = (h.x + rng.uniform(-1.2, 1.2) * h.size, h.y + rng.uniform(-1.2, 1.2) * h.size)
+            else:
+                pos = (rng.uniform(x0, x1), rng.uniform(y0, y1))
+            w3 = [rng.choice([0, 1, 10]), rng.choice([1, 10, 2.5]), rng.choice([1, 10, 0.75])]
+            node = types.SimpleNamespace(position=pos)
+            r = cal.cost_of_edge(node, open_l, closed_l, w3)
+            edges.append({"world_seed": 300 + k, "n_habitats": len(habitats), "cell": 10.0 if k % 2 else 20.0, "n_bins": T,
+                          "cut": cut, "pos": list(pos), "weights": w3, "out": [float(r[0]), int(r[1]), int(r[2])]})
+        # habitat_shark_cost_point along the same points (visited list threaded through like performance.py:272)
+        if habitats:
+            visited = [False for _ in habitats]
+            grid = shark[list(shark.keys())[k % T]]
+            w3 = rng.choice([[-3, -3, -4], [-1, -1, -1]])
+            outs = []
+            for p in path[:40]:
+                c, visited = pp_cost.habitat_shark_cost_point(p, habitats, visited, grid, w3)
+                outs.append(float(c))
+            points.append({"world_seed": 300 + k, "n_habitats": len(habitats), "cell": 10.0 if k % 2 else 20.0, "n_bins": T,
+                           "bin": k % T, "pts": pts[:40], "weights": w3, "out": outs})
+    with open(os.path.join(HERE, "g12_cost_twins.json"), "w") as f:
+        json.dump({"twin": twin, "edges": edges, "points": points}, f)
+    print("wrote g12_cost_twins.json", len(twin), len(edges), len(points))
+
+
+# --------------------------------------------------------------------------------------------
+# G13: RRT.replanning (rrt_dubins.py:51-90): receding-horizon rounds of exploring on ONE RRT object
+# (time_bin persists, habitats are removed between rounds, every round starts at a non-zero
+# traj_time_stamp), global `random` stream seeded once
+# --------------------------------------------------------------------------------------------
+class ReplanClock:
+    """replanning passes plot_interval = 0.5 to exploring, so the unit-tick VirtualClock would allow one
+    iteration.  This clock restarts at 0 for every exploring invocation (new frame) and advances by `tick`
+    per while-test (calls from the exploring frame after the t_start read); other frames read the
+    current value.  The iteration count per round is whatever the reference's loop then does
+    (it is recorded and becomes the build's max_iter)."""
+
+    def __init__(self, tick):
+        self.tick, self.frame_id, self.q, self.now = tick, None, 0, 0.0
+
+    def time(self):
+        f = sys._getframe(1)
+        if f.f_code.co_name == "exploring":
+            if self.frame_id is not f:
+                self.frame_id, self.q = f, 0
+            self.now = self.tick * max(0, self.q - 1)
+            self.q += 1
+        return self.now
+
+    def sleep(self, s):
+        pass
+
+
+def g13():
+    rrt_mod, mpsm, cost_mod = import_rrt()
+    MPS = mpsm.Motion_plan_state
+    specs = [("g13_replan_a", 5, dict(seed=1, n_obstacles=64), 2.0, 150.0, 98.0, 1.0 / 256),
+             ("g13_replan_b", 21, dict(seed=4, n_obstacles=64, n_habitats=8), 1.5, 120.0, 78.5, 1.0 / 512)]
+    for name, seed, wk, budget, traj_len, interval, tick in specs:
+        world = synth.make_world(**wk)
+        obstacles, habitats, poly, cell_list, shark = ref_world(world, MPS)
+        rrt_mod.time = ReplanClock(tick)
+        # SharkUpdate / SharkOccupancyGrid are built at :67-68 and never read
+        rrt_mod.SharkUpdate = lambda *a, **k: None
+        rrt_mod.SharkOccupancyGrid = lambda *a, **k: None
+        rrt = rrt_mod.RRT(poly, obstacles, shark, cell_list)
+        iters = []
+        orig_exploring, orig_steer = rrt.exploring, rrt.steer
+        calls = []
+
+        def steer(*a, **k):
+            iters[-1] += 1
+            return orig_steer(*a, **k)
+
+        def exploring(initial, habs, *a, **k):
+            iters.append(0)
+            r = orig_exploring(initial, habs, *a, **k)
+            calls.append({"t0": initial.traj_time_stamp, "n_hab": len(habs), "max_traj_time": k["max_traj_time"],
+                          "cost": [float(r["cost"][0])] + [float(c) for c in r["cost"][1]],
+                          "path_length": float(r["path length"]), "n_path": len(r["path"][0])})
+            return r
+        rrt.steer, rrt.exploring = steer, exploring
+        random.seed(seed)
+        start = MPS(float(world["start"][0]), float(world["start"][1]))
+        hab_in = list(habitats)
+        with contextlib.redirect_stdout(io.StringIO()):
+            traj, time_dict, cost = rrt.replanning(start, hab_in, budget, traj_len, interval, [-3, -3, -4])
+        rng_after = random.random()
+        save_npz(name + ".npz", **world_arrays(world), start=world["start"], world_kwargs=json.dumps(wk), seed=seed,
+                 plan_time_budget=budget, traj_time_length=traj_len, replan_time_interval=interval,
+                 iters_per_round=np.array(iters, dtype=np.int32),
+                 traj=np.array([[p.x, p.y, p.theta, p.v, p.traj_time_stamp, p.length] for p in traj], dtype=np.float64),
+                 round_len=np.array([len(time_dict[k][0]) for k in time_dict], dtype=np.int32),
+                 round_habitats=np.array([len(time_dict[k][1]) for k in time_dict], dtype=np.int32),
+                 round_t0=np.array([c["t0"] for c in calls]), round_max_traj_time=np.array([c["max_traj_time"] for c in calls]),
+                 round_cost=np.array([c["cost"] for c in calls]), round_path_length=np.array([c["path_length"] for c in calls]),
+                 habitats_left=np.array([[h.x, h.y, h.size] for h in hab_in], dtype=np.float64).reshape(-1, 3),
+                 cost=np.array([float(cost[0])] + [float(c) for c in cost[1]]), rng_after=rng_after)
+        print(name, "rounds", len(calls), "iters", iters, "traj", len(traj), "habitats left", len(hab_in), "cost", cost[0])
+
+
 ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8, "g9": g9,
-       "g10": g10, "g11": g11}
+       "g10": g10, "g11": g11, "g12": g12, "g13": g13}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)

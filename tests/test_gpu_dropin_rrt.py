@@ -123,3 +123,29 @@ def test_cost_function_dropin():
             continue  # an empty dict has no cell order to pack; covered through the C-ABI test
         res = habitat_shark_cost_func(path, c["total"], habitats, sub, c["weights"])
         np.testing.assert_allclose([res[0]] + res[1], c["out"], rtol=1e-12, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["g13_replan_a", "g13_replan_b"])
+def test_replanning_matches_reference(name):
+    """RRT.replanning (rrt_dubins.py:51-90) vs the reference's own multi-round run (G13): rounds start at
+    non-zero traj_time_stamps, reuse one RRT object, remove habitats between rounds and continue one
+    global `random` stream.  max_iter = the iterations the reference's loop ran per round."""
+    from auv_sim_amd.rrt_dubins import RRT
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    obstacles, habitats, cell_list, shark, poly, start = _reference_style_inputs(g)
+    rrt = RRT(poly, obstacles, shark, cell_list)
+    iters = g["iters_per_round"].tolist()
+    assert len(set(iters)) == 1
+    random.seed(int(g["seed"]))
+    traj, time_dict, cost = rrt.replanning(start, habitats, float(g["plan_time_budget"]), float(g["traj_time_length"]),
+                                           float(g["replan_time_interval"]), [-3, -3, -4], max_iter=iters[0])
+    assert random.random() == float(g["rng_after"])
+    got = np.array([[p.x, p.y, p.theta, p.v, p.traj_time_stamp, p.length] for p in traj])
+    assert got.shape == g["traj"].shape
+    np.testing.assert_allclose(got, g["traj"], rtol=1e-9, atol=1e-9)
+    assert list(time_dict.keys()) == list(range(1, len(iters) + 1))
+    assert [len(time_dict[k][0]) for k in time_dict] == g["round_len"].tolist()
+    assert [len(time_dict[k][1]) for k in time_dict] == g["round_habitats"].tolist()
+    # the caller's habitat list was mutated like the reference's (removeHabitat :604-610)
+    assert [[h.x, h.y, h.size] for h in habitats] == g["habitats_left"].tolist()
+    np.testing.assert_allclose([cost[0]] + list(cost[1]), g["cost"], rtol=0, atol=1e-6)

@@ -74,3 +74,40 @@ def test_habitat_grid_matches_reference_layout():
         assert [int(grid.within_habitat_env(p)) for p in g[f"c{k}_query"]] == g[f"c{k}_within"].tolist()
         k += 1
     assert k == 4
+
+
+def _g12_world(c):
+    from auv_sim_amd import synth
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    world = synth.make_world(seed=c["world_seed"], n_obstacles=3, n_habitats=c["n_habitats"], cell=c["cell"],
+                             n_bins=c["n_bins"])
+    cells = [tuple(r) for r in world["cells"].tolist()]
+    keys = [(int(b[0]), int(b[1])) for b in world["bins"].tolist()]
+    shark = {k: {cells[i]: p for i, p in enumerate(world["prob"][t].tolist())} for t, k in enumerate(keys)}
+    habitats = [MPS(h[0], h[1], size=h[2]) for h in world["habitats"].tolist()]
+    return shark, habitats
+
+
+def test_cost_of_edge_and_point_form_match_reference():
+    """Cost.cost_of_edge (cost.py:66) and habitat_shark_cost_point (path_planning/cost.py:209) vs G12"""
+    import json
+    import os
+    import types
+    from conftest import GOLDEN
+    from auv_sim_amd.cost import Cost, habitat_shark_cost_point
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    g = json.load(open(os.path.join(GOLDEN, "g12_cost_twins.json")))
+    cal = Cost.__new__(Cost)  # host arithmetic only: no device context needed
+    for c in g["edges"]:
+        _, habitats = _g12_world(c)
+        node = types.SimpleNamespace(position=tuple(c["pos"]))
+        r = cal.cost_of_edge(node, habitats[:c["cut"]], habitats[c["cut"]:], c["weights"])
+        assert [float(r[0]), r[1], r[2]] == c["out"]
+    for c in g["points"]:
+        shark, habitats = _g12_world(c)
+        grid = shark[list(shark.keys())[c["bin"]]]
+        visited = [False for _ in habitats]
+        for p, want in zip(c["pts"], c["out"]):
+            got, visited = habitat_shark_cost_point(MPS(p[0], p[1], traj_time_stamp=p[2]), habitats, visited, grid, c["weights"])
+            assert float(got) == want
+        assert not any(visited)
