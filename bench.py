@@ -58,6 +58,95 @@ def cpu_baseline(world, n_iter, args):
                       % (eps, n_iter, eps - 1, t_used)}
 
 
+def _cpu_episode(job):
+    """pool worker: one oracle episode (runs in a forked child that never touches the GPU)"""
+    world, seed, n_iter, mode = job
+    from oracle import orc
+    w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    init = [world["start"][0], world["start"][1], 0, 0, 0, 0]
+    return orc.rrt_explore(w, seed, n_iter, mode=mode, init=init, kind="libm", want_path=False)["iters_run"]
+
+
+def cpu_baseline_all_cores(world, n_iter, args):
+    """the same CPU checker on ALL host cores, one episode per core (episodes are the natural
+    parallel unit on the CPU too).  Must be called before this process initialises HIP (it forks)."""
+    import multiprocessing as mp
+    from oracle import orc
+    orc.build()
+    cores, how = effective_cores()
+    jobs = [(world, 1000 + s, n_iter, args.mode) for s in range(cores)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_cpu_episode, [(world, 0, 10, args.mode)] * cores, chunksize=1)  # start the workers, load the library
+        t0 = time.perf_counter()
+        done = sum(pool.map(_cpu_episode, jobs, chunksize=1))
+        dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "expansions/s", "cores": cores, "kind": "port",
+            "sample": "%d episodes x %d iterations, one per usable core (%s; os.cpu_count() = %d), oracle/ libm build, %.1f s"
+                      % (cores, n_iter, how, os.cpu_count() or 1, dt)}
+
+
+def effective_cores(cap=64):
+    """cores this process may actually use: scheduler affinity, clipped by the cgroup CPU quota, capped so the
+    bounded sample stays bounded"""
+    n, how = len(os.sched_getaffinity(0)), "sched_getaffinity"
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max" and int(float(q) / float(p)) < n:
+            n, how = max(1, int(float(q) / float(p))), "cgroup cpu.max"
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and q // p < n:
+                n, how = max(1, q // p), "cgroup cfs quota"
+        except (OSError, ValueError):
+            pass
+    if n > cap:
+        n, how = cap, how + ", capped at %d" % cap
+    return n, how
+
+
+def bench_single_episode(ctx, world, args, reps=3):
+    """SURVEY 8(d) config 2 latency test: ONE episode on one GPU (a serial chain: one wavefront busy)."""
+    init = np.zeros((1, 6))
+    init[0, 0], init[0, 1] = world["start"]
+    ms = []
+    for i in range(reps + 1):
+        summ = ctx.rrt_explore_batch(init, np.array([7], dtype=np.uint64), args.iters, mode=args.mode, freq=30, bin_interval=5,
+                                     v=2, max_traj_time=500.0, weights=(-3, -3, -4))
+        if i:
+            ms.append(ctx.last_kernel_ms())
+    k_ms = float(np.mean(ms))
+    return {"metric": "single-episode latency (seed 7)", "kernel_ms": k_ms, "iters": int(summ[0]["iters_run"]),
+            "expansions_per_s": float(summ[0]["iters_run"]) / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / float(summ[0]["iters_run"])}
+
+
+def bench_config5(ctx, n_ep=12500, max_step=200, reps=2):
+    """every particle hypothesis of a shark position becomes the goal of one
+    Planner_RRT episode with a 200-step budget; 12 500 episodes per GPU (100 000 over 8 GPUs)."""
+    from auv_sim_amd import synth
+    from auv_sim_amd._prrt_lib import PlannerBatch
+    w = synth.make_rect_world(seed=3, n_obstacles=256)
+    ctx.set_world(obstacles=w["obstacles"])
+    rng = np.random.default_rng(5)
+    starts = np.tile(np.array([w["start"][0], w["start"][1], 0.0, 0.0]), (n_ep, 1))
+    goals = np.clip(np.asarray(w["goal"])[None, :] + rng.normal(0.0, 25.0, size=(n_ep, 2)), w["rect"][0] + 5, w["rect"][2] - 5)
+    seeds = np.arange(n_ep, dtype=np.uint64)
+    ms, steps, done = [], 0, 0
+    for i in range(reps + 1):
+        pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, freq=10, cell=5, subs=1)
+        summ = pb.plan()
+        if i:
+            ms.append(ctx.last_kernel_ms())
+        steps, done = int(summ["steps"].sum()), int(summ["done"].sum())
+        if (summ["status"] < 0).any():
+            return {"error": "episode status %s" % np.unique(summ["status"])}
+    k_ms = float(np.mean(ms))
+    return {"metric": "config 5: Planner_RRT steps/s, one episode per particle hypothesis", "value": steps / (k_ms * 1e-3),
+            "unit": "steps/s", "episodes": n_ep, "max_step": max_step, "steps_per_launch": steps, "episodes_done": done,
+            "kernel_ms": k_ms, "episodes_per_s": n_ep / (k_ms * 1e-3)}
+
+
 def bench_astar(ctx, with_cpu, n_inst=1024, reps=3):
     """BASELINE config 3: 1024 independent astar_fixLenSOG searches (starts on the 10 m lattice,
     pathLenLimit in {100,200,300}) over one shared world: 64 obstacles, 10 habitats, rectangle polygon,
@@ -89,6 +178,24 @@ def bench_astar(ctx, with_cpu, n_inst=1024, reps=3):
            # ~0.1 KB algorithmic HBM bytes per child cell (node write 68 + visited 1 + SOG 16 + scan share)
            "roofline": {"bound": "hbm", "achieved": cells * 100.0 / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": cells * 100.0 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+    # SURVEY 8(d) config 3 also asks for the same batch through astar_fixLen (no grid) and astar.astar (start -> goal
+    # pairs on the 50x50 lattice of config 1): reported side by side, labelled
+    def variant(name, st, **k):
+        _astar_lib.run_batch(ctx, name, st, **k)
+        vms, vc, vf = [], 0, 0
+        for _ in range(reps):
+            res = _astar_lib.run_batch(ctx, name, st, **k)
+            vms.append(ctx.last_kernel_ms())
+            vc, vf = sum(r["n_children"] for r in res), sum(r["found"] for r in res)
+            if any(r["status"] < 0 for r in res):
+                return {"error": "instance status %s" % sorted({r["status"] for r in res if r["status"] < 0})}
+        return {"value": vc / (float(np.mean(vms)) * 1e-3), "unit": "cells/s", "cells_per_launch": vc, "found": vf,
+                "kernel_ms": float(np.mean(vms))}
+    out["variants"] = {"astar_fixLen": variant("astar_fixLen", starts, limits=limits, weights=(0, 10, 10), cap_nodes=20000)}
+    lw = synth.make_lattice_world(seed=11, n_obstacles=30, r_range=(10, 22))
+    ctx.set_world(lw["obstacles"], None, None, None, None, None)
+    lst = np.column_stack([10.0 * rng.integers(0, 20, n_inst), 10.0 * rng.integers(0, 20, n_inst)])
+    out["variants"]["astar"] = variant("astar", lst, goals=np.tile([490.0, 490.0], (n_inst, 1)), box=lw["box"], cap_nodes=60000)
     if with_cpu:
         from oracle import orc_astar as oa
         t0, c, n = time.perf_counter(), 0, 0
@@ -260,9 +367,17 @@ def main():
                      % (args.gpus, args.gpus))
         args.gpus = world_size
 
+    from auv_sim_amd import synth
+    half = 0.5 * args.grid * 10.0
+    world = synth.make_world(seed=2, n_obstacles=args.obstacles, box=(-half, -half, half, half), cell=10.0,
+                             n_bins=10, bin_len=50, n_habitats=10)
+    cpu_all = None
+    if world_size == 1 and not args.no_cpu:
+        cpu_all = cpu_baseline_all_cores(world, args.iters, args)  # forks: must precede any HIP initialisation
+
     import torch
     import torch.distributed as dist
-    from auv_sim_amd import _lib, synth
+    from auv_sim_amd import _lib
     from auv_sim_amd import distributed as D
 
     torch.cuda.set_device(local_rank)
@@ -271,9 +386,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
-    half = 0.5 * args.grid * 10.0
-    world = synth.make_world(seed=2, n_obstacles=args.obstacles, box=(-half, -half, half, half), cell=10.0,
-                             n_bins=10, bin_len=50, n_habitats=10)
     ctx = _lib.Context(local_rank)
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     E = args.episodes
@@ -360,13 +472,16 @@ def main():
         }
         if world_size == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(world, args.iters, args)
+            out["cpu_baseline_all_cores"] = cpu_all
         else:
             out["cpu_baseline"] = None
         if not args.no_extra:
             # the other two planner families of the path, per GPU (rank 0's device), outside the timed region
+            out["single_episode"] = bench_single_episode(ctx, world, args)
             out["astar"] = bench_astar(ctx, with_cpu=(world_size == 1 and not args.no_cpu))
             out["planner_rrt"] = bench_planner(ctx, with_cpu=(world_size == 1 and not args.no_cpu))
             # the callers either side of the planners
+            out["config5"] = bench_config5(ctx)
             out["shark_grid"] = bench_shark_grid(local_rank, with_cpu=(world_size == 1 and not args.no_cpu))
             out["particle_filter"] = bench_particle_filter(local_rank, with_cpu=(world_size == 1 and not args.no_cpu))
         print(json.dumps(out))
