@@ -31,6 +31,18 @@ struct WorldDev {
   // the bucket of miny}; the last column lets the scan stop as soon as no later cell can match
   const double* xb_data;    // [xb_off[NB]][4]
   double xb_x0, xb_inv_w;
+  // region index over the same cells (exact, O(log) lookup).  The test `minx <= x <= min(maxx,maxy)` only
+  // changes at the breakpoints {minx} U {min(maxx,maxy)}: for x on a breakpoint, or strictly between two
+  // consecutive ones ("region"), the set of cells passing it is constant.  Region r lists that set in
+  // cell_list order with the running minimum of miny, so the first cell with miny <= y is a binary search
+  // on a non-increasing array.  Built when it fits the entry budget (always for grid-like cell lists);
+  // otherwise rg_enabled = 0 and the bucket scan above is used.
+  int32_t rg_enabled, n_rg_bp;
+  const int32_t* rg_first;  // [NB+1] number of breakpoints that fall in earlier x-buckets
+  const double* rg_bp;      // [m] breakpoints, ascending
+  const int32_t* rg_off;    // [2m+2] candidate range of region r: 2i = (bp[i-1], bp[i]), 2i+1 = {bp[i]}
+  const double* rg_pm;      // [total] running min of miny along the region's list
+  const int32_t* rg_id;     // [total] cell id
   double bb[4];  // polygon bounds xmin,ymin,xmax,ymax (get_random_mps, :334)
   double safe_box[4];    // when the polygon is an axis-aligned rectangle: its corners (strict interior test)
   int32_t has_safe_box, _pad1;
@@ -58,6 +70,16 @@ struct RrtBuffers {
   double* node_f;    // [E][cap_nodes][8]  x, y, theta, traj_t, length, -, -, -   (64 B per node)
   int32_t* node_i;   // [E][cap_nodes][4]  plan_iter, parent, pt_off, pt_cnt       (16 B per node)
   double* points;    // [E][6][cap_points] SoA x, y, theta, v, traj_t, length
+  // cost-walk acceleration (derived data, never returned):
+  //  * a path element's contribution to habitat_shark_cost_func -- w3*prob of its cell in its time bin, and
+  //    the habitat it lies in -- does not depend on the leaf that walks over it (its bin is always part of
+  //    the leaf's sub-dict), so it is evaluated the first time a walk meets it and kept:
+  //    points in pt_term / pt_hab, nodes in node_f[6] / node_f[7]; hab = -2 marks "not evaluated yet"
+  //  * anc[n] = the node_i records of n's parent, grandparent, ... (4 levels, one 64-B line), so the
+  //    leaf -> root walk follows one dependent load per four ancestors
+  double* pt_term;   // [E][cap_points]
+  int8_t* pt_hab;    // [E][cap_points]
+  int32_t* anc;      // [E][cap_nodes][16]
   int32_t* bin_items;                       // [E][K+1][bin_cap]
   int32_t* bin_count;                       // [E][K+1] (copied out of LDS at the end)
   uint32_t* mt;                             // [E][624] generator state in

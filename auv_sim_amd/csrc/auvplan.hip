@@ -48,14 +48,15 @@ struct auvp_handle {
   // world
   bool have_world = false;
   WorldDev W{};
-  DevBuf d_ox, d_oy, d_ot, d_hab, d_habt, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems, d_xdata;
+  DevBuf d_ox, d_oy, d_ot, d_hab, d_habt, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems, d_xdata, d_rgfirst, d_rgbp, d_rgoff,
+      d_rgpm, d_rgid;
   // rrt batch
   int E = 0;
   RrtParamsDev P{};
   RrtBuffers B{};
   int max_pts = 0;
   DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_phase, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+      d_leaf_c, d_leaf_i, d_phase, d_pt_term, d_pt_hab, d_anc, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
@@ -237,7 +238,64 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   } else {
     xoff.assign(2, 0);
   }
+  // region index (auvp_types.h): breakpoints, per-region candidate lists with running min of miny
+  std::vector<double> bp, rpm;
+  std::vector<int32_t> rfirst(NB + 1, 0), roff(2, 0), rid;
+  int rg_enabled = 0;
+  if (C > 0) {
+    bp.reserve((size_t)2 * C);
+    for (int c = 0; c < C; c++) {
+      const double a = cells[4 * c], b = std::min(cells[4 * c + 2], cells[4 * c + 3]);
+      if (b < a || a != a || b != b) continue;
+      bp.push_back(a); bp.push_back(b);
+    }
+    std::sort(bp.begin(), bp.end());
+    bp.erase(std::unique(bp.begin(), bp.end()), bp.end());
+    const size_t m = bp.size();
+    auto bucket_of = [&](double x) {
+      const double fb = std::floor((x - X0) * inv_w);
+      return fb < 0.0 ? 0 : (fb >= (double)NB ? NB - 1 : (int)fb);
+    };
+    for (size_t i = 0; i < m; i++) rfirst[bucket_of(bp[i]) + 1]++;
+    for (int k = 0; k < NB; k++) rfirst[k + 1] += rfirst[k];
+    const size_t R = 2 * m + 1;
+    std::vector<int64_t> cnt(R + 1, 0);
+    std::vector<int32_t> r0(C, 0), r1(C, -1);
+    for (int c = 0; c < C; c++) {
+      const double a = cells[4 * c], b = std::min(cells[4 * c + 2], cells[4 * c + 3]);
+      if (b < a || a != a || b != b) continue;
+      r0[c] = 2 * (int32_t)(std::lower_bound(bp.begin(), bp.end(), a) - bp.begin()) + 1;
+      r1[c] = 2 * (int32_t)(std::lower_bound(bp.begin(), bp.end(), b) - bp.begin()) + 1;
+      cnt[r0[c]]++; cnt[r1[c] + 1]--;
+    }
+    int64_t total = 0, run = 0;
+    for (size_t r = 0; r < R; r++) { run += cnt[r]; total += run; }
+    int64_t budget = 32ll << 20;
+    if (const char* e = getenv("AUVP_RG_MAX_ENTRIES")) budget = atoll(e);
+    if (total <= budget && R + 1 < (size_t)INT32_MAX) {
+      rg_enabled = 1;
+      roff.assign(R + 1, 0);
+      run = 0;
+      for (size_t r = 0; r < R; r++) { run += cnt[r]; roff[r + 1] = roff[r] + (int32_t)run; }
+      rpm.resize((size_t)total); rid.resize((size_t)total);
+      std::vector<int32_t> fill(roff.begin(), roff.end() - 1);
+      for (int c = 0; c < C; c++)
+        for (int32_t r = r0[c]; r <= r1[c]; r++) {
+          const int32_t k = fill[r]++;
+          rid[k] = c;
+          rpm[k] = (k > roff[r]) ? std::min(rpm[k - 1], cells[4 * c + 1]) : cells[4 * c + 1];
+        }
+    } else {
+      bp.clear();
+      std::fill(rfirst.begin(), rfirst.end(), 0);
+    }
+  }
   int rc;
+  if ((rc = upload(h, h->d_rgfirst, rfirst.data(), rfirst.size()))) return rc;
+  if ((rc = upload(h, h->d_rgbp, bp.data(), bp.size()))) return rc;
+  if ((rc = upload(h, h->d_rgoff, roff.data(), roff.size()))) return rc;
+  if ((rc = upload(h, h->d_rgpm, rpm.data(), rpm.size()))) return rc;
+  if ((rc = upload(h, h->d_rgid, rid.data(), rid.size()))) return rc;
   if ((rc = upload(h, h->d_ox, ox.data(), O))) return rc;
   if ((rc = upload(h, h->d_oy, oy.data(), O))) return rc;
   if ((rc = upload(h, h->d_ot, ot.data(), O))) return rc;
@@ -263,6 +321,9 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   W.cells = h->d_cells.as<double>(); W.prob = h->d_prob.as<double>();
   W.xb_off = h->d_xoff.as<int32_t>(); W.xb_items = h->d_xitems.as<int32_t>(); W.xb_data = h->d_xdata.as<double>();
   W.xb_x0 = X0; W.xb_inv_w = inv_w;
+  W.rg_enabled = rg_enabled; W.n_rg_bp = (int32_t)bp.size();
+  W.rg_first = h->d_rgfirst.as<int32_t>(); W.rg_bp = h->d_rgbp.as<double>(); W.rg_off = h->d_rgoff.as<int32_t>();
+  W.rg_pm = h->d_rgpm.as<double>(); W.rg_id = h->d_rgid.as<int32_t>();
   double bb[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
   for (int i = 0; i < V; i++) {
     bb[0] = std::min(bb[0], polygon[2 * i]); bb[1] = std::min(bb[1], polygon[2 * i + 1]);
@@ -368,9 +429,15 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   HIPCHK(h, h->d_bin_items.reserve((size_t)E * (P.K + 1) * B.bin_cap * sizeof(int32_t)));
   HIPCHK(h, h->d_bin_count.reserve((size_t)E * (P.K + 1) * sizeof(int32_t)));
   HIPCHK(h, h->d_summary.reserve((size_t)E * sizeof(RrtSummary)));
+  HIPCHK(h, h->d_pt_term.reserve(cpnt * sizeof(double)));
+  HIPCHK(h, h->d_pt_hab.reserve(cpnt));
+  HIPCHK(h, h->d_anc.reserve(cn * 16 * sizeof(int32_t)));
   B.node_f = h->d_nodes_f.as<double>();
   B.node_i = h->d_nodes_i.as<int32_t>();
   B.points = h->d_points.as<double>();
+  B.pt_term = h->d_pt_term.as<double>();
+  B.pt_hab = h->d_pt_hab.as<int8_t>();
+  B.anc = h->d_anc.as<int32_t>();
   B.bin_items = h->d_bin_items.as<int32_t>();
   B.bin_count = h->d_bin_count.as<int32_t>();
   B.summary = h->d_summary.as<RrtSummary>();

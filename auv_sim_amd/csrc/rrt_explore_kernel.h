@@ -105,6 +105,19 @@ __device__ __forceinline__ int cell_lookup(const WorldDev& W, double x, double y
   if (W.n_cells == 0) return -1;
   double fb = auvp_floor((x - W.xb_x0) * W.xb_inv_w);
   int b = fb < 0.0 ? 0 : (fb >= (double)W.n_xbuckets ? W.n_xbuckets - 1 : (int)fb);
+  if (W.rg_enabled) {
+    // region of x: breakpoints in earlier buckets are < x, in later buckets > x (the bucket map is monotone)
+    int lo = W.rg_first[b], hi = W.rg_first[b + 1];
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (W.rg_bp[mid] < x) lo = mid + 1; else hi = mid; }
+    const int r = 2 * lo + ((lo < W.n_rg_bp && W.rg_bp[lo] == x) ? 1 : 0);
+    const int s = W.rg_off[r], e = W.rg_off[r + 1];
+    if (s == e) return -1;
+    if (W.rg_pm[s] <= y) return W.rg_id[s];      // the usual case on a grid
+    if (!(W.rg_pm[e - 1] <= y)) return -1;       // no candidate reaches down to y
+    lo = s; hi = e - 1;                          // pm[lo] > y >= pm[hi]: first index with pm <= y
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (W.rg_pm[mid] <= y) hi = mid; else lo = mid; }
+    return W.rg_id[hi];
+  }
   int e = W.xb_off[b + 1];
   for (int k = W.xb_off[b]; k < e; k++) {
     const double4 d = reinterpret_cast<const double4*>(W.xb_data)[k];
@@ -121,20 +134,18 @@ struct CostAcc {
   int hits;                    // number of path points inside some habitat
 };
 
-// One pass of up to 64 path elements (lane order = path order).
-// habitat_shark_cost_func body, path_planning/cost.py:171-193.  `term` is 64 doubles of wave LDS.
-__device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtSharedLds& S, int bin_lo, int bin_hi, double w3,
-                                          int n_valid, double x, double y, double t, double* term, CostAcc& acc) {
-  const int lane = lane_id();
-  const bool valid = lane < n_valid;
+// One path element of habitat_shark_cost_func (path_planning/cost.py:171-193): its shark term w3*prob
+// (0.0 when it has none: x + 0.0 == x, an exact no-op in the ordered sum) and the first habitat that
+// contains it (-1: none).  An element whose time stamp lies in no bin of [bin_lo, bin_hi) is skipped
+// entirely by the reference: (0.0, -1).
+__device__ __forceinline__ void cost_element(const WorldDev& W, const RrtSharedLds& S, int bin_lo, int bin_hi, double w3,
+                                             double x, double y, double t, double& tv, int& hab) {
   int tb = -1;
-  if (valid) {
-    for (int b = bin_lo; b < bin_hi; b++) {
-      if (t >= S.bins[b][0] && t <= S.bins[b][1]) { tb = b; break; }
-    }
+  for (int b = bin_lo; b < bin_hi; b++) {
+    if (t >= S.bins[b][0] && t <= S.bins[b][1]) { tb = b; break; }
   }
-  double tv = 0.0;  // x + 0.0 == x: elements without a shark term add an exact zero
-  int hab = -1;
+  tv = 0.0;
+  hab = -1;
   if (tb >= 0) {
     int c = cell_lookup(W, x, y);
     if (c >= 0) tv = w3 * W.prob[(size_t)tb * W.n_cells + c];
@@ -144,6 +155,12 @@ __device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtSharedLds&
       if (ddx * ddx + ddy * ddy <= S.hab[h][3]) { hab = h; break; }
     }
   }
+}
+
+// One pass of up to 64 evaluated elements (lane order = path order) into the running cost.
+// `term` is 64 doubles of wave LDS.
+__device__ __forceinline__ void cost_accumulate(int n_valid, double tv, int hab, double* term, CostAcc& acc) {
+  const int lane = lane_id();
   term[lane] = tv;
   unsigned long long hm = __ballot(hab >= 0);
   acc.hits += __popcll(hm);
@@ -162,6 +179,15 @@ __device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtSharedLds&
   for (int i = 0; i < n_valid; i++) c2 = c2 + term[i];
   acc.c2 = c2;
   wave_sync();
+}
+
+// evaluate + accumulate up to 64 elements given by value (the standalone cost probe)
+__device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtSharedLds& S, int bin_lo, int bin_hi, double w3,
+                                          int n_valid, double x, double y, double t, double* term, CostAcc& acc) {
+  double tv = 0.0;
+  int hab = -1;
+  if (lane_id() < n_valid) cost_element(W, S, bin_lo, bin_hi, w3, x, y, t, tv, hab);
+  cost_accumulate(n_valid, tv, hab, term, acc);
 }
 
 template <int J, int MODE, bool DIAG>
@@ -215,6 +241,9 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
   double* nodeF = B.node_f + (size_t)ep * capn * 8;                       // [capn][8] x,y,theta,t,length
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;    // plan_iter,parent,pt_off,pt_cnt
   double* ptF = B.points + (size_t)ep * capp * 6;                         // SoA [6][capp]
+  double* ptTerm = B.pt_term + (size_t)ep * capp;                         // cost-walk cache (auvp_types.h)
+  int8_t* ptHab = B.pt_hab + (size_t)ep * capp;
+  int32_t* anc = B.anc + (size_t)ep * capn * 16;
   int32_t* bin_items = B.bin_items + (size_t)ep * (P.K + 1) * bcap;
   const double* init = B.init + (size_t)ep * 6;
   const int K = P.K;
@@ -239,8 +268,10 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
   if (lane == 0) {
     nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
     nodeI[0] = make_int4(0, -1, 0, 0);
+    nodeF[7] = -2.0;
     if (MODE == 0) { bin_items[(size_t)(K >= 1 ? 1 : 0) * bcap] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
   }
+  if (lane < 16) anc[lane] = -1;  // the root has no ancestors
   wave_sync();
   const double init_t = readfirst_f64(init[3]);
   int n_nodes = 1, n_points = 0, n_leaves = 0, status = 0, best_leaf = -1, best_L = 0;
@@ -333,6 +364,11 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
     }
 
     AUVP_PHASE(0);
+    // the new node's ancestor line = the parent's record + the parent's first three ancestors: requested now,
+    // consumed at accept (the loads overlap the steer)
+    int anc_v = -1;
+    if (lane < 4) anc_v = reinterpret_cast<const int32_t*>(nodeI + par)[lane];
+    else if (lane < 16) anc_v = anc[(size_t)par * 16 + (lane - 4)];
     // ------------------------------------------------------------ steer (:252-295)
     double cx, cy, cth, ctt, clen;
     {
@@ -467,6 +503,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
         size_t gi = (size_t)(n_points + cnt + rank);  // speculative: committed only if the node is accepted
         ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * (size_t)capp + gi] = myth; ptF[3 * (size_t)capp + gi] = vt;
         ptF[4 * (size_t)capp + gi] = mt_; ptF[5 * (size_t)capp + gi] = ml;
+        ptHab[gi] = -2;  // cost contribution not evaluated yet
         pts[cnt + rank + 1][0] = mx;
         pts[cnt + rank + 1][1] = my;
       }
@@ -533,8 +570,10 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
       *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
       *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
       nf[4] = clen;
+      nf[7] = -2.0;
       nodeI[me] = make_int4(it, par, n_points, cnt);
     }
+    if (lane < 16) anc[(size_t)me * 16 + lane] = anc_v;
     n_nodes++;
     n_points += cnt;
     if (MODE == 0) {
@@ -582,25 +621,45 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
       auto flush = [&]() {
         for (int b0 = 0; b0 < fill; b0 += 64) {
           const int nv = (fill - b0) < 64 ? (fill - b0) : 64;
-          double ex = 0.0, ey = 0.0, et = 0.0;
+          // an element's (term, habitat) is the same for every leaf above it (its time bin is always one of the
+          // leaf's bins): read it if an earlier walk left it, evaluate and keep it otherwise
+          double tv = 0.0;
+          int hab = -1, id = 0;
+          bool need = false;
           if (lane < nv) {
-            int id = elist[b0 + lane];
-            if (id >= 0) { ex = ptF[id]; ey = ptF[(size_t)capp + id]; et = ptF[4 * (size_t)capp + id]; }
+            id = elist[b0 + lane];
+            if (id >= 0) { hab = ptHab[id]; tv = ptTerm[id]; }
             else {
-              const double* nf = nodeF + (size_t)(~id) * 8;
-              const double2 a = *reinterpret_cast<const double2*>(nf);
-              ex = a.x; ey = a.y; et = nf[3];
+              const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)(~id) * 8 + 6);
+              tv = c.x; hab = (int)c.y;
+            }
+            need = hab == -2;
+          }
+          if (__any(need)) {
+            if (need) {
+              double ex, ey, et;
+              if (id >= 0) { ex = ptF[id]; ey = ptF[(size_t)capp + id]; et = ptF[4 * (size_t)capp + id]; }
+              else {
+                const double* nf = nodeF + (size_t)(~id) * 8;
+                const double2 a = *reinterpret_cast<const double2*>(nf);
+                ex = a.x; ey = a.y; et = nf[3];
+              }
+              cost_element(W, S, 0, W.n_bins, P.w[2], ex, ey, et, tv, hab);
+              if (id >= 0) { ptTerm[id] = tv; ptHab[id] = (int8_t)hab; }
+              else *reinterpret_cast<double2*>(nodeF + (size_t)(~id) * 8 + 6) = make_double2(tv, (double)hab);
             }
           }
           wave_sync();
-          cost_pass(W, S, blo, bhi, P.w[2], nv, ex, ey, et, term, acc);
+          cost_accumulate(nv, tv, hab, term, acc);
         }
         Lp += fill;
         fill = 0;
       };
       if (lane == 0) elist[0] = ~me;
       fill = 1;
-      int m = me, mcnt = cnt, moff = n_points - cnt, mpar = par;
+      int mcnt = cnt, moff = n_points - cnt, mpar = par;
+      // node records of the next ancestors come four at a time out of one 64-B line (lanes 0..15)
+      int cur = me, kanc = 0, av = anc_v;
       for (;;) {
         // segment of node m: its appended points last-to-first, then the node it grew from
         for (int s0 = 0; s0 < mcnt + 1; s0 += 64) {
@@ -610,11 +669,17 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
           if (lane < seg) elist[fill + lane] = (i < mcnt) ? (moff + (mcnt - 1 - i)) : ~mpar;
           fill += seg;
         }
-        m = mpar;
-        const int4 rec = nodeI[m];
-        const int gp = uni(rec.y);
-        if (gp < 0) break;
-        mcnt = uni(rec.w); moff = uni(rec.z); mpar = gp;
+        if (kanc == 4) {  // `cur` is the fourth ancestor of the previous anchor: continue from its line
+          av = lane < 16 ? anc[(size_t)cur * 16 + lane] : -1;
+          kanc = 0;
+        }
+        const int gp = __builtin_amdgcn_readlane(av, 4 * kanc + 1);
+        if (gp < 0) break;  // mpar is the root: no path of its own
+        mcnt = __builtin_amdgcn_readlane(av, 4 * kanc + 3);
+        moff = __builtin_amdgcn_readlane(av, 4 * kanc + 2);
+        cur = mpar;
+        mpar = gp;
+        kanc++;
       }
       wave_sync();
       flush();

@@ -12,7 +12,10 @@ ap.add_argument("--obstacles", type=int, default=256)
 ap.add_argument("--grid", type=int, default=200)
 ap.add_argument("--mode", default="timebin")
 ap.add_argument("--clocks", type=int, default=1)
+ap.add_argument("--lib", default=None, help="alternative libauvplan.so (kernel experiments)")
 a = ap.parse_args()
+if a.lib:
+    _lib.LIB_PATH = os.path.abspath(a.lib)
 half = 0.5 * a.grid * 10.0
 world = synth.make_world(seed=2, n_obstacles=a.obstacles, box=(-half, -half, half, half), cell=10.0)
 ctx = _lib.Context(0)
