@@ -79,20 +79,25 @@ __global__ __launch_bounds__(256) void sog_grid_kernel(SogDev D) {
   const int t = (int)(i / G), g = (int)(i % G), row = g / D.cols, col = g % D.cols;
   const int count = D.count, m = D.mult[g];
   const long long c2 = (long long)count * count;
+  // The reference scans the 4count x 4count window [row-2count, row+2count) x [col-2count, col+2count) in (i, j)
+  // order and keeps d2 <= count^2: only rows |dr| <= count contribute, each over |dc| <= floor(sqrt(count^2 - dr^2)),
+  // all of which lie inside the window (count < 2 count).  Visiting exactly those cells in the same order gives the
+  // same sequence of additions.
+  const int r_lo = max(row - count, 0), r_hi = min(row + count, D.rows - 1);
   double total = 0.0;
   for (int s = 0; s < D.n_sharks; s++) {
     const double* occ = D.occ + ((size_t)t * D.n_sharks + s) * G;
     double a = 0.0;
-    for (int rep = 0; rep < m; rep++) {  // once per listed cell that maps here (constructAUVGrid's loop over cell_list)
-      for (int ii = 0; ii < 4 * count; ii++) {
-        const int rt = row - 2 * count + ii;
-        if (rt < 0 || rt >= D.rows) continue;
-        for (int jj = 0; jj < 4 * count; jj++) {
-          const int ct = col - 2 * count + jj;
-          if (ct < 0 || ct >= D.cols) continue;
-          const long long d2 = (long long)(rt - row) * (rt - row) + (long long)(ct - col) * (ct - col);
-          if (d2 <= c2) a = a + occ[(size_t)rt * D.cols + ct];
-        }
+    for (int rep = 0; rep < (count > 0 ? m : 0); rep++) {  // once per listed cell that maps here (constructAUVGrid's loop
+                                                            // over cell_list); count == 0: the window is empty
+      for (int rt = r_lo; rt <= r_hi; rt++) {
+        const long long rem = c2 - (long long)(rt - row) * (rt - row);
+        int w = (int)sqrt((double)rem);  // integer square root, corrected for the rounding of the cast
+        while ((long long)w * w > rem) w--;
+        while ((long long)(w + 1) * (w + 1) <= rem) w++;
+        const int c_lo = max(col - w, 0), c_hi = min(col + w, D.cols - 1);
+        const double* orow = occ + (size_t)rt * D.cols;
+        for (int ct = c_lo; ct <= c_hi; ct++) a = a + orow[ct];
       }
     }
     total = total + a;  // grid[i][j] + tempAUVGrid[i][j], sharks in dict order (:163-167)
@@ -152,7 +157,9 @@ extern "C" int auvp_sog_convert(auvp_handle* h, const double* cells, int32_t C, 
     X0 = lo; inv_w = span > 0 ? (double)NB / span : 0.0;
     std::vector<std::vector<int32_t>> lists(NB);
     for (int c = 0; c < C; c++) {
-      int b0 = (int)std::floor((cells[4 * c] - X0) * inv_w) - 1, b1 = (int)std::floor((cells[4 * c + 2] - X0) * inv_w) + 1;
+      // the device computes the same floor((x - X0) * inv_w), clamped: a monotone map, so every x in [minx, maxx]
+      // lands in a bucket between those of the two ends
+      int b0 = (int)std::floor((cells[4 * c] - X0) * inv_w), b1 = (int)std::floor((cells[4 * c + 2] - X0) * inv_w);
       b0 = std::max(0, std::min(NB - 1, b0)); b1 = std::max(0, std::min(NB - 1, b1));
       for (int k = b0; k <= b1; k++) lists[k].push_back(c);
     }

@@ -86,3 +86,49 @@ def test_astar_without_obstacles(ctx, orc):
         assert res[e]["found"] and o["found"]
         assert np.array_equal(res[e]["path"], o["path"]) and np.array_equal(res[e]["expansions"], o["expansions"])
     assert len(res[1]["path"]) == 1  # start == goal: popped immediately
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_cell_lookup_index_is_exact_for_arbitrary_cell_lists(ctx, orc, seed, monkeypatch):
+    """cost.py:181-184 first-match scan (with its `x <= maxy` comparison) over cell lists that are NOT grids:
+    overlapping rectangles in random order, degenerate cells, query points exactly on minx / maxx / maxy values.
+    The region index (default), the bucket scan (index budget forced to 0) and the CPU checker must agree bit
+    for bit."""
+    rng = np.random.default_rng(seed)
+    C, T = 300, 3
+    x0 = np.round(rng.uniform(-60, 60, C), 1)
+    y0 = np.round(rng.uniform(-60, 60, C), 1)
+    cells = np.stack([x0, y0, x0 + np.round(rng.uniform(0, 40, C), 1), y0 + np.round(rng.uniform(0, 40, C), 1)], axis=1)
+    cells[::17, 2] = cells[::17, 0]            # zero-width cells
+    cells[5::29, 3] = cells[5::29, 0] - 1.0    # maxy < minx: can never match (x <= maxy fails)
+    bins = np.array([[0.0, 50.0], [50.0, 100.0], [100.0, 150.0]])
+    prob = rng.uniform(0, 0.3, size=(T, C))
+    habitats = np.array([[10.0, 5.0, 12.0], [-30.0, -20.0, 8.0]])
+    edges = np.concatenate([cells[:, 0], cells[:, 2], cells[:, 3]])
+    paths, los, his, tots, ws = [], [], [], [], []
+    for _ in range(40):
+        n = int(rng.integers(1, 150))
+        x = rng.uniform(-70, 110, n)
+        on = rng.random(n) < 0.4
+        x[on] = rng.choice(edges, on.sum())    # exactly on a breakpoint of the index
+        y = rng.uniform(-70, 110, n)
+        yon = rng.random(n) < 0.2
+        y[yon] = rng.choice(cells[:, 1], yon.sum())
+        t = rng.uniform(-10, 160, n)
+        paths.append(np.stack([x, y, t], axis=1))
+        lo = int(rng.integers(0, T))
+        los.append(lo)
+        his.append(int(rng.integers(lo, T + 1)))
+        tots.append(float(rng.choice([0.0, 37.5, 200.0])))
+        ws.append([-3.0, -3.0, -4.0])
+    w = orc.WorldArrays(None, habitats, None, bins, cells, prob)
+    want = np.array([orc.cost(w, lo, hi, p, tt, ww, kind="portable") for p, lo, hi, tt, ww in zip(paths, los, his, tots, ws)])
+    ctx.set_world(None, habitats, None, bins, cells, prob)
+    got_index = ctx.cost_paths(paths, los, his, tots, ws)
+    monkeypatch.setenv("AUVP_RG_MAX_ENTRIES", "0")
+    ctx.set_world(None, habitats, None, bins, cells, prob)
+    got_scan = ctx.cost_paths(paths, los, his, tots, ws)
+    monkeypatch.delenv("AUVP_RG_MAX_ENTRIES")
+    assert np.array_equal(got_index, want)
+    assert np.array_equal(got_scan, want)
+    assert (want[:, 3] != 0).sum() > 10

@@ -8,7 +8,9 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 dst = os.path.join(REPO, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-for f in ("bench.json", "trace_bench.json"):
+for f in glob.glob(os.path.join(src, "trace_main", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+for f in ("bench.json", "trace_bench.json", "trace_main_bench.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")) + glob.glob(os.path.join(src, "trace", "*domain_stats.csv")):

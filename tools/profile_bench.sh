@@ -10,7 +10,10 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="$@"
 # 1) un-profiled bench line
 python3 $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
-# 2) kernel trace + stats of the same command
+# 2) kernel trace + stats of the same command.  The side measurements launch rrt_explore_kernel too (the
+#    single-episode latency leg), so the headline kernel is traced alone first (--no-extra: its average must
+#    agree with roofline.kernel_ms), then the full command for the other kernels.
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_main -o trace_main -- python3 $R/bench.py $ARGS --no-cpu --no-extra > $OUT/trace_main_bench.json 2> $OUT/trace_main.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $R/bench.py $ARGS --no-cpu > $OUT/trace_bench.json 2> $OUT/trace.err
 # 3) PMC passes (separate runs, counters only)
 for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
