@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libauvplan.so")
+LIB_PATH = os.environ.get("AUVPLAN_LIBRARY") or os.path.join(HERE, "libauvplan.so")  # override: kernel experiments
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)

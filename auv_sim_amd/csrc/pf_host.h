@@ -162,21 +162,27 @@ int auvp_pf_run(auvp_handle* h, int32_t n_steps, int32_t n_auv, int32_t phases, 
     D.choice = P.choice.as<int32_t>();
   }
   const size_t lds = auvp::pf_lds_bytes(N);
-  const int ppt = (N + PF_T - 1) / PF_T;
+  // threads per filter: measured on MI355X at N = 1000 (4096 filters x 20 steps): 256 -> 11.6 ms, 1024 -> 14.4 ms
+  // (the step is bound by its ~100 workgroup barriers and the serial MT19937 / mean chains, which more waves make
+  // more expensive, not by the per-particle math)
+#ifndef AUVP_PF_THREADS
+#define AUVP_PF_THREADS 256
+#endif
+  constexpr int T = AUVP_PF_THREADS, P1 = 1024 / T, P2 = 2048 / T;
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  if (ppt <= 4) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)auvp::pf_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(auvp::pf_step_kernel<4>, dim3(F), dim3(PF_T), lds, h->stream, D);
+  if (N <= 1024) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)auvp::pf_step_kernel<T, P1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((auvp::pf_step_kernel<T, P1>), dim3(F), dim3(T), lds, h->stream, D);
   } else {
-    HIPCHK(h, hipFuncSetAttribute((const void*)auvp::pf_step_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(auvp::pf_step_kernel<8>, dim3(F), dim3(PF_T), lds, h->stream, D);
+    HIPCHK(h, hipFuncSetAttribute((const void*)auvp::pf_step_kernel<T, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((auvp::pf_step_kernel<T, P2>), dim3(F), dim3(T), lds, h->stream, D);
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  h->last_ms = ms; h->last_grid = F; h->last_block = PF_T; h->last_lds = (int)lds;
+  h->last_ms = ms; h->last_grid = F; h->last_block = AUVP_PF_THREADS; h->last_lds = (int)lds;
   return AUVP_OK;
 }
 

@@ -1,5 +1,6 @@
-// pf_kernel.h -- the shark particle filter (particleFilter.py) on gfx950: one 256-thread workgroup = one
-// filter (N particles, PPT consecutive list positions per thread), F filters per launch, S steps per launch.
+// pf_kernel.h -- the shark particle filter (particleFilter.py) on gfx950: one T-thread workgroup = one filter
+// (N particles, PPT consecutive list positions per thread; T = 256 measured fastest, pf_host.h), F filters per
+// launch, S steps per launch.
 //
 //   pf_create_kernel   Particle.__init__ x N                       particleFilter.py:44-53, 311-317
 //   pf_step_kernel     create_and_update                           :277-282  (Particle.update_particle :55-75)
@@ -83,12 +84,13 @@ __device__ __forceinline__ void pf_refill(uint32_t* mt, int tid) {
 }
 
 // the next `count` tempered outputs -> dst[0..count) (LDS); ends with a barrier
+template <int T>
 __device__ __forceinline__ void pf_gen_words(PfRng& r, uint32_t* dst, int count, int tid) {
   int done = 0;
   while (done < count) {
     if (r.pos >= 624) { pf_refill(r.mt, tid); r.pos = 0; }
     const int take = min(624 - r.pos, count - done);
-    for (int i = tid; i < take; i += PF_T) dst[done + i] = mt_temper(r.mt[r.pos + i]);
+    for (int i = tid; i < take; i += T) dst[done + i] = mt_temper(r.mt[r.pos + i]);
     r.pos += take;
     done += take;
     __syncthreads();
@@ -112,17 +114,19 @@ __device__ __forceinline__ bool pf_angle_wrap(double& a) {
   return false;
 }
 
+template <int T>
 __device__ __forceinline__ double pf_block_max(double v, double* red, int tid) {
   for (int o = 32; o; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();
   double m = red[0];
-  for (int w = 1; w < PF_T / 64; w++) m = red[w] > m ? red[w] : m;
+  for (int w = 1; w < T / 64; w++) m = red[w] > m ? red[w] : m;
   return m;
 }
 
 // exclusive scan of one int per thread over the workgroup; *total = sum
+template <int T>
 __device__ __forceinline__ int pf_block_scan(int v, int* red, int tid, int* total) {
   int inc = v;
   for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if ((tid & 63) >= o) inc += t; }
@@ -130,7 +134,7 @@ __device__ __forceinline__ int pf_block_scan(int v, int* red, int tid, int* tota
   if ((tid & 63) == 63) red[tid >> 6] = inc;
   __syncthreads();
   int base = 0, tot = 0;
-  for (int w = 0; w < PF_T / 64; w++) { if (w < (tid >> 6)) base += red[w]; tot += red[w]; }
+  for (int w = 0; w < T / 64; w++) { if (w < (tid >> 6)) base += red[w]; tot += red[w]; }
   *total = tot;
   return base + inc - v;
 }
@@ -140,15 +144,16 @@ struct PfLds {
 };
 __host__ __device__ inline size_t pf_lds_bytes(int N) {
   const size_t n2 = (size_t)(N + 2) & ~(size_t)1;
-  return 624 * 4 + 8 * 4 + 16 * 8 + 5 * n2 * 8 + n2 * 4 + (size_t)5 * n2 * 4;
+  return 624 * 4 + 32 * 4 + 40 * 8 + 5 * n2 * 8 + n2 * 4 + (size_t)5 * n2 * 4;
 }
 __device__ __forceinline__ PfLds pf_carve(unsigned char* smem, int N) {
   const size_t n2 = (size_t)(N + 2) & ~(size_t)1;
   PfLds L;
   L.mt = (uint32_t*)smem;
   L.red_i = (int*)(L.mt + 624);
-  L.red_d = (double*)(L.red_i + 8);
-  L.sx = L.red_d + 16; L.sy = L.sx + n2; L.sv = L.sy + n2; L.sth = L.sv + n2; L.sw = L.sth + n2;
+  L.red_d = (double*)(L.red_i + 32);  // red_i [0,16): reductions, 16: choice cursor
+  L.sx = L.red_d + 40;                // red_d [0,16): reductions, 16..17: means
+  L.sy = L.sx + n2; L.sv = L.sy + n2; L.sth = L.sv + n2; L.sw = L.sth + n2;
   L.off = (int*)(L.sw + n2);
   L.wbuf = (uint32_t*)(L.off + n2);  // 5*n2 words: the RNG window, then the alias slots, then the drawn indices
   L.slot = (int*)L.wbuf;
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(PF_T) void pf_create_kernel(PfDev D) {
   const int chunk = (5 * ((N + 2) & ~1)) / 8;  // particles per RNG window (8 words each)
   for (int base = 0; base < N; base += chunk) {
     const int cnt = min(chunk, N - base);
-    pf_gen_words(r, L.wbuf, 8 * cnt, tid);
+    pf_gen_words<PF_T>(r, L.wbuf, 8 * cnt, tid);
     for (int i = tid; i < cnt; i += PF_T) {
       const uint32_t* w = L.wbuf + 8 * i;
       const int p = base + i;
@@ -184,15 +189,15 @@ __global__ __launch_bounds__(PF_T) void pf_create_kernel(PfDev D) {
   if (tid == 0) { D.mtpos[f] = r.pos; D.llen[f] = N; D.ndraw[f] += r.drawn; D.status[f] = PF_OK; }
 }
 
-template <int PPT>
-__global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
+template <int T, int PPT>
+__global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int f = blockIdx.x, tid = threadIdx.x, N = D.N, A = D.A;
   PfLds L = pf_carve(smem, N);
   PfRng r{L.mt, D.mtpos[f], 0ull};
   double* st = D.st + (size_t)f * 5 * N;
-  for (int i = tid; i < 624; i += PF_T) L.mt[i] = D.mt[(size_t)f * 624 + i];
-  for (int i = tid; i < N; i += PF_T) {
+  for (int i = tid; i < 624; i += T) L.mt[i] = D.mt[(size_t)f * 624 + i];
+  for (int i = tid; i < N; i += T) {
     L.sx[i] = st[i]; L.sy[i] = st[N + i]; L.sv[i] = st[2 * N + i]; L.sth[i] = st[3 * N + i]; L.sw[i] = st[4 * N + i];
   }
   int e[PPT];
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
   for (int s = 0; s < D.S; s++) {
     if (D.phases & PF_PHASE_UPDATE) {
       // ---- create_and_update: list position p consumes uniforms 2p, 2p+1 of this step
-      pf_gen_words(r, L.wbuf, 4 * N, tid);
+      pf_gen_words<T>(r, L.wbuf, 4 * N, tid);
       double u0[PPT], u1[PPT];
 #pragma unroll
       for (int j = 0; j < PPT; j++) {
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
         if (p < N) { u0[j] = pf_double(L.wbuf[4 * p], L.wbuf[4 * p + 1]); u1[j] = pf_double(L.wbuf[4 * p + 2], L.wbuf[4 * p + 3]); }
       }
       __syncthreads();
-      for (int i = tid; i < llen; i += PF_T) L.slot[i] = 0x7fffffff;
+      for (int i = tid; i < llen; i += T) L.slot[i] = 0x7fffffff;
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < PPT; j++) if (p0 + j < N) atomicMin(&L.slot[e[j]], p0 + j);
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
       __syncthreads();
       if (D.updated) {
         double* u = D.updated + ((size_t)s * D.F + f) * N * 5;
-        for (int i = tid; i < N; i += PF_T) { u[5 * i] = L.sx[i]; u[5 * i + 1] = L.sy[i]; u[5 * i + 2] = L.sv[i]; u[5 * i + 3] = L.sth[i]; u[5 * i + 4] = L.sw[i]; }
+        for (int i = tid; i < N; i += T) { u[5 * i] = L.sx[i]; u[5 * i + 1] = L.sy[i]; u[5 * i + 2] = L.sv[i]; u[5 * i + 3] = L.sth[i]; u[5 * i + 4] = L.sw[i]; }
       }
       // positions are independent copies again after correct; until then the shared object id stays
     }
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
             lmax = w > lmax ? w : lmax;
           }
         }
-        const double den = pf_block_max(lmax, L.red_d, tid);
+        const double den = pf_block_max<T>(lmax, L.red_d, tid);
         // normalize (:133-139) in place
 #pragma unroll
         for (int j = 0; j < PPT; j++) { const int p = p0 + j; if (p < N) wl[(size_t)a * N + p] = (1 / den) * wl[(size_t)a * N + p]; }
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
         nw[j] = 0;
         if (p < N) { for (int a = 0; a < A; a++) nw[j] += wl[(size_t)a * N + p]; lmax = nw[j] > lmax ? nw[j] : lmax; }
       }
-      const double fden = pf_block_max(lmax, L.red_d, tid);
+      const double fden = pf_block_max<T>(lmax, L.red_d, tid);
       // ---- correct (:179-252): 1..5 deep copies by weight class, then N index draws
       int k[PPT], ksum = 0;
 #pragma unroll
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
         }
       }
       int total = 0;
-      int run = pf_block_scan(ksum, L.red_i, tid, &total);
+      int run = pf_block_scan<T>(ksum, L.red_i, tid, &total);
 #pragma unroll
       for (int j = 0; j < PPT; j++) if (p0 + j < N) { L.off[p0 + j] = run; run += k[j]; }
       if (tid == 0) L.off[N] = total;
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
       if (len == 0) { status = PF_ERR_EMPTY; break; }  // numpy raises ValueError
       int* cho = L.slot;
       if (len == 1) {
-        for (int i = tid; i < N; i += PF_T) cho[i] = 0;  // randint(0, 1): no draw
+        for (int i = tid; i < N; i += T) cho[i] = 0;  // randint(0, 1): no draw
         __syncthreads();
       } else {
         const uint32_t rng = (uint32_t)len - 1u;
@@ -340,36 +345,37 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
         while (got < N) {
           if (r.pos >= 624) { pf_refill(r.mt, tid); r.pos = 0; }
           const int avail = 624 - r.pos;
-          // thread t looks at words [3t, 3t+3) of the block (768 >= 624)
-          uint32_t val[3];
+          // thread t looks at words [WPT t, WPT t + WPT) of the block (WPT T >= 624)
+          constexpr int WPT = (624 + T - 1) / T;
+          uint32_t val[WPT];
           int cnt = 0;
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
-            const int i = 3 * tid + c;
+          for (int c = 0; c < WPT; c++) {
+            const int i = WPT * tid + c;
             val[c] = 0xffffffffu;
             if (i < avail) { const uint32_t v = mt_temper(r.mt[r.pos + i]) & mask; if (v <= rng) { val[c] = v; cnt++; } }
           }
           int tot = 0;
-          int rank = got + pf_block_scan(cnt, L.red_i, tid, &tot);
-          if (tid == 0) L.red_i[4] = avail - 1;
+          int rank = got + pf_block_scan<T>(cnt, L.red_i, tid, &tot);
+          if (tid == 0) L.red_i[16] = avail - 1;
           __syncthreads();
 #pragma unroll
-          for (int c = 0; c < 3; c++) {
+          for (int c = 0; c < WPT; c++) {
             if (val[c] != 0xffffffffu) {
               if (rank < N) cho[rank] = (int)val[c];
-              if (rank == N - 1) L.red_i[4] = 3 * tid + c;  // the word that completes the N draws
+              if (rank == N - 1) L.red_i[16] = WPT * tid + c;  // the word that completes the N draws
               rank++;
             }
           }
           __syncthreads();
-          const int used = L.red_i[4] + 1;
+          const int used = L.red_i[16] + 1;
           r.pos += used;
           r.drawn += (unsigned long long)used;
           got = min(N, got + tot);
           __syncthreads();
         }
       }
-      if (D.choice) for (int i = tid; i < N; i += PF_T) D.choice[((size_t)s * D.F + f) * N + i] = cho[i];
+      if (D.choice) for (int i = tid; i < N; i += T) D.choice[((size_t)s * D.F + f) * N + i] = cho[i];
       // ---- the new list: position n = copy of the source of list_of_new_particles[cho[n]]
       double gx[PPT], gy[PPT], gv[PPT], gt[PPT], gw[PPT];
 #pragma unroll
@@ -399,12 +405,20 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
       if (tid == 0 || tid == 64) {
         const double* src = tid == 0 ? L.sx : L.sy;
         double sum = 0;
-        for (int i = 0; i < N; i++) sum += src[i];
-        L.red_d[8 + (tid >> 6)] = sum / N;
+        int i = 0;
+        for (; i + 16 <= N; i += 16) {  // 16 LDS reads in flight, then the 16 dependent adds in list order
+          double v[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) v[k] = src[i + k];
+#pragma unroll
+          for (int k = 0; k < 16; k++) sum += v[k];
+        }
+        for (; i < N; i++) sum += src[i];
+        L.red_d[16 + (tid >> 6)] = sum / N;
       }
       __syncthreads();
       if (tid == 0) {
-        const double xm = L.red_d[8], ym = L.red_d[9];
+        const double xm = L.red_d[16], ym = L.red_d[17];
         const double* sh = D.shark + ((size_t)s * D.F + f) * 2;
         const double xd = xm - sh[0], yd = ym - sh[1];
         D.mean[((size_t)s * D.F + f) * 2] = xm;
@@ -416,8 +430,8 @@ __global__ __launch_bounds__(PF_T) void pf_step_kernel(PfDev D) {
   }
 
   // ---- persist
-  for (int i = tid; i < 624; i += PF_T) D.mt[(size_t)f * 624 + i] = L.mt[i];
-  for (int i = tid; i < N; i += PF_T) {
+  for (int i = tid; i < 624; i += T) D.mt[(size_t)f * 624 + i] = L.mt[i];
+  for (int i = tid; i < N; i += T) {
     st[i] = L.sx[i]; st[N + i] = L.sy[i]; st[2 * N + i] = L.sv[i]; st[3 * N + i] = L.sth[i]; st[4 * N + i] = L.sw[i];
   }
 #pragma unroll

@@ -174,9 +174,16 @@ __device__ __forceinline__ void cost_accumulate(int n_valid, double tv, int hab,
   acc.visited = vis;
   wave_sync();
   // cost[2] += w3*prob in path order: one dependent add per element, LDS reads run ahead
+  // Entries past n_valid hold +0.0 (every lane stored its tv) and c2 is never -0.0, so adding them is an exact
+  // no-op: the sum runs in batches of 8 -- 8 LDS reads in flight, then 8 dependent adds.
   double c2 = acc.c2;
-#pragma unroll 8
-  for (int i = 0; i < n_valid; i++) c2 = c2 + term[i];
+  for (int i = 0; i < n_valid; i += 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = term[i + k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c2 = c2 + v[k];
+  }
   acc.c2 = c2;
   wave_sync();
 }
