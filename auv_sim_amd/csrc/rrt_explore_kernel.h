@@ -64,7 +64,7 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
   p.pts = ((max_pts * 16) + 15) & ~15;
   p.bins = (((K + 2) * 4) + 15) & ~15;
   p.per_wave = p.scratch + p.mt + p.pts + p.bins;
-  p.total = (int)sizeof(RrtSharedLds) + RRT_WAVES * p.per_wave + obst_slots * 3 * 8;  // + obstacle tile x,y,T
+  p.total = (int)sizeof(RrtSharedLds) + RRT_WAVES * p.per_wave + obst_slots * 4 * 8;  // + obstacle tile x,y,T,r
   return p;
 }
 
@@ -232,11 +232,14 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
   double* olx = reinterpret_cast<double*>(smem + sizeof(RrtSharedLds) + (size_t)RRT_WAVES * plan.per_wave);
   double* oly = olx + J * 64;
   double* olt = oly + J * 64;
+  double* olr = olt + J * 64;  // cull radius: >= sqrt(T) with margin; -inf where nothing can collide
   for (int i = threadIdx.x; i < J * 64; i += blockDim.x) {
     const bool ok = i < W.n_obstacles;
+    const double t = ok ? W.ot[i] : -1.0;  // d2 >= 0 > -1: padding never collides
     olx[i] = ok ? W.ox[i] : 0.0;
     oly[i] = ok ? W.oy[i] : 0.0;
-    olt[i] = ok ? W.ot[i] : -1.0;  // d2 >= 0 > -1: padding never collides
+    olt[i] = t;
+    olr[i] = t >= 0.0 ? auvp_sqrt(t) * (1.0 + 0x1p-30) + 0x1p-40 : -__builtin_inf();
   }
   __syncthreads();
 
@@ -536,15 +539,20 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
     // Exact cull first: an obstacle whose effective disc does not reach the bounding box of the
     // path cannot be within T_i of any path point (a point in the box is at least as far from the
     // centre as the box is), so a slot of 64 obstacles with no candidate is skipped as a whole.
+    // The cull only has to be conservative (a candidate slot runs the exact test below): the obstacle's
+    // bounding square of half-width olr >= sqrt(T_i) against the box around its centre, both inflated by
+    // 2^-30 relative -- eight orders of magnitude above any rounding in these few operations.
     const double bx0 = bbox_l[0], by0 = bbox_l[1], bx1 = bbox_l[2], by1 = bbox_l[3];
+    const double cxm = (bx0 + bx1) * 0.5, cym = (by0 + by1) * 0.5;
+    const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + 1.0);
+    const double hx = (bx1 - bx0) * 0.5 + slack, hy = (by1 - by0) * 0.5 + slack;
     int hit = 0;
 #pragma unroll
     for (int j = 0; j < J; j++) {
-      const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], otj = olt[j * 64 + lane];
-      const double ex = oxj < bx0 ? bx0 - oxj : (oxj > bx1 ? oxj - bx1 : 0.0);
-      const double ey = oyj < by0 ? by0 - oyj : (oyj > by1 ? oyj - by1 : 0.0);
-      const bool cand = ex * ex + ey * ey <= otj * (1.0 + 0x1p-40);
+      const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = olr[j * 64 + lane];
+      const bool cand = !(auvp_fabs(oxj - cxm) > hx + orj || auvp_fabs(oyj - cym) > hy + orj);
       if (__any(cand)) {
+        const double otj = olt[j * 64 + lane];
         double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
         for (int p = 0; p < P_n; p++) {
           // next point's LDS read is in flight while this one is tested (pts has room for P_n + 1)
