@@ -37,6 +37,10 @@ struct RrtSharedLds {
   double hab[RRT_MAX_HAB][4];  // x, y, size, T(size)
   double poly[RRT_MAX_POLY][2];
   double bins[RRT_MAX_BINS][2];
+  // copy of the kernel argument for the code that runs rarely (evaluating a path element for the cost):
+  // reading the table pointers from here when they are needed keeps ~40 scalar registers out of the
+  // expansion loop, which otherwise spills them to vector-register lanes and reloads them every iteration
+  WorldDev world;
 };
 
 // Per-wave LDS layout (bytes), all sizes multiples of 16:
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
     S.hab[i][0] = W.hab[3 * i]; S.hab[i][1] = W.hab[3 * i + 1]; S.hab[i][2] = W.hab[3 * i + 2];
     S.hab[i][3] = W.hab_t[i];
   }
+  if (threadIdx.x == 0) S.world = W;
   for (int i = threadIdx.x; i < W.n_poly * 2; i += blockDim.x) (&S.poly[0][0])[i] = W.poly[i];
   for (int i = threadIdx.x; i < W.n_bins * 2; i += blockDim.x) (&S.bins[0][0])[i] = W.bins[i];
   // obstacles: SoA tile shared by the 4 episodes of the workgroup, padded to J*64 (slot j, lane l =
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
                 const double2 a = *reinterpret_cast<const double2*>(nf);
                 ex = a.x; ey = a.y; et = nf[3];
               }
-              cost_element(W, S, 0, W.n_bins, P.w[2], ex, ey, et, tv, hab);
+              cost_element(S.world, S, 0, S.world.n_bins, P.w[2], ex, ey, et, tv, hab);
               if (id >= 0) { ptTerm[id] = tv; ptHab[id] = (int8_t)hab; }
               else *reinterpret_cast<double2*>(nodeF + (size_t)(~id) * 8 + 6) = make_double2(tv, (double)hab);
             }
