@@ -91,17 +91,20 @@ __device__ __forceinline__ uint32_t rng_randbelow(WaveRng& r, uint32_t n) {
 }
 
 // any of n points (x,y in LDS) inside an obstacle's effective disc?  lanes = obstacles (J each);
-// slot j is skipped when no obstacle of the slot can reach the points' bounding box (exact cull:
-// a point inside the box is at least as far from the centre as the box is).
+// slot j is skipped when no obstacle of the slot can reach the points' bounding box.
 template <int J>
 __device__ __forceinline__ bool prrt_hits(const double (&ox)[J], const double (&oy)[J], const double (&ot)[J],
-                                          const double (*pts)[2], int n, double bx0, double by0, double bx1, double by1) {
+                                          const double (&orr)[J], const double (*pts)[2], int n, double bx0, double by0,
+                                          double bx1, double by1) {
+  // conservative cull (a candidate slot runs the exact test): bounding square of half-width orr >= sqrt(T) against
+  // the box around its centre, both inflated by 2^-30 relative (see rrt_explore_kernel.h)
+  const double cxm = (bx0 + bx1) * 0.5, cym = (by0 + by1) * 0.5;
+  const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + 1.0);
+  const double hx = (bx1 - bx0) * 0.5 + slack, hy = (by1 - by0) * 0.5 + slack;
   int hit = 0;
 #pragma unroll
   for (int j = 0; j < J; j++) {
-    double ddx = ox[j] < bx0 ? bx0 - ox[j] : (ox[j] > bx1 ? ox[j] - bx1 : 0.0);
-    double ddy = oy[j] < by0 ? by0 - oy[j] : (oy[j] > by1 ? oy[j] - by1 : 0.0);
-    bool cand = ddx * ddx + ddy * ddy <= ot[j] * (1.0 + 0x1p-40);
+    const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
     if (__any(cand)) {
       double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
       for (int p = 0; p < n; p++) {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
   const int step_bucket = P.step_mode ? uni(B.step_bucket[ep]) : 0;
   if (P.step_mode && step_bucket < 0) return;
 
-  double ox[J], oy[J], ot[J];
+  double ox[J], oy[J], ot[J], orr[J];
 #pragma unroll
   for (int j = 0; j < J; j++) {
     int i = j * 64 + lane;
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
     ox[j] = ok ? W.ox[i] : 0.0;
     oy[j] = ok ? W.oy[i] : 0.0;
     ot[j] = ok ? W.ot[i] : -1.0;
+    orr[j] = ot[j] >= 0.0 ? auvp_sqrt(ot[j]) * (1.0 + 0x1p-30) + 0x1p-40 : -__builtin_inf();
   }
 
   const int capn = B.cap_nodes;
@@ -198,18 +202,29 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
     }
     const int rsel = (int)rng_randbelow(rng, (uint32_t)cnt_b);
     int par = -1;
-    for (int base = 0, seen = 0; base < n_nodes; base += 64) {
-      int m = base + lane;
-      bool is = m < n_nodes && nbucket[m] == b;
-      unsigned long long bal = __ballot(is);
-      int c = __popcll(bal);
-      if (seen + c > rsel) {
-        int want = rsel - seen;
-        unsigned long long sel = __ballot(is && __popcll(bal & ((1ull << lane) - 1ull)) == want);
-        par = base + (__ffsll((long long)sel) - 1);
-        break;
+    // the rsel-th node (list order) whose bucket is b: 256 bucket ids are requested at a time so their loads
+    // overlap (one dependent round trip per 256 nodes instead of per 64)
+    for (int base = 0, seen = 0; base < n_nodes && par < 0; base += 256) {
+      int v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int m = base + 64 * k + lane;
+        v[k] = m < n_nodes ? nbucket[m] : -1;  // b >= 0: the filler never matches
       }
-      seen += c;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (par < 0) {
+          const bool is = v[k] == b;
+          const unsigned long long bal = __ballot(is);
+          const int c = __popcll(bal);
+          if (seen + c > rsel) {
+            const int want = rsel - seen;
+            const unsigned long long sel = __ballot(is && __popcll(bal & ((1ull << lane) - 1ull)) == want);
+            par = base + 64 * k + (__ffsll((long long)sel) - 1);
+          }
+          seen += c;
+        }
+      }
     }
     par = uni(par);
     if (par < 0) { status = -4; break; }
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
         outside = outside | !(wx && wy);
       }
       const double bx0 = wave_min_f64(lx0), by0 = wave_min_f64(ly0), bx1 = -wave_min_f64(-lx1), by1 = -wave_min_f64(-ly1);
-      ok = !prrt_hits<J>(ox, oy, ot, pts, P_n, bx0, by0, bx1, by1) && !__any(outside);
+      ok = !prrt_hits<J>(ox, oy, ot, orr, pts, P_n, bx0, by0, bx1, by1) && !__any(outside);
     }
     int me = -1;
     if (ok) {
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
               const double bx0 = wave_min_f64(lane < nv ? ax : inf), by0 = wave_min_f64(lane < nv ? ay : inf);
               const double bx1 = -wave_min_f64(lane < nv ? -ax : inf), by1 = -wave_min_f64(lane < nv ? -ay : inf);
               wave_sync();
-              if (__any(outside) || prrt_hits<J>(ox, oy, ot, arc_pts, nv, bx0, by0, bx1, by1)) free_ = false;
+              if (__any(outside) || prrt_hits<J>(ox, oy, ot, orr, arc_pts, nv, bx0, by0, bx1, by1)) free_ = false;
             }
             arc_free = free_ ? 1 : 0;
             if (free_) {
