@@ -2,7 +2,7 @@
 //
 // One wavefront = one episode, persistent over the whole iteration budget.  A 256-thread workgroup
 // carries 4 independent episodes that share the LDS copy of the small world tables (habitats,
-// polygon, time bins); obstacles live in registers (J per lane), the tree lives in HBM.
+// polygon, time bins, obstacle tile); the tree lives in HBM.
 //
 // Inside one expansion the 64 lanes split the work:
 //   steer        lane s = sub-arc s: RNG window tempering, arc geometry and sin/cos in parallel;
@@ -10,8 +10,9 @@
 //                they must be, to keep the reference's left-to-right fp64 addition order
 //   collision    lane = obstacle (J each), loop over the path points broadcast from LDS
 //   polygon      lane = path point
-//   cost         lane = path element; the leaf->root walk only collects element ids, the lookups
-//                run 64 elements per pass, the shark term is summed in path order
+//   cost         lane = path element; the leaf->root walk only collects element ids (four ancestors per
+//                dependent load), an element's contribution is evaluated once and cached, the shark
+//                term is summed in path order
 // The steer draw count is data dependent (a sub-arc consumes 2 or 3 random() values): the lanes
 // temper a window of the stream, ballot the "taken" predicate for every possible start offset, and
 // a lane-parallel fixed-point iteration resolves where each sub-arc starts.
@@ -48,7 +49,7 @@ struct RrtSharedLds {
 //   [mt]       624 u32
 //   [pts]      max_pts * 2 f64
 //   [bins]     (K+2) i32
-// after the 4 per-wave blocks: obstacle tile [3][J*64] f64 shared by the workgroup
+// after the 4 per-wave blocks: obstacle tile [4][J*64] f64 (x, y, T, cull radius) shared by the workgroup
 struct RrtLdsPlan {
   int chunk;  // C
   int scratch, mt, pts, bins, per_wave, total;
