@@ -328,8 +328,8 @@ int orc_rrt_explore(const orc_world* w, const orc_rrt_params* p, uint64_t seed, 
   memcpy(o->best_cost, opt_cost, sizeof opt_cost);
   o->n_bins = K;
   for (int i = 0; i < K && i < o->cap_bins; i++) o->bin_sizes[i] = bins[i + 1].n;
+  o->n_draw32 = rng.n_draw32; /* what exploring consumed; the peek below is a test probe, not part of it */
   o->rng_after = cpy_random(&rng);
-  o->n_draw32 = rng.n_draw32;
   if (status == ORC_OK && opt_leaf < 0) status = ORC_NO_QUALIFYING_LEAF;
   o->status = status;
   if (bins) { for (int i = 0; i <= K; i++) free(bins[i].v); free(bins); }
