@@ -103,15 +103,15 @@ __device__ __forceinline__ double pf_double(uint32_t w0, uint32_t w1) {
 }
 
 // angle_wrap (:18-33): one rounded add per recursion level; false = nan / deeper than CPython recurses
+// The direction never flips: 2*PF_PI is exactly twice PF_PI and rounding is monotone, so a value above pi lands
+// in [-pi, pi] or stays above pi (and likewise below -pi).  One compare and one add per level.
 __device__ __forceinline__ bool pf_angle_wrap(double& a) {
   double ang = a;
-  for (int depth = 0; depth < 900; depth++) {
-    if (-PF_PI <= ang && ang <= PF_PI) { a = ang; return true; }
-    else if (ang > PF_PI) ang += (-2 * PF_PI);
-    else if (ang < -PF_PI) ang += (2 * PF_PI);
-    else return false;
-  }
-  return false;
+  int depth = 0;
+  while (ang > PF_PI && depth < 899) { ang += (-2 * PF_PI); depth++; }   // 899 adds = the deepest chain the
+  while (ang < -PF_PI && depth < 899) { ang += (2 * PF_PI); depth++; }   // checker's 900-level loop accepts
+  a = ang;
+  return -PF_PI <= ang && ang <= PF_PI;  // false: nan, or a chain deeper than CPython recurses
 }
 
 template <int T>
