@@ -136,7 +136,6 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
   double* inc = scratch;                          // [(C+1)*3]  aliases u_win
   double* sc = scratch + (size_t)(C + 1) * 3;     // [(C+1)*2]
   double* phi_l = scratch + (size_t)(C + 1) * 5;  // [C+1]
-  double(*arc_pts)[2] = reinterpret_cast<double(*)[2]>(wbase);  // [64 (+1)] arc chunk, aliases the steer scratch
   uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + scratch_b);
   double(*pts)[2] = reinterpret_cast<double(*)[2]>(wbase + scratch_b + 624 * 4);
 
@@ -422,13 +421,43 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
                 bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
                 outside = !(wx && wy);
               }
-              wave_sync();
-              if (lane < nv) { arc_pts[lane][0] = ax; arc_pts[lane][1] = ay; }
-              const double inf = __builtin_inf();
-              const double bx0 = wave_min_f64(lane < nv ? ax : inf), by0 = wave_min_f64(lane < nv ? ay : inf);
-              const double bx1 = -wave_min_f64(lane < nv ? -ax : inf), by1 = -wave_min_f64(lane < nv ? -ay : inf);
-              wave_sync();
-              if (__any(outside) || prrt_hits<J>(ox, oy, ot, orr, arc_pts, nv, bx0, by0, bx1, by1)) free_ = false;
+              if (__any(outside)) { free_ = false; break; }
+              // Here the lanes hold the POINTS (up to 64 of them), so the roles are swapped with respect to
+              // prrt_hits: a conservative box of this piece of the arc picks the candidate obstacles (lanes =
+              // obstacles, one ballot per slot), and each candidate is broadcast and tested against all points
+              // at once -- a few dozen instructions per candidate instead of a 64-point loop per slot.
+              // Box: the samples lie on the circle (centre C, radius |radius|) between the first and the last
+              // sample of the pass; an arc of angle d < pi stays within |radius| (1 - cos(d/2)) <= |radius| d^2 / 8
+              // of its chord, a longer one within the circle's own box.  Inflated by 2^-30 relative.
+              const double rad = auvp_fabs(radius), dth = auvp_fabs(ang_vel) * (double)(nv - 1);
+              double bx0, by0, bx1, by1;
+              if (dth < AUVP_PI) {
+                const double x0 = readlane_f64(ax, 0), y0 = readlane_f64(ay, 0);
+                const double x1 = readlane_f64(ax, nv - 1), y1 = readlane_f64(ay, nv - 1);
+                double sag = rad * dth * dth * 0.125;
+                sag = sag < 2.0 * rad ? sag : 2.0 * rad;
+                bx0 = (x0 < x1 ? x0 : x1) - sag; bx1 = (x0 < x1 ? x1 : x0) + sag;
+                by0 = (y0 < y1 ? y0 : y1) - sag; by1 = (y0 < y1 ? y1 : y0) + sag;
+              } else {
+                bx0 = x_C - rad; bx1 = x_C + rad; by0 = y_C - rad; by1 = y_C + rad;
+              }
+              const double cxm = (bx0 + bx1) * 0.5, cym = (by0 + by1) * 0.5;
+              const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + rad + 1.0);
+              const double hx = (bx1 - bx0) * 0.5 + slack, hy = (by1 - by0) * 0.5 + slack;
+              bool hitl = false;
+#pragma unroll
+              for (int j = 0; j < J; j++) {
+                const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
+                unsigned long long cm = __ballot(cand);
+                while (cm) {
+                  const int l = __ffsll((long long)cm) - 1;
+                  cm &= cm - 1ull;
+                  const double oxl = readlane_f64(ox[j], l), oyl = readlane_f64(oy[j], l), otl = readlane_f64(ot[j], l);
+                  const double ex = ax - oxl, ey = ay - oyl;
+                  hitl |= (lane < nv) && (ex * ex + ey * ey <= otl);
+                }
+              }
+              if (__any(hitl)) free_ = false;
             }
             arc_free = free_ ? 1 : 0;
             if (free_) {
