@@ -10,7 +10,9 @@
 // collision + closed-rectangle test (:435-484), grid insert (:108-159), then the arc from the LAST
 // list node to the goal (:374-423), sampled 64 points per pass with an early exit at the first
 // obstacle / boundary hit.  Obstacle tests use the same suffix-max / squared-threshold form as the
-// exploring kernel, plus an exact bounding-box cull of obstacle slots per pass.
+// exploring kernel behind a conservative bounding-box cull: for the steer the lanes are the obstacles
+// and loop over the few path points; for the goal arc the lanes are the 64 points of the pass and the
+// candidate obstacles are broadcast one by one.
 #ifndef AUVP_PLANNER_RRT_KERNEL_H
 #define AUVP_PLANNER_RRT_KERNEL_H
 #include "auvp_math.h"
