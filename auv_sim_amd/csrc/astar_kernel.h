@@ -11,7 +11,10 @@
 //   open-set scan       lane-strided min over every node created so far (open flag), first index wins
 //   bounds + collision  lane = (neighbour k, slice s): 8 x 8 lanes cover the 8 neighbours, each slice
 //                       takes every 8th fan triangle / obstacle
-//   SOG cell lookup     64 cells per pass in dict order, first match by ballot
+//   SOG cell lookup     one sweep over the cells per expansion, 64 cells per pass in dict order, each cell
+//                       tested against all eight neighbour positions, first match per neighbour by ballot
+//   SOG children        lane k = neighbour k: time bin, probability, top-n prefix, visited flag and the node
+//                       record of all children at once (they touch eight distinct lattice points)
 // Quirks kept: no dedup apart from the visited bitmap, fixLen's h with pathLen == 0,
 // update_habitat_coverage popping while it enumerates, get_cell_prob's rounded corners.
 #ifndef AUVP_ASTAR_KERNEL_H
@@ -92,10 +95,13 @@ __device__ __forceinline__ bool astar_point_free(const AstarWorldDev& W, double 
 
 constexpr int ASTAR_WAVES = 4;
 constexpr int ASTAR_MAX_HAB = 64;
+constexpr int ASTAR_MAX_BINS = 64;
 
 __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W, AstarParamsDev P, AstarBuffers B, int n_inst) {
   __shared__ int32_t s_hopen[ASTAR_WAVES][ASTAR_MAX_HAB];
   __shared__ int32_t s_hclosed[ASTAR_WAVES][ASTAR_MAX_HAB];
+  __shared__ int32_t s_keys[ASTAR_WAVES][8];
+  __shared__ double s_bins[ASTAR_WAVES][ASTAR_MAX_BINS][2];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   const int ep = (int)blockIdx.x * ASTAR_WAVES + wave;
@@ -119,6 +125,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   const bool logx = (P.flags & 1) != 0 && B.exp_log != nullptr;
 
   for (int i = lane; i < H; i += 64) hopen[i] = i;
+  for (int i = lane; i < 2 * T && i < 2 * ASTAR_MAX_BINS; i += 64) (&s_bins[wave][0][0])[i] = W.bins[i];
   int n_hopen = H, n_hclosed = 0;
   if (lane == 0) {
     nx[0] = sx; ny[0] = sy; ng[0] = 0.0; nh[0] = 0.0; nf[0] = 0.0; ncost[0] = 0.0; nlen[0] = 0.0;
@@ -231,8 +238,72 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         wave_sync();
       }
     }
+    // get_cell_prob (:485-514) for ALL children of this expansion in one sweep over the cells: a lane loads one
+    // cell per pass and tests it against the (uniform) positions of the eight neighbours, so the sweep costs
+    // ceil(C / 64) independent loads instead of that many dependent round trips per child
+    int keys[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    if (V == 3 && childmask) {
+      double cpx[8], cpy[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) { cpx[k] = readfirst_f64(__shfl(qx, k * 8, 64)); cpy[k] = readfirst_f64(__shfl(qy, k * 8, 64)); }
+      for (int c0 = 0; c0 < C; c0 += 64) {
+        const int ci = c0 + lane;
+        const bool in = ci < C;
+        const double4 r = in ? reinterpret_cast<const double4*>(W.rcells)[ci] : make_double4(0.0, 0.0, 0.0, 0.0);
+        const double ddx = auvp_fabs(r.x - r.z), ddy = auvp_fabs(r.y - r.w);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const bool m = in && (auvp_fabs(cpx[k] - r.x) <= ddx && auvp_fabs(cpx[k] - r.z) <= ddx) &&
+                         (auvp_fabs(cpy[k] - r.y) <= ddy && auvp_fabs(cpy[k] - r.w) <= ddy);
+          const unsigned long long mm = __ballot(m);
+          if (keys[k] < 0 && mm) keys[k] = c0 + (__ffsll((long long)mm) - 1);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (lane == k) s_keys[wave][k] = keys[k];
+      wave_sync();
+    }
+    if (V == 3) {
+      // children of the SOG variant, lane k < 8 = neighbour k: nothing one child does is seen by another (eight
+      // distinct lattice points, so eight distinct visited cells), so their table reads go out together
+      const int kk = lane & 7;
+      const bool mine = lane < 8 && ((childmask >> kk) & 1);
+      const double px = __shfl(qx, kk * 8, 64), py = __shfl(qy, kk * 8, 64);
+      const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
+      const double dist_left = auvp_fabs(limit - len_);
+      const int ts_ = (int)(len_ / P.velocity);
+      int tb = -1;
+      for (int t = 0; t < T; t++) {
+        if ((double)ts_ <= s_bins[wave][t][1] && (double)ts_ >= s_bins[wave][t][0]) { tb = t; break; }
+      }
+      const int key = s_keys[wave][kk];
+      const int ntop = (int)dist_left;
+      int xi = (int)(px + 500), yi = (int)(py + 200);
+      if (xi < 0) xi += P.vx;
+      if (yi < 0) yi += P.vy;
+      const bool bad = mine && (tb < 0 || key < 0 || ntop > C || xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy);
+      if (__any(bad)) { status = -1; break; }
+      const size_t vi = (size_t)xi * P.vy + yi;
+      double pr = 0.0, tn = 0.0;
+      int was = 0;
+      if (mine) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; was = (int)visited[vi]; }
+      const double g_ = ccost - w4 * pr;
+      const double h_ = -w2 * dist_left - w3 * (double)H - w4 * tn;
+      const double f_ = g_ + h_;
+      const int open_ = was ? 0 : 1;
+      if (mine) {
+        const int c = n_nodes + __popc(childmask & ((1 << kk) - 1));
+        nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = g_; nlen[c] = len_;
+        npar[c] = cur; nts[c] = ts_; nopen[c] = open_;
+        if (!was) visited[vi] = 1;
+      }
+      const int opened = __popcll(__ballot(mine && open_));
+      n_open += opened;
+      visited_count += opened;
+      wave_sync();
+    }
     int slot = 0;
-    for (int k = 0; k < 8 && status == 0; k++) {
+    for (int k = 0; k < 8 && status == 0 && V != 3; k++) {
       if (!((childmask >> k) & 1)) continue;
       const int c = n_nodes + slot;
       slot++;
@@ -261,34 +332,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         f_ = g_ + h_;
         len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
       } else {
-        len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
-        const double dist_left = auvp_fabs(limit - len_);
-        ts_ = (int)(len_ / P.velocity);
-        int tb = -1;
-        for (int t = 0; t < T; t++) {
-          if ((double)ts_ <= W.bins[2 * t + 1] && (double)ts_ >= W.bins[2 * t]) { tb = t; break; }
-        }
-        if (tb < 0) { status = -1; break; }
-        // get_cell_prob (:485-514): first cell in dict order whose rounded corners bracket the point
-        int key = -1;
-        for (int c0 = 0; c0 < C && key < 0; c0 += 64) {
-          int ci = c0 + lane;
-          bool m = false;
-          if (ci < C) {
-            const double4 r = reinterpret_cast<const double4*>(W.rcells)[ci];
-            double ddx = auvp_fabs(r.x - r.z), ddy = auvp_fabs(r.y - r.w);
-            m = (auvp_fabs(px - r.x) <= ddx && auvp_fabs(px - r.z) <= ddx) && (auvp_fabs(py - r.y) <= ddy && auvp_fabs(py - r.w) <= ddy);
-          }
-          unsigned long long mm = __ballot(m);
-          if (mm) key = c0 + (__ffsll((long long)mm) - 1);
-        }
-        if (key < 0) { status = -1; break; }
-        const int ntop = (int)dist_left;
-        if (ntop > C) { status = -1; break; }
-        g_ = ccost - w4 * W.prob[(size_t)tb * C + key];
-        cost_ = g_;
-        h_ = -w2 * dist_left - w3 * (double)H - w4 * W.topn[(size_t)tb * (C + 1) + ntop];
-        f_ = g_ + h_;
+        break;  // V == 3 is handled above (lane-parallel children); not reached
       }
       if (V >= 2) {
         // visited bitmap (:414-416 / :653-657), numpy index semantics (negative wraps)
