@@ -56,7 +56,7 @@ struct PrrtBuffers {
 __host__ __device__ inline int prrt_lds_per_wave(int max_pts, int nfreq) {
   int C = nfreq < 1 ? 1 : (nfreq > 63 ? 63 : nfreq);
   int u = (2 * C + 2) * 8;
-  int s = (C + 1) * 6 * 8;  // inc[(C+1)*3], sc[(C+1)*2], phi[C+1]
+  int s = ((C + 1) * 6 + 4) * 8;  // inc[(C+1)*3], sc[(C+1)*2], phi[C+1], path bounding box [4]
   int scratch = (((u > s ? u : s) > 1040 ? (u > s ? u : s) : 1040) + 15) & ~15;  // >= one 64(+1)-point arc chunk
   return scratch + 624 * 4 + ((max_pts * 16 + 15) & ~15);
 }
@@ -131,13 +131,14 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
   const int C = nfreq < 1 ? 1 : (nfreq > 63 ? 63 : nfreq);
   const int per_wave = prrt_lds_per_wave(B.max_pts, nfreq);
   unsigned char* wbase = smem + (size_t)wave * per_wave;
-  const int u_b = (2 * C + 2) * 8, s_b = (C + 1) * 6 * 8;
+  const int u_b = (2 * C + 2) * 8, s_b = ((C + 1) * 6 + 4) * 8;
   const int scratch_b = ((((u_b > s_b ? u_b : s_b) > 1040 ? (u_b > s_b ? u_b : s_b) : 1040)) + 15) & ~15;
   double* scratch = reinterpret_cast<double*>(wbase);
   double* u_win = scratch;                        // [2C+2]
   double* inc = scratch;                          // [(C+1)*3]  aliases u_win
   double* sc = scratch + (size_t)(C + 1) * 3;     // [(C+1)*2]
   double* phi_l = scratch + (size_t)(C + 1) * 5;  // [C+1]
+  double* bbox_l = scratch + (size_t)(C + 1) * 6;  // [4] xmin, ymin, xmax, ymax of the steer
   uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + scratch_b);
   double(*pts)[2] = reinterpret_cast<double(*)[2]>(wbase + scratch_b + 624 * 4);
 
@@ -294,8 +295,17 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
       wave_sync();
       if (lane < 3) {
         double acc = lane == 0 ? cx : (lane == 1 ? cy : ctt);
+        // lanes 0/1 also track the extent of x / y over every prefix position (= the path points and their parent)
+        double bmin = acc, bmax = acc;
+        if (c0 != 0 && lane < 2) { bmin = bbox_l[lane]; bmax = bbox_l[2 + lane]; }
 #pragma unroll 4
-        for (int s = 0; s < n; s++) { acc = acc + inc[3 * s + lane]; inc[3 * s + lane] = acc; }
+        for (int s = 0; s < n; s++) {
+          acc = acc + inc[3 * s + lane];
+          inc[3 * s + lane] = acc;
+          bmin = acc < bmin ? acc : bmin;
+          bmax = acc > bmax ? acc : bmax;
+        }
+        if (lane < 2) { bbox_l[lane] = bmin; bbox_l[2 + lane] = bmax; }
       }
       wave_sync();
       double mx = 0.0, my = 0.0, mt_ = 0.0;
@@ -318,6 +328,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
       wave_sync();
     }
     if (cap_err) { status = -2; break; }
+    if (n_total == 0 && lane < 2) { bbox_l[lane] = lane == 0 ? cx : cy; bbox_l[2 + lane] = lane == 0 ? cx : cy; }
     wave_sync();
     const int P_n = cnt + 1;
 
@@ -325,16 +336,14 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
     bool ok;
     {
       // bounding box of the path points (lanes = points)
-      double lx0 = __builtin_inf(), ly0 = __builtin_inf(), lx1 = -__builtin_inf(), ly1 = -__builtin_inf();
       bool outside = false;
       for (int p = lane; p < P_n; p += 64) {
         double x = pts[p][0], y = pts[p][1];
-        lx0 = x < lx0 ? x : lx0; lx1 = x > lx1 ? x : lx1; ly0 = y < ly0 ? y : ly0; ly1 = y > ly1 ? y : ly1;
         bool wx = (x >= P.rect[0]) && (x <= P.rect[2]);
         bool wy = (y >= P.rect[1]) && (y <= P.rect[3]);
         outside = outside | !(wx && wy);
       }
-      const double bx0 = wave_min_f64(lx0), by0 = wave_min_f64(ly0), bx1 = -wave_min_f64(-lx1), by1 = -wave_min_f64(-ly1);
+      const double bx0 = bbox_l[0], by0 = bbox_l[1], bx1 = bbox_l[2], by1 = bbox_l[3];
       ok = !prrt_hits<J>(ox, oy, ot, orr, pts, P_n, bx0, by0, bx1, by1) && !__any(outside);
     }
     int me = -1;
