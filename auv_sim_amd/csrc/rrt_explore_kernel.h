@@ -619,20 +619,16 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
     // ------------------------------------------------------------ qualifying leaf (:158-171)
     if (ctt >= P.max_traj_time - 30) {
       // which bins make up the leaf's sub-dict (:160-165): lane b judges bin b (n_bins <= 64)
-      int blo = 0, bhi = 0, nsel = 0;
+      // (an element's own bin is always one of them -- DESIGN.md -- so only their number is needed, for the
+      // leaf log)
+      int nsel = 0;
       {
         bool sel = false;
         if (lane < W.n_bins) {
           const double b0 = S.bins[lane][0], b1 = S.bins[lane][1];
           sel = (init_t >= b0 && init_t <= b1) || (b0 >= init_t && b1 <= ctt) || (ctt >= b0 && ctt <= b1);
         }
-        const unsigned long long sm = __ballot(sel);
-        if (sm) {
-          blo = __ffsll((long long)sm) - 1;
-          bhi = 64 - __clzll((long long)sm);
-          nsel = __popcll(sm);
-          if (nsel != bhi - blo) { status = -1; break; }  // a sub-dict with a gap is not supported
-        }
+        nsel = __popcll(__ballot(sel));
       }
       CostAcc acc;
       acc.c2 = 0.0; acc.visited = 0ull; acc.hits = 0;

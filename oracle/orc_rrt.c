@@ -80,8 +80,20 @@ int orc_check_collision(const orc_world* w, int npts, const double* pts_xy) {
 
 /* habitat_shark_cost_func (path_planning/cost.py:145-207) over the sub-dict of bins [bin_lo,bin_hi).
  * out4 = {sum(cost), cost[0], cost[1], cost[2]} */
+static void cost_selected(const orc_world* w, const unsigned char* sel, int npts, const double* pts_xyt,
+                          double total_traj_time, const double* weights, double* out4);
+
 void orc_cost(const orc_world* w, int bin_lo, int bin_hi, int npts, const double* pts_xyt,
               double total_traj_time, const double* weights, double* out4) {
+  unsigned char* sel = (unsigned char*)calloc(w->n_bins > 0 ? w->n_bins : 1, 1);
+  for (int b = bin_lo; b < bin_hi && b < w->n_bins; b++) sel[b] = 1;
+  cost_selected(w, sel, npts, pts_xyt, total_traj_time, weights, out4);
+  free(sel);
+}
+
+/* the same over an arbitrary sub-dict: sel[b] != 0 <=> bin b is a key of it (dict order = bin order) */
+static void cost_selected(const orc_world* w, const unsigned char* sel, int npts, const double* pts_xyt,
+                          double total_traj_time, const double* weights, double* out4) {
   double w1 = weights[0], w2 = weights[1], w3 = weights[2];
   double c0 = 0.0, c1 = 0.0, c2 = 0.0;
   int H = w->n_habitats, C = w->n_cells;
@@ -89,8 +101,8 @@ void orc_cost(const orc_world* w, int bin_lo, int bin_hi, int npts, const double
   for (int i = 0; i < npts; i++) {
     double x = pts_xyt[3 * i], y = pts_xyt[3 * i + 1], t = pts_xyt[3 * i + 2];
     int tb = -1;
-    for (int b = bin_lo; b < bin_hi; b++) {
-      if (t >= w->bins[2 * b] && t <= w->bins[2 * b + 1]) { tb = b; break; }
+    for (int b = 0; b < w->n_bins; b++) {
+      if (sel[b] && t >= w->bins[2 * b] && t <= w->bins[2 * b + 1]) { tb = b; break; }
     }
     if (tb < 0) continue; /* no bin: neither the shark nor the habitat term (cost.py:178-179) */
     const double* pr = w->prob + (size_t)tb * C;
@@ -187,6 +199,7 @@ int orc_rrt_explore(const orc_world* w, const orc_rrt_params* p, uint64_t seed, 
   double* path_xy = (double*)malloc(sizeof(double) * 2 * (size_t)(max_pts + 1));
   double* tmp_pts = (double*)malloc(sizeof(double) * 7 * (size_t)(max_pts + 1));
   double* course = NULL;
+  unsigned char* bin_sel = (unsigned char*)calloc(w->n_bins > 0 ? w->n_bins : 1, 1);
   int course_cap = 0;
   const double init_t = p->init[3];
   int it;
@@ -300,19 +313,14 @@ int orc_rrt_explore(const orc_world* w, const orc_rrt_params* p, uint64_t seed, 
         course[3 * pos] = q[0]; course[3 * pos + 1] = q[1]; course[3 * pos + 2] = q[3]; pos++;
       }
       /* shark bins overlapping [initial.t, leaf.t] (:161-166); dict order preserved */
-      int lo = -1, hi = -1, nsel = 0, contiguous = 1;
+      int nsel = 0;
       for (int b = 0; b < w->n_bins; b++) {
         double b0 = w->bins[2 * b], b1 = w->bins[2 * b + 1];
-        if ((init_t >= b0 && init_t <= b1) || (b0 >= init_t && b1 <= tt) || (tt >= b0 && tt <= b1)) {
-          if (lo < 0) lo = b;
-          else if (b != hi) contiguous = 0;
-          hi = b + 1; nsel++;
-        }
+        bin_sel[b] = (init_t >= b0 && init_t <= b1) || (b0 >= init_t && b1 <= tt) || (tt >= b0 && tt <= b1);
+        nsel += bin_sel[b];
       }
       double c4[4];
-      if (nsel == 0) { lo = hi = 0; }
-      if (!contiguous) { status = ORC_ERR_ARG; break; } /* non-monotone bin tables are out of scope */
-      orc_cost(w, lo, hi, L, course, tt, p->w, c4);
+      cost_selected(w, bin_sel, L, course, tt, p->w, c4);
       if (n_leaves < o->cap_leaves) {
         double* lc = o->leaf_cost + 6 * (size_t)n_leaves;
         lc[0] = c4[0]; lc[1] = c4[1]; lc[2] = c4[2]; lc[3] = c4[3]; lc[4] = (double)L; lc[5] = (double)nsel;
@@ -333,6 +341,6 @@ int orc_rrt_explore(const orc_world* w, const orc_rrt_params* p, uint64_t seed, 
   if (status == ORC_OK && opt_leaf < 0) status = ORC_NO_QUALIFYING_LEAF;
   o->status = status;
   if (bins) { for (int i = 0; i <= K; i++) free(bins[i].v); free(bins); }
-  free(path_xy); free(tmp_pts); free(course);
+  free(path_xy); free(tmp_pts); free(course); free(bin_sel);
   return status;
 }

@@ -132,3 +132,32 @@ def test_cell_lookup_index_is_exact_for_arbitrary_cell_lists(ctx, orc, seed, mon
     assert np.array_equal(got_index, want)
     assert np.array_equal(got_scan, want)
     assert (want[:, 3] != 0).sum() > 10
+
+
+def test_exploring_with_unordered_overlapping_bins(ctx, orc):
+    """shark dict whose time bins are neither sorted nor disjoint: a leaf's sub-dict (rrt_dubins.py:160-165) then has
+    gaps in dict order, and an element's bin is its first match in that order"""
+    from auv_sim_amd import synth
+    world = synth.make_world(seed=31, n_obstacles=64, n_bins=6, bin_len=50)
+    bins = np.array([[100.0, 150.0], [0.0, 50.0], [30.0, 120.0], [250.0, 300.0], [50.0, 100.0], [150.0, 250.0]])
+    prob = world["prob"][:6]
+    ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], bins, world["cells"], prob)
+    w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], bins, world["cells"], prob)
+    E, n_iter = 6, 900
+    init = np.zeros((E, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    init[:, 3] = [0.0, 10.0, 40.0, 60.0, 0.0, 95.0]   # start times inside different bins
+    seeds = np.arange(50, 50 + E, dtype=np.uint64)
+    kw = dict(mode="timebin", max_traj_time=260.0)
+    summ = ctx.rrt_explore_batch(init, seeds, n_iter, leaf_log=True, **kw)
+    n_checked = 0
+    for e in range(E):
+        r = orc.rrt_explore(w, int(seeds[e]), n_iter, init=init[e], kind="portable", **kw)
+        s = summ[e]
+        assert s["status"] == r["status"] and s["n_nodes"] == r["n_nodes"] and s["n_leaves"] == r["n_leaves"]
+        lc, li = ctx.leaf_log(e, s)
+        assert np.array_equal(lc, r["leaf_cost"][:len(lc)]) and np.array_equal(li, r["leaf_iter"][:len(li)])
+        if r["status"] == 0:
+            assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])
+            n_checked += 1
+    assert n_checked >= 3
