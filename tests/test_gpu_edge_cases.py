@@ -161,3 +161,43 @@ def test_exploring_with_unordered_overlapping_bins(ctx, orc):
             assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])
             n_checked += 1
     assert n_checked >= 3
+
+
+@pytest.mark.parametrize("case", [
+    dict(freq=1, n_iter=400),                                            # at most 0 sub-arcs: every node sits on its parent
+    dict(freq=2, n_iter=400, max_traj_time=20.0),
+    dict(freq=63, n_iter=250, max_traj_time=300.0),                      # one steer chunk of up to 62 sub-arcs
+    dict(freq=90, n_iter=200, max_traj_time=300.0),                      # more than one chunk per steer
+    dict(freq=30, n_iter=500, weights=(-0.37, -2.25, -1.7)),             # non-integer w2: c1 by repeated addition
+    dict(freq=30, n_iter=500, bin_interval=7.5, max_traj_time=130.0),    # fractional bin keys
+    dict(freq=30, n_iter=500, v=0.7, dist_to_end=5.0, diff_max=2.0, min_dist=1.5, max_traj_time=400.0),
+    dict(freq=12, n_iter=500, mode="nn", max_traj_time=150.0),
+    dict(freq=12, n_iter=500, mode="plantime", max_traj_time=150.0),
+], ids=lambda c: "-".join("%s%s" % (k[:4], v) for k, v in c.items() if k != "n_iter"))
+def test_exploring_parameter_corners(ctx, orc, case):
+    """unusual parameter combinations of RRT(...) / exploring(...), each episode equal to its checker run"""
+    from auv_sim_amd import synth
+    case = dict(case)
+    n_iter = case.pop("n_iter")
+    world = synth.make_world(seed=41, n_obstacles=64)
+    ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    E = 5
+    init = np.zeros((E, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    init[:, 2] = np.linspace(-2.5, 2.5, E)
+    seeds = np.arange(900, 900 + E, dtype=np.uint64)
+    summ = ctx.rrt_explore_batch(init, seeds, n_iter, leaf_log=True, **case)
+    for e in range(E):
+        r = orc.rrt_explore(w, int(seeds[e]), n_iter, init=init[e], kind="portable", **case)
+        s = summ[e]
+        assert s["status"] == r["status"], (e, s["status"], r["status"])
+        assert (s["n_nodes"], s["n_points"], s["n_leaves"]) == (r["n_nodes"], r["n_points"], r["n_leaves"])
+        assert s["rng_after"] == r["rng_after"] and int(s["n_draw32"]) == int(r["n_draw32"])
+        t = ctx.tree(e, s)
+        assert np.array_equal(t["parent"], r["parent"]) and np.array_equal(t["nodes"], r["nodes"])
+        assert np.array_equal(t["points"], r["points"])
+        lc, li = ctx.leaf_log(e, s)
+        assert np.array_equal(lc, r["leaf_cost"][:len(lc)])
+        if r["status"] == 0:
+            assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])
