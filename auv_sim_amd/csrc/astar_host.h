@@ -15,7 +15,7 @@ struct AstarState {
   auvp::AstarParamsDev P{};
   auvp::AstarBuffers B{};
   DevBuf ox, oy, ot, hab, poly, bins, rcells, prob, topn;
-  DevBuf start, goal, limit, nodes, node_i, visited, hab_left, exp_log, summary, off, path, cost, npath, smooth;
+  DevBuf start, goal, limit, nodes, node_i, visited, keycache, hab_left, exp_log, summary, off, path, cost, npath, smooth;
   long long visited_set_for = -1;  // byte size of a bitmap uploaded by auvp_astar_set_visited, -1 none
 };
 
@@ -140,6 +140,14 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
     }
     S.visited_set_for = -1;
     B.visited = S.visited.as<uint8_t>();
+  }
+  B.keycache = nullptr;
+  if (p->variant == 3) {
+    if (S.W.n_cells >= 32767) return fail(h, AUVP_ERR_ARG, "n_cells %d does not fit the 16-bit cell-key cache", S.W.n_cells);
+    const size_t kb = (size_t)E * P.vx * P.vy * sizeof(int16_t);
+    HIPCHK(h, S.keycache.reserve(kb));
+    HIPCHK(h, hipMemsetAsync(S.keycache.p, 0, kb, h->stream));
+    B.keycache = S.keycache.as<int16_t>();
   }
   B.exp_log = nullptr;
   if (P.cap_exp) {

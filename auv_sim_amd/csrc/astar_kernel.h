@@ -8,7 +8,8 @@
 //
 // The search itself is a serial chain (pop the first minimum f, expand 8 neighbours); the lanes
 // split the work inside one expansion:
-//   open-set scan       lane-strided min over every node created so far (open flag), first index wins
+//   open-set pop        min over (f, index) of a compact open list kept in LDS (768 entries per instance); an
+//                       instance that outgrows it scans the open flags of every node in HBM instead
 //   bounds + collision  lane = (neighbour k, slice s): 8 x 8 lanes cover the 8 neighbours, each slice
 //                       takes every 8th fan triangle / obstacle
 //   SOG cell lookup     one sweep over the cells per expansion, 64 cells per pass in dict order, each cell
@@ -58,6 +59,7 @@ struct AstarBuffers {
   double* nodes;         // [E][7][cap_nodes] SoA x, y, g, h, f, cost, pathLen
   int32_t* node_i;       // [E][3][cap_nodes] parent, time_stamp, open
   uint8_t* visited;      // [E][vx*vy]
+  int16_t* keycache;     // [E][vx*vy] variant 3: 1 + cell key of a lattice point once get_cell_prob found it (0 = not yet)
   int32_t* hab_left;     // [E][H]
   double* exp_log;       // optional [E][cap_exp][8]
   AstarSummary* summary; // [E]
@@ -95,12 +97,17 @@ __device__ __forceinline__ bool astar_point_free(const AstarWorldDev& W, double 
 
 constexpr int ASTAR_WAVES = 4;
 constexpr int ASTAR_MAX_HAB = 64;
+constexpr int ASTAR_OPEN_CAP = 768;
 constexpr int ASTAR_MAX_BINS = 64;
 
 __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W, AstarParamsDev P, AstarBuffers B, int n_inst) {
   __shared__ int32_t s_hopen[ASTAR_WAVES][ASTAR_MAX_HAB];
   __shared__ int32_t s_hclosed[ASTAR_WAVES][ASTAR_MAX_HAB];
   __shared__ int32_t s_keys[ASTAR_WAVES][8];
+  // compact list of the open nodes (f, index): the pop is a min over this list while it fits; the open flags in
+  // HBM stay authoritative, so an instance that outgrows the list falls back to scanning them
+  __shared__ double s_of[ASTAR_WAVES][ASTAR_OPEN_CAP];
+  __shared__ int32_t s_oi[ASTAR_WAVES][ASTAR_OPEN_CAP];
   __shared__ double s_bins[ASTAR_WAVES][ASTAR_MAX_BINS][2];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   int32_t* ni = B.node_i + (size_t)ep * 3 * cap;
   int32_t *npar = ni, *nts = ni + cap, *nopen = ni + 2 * (size_t)cap;
   uint8_t* visited = B.visited ? B.visited + (size_t)ep * P.vx * P.vy : nullptr;
+  int16_t* keycache = B.keycache ? B.keycache + (size_t)ep * P.vx * P.vy : nullptr;
   int32_t* hopen = s_hopen[wave];
   int32_t* hclosed = s_hclosed[wave];
   const int H = W.n_habitats, C = W.n_cells, T = W.n_bins;
@@ -134,6 +142,12 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   wave_sync();
   int n_nodes = 1, n_open = 1, n_exp = 0, n_children = 0, status = 0, found = -1, visited_count = 0;
   int first_open = 0;  // every node below this index is closed
+  double* of_l = s_of[wave];
+  int32_t* oi_l = s_oi[wave];
+  int n_list = 1;
+  bool list_ok = true;
+  if (lane == 0) { of_l[0] = 0.0; oi_l[0] = 0; }
+  wave_sync();
 
   // neighbour offsets: lane k = lane >> 3 handles neighbour k, slice s = lane & 7
   const int k8 = lane >> 3, s8 = lane & 7;
@@ -149,11 +163,19 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   while (n_open > 0) {
     // ------------------------------------------------------------ pop the first minimum f
     double bf = __builtin_inf();
-    int bi = 0x7fffffff;
-    for (int i = first_open + lane; i < n_nodes; i += 64) {
-      if (nopen[i]) {
-        double f = nf[i];
-        if (bi == 0x7fffffff || f < bf) { bf = f; bi = i; }
+    int bi = 0x7fffffff, bpos = -1;
+    if (list_ok) {
+      for (int q = lane; q < n_list; q += 64) {
+        const double f = of_l[q];
+        const int i = oi_l[q];
+        if (bi == 0x7fffffff || f < bf || (f == bf && i < bi)) { bf = f; bi = i; bpos = q; }
+      }
+    } else {
+      for (int i = first_open + lane; i < n_nodes; i += 64) {
+        if (nopen[i]) {
+          double f = nf[i];
+          if (bi == 0x7fffffff || f < bf) { bf = f; bi = i; }
+        }
       }
     }
     // reduce: smaller f wins; on equal f the smaller index wins (list order)
@@ -161,11 +183,19 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     for (int o = 32; o >= 1; o >>= 1) {
       double of = __shfl_xor(bf, o, 64);
       int oi = __shfl_xor(bi, o, 64);
+      int op = __shfl_xor(bpos, o, 64);
       bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || of < bf || (of == bf && oi < bi));
       bf = take ? of : bf;
       bi = take ? oi : bi;
+      bpos = take ? op : bpos;
     }
     const int cur = uni(bi);
+    if (list_ok) {  // the last entry takes the place of the popped one (the order of the list does not matter)
+      const int pp = uni(bpos);
+      if (lane == 0 && pp != n_list - 1) { of_l[pp] = of_l[n_list - 1]; oi_l[pp] = oi_l[n_list - 1]; }
+      n_list--;
+      wave_sync();
+    }
     if (lane == 0) nopen[cur] = 0;
     n_open--;
     if (cur == first_open) first_open++;
@@ -238,11 +268,35 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         wave_sync();
       }
     }
+    if (V == 3) {
+      // children of the SOG variant, lane k < 8 = neighbour k: nothing one child does is seen by another (eight
+      // distinct lattice points, so eight distinct visited cells), so their table reads go out together
+      const int kk = lane & 7;
+      const bool mine = lane < 8 && ((childmask >> kk) & 1);
+      const double px = __shfl(qx, kk * 8, 64), py = __shfl(qy, kk * 8, 64);
+      const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
+      const double dist_left = auvp_fabs(limit - len_);
+      const int ts_ = (int)(len_ / P.velocity);
+      int tb = -1;
+      for (int t = 0; t < T; t++) {
+        if ((double)ts_ <= s_bins[wave][t][1] && (double)ts_ >= s_bins[wave][t][0]) { tb = t; break; }
+      }
+      const int ntop = (int)dist_left;
+      int xi = (int)(px + 500), yi = (int)(py + 200);
+      if (xi < 0) xi += P.vx;
+      if (yi < 0) yi += P.vy;
+      const bool oob = mine && (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy);
+      if (__any(oob)) { status = -1; break; }
+      const size_t vi = (size_t)xi * P.vy + yi;
+      // the cell of a lattice point is looked up once per search: within one instance the visited-bitmap index
+      // identifies the point (points are 10 apart), so the key is kept next to it
+      int key = mine ? (int)keycache[vi] - 1 : 0;
+      const bool need_key = mine && key < 0;
     // get_cell_prob (:485-514) for ALL children of this expansion in one sweep over the cells: a lane loads one
     // cell per pass and tests it against the (uniform) positions of the eight neighbours, so the sweep costs
     // ceil(C / 64) independent loads instead of that many dependent round trips per child
-    int keys[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-    if (V == 3 && childmask) {
+      if (__any(need_key)) {
+        int keys[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
       double cpx[8], cpy[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) { cpx[k] = readfirst_f64(__shfl(qx, k * 8, 64)); cpy[k] = readfirst_f64(__shfl(qy, k * 8, 64)); }
@@ -263,27 +317,9 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       for (int k = 0; k < 8; k++) if (lane == k) s_keys[wave][k] = keys[k];
       wave_sync();
     }
-    if (V == 3) {
-      // children of the SOG variant, lane k < 8 = neighbour k: nothing one child does is seen by another (eight
-      // distinct lattice points, so eight distinct visited cells), so their table reads go out together
-      const int kk = lane & 7;
-      const bool mine = lane < 8 && ((childmask >> kk) & 1);
-      const double px = __shfl(qx, kk * 8, 64), py = __shfl(qy, kk * 8, 64);
-      const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
-      const double dist_left = auvp_fabs(limit - len_);
-      const int ts_ = (int)(len_ / P.velocity);
-      int tb = -1;
-      for (int t = 0; t < T; t++) {
-        if ((double)ts_ <= s_bins[wave][t][1] && (double)ts_ >= s_bins[wave][t][0]) { tb = t; break; }
-      }
-      const int key = s_keys[wave][kk];
-      const int ntop = (int)dist_left;
-      int xi = (int)(px + 500), yi = (int)(py + 200);
-      if (xi < 0) xi += P.vx;
-      if (yi < 0) yi += P.vy;
-      const bool bad = mine && (tb < 0 || key < 0 || ntop > C || xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy);
+      if (need_key) { key = s_keys[wave][kk]; if (key >= 0) keycache[vi] = (int16_t)(key + 1); }
+      const bool bad = mine && (tb < 0 || key < 0 || ntop > C);
       if (__any(bad)) { status = -1; break; }
-      const size_t vi = (size_t)xi * P.vy + yi;
       double pr = 0.0, tn = 0.0;
       int was = 0;
       if (mine) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; was = (int)visited[vi]; }
@@ -297,7 +333,18 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         npar[c] = cur; nts[c] = ts_; nopen[c] = open_;
         if (!was) visited[vi] = 1;
       }
-      const int opened = __popcll(__ballot(mine && open_));
+      const unsigned long long om = __ballot(mine && open_);
+      const int opened = __popcll(om);
+      if (list_ok) {
+        if (n_list + opened > ASTAR_OPEN_CAP) list_ok = false;
+        else {
+          if (mine && open_) {
+            const int q = n_list + __popcll(om & ((1ull << lane) - 1ull));
+            of_l[q] = f_; oi_l[q] = n_nodes + __popc(childmask & ((1 << kk) - 1));
+          }
+          n_list += opened;
+        }
+      }
       n_open += opened;
       visited_count += opened;
       wave_sync();
@@ -351,6 +398,10 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       if (lane == 0) {
         nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = cost_; nlen[c] = len_;
         npar[c] = cur; nts[c] = ts_; nopen[c] = open_;
+      }
+      if (list_ok && open_) {
+        if (n_list + 1 > ASTAR_OPEN_CAP) list_ok = false;
+        else { if (lane == 0) { of_l[n_list] = f_; oi_l[n_list] = c; } n_list++; }
       }
       n_open += open_;
       wave_sync();
