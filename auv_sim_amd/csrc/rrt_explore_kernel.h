@@ -60,7 +60,7 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
   p.chunk = nfreq < 1 ? 1 : (nfreq > RRT_MAX_CHUNK ? RRT_MAX_CHUNK : nfreq);
   const int C = p.chunk;
   int steer_u = (64 + 3 * C + 3) * 8;  // 64 leading random() values + the steer window
-  int steer_s = ((C + 1) * 7 + 4) * 8;  // + path bounding box (4 doubles)
+  int steer_s = (4 * ((C + 2) & ~1) + (C + 1) * 3 + 4) * 8;  // inc rows (16-byte aligned), sc, phi + path bounding box
   int cost = RRT_ELIST * 4 + 64 * 8;
   int s = steer_u > steer_s ? steer_u : steer_s;
   s = s > cost ? s : cost;
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
   double* scratch = reinterpret_cast<double*>(wbase);
   double* u_win = scratch;                         // [3C+3]      (steer, phase 1)
   double* inc = scratch;                           // [(C+1)*4]   (steer, phase 2: aliases u_win)
-  double* sc = scratch + (size_t)(C + 1) * 4;      // [(C+1)*2]
-  double* phi_l = scratch + (size_t)(C + 1) * 6;   // [C+1]
-  double* bbox_l = scratch + (size_t)(C + 1) * 7;  // [4] xmin, ymin, xmax, ymax of the steer
+  double* sc = scratch + (size_t)4 * ((C + 2) & ~1);  // [(C+1)*2]
+  double* phi_l = sc + (size_t)(C + 1) * 2;           // [C+1]
+  double* bbox_l = phi_l + (C + 1);                   // [4] xmin, ymin, xmax, ymax of the steer
   int32_t* elist = reinterpret_cast<int32_t*>(wbase);                  // [192]  (cost walk)
   double* term = reinterpret_cast<double*>(wbase + RRT_ELIST * 4);     // [64]
   uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + plan.scratch);
@@ -470,8 +470,13 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
       // theta += phi, left to right, by one lane; prefix angles written back in place
       if (lane == 0) {
         double th = cth;
-#pragma unroll 4
-        for (int s = 0; s < n; s++) { th = th + phi_l[s]; phi_l[s] = th; }
+#pragma unroll 2
+        for (int s = 0; s < n; s += 2) {  // two steps per 16-byte access; entries past n hold exact zeros
+          double2 v = *reinterpret_cast<double2*>(phi_l + s);
+          th = th + v.x; v.x = th;
+          th = th + v.y; v.y = th;
+          *reinterpret_cast<double2*>(phi_l + s) = v;
+        }
       }
       wave_sync();
       const double myth = active ? phi_l[lane] : cth;  // idle lanes evaluate the chunk-entry angle
@@ -489,7 +494,9 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
         mv = auvp_sqrt(dx * dx + dy * dy);
         dt = mv / vt;
       }
-      if (active) { inc[4 * lane] = dx; inc[4 * lane + 1] = dy; inc[4 * lane + 2] = dt; inc[4 * lane + 3] = mv; }
+      const int CS = (C + 2) & ~1;  // chain-major: chain c owns inc[c*CS .. c*CS+C], 16-byte aligned rows
+      if (active) { inc[lane] = dx; inc[CS + lane] = dy; inc[2 * CS + lane] = dt; inc[3 * CS + lane] = mv; }
+      else if (lane <= C) { inc[lane] = 0.0; inc[CS + lane] = 0.0; inc[2 * CS + lane] = 0.0; inc[3 * CS + lane] = 0.0; }
       wave_sync();
       // x += dx; y += dy; t += dt; length += movement: four serial chains, one lane each
       if (lane < 4) {
@@ -498,18 +505,21 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
         // appended path points; the parent point is part of the path); kept in LDS between chunks
         double bmin = acc, bmax = acc;
         if (c0 != 0 && lane < 2) { bmin = bbox_l[lane]; bmax = bbox_l[2 + lane]; }
-#pragma unroll 4
-        for (int s = 0; s < n; s++) {
-          acc = acc + inc[4 * s + lane];
-          inc[4 * s + lane] = acc;
-          bmin = acc < bmin ? acc : bmin;
-          bmax = acc > bmax ? acc : bmax;
+        double* row = inc + lane * CS;
+#pragma unroll 2
+        for (int s = 0; s < n; s += 2) {  // two steps per 16-byte access (the row is zero past n: adding 0.0 changes nothing)
+          double2 v = *reinterpret_cast<double2*>(row + s);
+          acc = acc + v.x; v.x = acc;
+          bmin = acc < bmin ? acc : bmin; bmax = acc > bmax ? acc : bmax;
+          acc = acc + v.y; v.y = acc;
+          bmin = acc < bmin ? acc : bmin; bmax = acc > bmax ? acc : bmax;
+          *reinterpret_cast<double2*>(row + s) = v;
         }
         if (lane < 2) { bbox_l[lane] = bmin; bbox_l[2 + lane] = bmax; }
       }
       wave_sync();
       double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
-      if (active) { mx = inc[4 * lane]; my = inc[4 * lane + 1]; mt_ = inc[4 * lane + 2]; ml = inc[4 * lane + 3]; }
+      if (active) { mx = inc[lane]; my = inc[CS + lane]; mt_ = inc[2 * CS + lane]; ml = inc[3 * CS + lane]; }
       const bool app = taken && (mv >= P.min_dist);
       const unsigned long long amask = __ballot(app);
       const int napp = __popcll(amask);
