@@ -183,11 +183,11 @@ __device__ __forceinline__ void cost_accumulate(int n_valid, double tv, int hab,
   // no-op: the sum runs in batches of 8 -- 8 LDS reads in flight, then 8 dependent adds.
   double c2 = acc.c2;
   for (int i = 0; i < n_valid; i += 8) {
-    double v[8];
+    double2 v[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = term[i + k];
+    for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<const double2*>(term + i + 2 * k);
 #pragma unroll
-    for (int k = 0; k < 8; k++) c2 = c2 + v[k];
+    for (int k = 0; k < 4; k++) { c2 = c2 + v[k].x; c2 = c2 + v[k].y; }
   }
   acc.c2 = c2;
   wave_sync();
