@@ -145,7 +145,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   double* of_l = s_of[wave];
   int32_t* oi_l = s_oi[wave];
   int n_list = 1;
-  bool list_ok = true;
+  bool list_ok = V >= 2;  // astar.py / astar_real.py never close a cell: their open sets outgrow the list at once
   if (lane == 0) { of_l[0] = 0.0; oi_l[0] = 0; }
   wave_sync();
 
