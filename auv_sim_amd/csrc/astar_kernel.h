@@ -109,6 +109,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   __shared__ double s_of[ASTAR_WAVES][ASTAR_OPEN_CAP];
   __shared__ int32_t s_oi[ASTAR_WAVES][ASTAR_OPEN_CAP];
   __shared__ double s_bins[ASTAR_WAVES][ASTAR_MAX_BINS][2];
+  __shared__ double s_hab[ASTAR_WAVES][ASTAR_MAX_HAB][3];  // x, y, T(size) of every habitat
+  __shared__ int32_t s_cov[ASTAR_WAVES][ASTAR_MAX_HAB];     // fixLen: does the child cover habitat h
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   const int ep = (int)blockIdx.x * ASTAR_WAVES + wave;
@@ -132,7 +134,10 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   const double w2 = P.w[1], w3 = P.w[2], w4 = P.w[3];
   const bool logx = (P.flags & 1) != 0 && B.exp_log != nullptr;
 
-  for (int i = lane; i < H; i += 64) hopen[i] = i;
+  for (int i = lane; i < H; i += 64) {
+    hopen[i] = i;
+    s_hab[wave][i][0] = W.hab[4 * (size_t)i]; s_hab[wave][i][1] = W.hab[4 * (size_t)i + 1]; s_hab[wave][i][2] = W.hab[4 * (size_t)i + 3];
+  }
   for (int i = lane; i < 2 * T && i < 2 * ASTAR_MAX_BINS; i += 64) (&s_bins[wave][0][0])[i] = W.bins[i];
   int n_hopen = H, n_hclosed = 0;
   if (lane == 0) {
@@ -251,12 +256,16 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       for (int k = 0; k < 8; k++) {
         if (!((childmask >> k) & 1)) continue;
         const double px = __shfl(qx, k * 8, 64), py = __shfl(qy, k * 8, 64);
+        // which habitats cover this child: one lane per habitat; the list surgery below only reads the flags
+        if (lane < H) {
+          const double ddx = px - s_hab[wave][lane][0], ddy = py - s_hab[wave][lane][1];
+          s_cov[wave][lane] = (ddx * ddx + ddy * ddy <= s_hab[wave][lane][2]) ? 1 : 0;
+        }
+        wave_sync();
         if (lane == 0) {
           // update_habitat_coverage (:182-199): pop(index) while enumerating skips the next element
           for (int idx = 0; idx < n_hopen; idx++) {
-            const double* hb = W.hab + 4 * (size_t)hopen[idx];
-            double ddx = px - hb[0], ddy = py - hb[1];
-            if (ddx * ddx + ddy * ddy <= hb[3]) {
+            if (s_cov[wave][hopen[idx]]) {
               hclosed[n_hclosed++] = hopen[idx];
               for (int m = idx; m < n_hopen - 1; m++) hopen[m] = hopen[m + 1];
               n_hopen--;
@@ -366,9 +375,9 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         bool d2l = false, d3l = false;
         for (int i = lane; i < n_hopen + n_hclosed; i += 64) {
           const bool closed = i >= n_hopen;
-          const double* hb = W.hab + 4 * (size_t)(closed ? hclosed[i - n_hopen] : hopen[i]);
+          const double* hb = s_hab[wave][closed ? hclosed[i - n_hopen] : hopen[i]];
           double ddx = px - hb[0], ddy = py - hb[1];
-          bool cov = ddx * ddx + ddy * ddy <= hb[3];
+          bool cov = ddx * ddx + ddy * ddy <= hb[2];
           d2l = d2l | cov;
           d3l = d3l | (cov && closed);
         }
