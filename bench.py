@@ -121,6 +121,28 @@ def bench_single_episode(ctx, world, args, reps=3):
             "expansions_per_s": float(summ[0]["iters_run"]) / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / float(summ[0]["iters_run"])}
 
 
+def bench_rrt_o64(ctx, args, n_ep=4096, reps=2):
+    """BASELINE configs[1] as written: 64 obstacles (the headline uses 256), same 200x200-cell grid and 10k budget."""
+    from auv_sim_amd import synth
+    half = 0.5 * args.grid * 10.0
+    world = synth.make_world(seed=2, n_obstacles=64, box=(-half, -half, half, half), cell=10.0, n_bins=10, bin_len=50,
+                             n_habitats=10)
+    ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    init = np.zeros((n_ep, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    ctx.rrt_prepare(init, np.arange(n_ep, dtype=np.uint64), args.iters, mode=args.mode, freq=30, bin_interval=5, v=2,
+                    max_traj_time=500.0, weights=(-3, -3, -4))
+    ms = []
+    for i in range(reps + 1):
+        ctx.rrt_run()
+        if i:
+            ms.append(ctx.last_kernel_ms())
+    summ = ctx.summaries()
+    k_ms = float(np.mean(ms))
+    return {"metric": "RRT.exploring expansions/s, 64 obstacles", "value": float(summ["iters_run"].sum()) / (k_ms * 1e-3),
+            "unit": "expansions/s", "episodes": n_ep, "kernel_ms": k_ms, "accepted_nodes_per_episode": float((summ["n_nodes"] - 1).mean())}
+
+
 def bench_config5(ctx, n_ep=12500, max_step=200, reps=2):
     """every particle hypothesis of a shark position becomes the goal of one
     Planner_RRT episode with a 200-step budget; 12 500 episodes per GPU (100 000 over 8 GPUs)."""
@@ -480,6 +502,7 @@ def main():
         if not args.no_extra:
             # the other two planner families of the path, per GPU (rank 0's device), outside the timed region
             out["single_episode"] = bench_single_episode(ctx, world, args)
+            out["rrt_64_obstacles"] = bench_rrt_o64(ctx, args)
             out["astar"] = bench_astar(ctx, with_cpu=(world_size == 1 and not args.no_cpu))
             out["planner_rrt"] = bench_planner(ctx, with_cpu=(world_size == 1 and not args.no_cpu))
             # the callers either side of the planners
