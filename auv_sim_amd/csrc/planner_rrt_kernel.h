@@ -302,8 +302,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) vo
         for (int s = 0; s < n; s++) {
           acc = acc + inc[3 * s + lane];
           inc[3 * s + lane] = acc;
-          bmin = acc < bmin ? acc : bmin;
-          bmax = acc > bmax ? acc : bmax;
+          bmin = __builtin_fmin(acc, bmin);  // v_min_f64 / v_max_f64; nothing here is NaN
+          bmax = __builtin_fmax(acc, bmax);
         }
         if (lane < 2) { bbox_l[lane] = bmin; bbox_l[2 + lane] = bmax; }
       }

@@ -509,10 +509,12 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
 #pragma unroll 2
         for (int s = 0; s < n; s += 2) {  // two steps per 16-byte access (the row is zero past n: adding 0.0 changes nothing)
           double2 v = *reinterpret_cast<double2*>(row + s);
+          // fmin/fmax = one v_min_f64 / v_max_f64 each (a compare + select is three instructions per bound);
+          // nothing here is NaN and the sign of a zero bound does not matter to the cull
           acc = acc + v.x; v.x = acc;
-          bmin = acc < bmin ? acc : bmin; bmax = acc > bmax ? acc : bmax;
+          bmin = __builtin_fmin(acc, bmin); bmax = __builtin_fmax(acc, bmax);
           acc = acc + v.y; v.y = acc;
-          bmin = acc < bmin ? acc : bmin; bmax = acc > bmax ? acc : bmax;
+          bmin = __builtin_fmin(acc, bmin); bmax = __builtin_fmax(acc, bmax);
           *reinterpret_cast<double2*>(row + s) = v;
         }
         if (lane < 2) { bbox_l[lane] = bmin; bbox_l[2 + lane] = bmax; }
@@ -562,21 +564,31 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
     const double cxm = (bx0 + bx1) * 0.5, cym = (by0 + by1) * 0.5;
     const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + 1.0);
     const double hx = (bx1 - bx0) * 0.5 + slack, hy = (by1 - by0) * 0.5 + slack;
+    // lane = path point (the usual steer has < 64 of them): the few obstacles that survive the cull are tested one
+    // at a time against every point at once, read back from the tile with a wave-uniform address
     int hit = 0;
+    const bool pv0 = lane < P_n;
+    double2 q0 = make_double2(0.0, 0.0);
+    if (pv0) q0 = *reinterpret_cast<const double2*>(&pts[lane][0]);
 #pragma unroll
     for (int j = 0; j < J; j++) {
       const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = olr[j * 64 + lane];
       const bool cand = !(auvp_fabs(oxj - cxm) > hx + orj || auvp_fabs(oyj - cym) > hy + orj);
-      if (__any(cand)) {
-        const double otj = olt[j * 64 + lane];
-        double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
-        for (int p = 0; p < P_n; p++) {
-          // next point's LDS read is in flight while this one is tested (pts has room for P_n + 1)
-          const double2 qn = *reinterpret_cast<const double2*>(&pts[p + 1][0]);
-          double ddx = q.x - oxj, ddy = q.y - oyj;
-          double d2 = ddx * ddx + ddy * ddy;
-          hit |= (d2 <= otj) ? 1 : 0;  // no short-circuit: straight-line code
-          q = qn;
+      unsigned long long cm = __ballot(cand);
+      while (cm) {
+        const int idx = uni(j * 64 + (__ffsll((long long)cm) - 1));
+        cm &= cm - 1ull;
+        const double ox = olx[idx], oy = oly[idx], ot = olt[idx];
+        {
+          const double ddx = q0.x - ox, ddy = q0.y - oy;
+          const double d2 = ddx * ddx + ddy * ddy;
+          hit |= (pv0 && d2 <= ot) ? 1 : 0;
+        }
+        for (int p = 64 + lane; p < P_n; p += 64) {  // only steers with freq > 63
+          const double2 q = *reinterpret_cast<const double2*>(&pts[p][0]);
+          const double ddx = q.x - ox, ddy = q.y - oy;
+          const double d2 = ddx * ddx + ddy * ddy;
+          hit |= (d2 <= ot) ? 1 : 0;
         }
       }
     }
