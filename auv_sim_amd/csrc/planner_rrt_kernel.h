@@ -107,13 +107,16 @@ __device__ __forceinline__ bool prrt_hits(const double (&ox)[J], const double (&
 #pragma unroll
   for (int j = 0; j < J; j++) {
     const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
-    if (__any(cand)) {
-      double2 q = *reinterpret_cast<const double2*>(&pts[0][0]);
-      for (int p = 0; p < n; p++) {
-        const double2 qn = *reinterpret_cast<const double2*>(&pts[p + 1][0]);  // room for n + 1
-        double ex = q.x - ox[j], ey = q.y - oy[j];
-        hit |= (ex * ex + ey * ey <= ot[j]) ? 1 : 0;
-        q = qn;
+    // lanes = path points: each candidate is broadcast and tested against every point at once
+    unsigned long long cm = __ballot(cand);
+    while (cm) {
+      const int c = __ffsll((long long)cm) - 1;
+      cm &= cm - 1ull;
+      const double cox = readlane_f64(ox[j], c), coy = readlane_f64(oy[j], c), cot = readlane_f64(ot[j], c);
+      for (int p = lane_id(); p < n; p += 64) {
+        const double2 q = *reinterpret_cast<const double2*>(&pts[p][0]);
+        const double ex = q.x - cox, ey = q.y - coy;
+        hit |= (ex * ex + ey * ey <= cot) ? 1 : 0;
       }
     }
   }
