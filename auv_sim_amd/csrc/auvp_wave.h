@@ -110,7 +110,7 @@ __device__ __forceinline__ double rng_random_at(const WaveRng& r, uint32_t j) {
 }
 
 __device__ __forceinline__ void rng_advance_words(WaveRng& r, uint32_t nwords) {
-  uint32_t p = r.pslot + nwords;
+  uint32_t p = (uint32_t)uni((int)(r.pslot + nwords));  // scalar: the wrap below stays off the vector unit
   while (p >= 624u) p -= 624u;
   r.pslot = (uint32_t)uni((int)p);
   r.avail = (uint32_t)uni((int)(r.avail - nwords));

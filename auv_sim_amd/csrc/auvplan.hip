@@ -495,7 +495,8 @@ int auvp_rrt_run(auvp_handle* h) {
   const int nfreq = (int)std::floor(P.freq);
   const int O_ = h->W.n_obstacles;
   const int jslots = (O_ <= 64 ? 1 : (O_ <= 128 ? 2 : (O_ <= 256 ? 4 : (O_ <= 512 ? 8 : 16)))) * 64;
-  const size_t lds = (size_t)rrt_lds_plan(P.K, h->max_pts, nfreq, jslots).total;
+  const size_t lds = (size_t)rrt_lds_plan(P.K, h->max_pts, nfreq, jslots,
+                                          rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins)).total;
   if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB (K=%d, freq=%d)", lds, P.K, nfreq);
   const int grid = (E + RRT_WAVES - 1) / RRT_WAVES;
   const int O = h->W.n_obstacles;

@@ -35,14 +35,11 @@ __global__ __launch_bounds__(64) void cost_probe_kernel(WorldDev W, int n_paths,
                                                         const double* __restrict__ pts, const int32_t* __restrict__ blo,
                                                         const int32_t* __restrict__ bhi, const double* __restrict__ total,
                                                         const double* __restrict__ w, double* __restrict__ out) {
-  __shared__ RrtSharedLds S;
+  __shared__ __align__(16) unsigned char tables[RRT_WORLD_BYTES + RRT_MAX_HAB * 32 + RRT_MAX_POLY * 16 + RRT_MAX_BINS * 16];
+  const RrtTables S = rrt_tables_view(tables, W.n_habitats, W.n_poly);
   const int lane = lane_id();
   __shared__ double term[64];
-  for (int i = lane; i < W.n_habitats; i += 64) {
-    S.hab[i][0] = W.hab[3 * i]; S.hab[i][1] = W.hab[3 * i + 1]; S.hab[i][2] = W.hab[3 * i + 2];
-    S.hab[i][3] = W.hab_t[i];
-  }
-  for (int i = lane; i < W.n_bins * 2; i += 64) (&S.bins[0][0])[i] = W.bins[i];
+  rrt_tables_stage(S, W);
   __syncthreads();
   const int p = blockIdx.x;
   if (p >= n_paths) return;

@@ -34,28 +34,55 @@ constexpr int RRT_MAX_POLY = 64;
 constexpr int RRT_MAX_BINS = 64;
 constexpr int RRT_ELIST = 192;     // path elements collected per cost pass group
 
-struct RrtSharedLds {
-  double hab[RRT_MAX_HAB][4];  // x, y, size, T(size)
-  double poly[RRT_MAX_POLY][2];
-  double bins[RRT_MAX_BINS][2];
-  // copy of the kernel argument for the code that runs rarely (evaluating a path element for the cost):
-  // reading the table pointers from here when they are needed keeps ~40 scalar registers out of the
-  // expansion loop, which otherwise spills them to vector-register lanes and reloads them every iteration
-  WorldDev world;
+// The world tables every episode of a workgroup shares, at the start of its LDS and sized by the world at hand
+// (a fixed 64-row layout costs 4.4 KB where the Catalina-like world needs 0.9 KB -- the difference decides
+// whether five workgroups fit a CU):
+//   [WorldDev]  copy of the kernel argument for the code that runs rarely (evaluating a path element for the
+//               cost): reading the table pointers from here when they are needed keeps ~40 scalar registers out
+//               of the expansion loop, which otherwise spills them to vector-register lanes
+//   [hab]       n_habitats x {x, y, size, T(size)}      [poly] n_poly x {x, y}      [bins] n_bins x {t0, t1}
+struct RrtTables {
+  WorldDev* world;
+  double (*hab)[4];
+  double (*poly)[2];
+  double (*bins)[2];
 };
+constexpr int RRT_WORLD_BYTES = (int)((sizeof(WorldDev) + 15) & ~(size_t)15);
+__host__ __device__ inline int rrt_tables_bytes(int n_habitats, int n_poly, int n_bins) {
+  return RRT_WORLD_BYTES + n_habitats * 32 + n_poly * 16 + n_bins * 16;
+}
+__device__ __forceinline__ RrtTables rrt_tables_view(unsigned char* base, int n_habitats, int n_poly) {
+  RrtTables t;
+  t.world = reinterpret_cast<WorldDev*>(base);
+  t.hab = reinterpret_cast<double(*)[4]>(base + RRT_WORLD_BYTES);
+  t.poly = reinterpret_cast<double(*)[2]>(base + RRT_WORLD_BYTES + n_habitats * 32);
+  t.bins = reinterpret_cast<double(*)[2]>(base + RRT_WORLD_BYTES + n_habitats * 32 + n_poly * 16);
+  return t;
+}
+// fill the tables (whole workgroup; the caller synchronises)
+__device__ __forceinline__ void rrt_tables_stage(const RrtTables& S, const WorldDev& W) {
+  for (int i = threadIdx.x; i < W.n_habitats; i += blockDim.x) {
+    S.hab[i][0] = W.hab[3 * i]; S.hab[i][1] = W.hab[3 * i + 1]; S.hab[i][2] = W.hab[3 * i + 2];
+    S.hab[i][3] = W.hab_t[i];
+  }
+  if (threadIdx.x == 0) *S.world = W;
+  for (int i = threadIdx.x; i < W.n_poly * 2; i += blockDim.x) (&S.poly[0][0])[i] = W.poly[i];
+  for (int i = threadIdx.x; i < W.n_bins * 2; i += blockDim.x) (&S.bins[0][0])[i] = W.bins[i];
+}
 
 // Per-wave LDS layout (bytes), all sizes multiples of 16:
 //   [scratch]  steer: u[3C+3] | {inc[(C+1)*4], sc[(C+1)*2], phi[C+1]}   cost: elist[192] i32 + term[64] f64
 //   [mt]       624 u32
 //   [pts]      max_pts * 2 f64
 //   [bins]     (K+2) i32
-// after the 4 per-wave blocks: obstacle tile [4][J*64] f64 (x, y, T, cull radius) shared by the workgroup
+// before them the world tables (RrtTables); after the 4 per-wave blocks the obstacle tile shared by the
+// workgroup: x, y, T as f64 [J*64] each and the cull radius as f32 [J*64]
 struct RrtLdsPlan {
   int chunk;  // C
-  int scratch, mt, pts, bins, per_wave, total;
+  int tables, scratch, mt, pts, bins, per_wave, total;
 };
 
-__host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq, int obst_slots) {
+__host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq, int obst_slots, int tables_bytes) {
   RrtLdsPlan p;
   p.chunk = nfreq < 1 ? 1 : (nfreq > RRT_MAX_CHUNK ? RRT_MAX_CHUNK : nfreq);
   const int C = p.chunk;
@@ -69,7 +96,8 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
   p.pts = ((max_pts * 16) + 15) & ~15;
   p.bins = (((K + 2) * 4) + 15) & ~15;
   p.per_wave = p.scratch + p.mt + p.pts + p.bins;
-  p.total = (int)sizeof(RrtSharedLds) + RRT_WAVES * p.per_wave + obst_slots * 4 * 8;  // + obstacle tile x,y,T,r
+  p.tables = (tables_bytes + 15) & ~15;
+  p.total = p.tables + RRT_WAVES * p.per_wave + obst_slots * (3 * 8 + 4);  // + obstacle tile x,y,T (f64), r (f32)
   return p;
 }
 
@@ -143,7 +171,7 @@ struct CostAcc {
 // (0.0 when it has none: x + 0.0 == x, an exact no-op in the ordered sum) and the first habitat that
 // contains it (-1: none).  An element whose time stamp lies in no bin of [bin_lo, bin_hi) is skipped
 // entirely by the reference: (0.0, -1).
-__device__ __forceinline__ void cost_element(const WorldDev& W, const RrtSharedLds& S, int bin_lo, int bin_hi, double w3,
+__device__ __forceinline__ void cost_element(const WorldDev& W, const RrtTables& S, int bin_lo, int bin_hi, double w3,
                                              double x, double y, double t, double& tv, int& hab) {
   int tb = -1;
   for (int b = bin_lo; b < bin_hi; b++) {
@@ -194,7 +222,7 @@ __device__ __forceinline__ void cost_accumulate(int n_valid, double tv, int hab,
 }
 
 // evaluate + accumulate up to 64 elements given by value (the standalone cost probe)
-__device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtSharedLds& S, int bin_lo, int bin_hi, double w3,
+__device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtTables& S, int bin_lo, int bin_hi, double w3,
                                           int n_valid, double x, double y, double t, double* term, CostAcc& acc) {
   double tv = 0.0;
   int hab = -1;
@@ -203,16 +231,16 @@ __device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtSharedLds&
 }
 
 template <int J, int MODE, bool DIAG>
-__global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
+__global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
                                                                      int n_episodes, int max_pts) {
   extern __shared__ __align__(16) unsigned char smem[];
-  RrtSharedLds& S = *reinterpret_cast<RrtSharedLds*>(smem);
+  const RrtTables S = rrt_tables_view(smem, W.n_habitats, W.n_poly);
   const int wave = uni((int)(threadIdx.x >> 6));  // wave-uniform: keeps every per-episode address scalar
   const int lane = lane_id();
   const int nfreq = (int)P.freq;
-  const RrtLdsPlan plan = rrt_lds_plan(P.K, max_pts, nfreq, J * 64);
+  const RrtLdsPlan plan = rrt_lds_plan(P.K, max_pts, nfreq, J * 64, rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins));
   const int C = plan.chunk;
-  unsigned char* wbase = smem + sizeof(RrtSharedLds) + (size_t)wave * plan.per_wave;
+  unsigned char* wbase = smem + plan.tables + (size_t)wave * plan.per_wave;
   double* scratch = reinterpret_cast<double*>(wbase);
   double* u_win = scratch;                         // [3C+3]      (steer, phase 1)
   double* inc = scratch;                           // [(C+1)*4]   (steer, phase 2: aliases u_win)
@@ -226,26 +254,25 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
   int32_t* bin_count = reinterpret_cast<int32_t*>(wbase + plan.scratch + plan.mt + plan.pts);
 
   // ---- stage the shared world tables (whole workgroup) ----
-  for (int i = threadIdx.x; i < W.n_habitats; i += blockDim.x) {
-    S.hab[i][0] = W.hab[3 * i]; S.hab[i][1] = W.hab[3 * i + 1]; S.hab[i][2] = W.hab[3 * i + 2];
-    S.hab[i][3] = W.hab_t[i];
-  }
-  if (threadIdx.x == 0) S.world = W;
-  for (int i = threadIdx.x; i < W.n_poly * 2; i += blockDim.x) (&S.poly[0][0])[i] = W.poly[i];
-  for (int i = threadIdx.x; i < W.n_bins * 2; i += blockDim.x) (&S.bins[0][0])[i] = W.bins[i];
+  rrt_tables_stage(S, W);
   // obstacles: SoA tile shared by the 4 episodes of the workgroup, padded to J*64 (slot j, lane l =
   // obstacle j*64 + l); with the bounding-box cull most slots are only touched by 3 reads per expansion
-  double* olx = reinterpret_cast<double*>(smem + sizeof(RrtSharedLds) + (size_t)RRT_WAVES * plan.per_wave);
+  double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)RRT_WAVES * plan.per_wave);
   double* oly = olx + J * 64;
   double* olt = oly + J * 64;
-  double* olr = olt + J * 64;  // cull radius: >= sqrt(T) with margin; -inf where nothing can collide
+  // cull radius: >= sqrt(T) with margin, rounded up to a float (it only has to be conservative; 1 KB less LDS
+  // at 256 obstacles); -inf where nothing can collide
+  float* olr = reinterpret_cast<float*>(olt + J * 64);
   for (int i = threadIdx.x; i < J * 64; i += blockDim.x) {
     const bool ok = i < W.n_obstacles;
     const double t = ok ? W.ot[i] : -1.0;  // d2 >= 0 > -1: padding never collides
     olx[i] = ok ? W.ox[i] : 0.0;
     oly[i] = ok ? W.oy[i] : 0.0;
     olt[i] = t;
-    olr[i] = t >= 0.0 ? auvp_sqrt(t) * (1.0 + 0x1p-30) + 0x1p-40 : -__builtin_inf();
+    const double rd = t >= 0.0 ? auvp_sqrt(t) * (1.0 + 0x1p-30) + 0x1p-40 : -__builtin_inf();
+    float rf = (float)rd;
+    if ((double)rf < rd) rf = __uint_as_float(__float_as_uint(rf) + 1u);  // rd > 0 here: the next float up
+    olr[i] = rf;
   }
   __syncthreads();
 
@@ -336,10 +363,10 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
         }
         rng_advance_words(rng, 120u);  // 60 unsuccessful draws (only while most bins are still empty)
       }
-      if (status) break;
+      if (uni(status)) break;  // (uni: the compiler cannot see that status is wave-uniform)
       const int ri = uni((int)py_uniform(0.0, (double)cnt, readlane_f64(u_me, f + 1)));
       par = uni(bin_items[(size_t)rb * bcap + ri]);
-      base = f + 2;
+      base = uni(f + 2);
     } else if (MODE == 1) {
       double u = rng_next_random(rng);
       double ran_time = py_uniform(0.0, P.max_plan_time * P.freq, u);
@@ -572,7 +599,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
     if (pv0) q0 = *reinterpret_cast<const double2*>(&pts[lane][0]);
 #pragma unroll
     for (int j = 0; j < J; j++) {
-      const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = olr[j * 64 + lane];
+      const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = (double)olr[j * 64 + lane];
       const bool cand = !(auvp_fabs(oxj - cxm) > hx + orj || auvp_fabs(oyj - cym) > hy + orj);
       unsigned long long cm = __ballot(cand);
       while (cm) {
@@ -685,7 +712,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 4 : (J <= 8 ? 2 : 1))) vo
                 const double2 a = *reinterpret_cast<const double2*>(nf);
                 ex = a.x; ey = a.y; et = nf[3];
               }
-              cost_element(S.world, S, 0, S.world.n_bins, P.w[2], ex, ey, et, tv, hab);
+              cost_element(*S.world, S, 0, S.world->n_bins, P.w[2], ex, ey, et, tv, hab);
               if (id >= 0) { ptTerm[id] = tv; ptHab[id] = (int8_t)hab; }
               else *reinterpret_cast<double2*>(nodeF + (size_t)(~id) * 8 + 6) = make_double2(tv, (double)hab);
             }

@@ -371,9 +371,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--episodes", type=int, default=8192,
-                    help="episodes per GPU per step (4096 wavefronts are resident at once: 8192 = two rounds, the second "
-                         "one back-fills as episodes of the first finish; 16.5 MB of tree storage each = 135 GB)")
+    ap.add_argument("--episodes", type=int, default=10240,
+                    help="episodes per GPU per step (5120 wavefronts are resident at once, 5 per SIMD: 10240 = two rounds, "
+                         "the second one back-fills as episodes of the first finish; 16.9 MB of tree storage each = 173 GB)")
     ap.add_argument("--iters", type=int, default=10000, help="expansion budget per episode (10k-node budget)")
     ap.add_argument("--obstacles", type=int, default=256)
     ap.add_argument("--grid", type=int, default=200, help="grid is grid x grid cells of 10 m")
