@@ -40,20 +40,24 @@ constexpr int RRT_ELIST = 192;     // path elements collected per cost pass grou
 //   [WorldDev]  copy of the kernel argument for the code that runs rarely (evaluating a path element for the
 //               cost): reading the table pointers from here when they are needed keeps ~40 scalar registers out
 //               of the expansion loop, which otherwise spills them to vector-register lanes
+//   [RrtParamsDev]  copy of the planning parameters (rrt_explore_kernel)
 //   [hab]       n_habitats x {x, y, size, T(size)}      [poly] n_poly x {x, y}      [bins] n_bins x {t0, t1}
 struct RrtTables {
   WorldDev* world;
+  RrtParamsDev* params;  // RRT.exploring only (staged by the kernel itself)
   double (*hab)[4];
   double (*poly)[2];
   double (*bins)[2];
 };
-constexpr int RRT_WORLD_BYTES = (int)((sizeof(WorldDev) + 15) & ~(size_t)15);
+constexpr int RRT_WORLD_ONLY_BYTES = (int)((sizeof(WorldDev) + 15) & ~(size_t)15);
+constexpr int RRT_WORLD_BYTES = RRT_WORLD_ONLY_BYTES + (int)((sizeof(RrtParamsDev) + 15) & ~(size_t)15);
 __host__ __device__ inline int rrt_tables_bytes(int n_habitats, int n_poly, int n_bins) {
   return RRT_WORLD_BYTES + n_habitats * 32 + n_poly * 16 + n_bins * 16;
 }
 __device__ __forceinline__ RrtTables rrt_tables_view(unsigned char* base, int n_habitats, int n_poly) {
   RrtTables t;
   t.world = reinterpret_cast<WorldDev*>(base);
+  t.params = reinterpret_cast<RrtParamsDev*>(base + RRT_WORLD_ONLY_BYTES);
   t.hab = reinterpret_cast<double(*)[4]>(base + RRT_WORLD_BYTES);
   t.poly = reinterpret_cast<double(*)[2]>(base + RRT_WORLD_BYTES + n_habitats * 32);
   t.bins = reinterpret_cast<double(*)[2]>(base + RRT_WORLD_BYTES + n_habitats * 32 + n_poly * 16);
@@ -255,6 +259,11 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
 
   // ---- stage the shared world tables (whole workgroup) ----
   rrt_tables_stage(S, W);
+  // The fp64 parameters are read from an LDS copy inside the expansion loop: as kernel arguments they sit in ~24
+  // scalar registers for the whole loop, get spilled to vector-register lanes and cost a VALU instruction per
+  // reload, whereas an LDS read feeds a vector operand directly (109 -> 92 spilled SGPRs, -4 % VALU instructions).
+  if (threadIdx.x == 0) *S.params = P;
+  const RrtParamsDev& Q = *S.params;
   // obstacles: SoA tile shared by the 4 episodes of the workgroup, padded to J*64 (slot j, lane l =
   // obstacle j*64 + l); with the bounding-box cull most slots are only touched by 3 reads per expansion
   double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)RRT_WAVES * plan.per_wave);
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       base = uni(f + 2);
     } else if (MODE == 1) {
       double u = rng_next_random(rng);
-      double ran_time = py_uniform(0.0, P.max_plan_time * P.freq, u);
+      double ran_time = py_uniform(0.0, Q.max_plan_time * Q.freq, u);
       int lo = 0, hi = n_nodes;  // list slicing of get_closest_mps_time (:515-528)
       while (hi - lo > 3) {
         int n = hi - lo;
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
         lo = uni(lo); hi = uni(hi);
       }
       par = lo;
-      if (nodeF[(size_t)par * 8 + 3] > P.max_traj_time) continue;
+      if (nodeF[(size_t)par * 8 + 3] > Q.max_traj_time) continue;
     } else {
       // get_random_mps (:333-343): x, y, theta, size draws; only x,y are used
       rng_ensure(rng, 8);
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
         cand = t < cand ? t : cand;
       }
       par = uni(cand);
-      if (nodeF[(size_t)par * 8 + 3] > P.max_traj_time) continue;
+      if (nodeF[(size_t)par * 8 + 3] > Q.max_traj_time) continue;
     }
 
     AUVP_PHASE(0);
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       u_me = rng_random_at(rng, (uint32_t)lane);
       base = 0;
     }
-    const int n_total = uni((int)auvp_floor(py_uniform(0.0, P.freq, readlane_f64(u_me, base)) / 1));
+    const int n_total = uni((int)auvp_floor(py_uniform(0.0, Q.freq, readlane_f64(u_me, base)) / 1));
     base += 1;
     int cnt = 0;  // appended path points
     if (lane == 0) { pts[0][0] = cx; pts[0][1] = cy; }
@@ -455,8 +464,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
           int jj = lane + 64 * t;
           bool f = false;
           if (jj + 1 < nwin) {
-            double dist = py_uniform(0.0, P.dist_to_end, uw[jj]);
-            double diff = py_uniform(-P.diff_max, P.diff_max, uw[jj + 1]);
+            double dist = py_uniform(0.0, Q.dist_to_end, uw[jj]);
+            double diff = py_uniform(-Q.diff_max, Q.diff_max, uw[jj + 1]);
             f = auvp_fabs(dist) > auvp_fabs(diff);
           }
           msk[t] = __ballot(f);
@@ -484,12 +493,12 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       const bool taken = (tmask >> lane) & 1ull;
       double radius = 0.0, phi = 0.0, vt = 1.0;
       if (taken) {
-        double dist = py_uniform(0.0, P.dist_to_end, uw[mypos]);
-        double diff = py_uniform(-P.diff_max, P.diff_max, uw[mypos + 1]);
+        double dist = py_uniform(0.0, Q.dist_to_end, uw[mypos]);
+        double diff = py_uniform(-Q.diff_max, Q.diff_max, uw[mypos + 1]);
         double s1 = dist + diff, s2 = dist - diff;
         radius = (s1 + s2) / (-s1 + s2);
         phi = (s1 + s2) / (2 * radius);
-        vt = py_uniform(0.0, 2 * P.v, uw[mypos + 2]);
+        vt = py_uniform(0.0, 2 * Q.v, uw[mypos + 2]);
       }
       wave_sync();  // the window is dead: its LDS becomes the steer scratch
       if (lane <= C) phi_l[lane] = phi;  // untaken / idle lanes add an exact 0.0
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       wave_sync();
       double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
       if (active) { mx = inc[lane]; my = inc[CS + lane]; mt_ = inc[2 * CS + lane]; ml = inc[3 * CS + lane]; }
-      const bool app = taken && (mv >= P.min_dist);
+      const bool app = taken && (mv >= Q.min_dist);
       const unsigned long long amask = __ballot(app);
       const int napp = __popcll(amask);
       if (n_points + cnt + napp > capp || cnt + napp + 1 > max_pts) { cap_err = true; break; }
@@ -621,8 +630,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
     }
     // polygon: when the path's bounding box lies strictly inside an axis-aligned rectangular boundary
     // every point is strictly inside it and the crossing test would say so too; skip it then
-    const bool box_inside = W.has_safe_box && bx0 > W.safe_box[0] && by0 > W.safe_box[1] && bx1 < W.safe_box[2] &&
-                            by1 < W.safe_box[3];
+    const double* sb = S.world->safe_box;  // the LDS copy: four doubles less held in scalar registers
+    const bool box_inside = W.has_safe_box && bx0 > sb[0] && by0 > sb[1] && bx1 < sb[2] && by1 < sb[3];
     const bool ok = !__any(hit != 0) && (box_inside || !any_point_outside(S.poly, W.n_poly, pts, P_n));
     if (log_it && lane == 0) {
       B.it_parent[logb + it] = par;
@@ -648,13 +657,13 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
     n_points += cnt;
     if (MODE == 0) {
       // curr_bin = (t // bin_interval + 1) * bin_interval, exact floor of the true quotient
-      double q = auvp_floor(ctt / P.bin_interval);
-      double r = auvp_fma(-q, P.bin_interval, ctt);
+      double q = auvp_floor(ctt / Q.bin_interval);
+      double r = auvp_fma(-q, Q.bin_interval, ctt);
       if (r < 0.0) q -= 1.0;
-      else if (r >= P.bin_interval) q += 1.0;
+      else if (r >= Q.bin_interval) q += 1.0;
       double fi = q + 1.0;
-      double curr_bin = fi * P.bin_interval;
-      bool over = curr_bin > P.max_traj_time;
+      double curr_bin = fi * Q.bin_interval;
+      bool over = curr_bin > Q.max_traj_time;
       if (!over || fi <= (double)K) {
         int bi = uni((int)fi);
         int c = over ? 0 : uni(bin_count[bi]);  // an overflowing regular key is reset first (:149-151)
@@ -666,7 +675,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
 
     AUVP_PHASE(3);
     // ------------------------------------------------------------ qualifying leaf (:158-171)
-    if (ctt >= P.max_traj_time - 30) {
+    if (ctt >= Q.max_traj_time - 30) {
       // which bins make up the leaf's sub-dict (:160-165): lane b judges bin b (n_bins <= 64)
       // (an element's own bin is always one of them -- DESIGN.md -- so only their number is needed, for the
       // leaf log)
@@ -712,7 +721,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
                 const double2 a = *reinterpret_cast<const double2*>(nf);
                 ex = a.x; ey = a.y; et = nf[3];
               }
-              cost_element(*S.world, S, 0, S.world->n_bins, P.w[2], ex, ey, et, tv, hab);
+              cost_element(*S.world, S, 0, S.world->n_bins, Q.w[2], ex, ey, et, tv, hab);
               if (id >= 0) { ptTerm[id] = tv; ptHab[id] = (int8_t)hab; }
               else *reinterpret_cast<double2*>(nodeF + (size_t)(~id) * 8 + 6) = make_double2(tv, (double)hab);
             }
@@ -752,11 +761,11 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       wave_sync();
       flush();
       double c0 = 0.0, c1 = 0.0, c2 = acc.c2;
-      const double w2 = P.w[1];
+      const double w2 = Q.w[1];
       if (w2 == auvp_rint(w2) && auvp_fabs(w2) < 1048576.0) c1 = w2 * (double)acc.hits;  // exact
       else for (int h = 0; h < acc.hits; h++) c1 = c1 + w2;
       if (ctt > 0) { c1 = c1 / ctt; c2 = c2 / ctt; }
-      if (W.n_habitats != 0) c0 = P.w[0] * (double)__popcll(acc.visited) / (double)W.n_habitats;
+      if (W.n_habitats != 0) c0 = Q.w[0] * (double)__popcll(acc.visited) / (double)W.n_habitats;
       double tot = ((0.0 + c0) + c1) + c2;
       tot = readfirst_f64(tot);
       if (log_leaf && n_leaves < B.cap_leaves && lane == 0) {
