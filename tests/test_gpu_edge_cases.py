@@ -201,3 +201,33 @@ def test_exploring_parameter_corners(ctx, orc, case):
         assert np.array_equal(lc, r["leaf_cost"][:len(lc)])
         if r["status"] == 0:
             assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])
+
+
+@pytest.mark.parametrize("H,V,T", [(64, 64, 64), (0, 3, 1), (33, 17, 5)])
+def test_exploring_table_sizes(ctx, orc, H, V, T):
+    """the shared LDS tables are sized by the world: the largest accepted world (64 habitats, a 64-vertex boundary,
+    64 time bins), the smallest, and an odd one -- every episode equal to its checker run, with and without the logs"""
+    from auv_sim_amd import synth
+    world = synth.make_world(seed=77, n_obstacles=96, n_bins=T, bin_len=max(1, 320 // T), n_habitats=H)
+    x0, y0, x1, y1 = world["box"]
+    cxm, cym, rad = 0.5 * (x0 + x1), 0.5 * (y0 + y1), 0.55 * min(x1 - x0, y1 - y0)
+    ang = 2.0 * np.pi * np.arange(V) / V
+    poly = np.stack([cxm + rad * np.cos(ang), cym + rad * np.sin(ang)], axis=1)  # a V-gon: the safe-box shortcut is off
+    ctx.set_world(world["obstacles"], world["habitats"], poly, world["bins"], world["cells"], world["prob"])
+    w = orc.WorldArrays(world["obstacles"], world["habitats"], poly, world["bins"], world["cells"], world["prob"])
+    E, n_iter = 6, 700
+    init = np.zeros((E, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    seeds = np.arange(300, 300 + E, dtype=np.uint64)
+    kw = dict(max_traj_time=150.0)
+    for logs in (False, True):
+        summ = ctx.rrt_explore_batch(init, seeds, n_iter, leaf_log=logs, **kw)
+        for e in range(E):
+            r = orc.rrt_explore(w, int(seeds[e]), n_iter, init=init[e], kind="portable", **kw)
+            s = summ[e]
+            assert (s["status"], s["n_nodes"], s["n_points"], s["n_leaves"]) == (r["status"], r["n_nodes"], r["n_points"], r["n_leaves"])
+            assert s["rng_after"] == r["rng_after"]
+            t = ctx.tree(e, s)
+            assert np.array_equal(t["parent"], r["parent"]) and np.array_equal(t["nodes"], r["nodes"])
+            if r["status"] == 0:
+                assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])
