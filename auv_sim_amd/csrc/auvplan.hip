@@ -498,12 +498,12 @@ int auvp_rrt_run(auvp_handle* h) {
   const size_t lds = (size_t)rrt_lds_plan(P.K, h->max_pts, nfreq, jslots,
                                           rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins)).total;
   if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB (K=%d, freq=%d)", lds, P.K, nfreq);
-  const int grid = (E + RRT_WAVES - 1) / RRT_WAVES;
+  const int grid = (E + RRT_X_WAVES - 1) / RRT_X_WAVES;
   const int O = h->W.n_obstacles;
   auto launch = [&](auto kern) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RRT_WAVES * 64), lds, h->stream, h->W, P, B, (int)E, h->max_pts);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(RRT_X_WAVES * 64), lds, h->stream, h->W, P, B, (int)E, h->max_pts);
     return hipGetLastError();
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
@@ -531,7 +531,7 @@ int auvp_rrt_run(auvp_handle* h) {
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  h->last_grid = grid; h->last_block = RRT_WAVES * 64; h->last_lds = (int)lds;
+  h->last_grid = grid; h->last_block = RRT_X_WAVES * 64; h->last_lds = (int)lds;
   h->have_batch = true;
   return AUVP_OK;
 }

@@ -1,7 +1,7 @@
 // rrt_explore_kernel.h -- RRT.exploring (path_planning/rrt_dubins.py:92-176) on gfx950.
 //
-// One wavefront = one episode, persistent over the whole iteration budget.  A 256-thread workgroup
-// carries 4 independent episodes that share the LDS copy of the small world tables (habitats,
+// One wavefront = one episode, persistent over the whole iteration budget.  A 512-thread workgroup
+// carries 8 independent episodes that share the LDS copy of the small world tables (habitats,
 // polygon, time bins, obstacle tile); the tree lives in HBM.
 //
 // Inside one expansion the 64 lanes split the work:
@@ -27,7 +27,11 @@
 
 namespace auvp {
 
-constexpr int RRT_WAVES = 4;       // episodes per workgroup
+constexpr int RRT_WAVES = 4;       // episodes per workgroup (Planner_RRT)
+// RRT.exploring: 8 episodes share one copy of the world tables and the obstacle tile, so three workgroups (24 waves,
+// six per SIMD) fit the CU's 160 KB of LDS; the register budget for six waves is 80 VGPRs, and what does not fit
+// (loop-invariant lane constants) is spilled once and reloaded about twice per expansion
+constexpr int RRT_X_WAVES = 8;
 constexpr int RRT_MAX_CHUNK = 63;  // sub-arcs per steer pass (one lane stays idle: chunk-entry angle)
 constexpr int RRT_MAX_HAB = 64;    // visited-habitat mask is one 64-bit word
 constexpr int RRT_MAX_POLY = 64;
@@ -79,7 +83,7 @@ __device__ __forceinline__ void rrt_tables_stage(const RrtTables& S, const World
 //   [mt]       624 u32
 //   [pts]      max_pts * 2 f64
 //   [bins]     (K+2) i32
-// before them the world tables (RrtTables); after the 4 per-wave blocks the obstacle tile shared by the
+// before them the world tables (RrtTables); after the RRT_X_WAVES per-wave blocks the obstacle tile shared by the
 // workgroup: x, y, T as f64 [J*64] each and the cull radius as f32 [J*64]
 struct RrtLdsPlan {
   int chunk;  // C
@@ -101,7 +105,7 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
   p.bins = (((K + 2) * 4) + 15) & ~15;
   p.per_wave = p.scratch + p.mt + p.pts + p.bins;
   p.tables = (tables_bytes + 15) & ~15;
-  p.total = p.tables + RRT_WAVES * p.per_wave + obst_slots * (3 * 8 + 4);  // + obstacle tile x,y,T (f64), r (f32)
+  p.total = p.tables + RRT_X_WAVES * p.per_wave + obst_slots * (3 * 8 + 4);  // + obstacle tile x,y,T (f64), r (f32)
   return p;
 }
 
@@ -235,7 +239,7 @@ __device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtTables& S,
 }
 
 template <int J, int MODE, bool DIAG>
-__global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
+__global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
                                                                      int n_episodes, int max_pts) {
   extern __shared__ __align__(16) unsigned char smem[];
   const RrtTables S = rrt_tables_view(smem, W.n_habitats, W.n_poly);
@@ -264,9 +268,9 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
   // reload, whereas an LDS read feeds a vector operand directly (109 -> 92 spilled SGPRs, -4 % VALU instructions).
   if (threadIdx.x == 0) *S.params = P;
   const RrtParamsDev& Q = *S.params;
-  // obstacles: SoA tile shared by the 4 episodes of the workgroup, padded to J*64 (slot j, lane l =
+  // obstacles: SoA tile shared by the episodes of the workgroup, padded to J*64 (slot j, lane l =
   // obstacle j*64 + l); with the bounding-box cull most slots are only touched by 3 reads per expansion
-  double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)RRT_WAVES * plan.per_wave);
+  double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)RRT_X_WAVES * plan.per_wave);
   double* oly = olx + J * 64;
   double* olt = oly + J * 64;
   // cull radius: >= sqrt(T) with margin, rounded up to a float (it only has to be conservative; 1 KB less LDS
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
   }
   __syncthreads();
 
-  const int ep = (int)blockIdx.x * RRT_WAVES + wave;
+  const int ep = (int)blockIdx.x * RRT_X_WAVES + wave;
   if (ep >= n_episodes) return;  // no workgroup barrier after this point
 
   // ---- per-episode views (scalar bases) ----

@@ -121,7 +121,7 @@ def bench_single_episode(ctx, world, args, reps=3):
             "expansions_per_s": float(summ[0]["iters_run"]) / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / float(summ[0]["iters_run"])}
 
 
-def bench_rrt_o64(ctx, args, n_ep=4096, reps=2):
+def bench_rrt_o64(ctx, args, n_ep=6144, reps=2):
     """BASELINE configs[1] as written: 64 obstacles (the headline uses 256), same 200x200-cell grid and 10k budget."""
     from auv_sim_amd import synth
     half = 0.5 * args.grid * 10.0
@@ -371,9 +371,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--episodes", type=int, default=10240,
-                    help="episodes per GPU per step (5120 wavefronts are resident at once, 5 per SIMD: 10240 = two rounds, "
-                         "the second one back-fills as episodes of the first finish; 16.9 MB of tree storage each = 173 GB)")
+    ap.add_argument("--episodes", type=int, default=12288,
+                    help="episodes per GPU per step (6144 wavefronts are resident at once, 6 per SIMD: 12288 = two rounds, "
+                         "the second one back-fills as episodes of the first finish; 16.9 MB of tree storage each = 208 GB)")
     ap.add_argument("--iters", type=int, default=10000, help="expansion budget per episode (10k-node budget)")
     ap.add_argument("--obstacles", type=int, default=256)
     ap.add_argument("--grid", type=int, default=200, help="grid is grid x grid cells of 10 m")
