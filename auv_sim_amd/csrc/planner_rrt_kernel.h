@@ -124,7 +124,8 @@ __device__ __forceinline__ bool prrt_hits(const double (&ox)[J], const double (&
 }
 
 template <int J>
-__global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 3 : (J <= 8 ? 2 : 1))) void prrt_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
+// (five waves per SIMD = 96 VGPRs, two spilled; six or eight spill 35+ and measure slower)
+__global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) void prrt_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
