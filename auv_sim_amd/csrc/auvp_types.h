@@ -64,12 +64,12 @@ struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h
 };
 
 // Per-episode tree storage, episode-major.  Nodes are records (one 16-B + one 64-B access per
-// node: they are read one at a time by the whole wave); path points are SoA (lane-parallel).
+// node: they are read one at a time by the whole wave); path points are 48-B records, a node's run contiguous.
 struct RrtBuffers {
   int32_t cap_nodes, cap_points, bin_cap, cap_leaves;
   double* node_f;    // [E][cap_nodes][8]  x, y, theta, traj_t, length, -, -, -   (64 B per node)
   int32_t* node_i;   // [E][cap_nodes][4]  plan_iter, parent, pt_off, pt_cnt       (16 B per node)
-  double* points;    // [E][6][cap_points] SoA x, y, theta, v, traj_t, length
+  double* points;    // [E][cap_points][6] x, y, theta, v, traj_t, length
   // cost-walk acceleration (derived data, never returned):
   //  * a path element's contribution to habitat_shark_cost_func -- w3*prob of its cell in its time bin, and
   //    the habitat it lies in -- does not depend on the leaf that walks over it (its bin is always part of

@@ -599,12 +599,11 @@ int auvp_rrt_tree(auvp_handle* h, int32_t ep, double* nodes6, int32_t* parent, i
     if (pt_cnt) pt_cnt[i] = ni[4 * (size_t)i + 3];
   }
   if (points7 && NP > 0) {
-    std::vector<double> col((size_t)NP);
+    std::vector<double> rec((size_t)NP * 6);
     const int dst[6] = {0, 1, 2, 3, 4, 6};
-    for (int c = 0; c < 6; c++) {
-      HIPCHK(h, hipMemcpy(col.data(), B.points + ((size_t)ep * 6 + c) * capp, (size_t)NP * sizeof(double), hipMemcpyDeviceToHost));
-      for (int i = 0; i < NP; i++) points7[7 * (size_t)i + dst[c]] = col[i];
-    }
+    HIPCHK(h, hipMemcpy(rec.data(), B.points + (size_t)ep * 6 * capp, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < NP; i++)
+      for (int c = 0; c < 6; c++) points7[7 * (size_t)i + dst[c]] = rec[6 * (size_t)i + c];
     // plan_time_stamp of a path point = iteration of the node that owns it
     for (int m = 0; m < N; m++) {
       const int off = ni[4 * (size_t)m + 2], cnt = ni[4 * (size_t)m + 3], plan = ni[4 * (size_t)m];

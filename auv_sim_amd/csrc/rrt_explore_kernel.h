@@ -8,7 +8,8 @@
 //   steer        lane s = sub-arc s: RNG window tempering, arc geometry and sin/cos in parallel;
 //                only the running sums (theta; then x, y, t, length on four lanes) are serial, and
 //                they must be, to keep the reference's left-to-right fp64 addition order
-//   collision    lane = obstacle (J each), loop over the path points broadcast from LDS
+//   collision    cull: lane = obstacle (J slots of 64) against the path's bounding box; the few candidates that
+//                survive are tested one at a time with lane = path point
 //   polygon      lane = path point
 //   cost         lane = path element; the leaf->root walk only collects element ids (four ancestors per
 //                dependent load), an element's contribution is evaluated once and cached, the shark
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
   double* nodeF = B.node_f + (size_t)ep * capn * 8;                       // [capn][8] x,y,theta,t,length
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;    // plan_iter,parent,pt_off,pt_cnt
-  double* ptF = B.points + (size_t)ep * capp * 6;                         // SoA [6][capp]
+  double* ptF = B.points + (size_t)ep * capp * 6;                         // [capp][6] x,y,theta,v,t,length
   double* ptTerm = B.pt_term + (size_t)ep * capp;                         // cost-walk cache (auvp_types.h)
   int8_t* ptHab = B.pt_hab + (size_t)ep * capp;
   int32_t* anc = B.anc + (size_t)ep * capn * 16;
@@ -569,8 +570,10 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       if (app) {
         int rank = __popcll(amask & ((1ull << lane) - 1ull));
         size_t gi = (size_t)(n_points + cnt + rank);  // speculative: committed only if the node is accepted
-        ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * (size_t)capp + gi] = myth; ptF[3 * (size_t)capp + gi] = vt;
-        ptF[4 * (size_t)capp + gi] = mt_; ptF[5 * (size_t)capp + gi] = ml;
+        // one 48-byte record per path point: a node's points are one contiguous run (three 16-byte stores per lane),
+        // not six 8-byte streams whose partly filled lines the L2 writes back early (-17 % HBM write traffic)
+        double2* rec = reinterpret_cast<double2*>(ptF + gi * 6);
+        rec[0] = make_double2(mx, my); rec[1] = make_double2(myth, vt); rec[2] = make_double2(mt_, ml);
         ptHab[gi] = -2;  // cost contribution not evaluated yet
         pts[cnt + rank + 1][0] = mx;
         pts[cnt + rank + 1][1] = my;
@@ -719,7 +722,11 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
           if (__any(need)) {
             if (need) {
               double ex, ey, et;
-              if (id >= 0) { ex = ptF[id]; ey = ptF[(size_t)capp + id]; et = ptF[4 * (size_t)capp + id]; }
+              if (id >= 0) {
+                const double* rec = ptF + (size_t)id * 6;
+                const double2 xy = *reinterpret_cast<const double2*>(rec);
+                ex = xy.x; ey = xy.y; et = rec[4];
+              }
               else {
                 const double* nf = nodeF + (size_t)(~id) * 8;
                 const double2 a = *reinterpret_cast<const double2*>(nf);
@@ -847,8 +854,9 @@ __global__ __launch_bounds__(64) void rrt_final_course_kernel(RrtBuffers B, cons
       // point k of the node sits k places after the node it grew from
       double* e = o + 7 * (size_t)(pos - cnt + 1 + k);
       size_t gi = (size_t)off + k;
-      e[0] = ptF[gi]; e[1] = ptF[capp + gi]; e[2] = ptF[2 * capp + gi]; e[3] = ptF[3 * capp + gi];
-      e[4] = ptF[4 * capp + gi]; e[5] = (double)r.x; e[6] = ptF[5 * capp + gi];
+      const double* rec = ptF + gi * 6;
+      e[0] = rec[0]; e[1] = rec[1]; e[2] = rec[2]; e[3] = rec[3];
+      e[4] = rec[4]; e[5] = (double)r.x; e[6] = rec[5];
     }
     pos -= cnt;
     if (lane == 0) node_elem(r.y, pos);
