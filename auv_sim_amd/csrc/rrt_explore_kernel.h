@@ -182,19 +182,24 @@ struct CostAcc {
 // entirely by the reference: (0.0, -1).
 __device__ __forceinline__ void cost_element(const WorldDev& W, const RrtTables& S, int bin_lo, int bin_hi, double w3,
                                              double x, double y, double t, double& tv, int& hab) {
+  // first matching bin / habitat in table order, scanned backwards without early exits (the last overwrite is the
+  // first match): the table reads (one LDS address for all lanes) are then independent of the compares and
+  // overlap instead of costing one LDS round trip per row
   int tb = -1;
-  for (int b = bin_lo; b < bin_hi; b++) {
-    if (t >= S.bins[b][0] && t <= S.bins[b][1]) { tb = b; break; }
+  for (int b = bin_hi - 1; b >= bin_lo; b--) {
+    const double2 r = *reinterpret_cast<const double2*>(&S.bins[b][0]);
+    tb = (t >= r.x && t <= r.y) ? b : tb;
   }
   tv = 0.0;
   hab = -1;
   if (tb >= 0) {
     int c = cell_lookup(W, x, y);
     if (c >= 0) tv = w3 * W.prob[(size_t)tb * W.n_cells + c];
-    for (int h = 0; h < W.n_habitats; h++) {
+    for (int h = W.n_habitats - 1; h >= 0; h--) {
       // dist <= size  <=>  d2 <= T(size): same decision as RN(sqrt(d2)) <= size, no sqrt
-      double ddx = S.hab[h][0] - x, ddy = S.hab[h][1] - y;
-      if (ddx * ddx + ddy * ddy <= S.hab[h][3]) { hab = h; break; }
+      const double2 hxy = *reinterpret_cast<const double2*>(&S.hab[h][0]);
+      const double ddx = hxy.x - x, ddy = hxy.y - y;
+      hab = (ddx * ddx + ddy * ddy <= S.hab[h][3]) ? h : hab;
     }
   }
 }
@@ -703,22 +708,32 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       // record per ancestor); the lookups run over 64 elements at a time.
       int fill = 0;
       auto flush = [&]() {
-        for (int b0 = 0; b0 < fill; b0 += 64) {
-          const int nv = (fill - b0) < 64 ? (fill - b0) : 64;
-          // an element's (term, habitat) is the same for every leaf above it (its time bin is always one of the
-          // leaf's bins): read it if an earlier walk left it, evaluate and keep it otherwise
-          double tv = 0.0;
-          int hab = -1, id = 0;
-          bool need = false;
-          if (lane < nv) {
-            id = elist[b0 + lane];
-            if (id >= 0) { hab = ptHab[id]; tv = ptTerm[id]; }
+        // the cached contributions of all (up to three) 64-element passes are requested before the first one is
+        // processed: one global round trip per flush instead of one per pass
+        double tvs[3];
+        int habs[3], ids[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+          tvs[p] = 0.0; habs[p] = -1; ids[p] = 0;
+          if (64 * p + lane < fill) {
+            const int id = elist[64 * p + lane];
+            ids[p] = id;
+            if (id >= 0) { habs[p] = ptHab[id]; tvs[p] = ptTerm[id]; }
             else {
               const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)(~id) * 8 + 6);
-              tv = c.x; hab = (int)c.y;
+              tvs[p] = c.x; habs[p] = (int)c.y;
             }
-            need = hab == -2;
           }
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+          const int b0 = 64 * p;
+          if (b0 < fill) {
+          const int nv = (fill - b0) < 64 ? (fill - b0) : 64;
+          double tv = tvs[p];
+          int hab = habs[p];
+          const int id = ids[p];
+          const bool need = lane < nv && hab == -2;
           if (__any(need)) {
             if (need) {
               double ex, ey, et;
@@ -739,6 +754,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
           }
           wave_sync();
           cost_accumulate(nv, tv, hab, term, acc);
+          }
         }
         Lp += fill;
         fill = 0;
