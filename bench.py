@@ -413,6 +413,19 @@ def main():
     ctx = _lib.Context(local_rank)
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     E = args.episodes
+    # the trees need ~17.5 MB of HBM per 10 000-iteration episode: if this GPU has less free than the requested batch
+    # needs, run the largest whole number of resident rounds (6144 episodes) that fits -- every rank the same
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    fit = int(0.92 * free_b / (17.5e6 * max(args.iters, 1) / 10000.0))
+    if fit < E:
+        fit = max(6144 * (fit // 6144), min(E, 1024))
+    e_fit = torch.tensor([min(E, fit)], dtype=torch.int64, device=dev)
+    if world_size > 1:
+        dist.all_reduce(e_fit, op=dist.ReduceOp.MIN)
+    if int(e_fit.item()) < E:
+        print("bench: %d episodes per GPU do not fit the free HBM (%.0f GB); running %d" % (E, free_b / 1e9, int(e_fit.item())),
+              file=sys.stderr)
+        E = int(e_fit.item())
     init = np.zeros((E, 6))
     init[:, 0], init[:, 1] = world["start"]
     seeds = np.arange(rank * E, (rank + 1) * E, dtype=np.uint64)  # global episode id = seed
