@@ -480,13 +480,22 @@ def main():
         k_ms = float(np.mean(kms))
         abytes = algorithmic_bytes(summ, args.iters)
         achieved = abytes / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(REPO, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                # PMC passes of tools/profile_bench.sh on the default workload (one wave = one episode, 10 000 iterations);
+                # a different batch is scaled by its number of expansions and says so
+                pj = json.load(open(pmc))
+                waves = float(pj["per_launch"].get("SQ_WAVES", 0.0))
+                traffic = pj.get("hbm_bytes_per_launch")
+                traffic_src = "profiles/%s/pmc_summary.json (FETCH_SIZE + WRITE_SIZE passes)" % pj.get("tag", "?")
+                if traffic is not None and waves > 0 and (int(waves) != E or args.iters != 10000):
+                    scale = (E * args.iters) / (waves * 10000.0)
+                    traffic *= scale
+                    traffic_src += ", scaled x%.3f from %d episodes x 10000 iterations" % (scale, int(waves))
             except Exception:
-                traffic = None
+                traffic, traffic_src = None, None
         grid, block, lds = ctx.last_launch()
         out = {
             "metric": "RRT-Dubins node expansions/s (RRT.exploring)", "value": value, "unit": "expansions/s",
@@ -498,7 +507,7 @@ def main():
                        "episodes_per_gpu": E, "iters": args.iters, "obstacles": args.obstacles,
                        "cells": int(len(world["cells"])), "parallelism": "episodes sharded x%d" % world_size},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rrt_explore_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,
                          "bytes_per_expansion": abytes / float(summ["iters_run"].sum()),
                          "launch": {"grid": grid, "block": block, "lds_bytes": lds},
