@@ -40,8 +40,8 @@ constexpr int RRT_MAX_BINS = 64;
 constexpr int RRT_ELIST = 192;     // path elements collected per cost pass group
 
 // The world tables every episode of a workgroup shares, at the start of its LDS and sized by the world at hand
-// (a fixed 64-row layout costs 4.4 KB where the Catalina-like world needs 0.9 KB -- the difference decides
-// whether five workgroups fit a CU):
+// (a fixed 64-row layout costs 4.4 KB where the Catalina-like world needs 0.9 KB; LDS is what limits the number of
+// resident episodes per CU):
 //   [WorldDev]  copy of the kernel argument for the code that runs rarely (evaluating a path element for the
 //               cost): reading the table pointers from here when they are needed keeps ~40 scalar registers out
 //               of the expansion loop, which otherwise spills them to vector-register lanes
