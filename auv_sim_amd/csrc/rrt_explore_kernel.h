@@ -260,7 +260,6 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   double* inc = scratch;                           // [(C+1)*4]   (steer, phase 2: aliases u_win)
   double* sc = scratch + (size_t)4 * ((C + 2) & ~1);  // [(C+1)*2]
   double* phi_l = sc + (size_t)(C + 1) * 2;           // [C+1]
-  double* bbox_l = phi_l + (C + 1);                   // [4] xmin, ymin, xmax, ymax of the steer
   int32_t* elist = reinterpret_cast<int32_t*>(wbase);                  // [192]  (cost walk)
   double* term = reinterpret_cast<double*>(wbase + RRT_ELIST * 4);     // [64]
   uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + plan.scratch);
@@ -439,6 +438,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       cx = readfirst_f64(a.x); cy = readfirst_f64(a.y); cth = readfirst_f64(b.x); ctt = readfirst_f64(b.y);
       clen = readfirst_f64(nodeF[(size_t)par * 8 + 4]);
     }
+    const double px0 = cx, py0 = cy, clen0 = clen;  // the parent's end: centre of the collision cull's box
     if (MODE != 0) {  // modes 1/2 consumed their selection draws one by one; open the window here
       rng_ensure(rng, 128u);
       u_me = rng_random_at(rng, (uint32_t)lane);
@@ -547,23 +547,14 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       // x += dx; y += dy; t += dt; length += movement: four serial chains, one lane each
       if (lane < 4) {
         double acc = lane == 0 ? cx : (lane == 1 ? cy : (lane == 2 ? ctt : clen));
-        // lanes 0/1 also track the extent of x / y over every prefix position (a superset of the
-        // appended path points; the parent point is part of the path); kept in LDS between chunks
-        double bmin = acc, bmax = acc;
-        if (c0 != 0 && lane < 2) { bmin = bbox_l[lane]; bmax = bbox_l[2 + lane]; }
         double* row = inc + lane * CS;
 #pragma unroll 2
         for (int s = 0; s < n; s += 2) {  // two steps per 16-byte access (the row is zero past n: adding 0.0 changes nothing)
           double2 v = *reinterpret_cast<double2*>(row + s);
-          // fmin/fmax = one v_min_f64 / v_max_f64 each (a compare + select is three instructions per bound);
-          // nothing here is NaN and the sign of a zero bound does not matter to the cull
           acc = acc + v.x; v.x = acc;
-          bmin = __builtin_fmin(acc, bmin); bmax = __builtin_fmax(acc, bmax);
           acc = acc + v.y; v.y = acc;
-          bmin = __builtin_fmin(acc, bmin); bmax = __builtin_fmax(acc, bmax);
           *reinterpret_cast<double2*>(row + s) = v;
         }
-        if (lane < 2) { bbox_l[lane] = bmin; bbox_l[2 + lane] = bmax; }
       }
       wave_sync();
       double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
@@ -594,7 +585,6 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     }
     if (n_total == 0) {
       rng_advance_words(rng, (uint32_t)(2 * base));  // selection + n_expand draws only
-      if (lane < 2) { bbox_l[lane] = lane == 0 ? cx : cy; bbox_l[2 + lane] = lane == 0 ? cx : cy; }
     }
     if (cap_err) { status = -2; break; }
     wave_sync();
@@ -608,10 +598,15 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     // The cull only has to be conservative (a candidate slot runs the exact test below): the obstacle's
     // bounding square of half-width olr >= sqrt(T_i) against the box around its centre, both inflated by
     // 2^-30 relative -- eight orders of magnitude above any rounding in these few operations.
-    const double bx0 = bbox_l[0], by0 = bbox_l[1], bx1 = bbox_l[2], by1 = bbox_l[3];
-    const double cxm = (bx0 + bx1) * 0.5, cym = (by0 + by1) * 0.5;
+    // The box: every prefix position of the steer lies within the steer's total movement (the growth of the
+    // length chain, which adds every sub-arc's chord) of the parent's end -- a square around the parent.  Looser than
+    // the exact extent, but at these obstacle densities it still leaves well under one candidate per expansion, and
+    // it costs nothing to maintain (tracking min/max in the serial chains was 30 instructions per expansion).
+    const double reach = clen - clen0;
+    const double bx0 = px0 - reach, by0 = py0 - reach, bx1 = px0 + reach, by1 = py0 + reach;
+    const double cxm = px0, cym = py0;
     const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + 1.0);
-    const double hx = (bx1 - bx0) * 0.5 + slack, hy = (by1 - by0) * 0.5 + slack;
+    const double hx = reach + slack, hy = reach + slack;
     // lane = path point (the usual steer has < 64 of them): the few obstacles that survive the cull are tested one
     // at a time against every point at once, read back from the tile with a wave-uniform address
     int hit = 0;
