@@ -52,6 +52,7 @@ struct RrtParamsDev {
   double dist_to_end, diff_max, freq, min_dist, bin_interval, v, max_traj_time, max_plan_time;
   double w[3];
   int32_t mode, max_iter, K, flags;
+  double inv_bin_interval;  // RN(1 / bin_interval): first guess of t // bin_interval (corrected exactly by the remainder)
 };
 
 struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h

@@ -97,8 +97,7 @@ __device__ __forceinline__ void rng_ensure(WaveRng& r, uint32_t need_words) {
 
 // tempered 32-bit output number `j` ahead of the consumer (j < avail)
 __device__ __forceinline__ uint32_t rng_word(const WaveRng& r, uint32_t j) {
-  uint32_t k = r.pslot + j;
-  k = k >= 624u ? k - 624u : k;
+  uint32_t k = r.pslot + j;      // pslot < 624 and j < avail <= 624: one wrap is enough
   k = k >= 624u ? k - 624u : k;
   return mt_temper(r.s[k]);
 }

@@ -410,6 +410,7 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   P.bin_interval = p->bin_interval; P.v = p->v; P.max_traj_time = p->max_traj_time; P.max_plan_time = p->max_plan_time;
   P.w[0] = p->w[0]; P.w[1] = p->w[1]; P.w[2] = p->w[2];
   P.mode = p->mode; P.max_iter = p->max_iter; P.flags = flags;
+  P.inv_bin_interval = p->bin_interval > 0 ? 1.0 / p->bin_interval : 0.0;
   P.K = p->mode == AUVP_MODE_TIMEBIN ? (int)std::ceil(p->max_traj_time / p->bin_interval) : 0;
   if (P.K > 1 << 20) return fail(h, AUVP_ERR_ARG, "too many time bins (%d)", P.K);
   const int nfreq = (int)std::floor(p->freq);

@@ -664,7 +664,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     n_points += cnt;
     if (MODE == 0) {
       // curr_bin = (t // bin_interval + 1) * bin_interval, exact floor of the true quotient
-      double q = auvp_floor(ctt / Q.bin_interval);
+      double q = auvp_floor(ctt * Q.inv_bin_interval);  // within one of the true floor; the remainder below settles it
       double r = auvp_fma(-q, Q.bin_interval, ctt);
       if (r < 0.0) q -= 1.0;
       else if (r >= Q.bin_interval) q += 1.0;
