@@ -488,10 +488,16 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       const bool active = lane < n;
       int cbelow = lane;
       unsigned long long tmask;
+      // this lane only ever looks at bits 2*lane .. 3*lane of the 192-bit predicate: cut that window out once
+      unsigned long long win;
+      {
+        const int sh = 2 * lane;
+        const unsigned long long lo = sh < 64 ? msk[0] : msk[1], hi = sh < 64 ? msk[1] : msk[2];
+        const int s6 = sh & 63;
+        win = (lo >> s6) | ((hi << 1) << (63 - s6));
+      }
       for (;;) {
-        int pos = 2 * lane + cbelow;
-        unsigned long long mm = pos < 64 ? msk[0] : (pos < 128 ? msk[1] : msk[2]);
-        bool tk = active && ((mm >> (pos & 63)) & 1ull);
+        bool tk = active && ((win >> cbelow) & 1ull);
         tmask = __ballot(tk);
         int cnew = __popcll(tmask & ((1ull << lane) - 1ull));
         bool changed = active && (cnew != cbelow);
