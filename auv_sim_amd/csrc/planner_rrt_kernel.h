@@ -184,6 +184,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
   int n_nodes = uni(sum.n_nodes), n_points = uni(sum.n_points), n_occ = uni(sum.n_occ), step = uni(sum.steps);
   int done = uni(sum.done), status = uni(sum.status);
   int last_accepted = 0, last_new = -1;
+  int prev_n_arc = -1;
+  bool have_prev_arc = false;
   const int step_end = P.step_mode ? step + 1 : P.max_step;
 
   while (status == 0 && !done && step < step_end) {
@@ -402,7 +404,11 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       lx = readfirst_f64(a.x); ly = readfirst_f64(a.y); th0 = readfirst_f64(c.x); ltt = readfirst_f64(c.y);
     }
     int n_arc = -1, arc_free = 0;
-    {
+    // connect_to_goal_curve_alt is a pure function of the newest node, the goal and the obstacles: a step that added
+    // no node repeats the previous step's evaluation, which was "not free" (or planning would have ended), so its
+    // result is reused instead of sampling the same arc again
+    if (!ok && have_prev_arc) n_arc = prev_n_arc;
+    else {
       const double theta = auvp_atan2(gy - ly, gx - lx);
       const double diff = prrt_angle_wrap(theta - th0);
       if (!(auvp_fabs(diff) > AUVP_PI / 2)) {
@@ -500,6 +506,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       }
     }
     (void)ltt;
+    prev_n_arc = n_arc; have_prev_arc = true;
     if (logst && lane == 0) {
       int32_t* l = B.st_log + ((size_t)ep * P.max_step + step) * 8;
       l[0] = b; l[1] = par; l[2] = ok ? 1 : 0; l[3] = done; l[4] = P_n; l[5] = n_arc; l[6] = arc_free; l[7] = me;
