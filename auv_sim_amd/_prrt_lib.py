@@ -36,6 +36,7 @@ def _bind():
     L.auvp_prrt_paths.argtypes = [vp, C.POINTER(C.c_int64), _dp]
     L.auvp_prrt_tree.argtypes = [vp, C.c_int32, _dp, _ip, _ip, _dp]
     L.auvp_prrt_grid.argtypes = [vp, C.c_int32, _ip, _ip, _ip]
+    L.auvp_prrt_node.argtypes = [vp, C.c_int32, C.c_int32, _dp, _ip, _ip, _dp, C.c_int32]
     L.auvp_prrt_step_log.argtypes = [vp, C.c_int32, _ip]
     L.auvp_prrt_summaries_dev.argtypes = [vp]
     L.auvp_prrt_summaries_dev.restype = C.c_void_p
@@ -113,6 +114,17 @@ class PlannerBatch:
         self.ctx._chk(self.L.auvp_prrt_tree(self.ctx.h, ep, _lib._p(nodes), _lib._p(ni, _ip), _lib._p(nb, _ip), _lib._p(pts)))
         return dict(nodes=nodes, step=ni[:, 0].copy(), parent=ni[:, 1].copy(), pt_off=ni[:, 2].copy(),
                     pt_cnt=ni[:, 3].copy(), node_bucket=nb, points=pts[:npnt])
+
+    def node(self, ep, node, cap_points=256):
+        """one node record + its path points (what a step-mode caller needs after an accepted step)"""
+        nf = np.zeros(4)
+        ni = np.zeros(4, np.int32)
+        nb = np.zeros(1, np.int32)
+        pts = np.zeros((cap_points, 4))
+        self.ctx._chk(self.L.auvp_prrt_node(self.ctx.h, ep, int(node), _lib._p(nf), _lib._p(ni, _ip), _lib._p(nb, _ip),
+                                            _lib._p(pts), cap_points))
+        return dict(node=nf, step=int(ni[0]), parent=int(ni[1]), pt_off=int(ni[2]), pt_cnt=int(ni[3]),
+                    bucket=int(nb[0]), points=pts[:int(ni[3])])
 
     def grid(self, ep):
         dims = np.zeros(4, np.int32)

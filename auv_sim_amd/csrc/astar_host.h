@@ -15,8 +15,12 @@ struct AstarState {
   auvp::AstarParamsDev P{};
   auvp::AstarBuffers B{};
   DevBuf ox, oy, ot, hab, poly, bins, rcells, prob, topn;
-  DevBuf start, goal, limit, nodes, node_i, visited, keycache, hab_left, exp_log, summary, off, path, cost, npath, smooth;
-  long long visited_set_for = -1;  // byte size of a bitmap uploaded by auvp_astar_set_visited, -1 none
+  DevBuf start, goal, limit, nodes, node_i, cellinfo, hab_left, exp_log, summary, off, path, cost, npath, smooth;
+  long long visited_set_for = -1;  // entry count of a bitmap uploaded by auvp_astar_set_visited, -1 none
+  // epoch of the words in `cellinfo` (astar_kernel.h): bumped per batch instead of clearing 1.4 MB per instance;
+  // cellinfo_clean_cap = capacity (bytes) that has been zeroed since the buffer was (re)allocated
+  uint32_t epoch = 0;
+  size_t cellinfo_clean_cap = 0;
 };
 
 AstarState* astar_of(auvp_handle* h) {
@@ -127,36 +131,36 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
   HIPCHK(h, S.hab_left.reserve((size_t)E * (H > 0 ? H : 1) * sizeof(int32_t)));
   B.nodes = S.nodes.as<double>(); B.node_i = S.node_i.as<int32_t>(); B.summary = S.summary.as<auvp::AstarSummary>();
   B.hab_left = S.hab_left.as<int32_t>();
-  B.visited = nullptr;
+  B.cellinfo = nullptr;
+  HIPCHK(h, hipEventRecord(h->ev0, h->stream));  // the batch time includes whatever reset the batch needs
   if (p->variant >= 2) {
-    const size_t vb = (size_t)E * P.vx * P.vy;
-    HIPCHK(h, S.visited.reserve(vb));
+    if (p->variant == 3 && S.W.n_cells >= 65535) return fail(h, AUVP_ERR_ARG, "n_cells %d does not fit the 16-bit cell-key field", S.W.n_cells);
+    const size_t entries = (size_t)E * P.vx * P.vy, vb = entries * sizeof(uint32_t);
+    HIPCHK(h, S.cellinfo.reserve(vb));
     if (flags & AUVP_FLAG_KEEP_VISITED) {
       // the reference keeps self.visited_nodes across astar() calls on one solver object
-      // (astar_fixLen.py:51, astar_fixLenSOG.py:117): the caller uploaded it with auvp_astar_set_visited
-      if (S.visited_set_for != (long long)vb) return fail(h, AUVP_ERR_STATE, "auvp_astar_set_visited not called for this batch shape");
+      // (astar_fixLen.py:51, astar_fixLenSOG.py:117): the caller uploaded it with auvp_astar_set_visited,
+      // tagged with the current epoch
+      if (S.visited_set_for != (long long)entries) return fail(h, AUVP_ERR_STATE, "auvp_astar_set_visited not called for this batch shape");
     } else {
-      HIPCHK(h, hipMemsetAsync(S.visited.p, 0, vb, h->stream));
+      // a fresh visited array = a new epoch; the words are only cleared when the buffer is new or the tag wraps
+      if (S.cellinfo_clean_cap != S.cellinfo.cap || S.epoch >= 255u) {
+        HIPCHK(h, hipMemsetAsync(S.cellinfo.p, 0, S.cellinfo.cap, h->stream));
+        S.cellinfo_clean_cap = S.cellinfo.cap;
+        S.epoch = 0;
+      }
+      S.epoch++;
     }
     S.visited_set_for = -1;
-    B.visited = S.visited.as<uint8_t>();
-  }
-  B.keycache = nullptr;
-  if (p->variant == 3) {
-    if (S.W.n_cells >= 32767) return fail(h, AUVP_ERR_ARG, "n_cells %d does not fit the 16-bit cell-key cache", S.W.n_cells);
-    const size_t kb = (size_t)E * P.vx * P.vy * sizeof(int16_t);
-    HIPCHK(h, S.keycache.reserve(kb));
-    HIPCHK(h, hipMemsetAsync(S.keycache.p, 0, kb, h->stream));
-    B.keycache = S.keycache.as<int16_t>();
+    P.epoch = S.epoch;
+    B.cellinfo = S.cellinfo.as<uint32_t>();
   }
   B.exp_log = nullptr;
   if (P.cap_exp) {
     HIPCHK(h, S.exp_log.reserve((size_t)E * P.cap_exp * 8 * sizeof(double)));
     B.exp_log = S.exp_log.as<double>();
   }
-  HIPCHK(h, hipStreamSynchronize(h->stream));
   const int grid = (E + auvp::ASTAR_WAVES - 1) / auvp::ASTAR_WAVES;
-  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipLaunchKernelGGL(auvp::astar_kernel, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -218,26 +222,39 @@ int auvp_astar_exp_log(auvp_handle* h, int32_t ep, double* out8) {
 }
 
 // visited bitmap in / out (variants 2,3): [E][vx*vy] bytes, vx = 550 (fixLen) or 600 (SOG), vy = 600;
-// set before auvp_astar_batch(..., AUVP_FLAG_KEEP_VISITED), get after any batch
+// set before auvp_astar_batch(..., AUVP_FLAG_KEEP_VISITED), get after any batch.  On the device the array is
+// the epoch-tagged word array of astar_kernel.h; the byte view of the reference is converted here.
 int auvp_astar_set_visited(auvp_handle* h, int32_t E, int32_t variant, const uint8_t* bitmap) {
   if (!h || !bitmap || E <= 0 || variant < 2 || variant > 3) return AUVP_ERR_ARG;
   AstarState& S = *astar_of(h);
   HIPCHK(h, hipSetDevice(h->device));
-  const size_t vb = (size_t)E * (variant == 2 ? 550 : 600) * 600;
-  int rc;
-  if ((rc = upload(h, S.visited, bitmap, vb))) return rc;
+  const size_t entries = (size_t)E * (variant == 2 ? 550 : 600) * 600;
+  HIPCHK(h, S.cellinfo.reserve(entries * sizeof(uint32_t)));
+  if (S.cellinfo_clean_cap != S.cellinfo.cap || S.epoch >= 255u) {
+    HIPCHK(h, hipMemsetAsync(S.cellinfo.p, 0, S.cellinfo.cap, h->stream));
+    S.cellinfo_clean_cap = S.cellinfo.cap;
+    S.epoch = 0;
+  }
+  S.epoch++;
+  std::vector<uint32_t> words(entries);
+  const uint32_t tag = S.epoch << 24;
+  for (size_t i = 0; i < entries; i++) words[i] = bitmap[i] ? (tag | 0x10000u) : 0u;
+  HIPCHK(h, hipMemcpyAsync(S.cellinfo.p, words.data(), entries * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  S.visited_set_for = (long long)vb;
+  S.visited_set_for = (long long)entries;
   return AUVP_OK;
 }
 
 int auvp_astar_get_visited(auvp_handle* h, int32_t ep, uint8_t* bitmap) {
   if (!h || !bitmap) return AUVP_ERR_ARG;
   AstarState& S = *astar_of(h);
-  if (!S.ready || ep < 0 || ep >= S.E || !S.B.visited) return fail(h, AUVP_ERR_STATE, "no visited bitmap");
+  if (!S.ready || ep < 0 || ep >= S.E || !S.B.cellinfo) return fail(h, AUVP_ERR_STATE, "no visited bitmap");
   HIPCHK(h, hipSetDevice(h->device));
   const size_t one = (size_t)S.P.vx * S.P.vy;
-  HIPCHK(h, hipMemcpy(bitmap, S.B.visited + (size_t)ep * one, one, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> words(one);
+  HIPCHK(h, hipMemcpy(words.data(), S.B.cellinfo + (size_t)ep * one, one * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  const uint32_t tag = S.P.epoch << 24;
+  for (size_t i = 0; i < one; i++) bitmap[i] = ((words[i] & 0xff000000u) == tag && (words[i] & 0x10000u)) ? 1 : 0;
   return AUVP_OK;
 }
 

@@ -46,6 +46,8 @@ struct AstarParamsDev {
   double velocity;
   double w[4];
   int32_t vx, vy;  // visited bitmap dims
+  uint32_t epoch;  // 1..255: tag of this batch in the cell-info words (see AstarBuffers::cellinfo)
+  int32_t _pad;
 };
 
 struct AstarSummary {  // must match auvp_astar_summary
@@ -58,8 +60,13 @@ struct AstarBuffers {
   const double* limit;   // [E]     (variants 2,3)
   double* nodes;         // [E][7][cap_nodes] SoA x, y, g, h, f, cost, pathLen
   int32_t* node_i;       // [E][3][cap_nodes] parent, time_stamp, open
-  uint8_t* visited;      // [E][vx*vy]
-  int16_t* keycache;     // [E][vx*vy] variant 3: 1 + cell key of a lattice point once get_cell_prob found it (0 = not yet)
+  // [E][vx*vy] one word per entry of the reference's visited_nodes array (variants 2,3):
+  //   bits 31..24  epoch of the batch that wrote the word; a word of another epoch reads as "never touched", so a new
+  //                batch needs no 360 KB-per-instance clear (the host bumps the epoch; a full clear every 255 batches)
+  //   bit 16       visited_nodes[x][y] == 1
+  //   bits 15..0   variant 3: 1 + cell key of this lattice point once get_cell_prob found it (0 = not yet); within one
+  //                instance the visited index identifies the point (points are 10 apart)
+  uint32_t* cellinfo;
   int32_t* hab_left;     // [E][H]
   double* exp_log;       // optional [E][cap_exp][8]
   AstarSummary* summary; // [E]
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
          *ncost = nd + 5 * (size_t)cap, *nlen = nd + 6 * (size_t)cap;
   int32_t* ni = B.node_i + (size_t)ep * 3 * cap;
   int32_t *npar = ni, *nts = ni + cap, *nopen = ni + 2 * (size_t)cap;
-  uint8_t* visited = B.visited ? B.visited + (size_t)ep * P.vx * P.vy : nullptr;
-  int16_t* keycache = B.keycache ? B.keycache + (size_t)ep * P.vx * P.vy : nullptr;
+  uint32_t* cellinfo = B.cellinfo ? B.cellinfo + (size_t)ep * P.vx * P.vy : nullptr;
+  const uint32_t ep_tag = P.epoch << 24;
   int32_t* hopen = s_hopen[wave];
   int32_t* hclosed = s_hclosed[wave];
   const int H = W.n_habitats, C = W.n_cells, T = W.n_bins;
@@ -299,7 +306,9 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       const size_t vi = (size_t)xi * P.vy + yi;
       // the cell of a lattice point is looked up once per search: within one instance the visited-bitmap index
       // identifies the point (points are 10 apart), so the key is kept next to it
-      int key = mine ? (int)keycache[vi] - 1 : 0;
+      const uint32_t ciw = mine ? cellinfo[vi] : 0u;
+      const bool ci_live = (ciw & 0xff000000u) == ep_tag;  // written by this batch (or uploaded for it)
+      int key = mine ? (ci_live ? (int)(ciw & 0xffffu) - 1 : -1) : 0;
       const bool need_key = mine && key < 0;
     // get_cell_prob (:485-514) for ALL children of this expansion in one sweep over the cells: a lane loads one
     // cell per pass and tests it against the (uniform) positions of the eight neighbours, so the sweep costs
@@ -326,12 +335,12 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       for (int k = 0; k < 8; k++) if (lane == k) s_keys[wave][k] = keys[k];
       wave_sync();
     }
-      if (need_key) { key = s_keys[wave][kk]; if (key >= 0) keycache[vi] = (int16_t)(key + 1); }
+      if (need_key) key = s_keys[wave][kk];
       const bool bad = mine && (tb < 0 || key < 0 || ntop > C);
       if (__any(bad)) { status = -1; break; }
       double pr = 0.0, tn = 0.0;
       int was = 0;
-      if (mine) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; was = (int)visited[vi]; }
+      if (mine) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; was = (ci_live && (ciw & 0x10000u)) ? 1 : 0; }
       const double g_ = ccost - w4 * pr;
       const double h_ = -w2 * dist_left - w3 * (double)H - w4 * tn;
       const double f_ = g_ + h_;
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         const int c = n_nodes + __popc(childmask & ((1 << kk) - 1));
         nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = g_; nlen[c] = len_;
         npar[c] = cur; nts[c] = ts_; nopen[c] = open_;
-        if (!was) visited[vi] = 1;
+        if (!was || need_key) cellinfo[vi] = ep_tag | 0x10000u | (uint32_t)(key + 1);  // visited from now on, key kept
       }
       const unsigned long long om = __ballot(mine && open_);
       const int opened = __popcll(om);
@@ -397,10 +406,11 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         if (yi < 0) yi += P.vy;
         if (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy) { status = -1; break; }
         const size_t vi = (size_t)xi * P.vy + yi;
-        const int was = uni((int)visited[vi]);
+        const uint32_t ciw = (uint32_t)uni((int)cellinfo[vi]);
+        const bool was = (ciw & 0xff000000u) == ep_tag && (ciw & 0x10000u);
         if (was) open_ = 0;
         else {
-          if (lane == 0) visited[vi] = 1;
+          if (lane == 0) cellinfo[vi] = ep_tag | 0x10000u;
           visited_count++;
         }
       }

@@ -69,6 +69,8 @@ struct auvp_handle {
   void (*astar_free)(void*) = nullptr;
   void* pf = nullptr;
   void (*pf_free)(void*) = nullptr;
+  void* comm = nullptr;  // RCCL communicator state (gather_host.h)
+  void (*comm_free)(void*) = nullptr;
 };
 
 namespace {
@@ -161,6 +163,7 @@ void auvp_destroy(auvp_handle* h) {
   if (h->prrt && h->prrt_free) h->prrt_free(h->prrt);
   if (h->astar && h->astar_free) h->astar_free(h->astar);
   if (h->pf && h->pf_free) h->pf_free(h->pf);
+  if (h->comm && h->comm_free) h->comm_free(h->comm);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -176,6 +179,9 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   if (O < 0 || H < 0 || V < 0 || T < 0 || C < 0) return fail(h, AUVP_ERR_ARG, "negative size");
   if (H > RRT_MAX_HAB) return fail(h, AUVP_ERR_ARG, "n_habitats %d > %d", H, RRT_MAX_HAB);
   if (V > RRT_MAX_POLY) return fail(h, AUVP_ERR_ARG, "n_poly %d > %d", V, RRT_MAX_POLY);
+  // a boundary needs at least three vertices (shapely's Polygon constructor raises for fewer); V == 0 means
+  // "no boundary" and is accepted for the world-only users (cost probe, A* with its own box)
+  if (V == 1 || V == 2) return fail(h, AUVP_ERR_ARG, "boundary polygon with %d vertices (need >= 3, or 0 for none)", V);
   if (T > RRT_MAX_BINS) return fail(h, AUVP_ERR_ARG, "n_bins %d > %d", T, RRT_MAX_BINS);
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<double> ox(O), oy(O), ot(O);
@@ -687,3 +693,4 @@ PrrtState* prrt_of(auvp_handle* h) {
 #include "sog_kernels.h"
 #include "pf_kernel.h"
 #include "pf_host.h"
+#include "gather_host.h"

@@ -211,6 +211,34 @@ int auvp_prrt_tree(auvp_handle* h, int32_t ep, double* nodes4, int32_t* node_i4,
   return AUVP_OK;
 }
 
+// one node of one episode: its record and its run of path points (what a step-mode caller needs to materialise the
+// node the device just accepted, instead of downloading the whole tree every step)
+int auvp_prrt_node(auvp_handle* h, int32_t ep, int32_t node, double* node4, int32_t* node_i4, int32_t* node_bucket,
+                   double* points4, int32_t cap_points) {
+  if (!h) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready || ep < 0 || ep >= S.E) return fail(h, AUVP_ERR_STATE, "bad episode");
+  if (node < 0 || node >= S.B.cap_nodes) return fail(h, AUVP_ERR_ARG, "node %d outside 0..%d", node, S.B.cap_nodes - 1);
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t at = (size_t)ep * S.B.cap_nodes + (size_t)node, capp = (size_t)S.B.cap_points;
+  int32_t ni[4];
+  HIPCHK(h, hipMemcpy(ni, S.B.node_i + at * 4, sizeof ni, hipMemcpyDeviceToHost));
+  if (node4) HIPCHK(h, hipMemcpy(node4, S.B.node_f + at * 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
+  if (node_i4) memcpy(node_i4, ni, sizeof ni);
+  if (node_bucket) HIPCHK(h, hipMemcpy(node_bucket, S.B.node_bucket + at, sizeof(int32_t), hipMemcpyDeviceToHost));
+  const int off = ni[2], cnt = ni[3];
+  if (points4 && cnt > 0) {
+    if (cnt > cap_points) return fail(h, AUVP_ERR_CAPACITY, "node has %d points, buffer holds %d", cnt, cap_points);
+    if (off < 0 || (size_t)off + (size_t)cnt > capp) return fail(h, AUVP_ERR_STATE, "node record out of range");
+    std::vector<double> col((size_t)cnt);
+    for (int c = 0; c < 4; c++) {  // the points are four SoA columns per episode
+      HIPCHK(h, hipMemcpy(col.data(), S.B.points + ((size_t)ep * 4 + c) * capp + off, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost));
+      for (int i = 0; i < cnt; i++) points4[4 * (size_t)i + c] = col[i];
+    }
+  }
+  return AUVP_OK;
+}
+
 int auvp_prrt_grid(auvp_handle* h, int32_t ep, int32_t* occupied, int32_t* bucket_counts, int32_t* dims4) {
   if (!h) return AUVP_ERR_ARG;
   PrrtState& S = *prrt_of(h);

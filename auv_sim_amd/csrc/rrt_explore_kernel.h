@@ -118,6 +118,9 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
 // n_pts points is not strictly inside.
 __device__ __forceinline__ bool any_point_outside(const double (*poly)[2], int nv, const double (*pts)[2], int n_pts) {
   const int lane = lane_id();
+  // no boundary polygon: no point is within it (the crossing loop of the definition never runs), so a path
+  // with any point at all is outside; also keeps 64 / nv below well defined
+  if (nv <= 0) return n_pts > 0;
   const int per = 64 / nv;  // points per pass (nv <= 64)
   const int e = lane % nv, pl = lane / nv;
   const int ej = e == 0 ? nv - 1 : e - 1;  // j trails i by one vertex

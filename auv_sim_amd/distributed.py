@@ -1,11 +1,22 @@
 """Multi-GPU sharding of independent planning episodes.
 
-Episodes share no mutable state, so the only cross-rank step is one gather of fixed-stride result
-records after the kernels: rank r plans episodes [r*E/G, (r+1)*E/G) (seed = global episode id, so
-results do not depend on G), then the per-episode summary records and the best paths are
-all-gathered -- `torch.distributed` backend "nccl" (= RCCL over xGMI) on the GPUs, "gloo" in the
-CPU tests.  No all-reduce sits on the data path; the payload is a few MB, so the step is latency
-bound (7 xGMI links x ~153 GB/s per GPU are nowhere near saturated)."""
+Episodes share no mutable state, so the only cross-rank step is one gather of result records after the
+kernels: rank r plans episodes shard_range(E, r, G) (seed = global episode id, so results do not depend
+on G), then the fixed-stride per-episode summary records and the variable-length best paths are gathered
+to every rank.  No all-reduce sits on the data path; the payload is a few MB, so the step is latency
+bound (7 xGMI links x ~153 GB/s per GPU are nowhere near saturated).
+
+Two transports with one interface (`gather_records`, `gather_paths`):
+  RcclGather   libauvplan.so's own RCCL entry points (auvp_comm_init / auvp_gather / auvp_gather_var,
+               include/auvplan.h): collectives on the planner handle's HIP stream, device pointers in and
+               out, no padding of the variable-length blocks.  What a C/C++ host would call; bench.py uses
+               it on the GPUs.
+  TorchGather  torch.distributed all-gathers ("nccl" = RCCL on ROCm, "gloo" in the CPU tests).
+Shards may be uneven (the first E % G ranks hold one episode more): records are padded to the largest
+shard for the equal-size collective and cut back on return.
+"""
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -18,42 +29,137 @@ def shard_range(n_total, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_records(records, group=None):
-    """all-gather equally sized per-rank record blocks.  records: uint8/float tensor [E_local, stride]
-    (same shape on every rank).  Returns [world, E_local, stride]."""
-    world = dist.get_world_size(group)
-    shape = tuple(records.shape)
-    out = torch.empty((world * shape[0],) + shape[1:], dtype=records.dtype, device=records.device)
-    dist.all_gather_into_tensor(out, records.contiguous(), group=group)  # concatenates along dim 0
-    return out.view((world,) + shape)
+def shard_sizes(n_total, world_size):
+    return [b - a for a, b in (shard_range(n_total, r, world_size) for r in range(world_size))]
 
 
-def gather_paths(paths, lengths, group=None):
-    """Two-phase gather of variable-length best paths.
-    paths [n_local_elems, 7] f64 (concatenated root->leaf courses), lengths [E_local] int64.
-    Phase 1 gathers the per-episode lengths, phase 2 the payload padded to the largest rank total.
-    Returns (all_lengths [world, E_local], list over ranks of [n_r, 7] tensors)."""
-    world = dist.get_world_size(group)
-    lengths = lengths.to(torch.int64).contiguous()
-    all_len = torch.empty(world * lengths.numel(), dtype=torch.int64, device=lengths.device)
-    dist.all_gather_into_tensor(all_len, lengths, group=group)
-    all_len = all_len.view(world, lengths.numel())
-    totals = all_len.sum(dim=1)
-    cap = int(totals.max().item())
-    pad = torch.zeros((max(cap, 1), 7), dtype=paths.dtype, device=paths.device)
-    n = int(lengths.sum().item())
-    if n:
-        pad[:n] = paths[:n]
-    allp = torch.empty((world * pad.shape[0], 7), dtype=paths.dtype, device=paths.device)
-    dist.all_gather_into_tensor(allp, pad, group=group)
-    allp = allp.view(world, pad.shape[0], 7)
-    return all_len, [allp[r, :int(totals[r].item())] for r in range(world)]
+class TorchGather:
+    """all-gathers through torch.distributed (process group already initialised)"""
+
+    name = "torch.distributed"
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.last_ms = None
+
+    def _counts(self, n, device):
+        mine = torch.tensor([int(n)], dtype=torch.int64, device=device)
+        allc = torch.empty(self.world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allc, mine, group=self.group)
+        return [int(v) for v in allc.tolist()]
+
+    def gather_records(self, records):
+        """records [E_local, stride] (E_local may differ between ranks) -> list over ranks of [E_r, stride]"""
+        records = records.contiguous()
+        counts = self._counts(records.shape[0], records.device)
+        cap = max(max(counts), 1)
+        pad = torch.zeros((cap,) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
+        pad[:records.shape[0]] = records
+        out = torch.empty((self.world * cap,) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        out = out.view((self.world, cap) + tuple(records.shape[1:]))
+        return [out[r, :counts[r]] for r in range(self.world)]
+
+    def gather_paths(self, paths, lengths):
+        """paths [n_local_elems, W] (concatenated per-episode blocks), lengths [E_local] int64 ->
+        (list over ranks of lengths [E_r], list over ranks of [n_r, W])"""
+        lens = self.gather_records(lengths.to(torch.int64).reshape(-1, 1))
+        lens = [l.reshape(-1) for l in lens]
+        n = int(lengths.sum().item())
+        blocks = self.gather_records(paths[:n])
+        return lens, blocks
+
+    def take_ms(self):
+        return None  # no stream timing on this transport
+
+
+class RcclGather:
+    """the C-ABI gather of libauvplan.so on the planner context's stream.  `exchange_id(id_bytes_or_None)` must
+    return rank 0's 128-byte id on every rank (e.g. through torch.distributed.broadcast_object_list, MPI, a file)."""
+
+    name = "rccl (auvp_gather, C-ABI)"
+
+    def __init__(self, ctx, rank, world, exchange_id):
+        from . import _lib
+        self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        L = _lib.load()
+        L.auvp_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+        L.auvp_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
+        L.auvp_comm_destroy.argtypes = [C.c_void_p]
+        L.auvp_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.auvp_gather_var.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.auvp_last_gather_ms.argtypes = [C.c_void_p]
+        L.auvp_last_gather_ms.restype = C.c_double
+        self.L = L
+        mine = None
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            rc = L.auvp_comm_unique_id(buf)
+            if rc != 0:
+                raise _lib.AuvpError(rc, "auvp_comm_unique_id failed (RCCL not loadable?)")
+            mine = bytes(buf)
+        uid = exchange_id(mine)
+        arr = (C.c_uint8 * 128).from_buffer_copy(uid)
+        ctx._chk(L.auvp_comm_init(ctx.h, self.world, self.rank, arr))
+        self.last_ms = None
+
+    def close(self):
+        if self.ctx is not None and getattr(self.ctx, "h", None):
+            self.L.auvp_comm_destroy(self.ctx.h)
+        self.ctx = None
+
+    def _var(self, t):
+        """variable-size all-gather of a contiguous device tensor's bytes -> (counts, uint8 tensor of all blocks)"""
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        counts = (C.c_int64 * self.world)()
+        self.ctx._chk(self.L.auvp_gather_var(self.ctx.h, C.c_void_p(t.data_ptr()), nbytes, None, 0, counts))
+        total = sum(counts)
+        out = torch.empty(max(total, 1), dtype=torch.uint8, device=t.device)
+        self.ctx._chk(self.L.auvp_gather_var(self.ctx.h, C.c_void_p(t.data_ptr()), nbytes, C.c_void_p(out.data_ptr()),
+                                             total, counts))
+        self.last_ms = (self.last_ms or 0.0) + float(self.L.auvp_last_gather_ms(self.ctx.h))
+        return list(counts), out
+
+    def gather_records(self, records):
+        records = records.contiguous()
+        row = int(np.prod(records.shape[1:])) * records.element_size() if records.dim() > 1 else records.element_size()
+        counts, raw = self._var(records)
+        out, pos = [], 0
+        for r in range(self.world):
+            blk = raw[pos:pos + counts[r]]
+            pos += counts[r]
+            out.append(blk.view(records.dtype).view((counts[r] // max(row, 1),) + tuple(records.shape[1:])))
+        return out
+
+    def gather_paths(self, paths, lengths):
+        lens = [l.reshape(-1) for l in self.gather_records(lengths.to(torch.int64).reshape(-1, 1))]
+        n = int(lengths.sum().item())
+        blocks = self.gather_records(paths[:n])
+        return lens, blocks
+
+    def take_ms(self):
+        """HIP-event time of the collectives since the last call (sum), then reset"""
+        ms, self.last_ms = self.last_ms, None
+        return ms
 
 
 def summaries_to_tensor(summ, device):
     """numpy structured summaries -> uint8 tensor [E, itemsize] on `device`"""
     raw = np.ascontiguousarray(summ).view(np.uint8).reshape(len(summ), summ.dtype.itemsize)
     return torch.from_numpy(raw.copy()).to(device)
+
+
+def device_records(ptr, n, itemsize, device):
+    """uint8 view [n, itemsize] of device-resident records (e.g. auvp_rrt_summaries_dev): no host round trip.
+    The memory stays owned by the planner handle; the view is only valid until the next batch."""
+    class _Mem:
+        pass
+    m = _Mem()
+    m.__cuda_array_interface__ = {"shape": (int(n), int(itemsize)), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(m, device=device)
 
 
 def tensor_to_summaries(t, dtype):

@@ -132,19 +132,18 @@ class Planner_RRT:
     def _pull_new_node(self, s, step_num):
         """materialise the node the device just accepted (and its path points) as Python objects"""
         me = int(s["last_new_node"])
-        t = self._pb.tree(0, s)
-        n = t["nodes"][me]
+        t = self._pb.node(0, me, cap_points=int(math.floor(self.freq)) + 4)  # this node only, not the whole tree
+        n = t["node"]
         node = Motion_plan_state(float(n[0]), float(n[1]), theta=float(n[2]), traj_time_stamp=float(n[3]),
                                  rl_state_id=step_num)
-        par = self.mps_list[int(t["parent"][me])]
+        par = self.mps_list[t["parent"]]
         node.parent = par
         node.path = [par]
-        o, c = int(t["pt_off"][me]), int(t["pt_cnt"][me])
-        for q in t["points"][o:o + c]:
+        for q in t["points"]:
             node.path.append(Motion_plan_state(float(q[0]), float(q[1]), theta=float(q[2]), traj_time_stamp=float(q[3]),
                                                rl_state_id=step_num))
         self.mps_list.append(node)
-        self._mirror_insert(node, int(t["node_bucket"][me]))
+        self._mirror_insert(node, t["bucket"])
         return node
 
     def _final_path(self, s, step_num):

@@ -89,6 +89,7 @@ class RRT:
         self._poly = _polygon_vertices(boundary)
         self._world_habitats = None
         self._ctx.set_world(_circles(obstacles), None, self._poly, self._bins, self._cells, self._prob)
+        self._cost_ctx = None   # cost-only context of replanning() (created on first use)
         self._last = None       # (summary, initial, E index) of the last exploring call
         self._mps_cache = None
 
@@ -157,57 +158,62 @@ class RRT:
 
     def replanning(self, start, habitats, plan_time_budget, traj_time_length, replan_time_interval, weight,
                    max_iter=None, seed=None):
-        """Receding-horizon loop over exploring (rrt_dubins.py:51-90).  The SharkUpdate /
-        SharkOccupancyGrid objects the reference builds at :67-68 are never read and are not built."""
+        """Receding-horizon planning (rrt_dubins.py:51-90): plan a horizon with `exploring`, commit the first
+        shark-interval bucket of the best course, drop the habitats that bucket visited, repeat until the
+        shark grid's last bin ends.  Returns [committed trajectory, {round: [bucket, habitats at that round]},
+        cost of the whole trajectory against the ORIGINAL habitat list].
+
+        The SharkUpdate / SharkOccupancyGrid objects the reference constructs at :67-68 are never read by it
+        and are not constructed here.  The final cost runs on a cost-only device context of its own, so this
+        object's obstacles and boundary stay on the device for later exploring() / check_collision() calls."""
         from .cost import habitat_shark_cost_func
-        traj = [start]
-        time_dict = {}
-        final_traj_time = list(self.sharkGrid.keys())[-1][1]
-        plan_time = plan_time_budget + replan_time_interval
-        count = 1
-        oriHabitats = habitats.copy()
-        rng = None if seed is None else random.Random(seed)
-        while (traj[-1].traj_time_stamp + plan_time) < final_traj_time:
-            if traj_time_length + traj[-1].traj_time_stamp > final_traj_time:
-                traj_time_length = final_traj_time - traj[-1].traj_time_stamp
-            temp = self.exploring(traj[-1], habitats, 0.5, 5, 2, plan_time, traj_time_stamp=True,
-                                  max_plan_time=plan_time_budget,
-                                  max_traj_time=(traj_time_length + traj[-1].traj_time_stamp), plan_time=True,
-                                  weights=weight, max_iter=max_iter,
-                                  seed=None if rng is None else rng.getrandbits(63))
-            temp_path = temp["path"][1][list(temp["path"][1].keys())[0]]
-            traj.extend(temp_path)
-            time_dict[count] = [temp_path, habitats.copy()]
-            habitats = self.removeHabitat(habitats, temp_path)
-            count += 1
-        cost = habitat_shark_cost_func(traj[1:], traj[-1].traj_time_stamp, oriHabitats, self.sharkGrid,
-                                       weight=[-3, -3, -4], device_context=self._ctx)
-        return [traj[1:], time_dict, cost]
+        horizon_end = list(self.sharkGrid.keys())[-1][1]
+        round_span = plan_time_budget + replan_time_interval  # also the shark_interval handed to exploring (:80)
+        all_habitats = list(habitats)
+        stream = random.Random(seed) if seed is not None else None
+        committed, rounds = [start], {}
+        while committed[-1].traj_time_stamp + round_span < horizon_end:
+            t_now = committed[-1].traj_time_stamp
+            if traj_time_length + t_now > horizon_end:  # stays clipped for the later rounds too (:76-77)
+                traj_time_length = horizon_end - t_now
+            plan = self.exploring(committed[-1], habitats, 0.5, 5, 2, round_span, traj_time_stamp=True,
+                                  max_plan_time=plan_time_budget, max_traj_time=traj_time_length + t_now,
+                                  plan_time=True, weights=weight, max_iter=max_iter,
+                                  seed=stream.getrandbits(63) if stream is not None else None)
+            buckets = plan["path"][1]
+            first_bucket = buckets[next(iter(buckets))]
+            committed += first_bucket
+            rounds[len(rounds) + 1] = [first_bucket, list(habitats)]
+            habitats = self.removeHabitat(habitats, first_bucket)
+        if self._cost_ctx is None:
+            self._cost_ctx = _lib.Context(self._ctx.device)
+        total = habitat_shark_cost_func(committed[1:], committed[-1].traj_time_stamp, all_habitats, self.sharkGrid,
+                                        weight=[-3, -3, -4], device_context=self._cost_ctx)
+        return [committed[1:], rounds, total]
 
     # ------------------------------------------------------------------ host-side helpers (reference names)
     def splitPath(self, path, shark_interval, traj_time):
-        """rrt_dubins.py:590-602"""
-        n_expand = math.floor(traj_time[1] / shark_interval)
-        res = {}
-        start = traj_time[0]
-        for i in range(n_expand):
-            res[(start + i * shark_interval, start + (i + 1) * shark_interval)] = []
-        spans = list(res.items())
+        """Bucket a course by shark interval (rrt_dubins.py:590-602): floor(traj_time[1] / shark_interval)
+        closed intervals starting at traj_time[0]; a point goes to the first interval that contains its
+        traj_time_stamp (so a point on a shared end belongs to the earlier one) or to none."""
+        t0 = traj_time[0]
+        edges = [(t0 + k * shark_interval, t0 + (k + 1) * shark_interval)
+                 for k in range(math.floor(traj_time[1] / shark_interval))]
+        buckets = {e: [] for e in edges}
         for point in path:
             t = point.traj_time_stamp
-            for key, arr in spans:
-                if t >= key[0] and t <= key[1]:
-                    arr.append(point)
-                    break
-        return res
+            hit = next((e for e in edges if e[0] <= t <= e[1]), None)
+            if hit is not None:
+                buckets[hit].append(point)
+        return buckets
 
     def removeHabitat(self, habitats, path):
-        """rrt_dubins.py:604-610 (mutates and returns the caller's list, like the reference)"""
+        """rrt_dubins.py:604-610: every path point removes the first habitat (current list order) that contains
+        it.  Mutates and returns the caller's list, like the reference."""
         for point in path:
-            for habitat in habitats:
-                if math.sqrt((point.x - habitat.x) ** 2 + (point.y - habitat.y) ** 2) <= habitat.size:
-                    habitats.remove(habitat)
-                    break
+            inside = next((h for h in habitats if math.sqrt((point.x - h.x) ** 2 + (point.y - h.y) ** 2) <= h.size), None)
+            if inside is not None:
+                habitats.remove(inside)
         return habitats
 
     def check_collision(self, mps, obstacleList=None):

@@ -27,7 +27,8 @@ enum {
   AUVP_ERR_CAPACITY = -2, /* a device buffer sized from the budget overflowed; nothing is truncated silently */
   AUVP_ERR_HIP = -3,
   AUVP_ERR_STATE = -4,
-  AUVP_ERR_KEY = -5 /* time-bin key outside 1..K: KeyError at rrt_dubins.py:124 */
+  AUVP_ERR_KEY = -5, /* time-bin key outside 1..K: KeyError at rrt_dubins.py:124 */
+  AUVP_ERR_COMM = -6 /* RCCL missing or a collective failed (auvp_comm_*, auvp_gather*) */
 };
 
 enum { AUVP_MODE_TIMEBIN = 0, AUVP_MODE_PLANTIME = 1, AUVP_MODE_NN = 2 };
@@ -148,6 +149,11 @@ int auvp_prrt_paths(auvp_handle* h, const int64_t* offsets, double* out);
  * node_bucket [n]; points4 [n_points,4] x,y,theta,traj_t */
 int auvp_prrt_tree(auvp_handle* h, int32_t episode, double* nodes4, int32_t* node_i4, int32_t* node_bucket,
                    double* points4);
+/* one node of one episode (the node generate_one_node just appended to mps_list, gym_rrt/envs/rrt_dubins.py:236-240):
+ * node4 x,y,theta,traj_t; node_i4 step,parent,pt_off,pt_cnt; its bucket; points4 [pt_cnt,4] (cap_points rows
+ * available, AUVP_ERR_CAPACITY if the node has more).  O(path points of the node), not O(tree). */
+int auvp_prrt_node(auvp_handle* h, int32_t episode, int32_t node, double* node4, int32_t* node_i4, int32_t* node_bucket,
+                   double* points4, int32_t cap_points);
 /* env_grid state: occupied_grid_cells_array as bucket ids, len(node_array) per bucket, dims4 =
  * rows, cols, subsections, n_occupied */
 int auvp_prrt_grid(auvp_handle* h, int32_t episode, int32_t* occupied, int32_t* bucket_counts, int32_t* dims4);
@@ -273,6 +279,28 @@ int auvp_rrt_phase_clocks(auvp_handle* h, uint64_t* out);
 /* HIP-event time (ms) of the last batch kernel on the handle's stream, and its launch geometry */
 double auvp_last_kernel_ms(auvp_handle* h);
 int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds_bytes);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Multi-GPU result gather (SURVEY.md 8(b) "auvp_gather(comm...)", 8(e)).  The reference is single-process;
+ * what these replace is the implicit "results are in this process" of its batch callers
+ * (path_planning/performance.py:65-73 collects one result per exploring() call in a Python list).  One
+ * process per GPU plans a block of the episode index; afterwards every rank holds every record.
+ * Collectives are RCCL (bound at run time) on the handle's stream; all buffers are DEVICE pointers.
+ *   auvp_comm_unique_id  rank 0 creates the 128-byte id and hands it to the other ranks (any channel)
+ *   auvp_comm_init       every rank, same id: joins the communicator (collective)
+ *   auvp_gather          all-gather of equally sized blocks: recv_dev [world][bytes_per_rank]
+ *   auvp_gather_var      variable-size blocks, two-phase: counts_out[world] always receives every rank's byte
+ *                        count; with recv_dev == NULL only that (size query), else the blocks are written back
+ *                        to back in rank order (AUVP_ERR_CAPACITY if recv_cap_bytes is too small)
+ *   auvp_last_gather_ms  HIP-event time of the last gather on the handle's stream */
+#define AUVP_COMM_ID_BYTES 128
+int auvp_comm_unique_id(uint8_t* id_out /* [AUVP_COMM_ID_BYTES] */);
+int auvp_comm_init(auvp_handle* h, int32_t world_size, int32_t rank, const uint8_t* id);
+int auvp_comm_destroy(auvp_handle* h);
+int auvp_gather(auvp_handle* h, const void* send_dev, size_t bytes_per_rank, void* recv_dev);
+int auvp_gather_var(auvp_handle* h, const void* send_dev, int64_t send_bytes, void* recv_dev, int64_t recv_cap_bytes,
+                    int64_t* counts_out);
+double auvp_last_gather_ms(auvp_handle* h);
 
 #ifdef __cplusplus
 }

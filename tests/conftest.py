@@ -36,3 +36,24 @@ def libm_matches_golden():
         if math.sin(x) != s or math.cos(x) != c or math.atan2(x, 1.0) != a or x ** 2 != p:
             return False
     return True
+
+
+def golden_world(g):
+    """World tables of a G3-style golden: stored arrays, or -- for the 40 000-cell bench world, whose 4.5 MB of
+    tables are not committed -- rebuilt with synth.make_world(**world_kwargs) and checked against the stored SHA-256."""
+    import hashlib
+    import json
+    import numpy as np
+    keys = ("obstacles", "habitats", "polygon", "bins", "cells", "prob")
+    if "cells" in g.files:
+        return {k: g[k] for k in keys}
+    from auv_sim_amd import synth
+    kw = json.loads(str(g["world_kwargs"]))
+    if "box" in kw:
+        kw["box"] = tuple(kw["box"])
+    w = synth.make_world(**kw)
+    h = hashlib.sha256()
+    for k in keys:
+        h.update(np.ascontiguousarray(w[k]).tobytes())
+    assert h.hexdigest() == str(g["world_sha"]), "synth.make_world no longer reproduces the golden's world"
+    return {k: w[k] for k in keys}

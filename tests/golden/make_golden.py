@@ -368,12 +368,28 @@ def g3():
         ("g3_tb_dense", 13, dict(seed=4, n_obstacles=64, obst_radius=(4.0, 9.0)), 600, "timebin",
          {"freq": 12}),
         ("g3_tb_o256_i10000", 7, dict(seed=2, n_obstacles=256), 10000, "timebin", {"keep_points": False}),
+        # the bench world itself (bench.py: 256 obstacles, 200x200 cells of 10 m = 40 000 cells, 10 bins) with a short
+        # horizon so the reference's linear cell scan (path_planning/cost.py:181-184, ~20 000 dict entries per path
+        # point) finishes: pins the device's cell index at the headline size against the reference.  The 4.5 MB of
+        # world tables are not stored: the world is synth.make_world(**world_kwargs) and its SHA-256 is.
+        ("g3_tb_c40000", 7, dict(seed=2, n_obstacles=256, box=(-1000.0, -1000.0, 1000.0, 1000.0), cell=10.0, n_bins=10,
+                                 bin_len=50, n_habitats=10), 1500, "timebin",
+         {"max_traj_time": 120.0, "shark_interval": 30, "keep_points": False, "store_world": False}),
     ]
+    only = os.environ.get("AUVP_G3_ONLY")
     for name, seed, wk, n_iter, mode, extra in specs:
+        if only and name not in only.split(","):
+            continue
+        extra = dict(extra)
+        store_world = extra.pop("store_world", True)
         world = synth.make_world(**wk)
         out = run_exploring(seed, world, n_iter, mode, **extra)
         meta = {"world_kwargs": json.dumps(wk)}
-        save_npz(name + ".npz", **world_arrays(world), start=world["start"], **meta, **out)
+        wa = world_arrays(world)
+        if not store_world:
+            meta["world_sha"] = sha(*[wa[k] for k in ("obstacles", "habitats", "polygon", "bins", "cells", "prob")])
+            wa = {}
+        save_npz(name + ".npz", **wa, start=world["start"], **meta, **out)
         print(name, "iters", out["iters_run"], "nodes", len(out["nodes"]), "leaves", len(out["leaf_iter"]),
               "err", out["error"], "cost", out.get("res_cost"))
 

@@ -21,23 +21,25 @@ def _free_port():
 def _worker(rank, world, port, E_total, q):
     import sys
     sys.path.insert(0, REPO)
-    from auv_sim_amd import _lib, distributed as D
+    from auv_sim_amd import _lib, _prrt_lib, distributed as D
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = D.TorchGather()
     lo, hi = D.shard_range(E_total, rank, world)
-    n = hi - lo
-    E_pad = -(-E_total // world)  # equal-size blocks for the gather
-    summ = np.zeros(E_pad, dtype=_lib.SUMMARY_DTYPE)
-    summ["status"] = -99
-    rng = np.random.default_rng(100 + rank)
+    n = hi - lo  # uneven when E_total % world != 0: rank 0 holds one episode more
+    summ = np.zeros(n, dtype=_lib.SUMMARY_DTYPE)
+    psumm = np.zeros(n, dtype=_prrt_lib.PRRT_SUMMARY_DTYPE)  # the Planner_RRT record goes through the same helpers
     for i in range(n):
         e = lo + i  # global episode id
-        summ[i]["status"] = 0
         summ[i]["best_leaf"] = e
         summ[i]["best_path_len"] = 3 + (e % 5)
         summ[i]["best_cost"] = [-(e + 0.5), 0, 0, 0]
-    lens = torch.from_numpy(np.where(summ["status"] == 0, summ["best_path_len"], 0).astype(np.int64))
+        psumm[i]["steps"] = 100 + e
+        psumm[i]["done"] = e % 2
+        psumm[i]["path_len"] = (2 + e % 3) if e % 2 else 0
+        psumm[i]["arc"] = [e, 0, 0, 0, 0, e + 0.25]
+    lens = torch.from_numpy(summ["best_path_len"].astype(np.int64))
     paths = torch.zeros((int(lens.sum()), 7), dtype=torch.float64)
     pos = 0
     for i in range(n):
@@ -45,25 +47,40 @@ def _worker(rank, world, port, E_total, q):
         paths[pos:pos + L, 0] = lo + i
         paths[pos:pos + L, 1] = torch.arange(L, dtype=torch.float64)
         pos += L
-    rec = D.gather_records(D.summaries_to_tensor(summ, "cpu"))
-    all_len, all_paths = D.gather_paths(paths, lens)
-    allsumm = D.tensor_to_summaries(rec, _lib.SUMMARY_DTYPE)
+    plens = torch.from_numpy(psumm["path_len"].astype(np.int64))
+    ppaths = torch.zeros((int(plens.sum()), 5), dtype=torch.float64)
+    pos = 0
+    for i in range(n):
+        L = int(plens[i])
+        ppaths[pos:pos + L, 0] = lo + i
+        pos += L
+    rec = G.gather_records(D.summaries_to_tensor(summ, "cpu"))
+    all_len, all_paths = G.gather_paths(paths, lens)
+    prec = G.gather_records(D.summaries_to_tensor(psumm, "cpu"))
+    pall_len, pall_paths = G.gather_paths(ppaths, plens)
     ok = True
     seen = []
     for r in range(world):
         rlo, rhi = D.shard_range(E_total, r, world)
-        pos = 0
+        rs = D.tensor_to_summaries(rec[r], _lib.SUMMARY_DTYPE)
+        ps = D.tensor_to_summaries(prec[r], _prrt_lib.PRRT_SUMMARY_DTYPE)
+        ok &= len(rs) == rhi - rlo and len(ps) == rhi - rlo and len(all_len[r]) == rhi - rlo
+        pos = ppos = 0
         for i in range(rhi - rlo):
             e = rlo + i
-            s = allsumm[r, i]
-            ok &= int(s["best_leaf"]) == e and float(s["best_cost"][0]) == -(e + 0.5)
-            L = int(all_len[r, i])
+            ok &= int(rs[i]["best_leaf"]) == e and float(rs[i]["best_cost"][0]) == -(e + 0.5)
+            ok &= int(ps[i]["steps"]) == 100 + e and float(ps[i]["arc"][5]) == e + 0.25
+            L = int(all_len[r][i])
             ok &= L == 3 + (e % 5)
             seg = all_paths[r][pos:pos + L]
             ok &= bool((seg[:, 0] == e).all()) and bool((seg[:, 1] == torch.arange(L, dtype=torch.float64)).all())
             pos += L
+            PL = int(pall_len[r][i])
+            ok &= PL == ((2 + e % 3) if e % 2 else 0)
+            ok &= bool((pall_paths[r][ppos:ppos + PL, 0] == e).all())
+            ppos += PL
             seen.append(e)
-        ok &= pos == all_paths[r].shape[0]
+        ok &= pos == all_paths[r].shape[0] and ppos == pall_paths[r].shape[0]
     ok &= seen == list(range(E_total))
     q.put((rank, bool(ok)))
     dist.barrier()
@@ -80,11 +97,15 @@ def test_shard_range_partitions_everything():
             assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
 
 
-def test_two_rank_gather_gloo():
+import pytest
+
+
+@pytest.mark.parametrize("E_total", [11, 12, 1])  # uneven split, even split, one rank with nothing
+def test_two_rank_gather_gloo(E_total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 11, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, E_total, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -149,3 +149,31 @@ def test_replanning_matches_reference(name):
     # the caller's habitat list was mutated like the reference's (removeHabitat :604-610)
     assert [[h.x, h.y, h.size] for h in habitats] == g["habitats_left"].tolist()
     np.testing.assert_allclose([cost[0]] + list(cost[1]), g["cost"], rtol=0, atol=1e-6)
+
+
+def test_world_survives_replanning(orc):
+    """One RRT object: replanning(), then exploring() and check_collision() again.  The object's obstacles and
+    boundary must still be on the device (round-1 advisor finding: the final cost call of replanning used to
+    replace the world of the planner's own context): the second exploring equals the CPU checker run on the full
+    world, and a path through an obstacle is still reported as colliding."""
+    from auv_sim_amd.rrt_dubins import RRT
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    g = np.load(os.path.join(GOLDEN, "g13_replan_a.npz"))
+    obstacles, habitats, cell_list, shark, poly, start = _reference_style_inputs(g)
+    rrt = RRT(poly, obstacles, shark, cell_list)
+    random.seed(int(g["seed"]))
+    rrt.replanning(start, list(habitats), float(g["plan_time_budget"]), float(g["traj_time_length"]),
+                   float(g["replan_time_interval"]), [-3, -3, -4], max_iter=int(g["iters_per_round"][0]))
+    assert rrt._ctx.world_sizes["O"] == len(obstacles) and rrt._ctx.world_sizes["V"] == len(g["polygon"])
+    n_iter = 700
+    res = rrt.exploring(start, habitats, float(n_iter), 5, 2, 50, traj_time_stamp=True, max_plan_time=float(n_iter),
+                        max_traj_time=200.0, plan_time=True, weights=[-3, -3, -4], max_iter=n_iter, seed=11)
+    w = orc.WorldArrays(g["obstacles"], g["habitats"], g["polygon"], g["bins"], g["cells"], g["prob"])
+    r = orc.rrt_explore(w, 11, n_iter, init=[start.x, start.y, 0, 0, 0, 0], max_traj_time=200.0, kind="portable")
+    assert r["status"] == 0
+    assert [res["cost"][0]] + res["cost"][1] == r["best_cost"].tolist()
+    assert len(rrt.mps_list) == r["n_nodes"]
+    o = obstacles[0]
+    through = MPS(o.x, o.y)
+    through.path = [MPS(o.x - 1.0, o.y), MPS(o.x, o.y)]
+    assert rrt.check_collision(through) is False

@@ -51,6 +51,29 @@ def test_exploring_empty_world_and_tiny_budget(ctx, orc):
                 assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])  # no grid, no habitats: all zeros
 
 
+def test_exploring_without_boundary_polygon(ctx, orc):
+    """V = 0 (the Python default polygon=None): no point is within an empty boundary, so every expansion is
+    rejected -- the checker's answer -- and the kernel must return that instead of dividing by zero; the
+    collision probe says "not free" for any path; a 1- or 2-vertex boundary is an argument error."""
+    from auv_sim_amd import _lib, synth
+    world = synth.make_world(seed=3, n_obstacles=8)
+    ctx.set_world(world["obstacles"], world["habitats"], None, world["bins"], world["cells"], world["prob"])
+    w = orc.WorldArrays(world["obstacles"], world["habitats"], None, world["bins"], world["cells"], world["prob"])
+    init = np.zeros((2, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    summ = ctx.rrt_explore_batch(init, [1, 2], 50)
+    for e in range(2):
+        r = orc.rrt_explore(w, 1 + e, 50, init=init[e], kind="portable")
+        assert r["n_nodes"] == 1 and r["status"] == 1
+        s = summ[e]
+        assert s["status"] == r["status"] and s["n_nodes"] == 1 and s["iters_run"] == 50 and s["rng_after"] == r["rng_after"]
+    assert ctx.check_collision([[[0.0, 0.0], [1.0, 1.0]]])[0] == False  # noqa: E712
+    assert not orc.check_collision(w, [[0.0, 0.0], [1.0, 1.0]], kind="portable")
+    for bad in ([[0.0, 0.0]], [[0.0, 0.0], [1.0, 0.0]]):
+        with pytest.raises(_lib.AuvpError):
+            ctx.set_world(world["obstacles"], None, bad)
+
+
 def test_planner_chunked_steer_and_many_subsections(ctx, orc):
     from auv_sim_amd import synth
     from auv_sim_amd._prrt_lib import PlannerBatch

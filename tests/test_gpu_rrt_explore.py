@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, golden_world
 
 pytestmark = pytest.mark.gpu
 
@@ -124,7 +124,8 @@ def _args(g):
 @pytest.mark.parametrize("path", G3, ids=[os.path.basename(p)[:-4] for p in G3])
 def test_exploring_vs_golden_and_oracle(ctx, orc, path):
     g = np.load(path)
-    ctx.set_world(g["obstacles"], g["habitats"], g["polygon"], g["bins"], g["cells"], g["prob"])
+    gw = golden_world(g)
+    ctx.set_world(gw["obstacles"], gw["habitats"], gw["polygon"], gw["bins"], gw["cells"], gw["prob"])
     init = np.array([[g["start"][0], g["start"][1], 0, 0, 0, 0]], dtype=np.float64)
     n_iter = int(g["n_iter"])
     summ = ctx.rrt_explore_batch(init, [int(g["seed"])], n_iter, iter_log=True, leaf_log=True, **_args(g))
@@ -156,7 +157,7 @@ def test_exploring_vs_golden_and_oracle(ctx, orc, path):
         bs = ctx.bin_sizes(0)
         assert np.array_equal(bs, g["bin_sizes"][:len(bs)])
     # ---- against the CPU checker built with the same portable math: bit-for-bit
-    w = orc.WorldArrays(g["obstacles"], g["habitats"], g["polygon"], g["bins"], g["cells"], g["prob"])
+    w = orc.WorldArrays(gw["obstacles"], gw["habitats"], gw["polygon"], gw["bins"], gw["cells"], gw["prob"])
     r = orc.rrt_explore(w, int(g["seed"]), n_iter, init=init[0], kind="portable", **_args(g))
     assert np.array_equal(t["nodes"], r["nodes"])
     assert np.array_equal(t["points"], r["points"])

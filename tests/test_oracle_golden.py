@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, libm_matches_golden
+from conftest import GOLDEN, golden_world, libm_matches_golden
 
 
 def test_rng_known_answers(orc):
@@ -75,7 +75,8 @@ G3 = sorted(glob.glob(os.path.join(GOLDEN, "g3_*.npz")))
 
 
 def _run(orc, g, kind):
-    w = orc.WorldArrays(g["obstacles"], g["habitats"], g["polygon"], g["bins"], g["cells"], g["prob"])
+    gw = golden_world(g)
+    w = orc.WorldArrays(gw["obstacles"], gw["habitats"], gw["polygon"], gw["bins"], gw["cells"], gw["prob"])
     init = [g["start"][0], g["start"][1], 0, 0, 0, 0]
     return orc.rrt_explore(w, int(g["seed"]), int(g["n_iter"]), str(g["mode"]), init=init,
                            freq=int(g["freq"]), bin_interval=int(g["bin_interval"]), v=int(g["v"]),
