@@ -37,6 +37,7 @@ def _bind():
     L.auvp_prrt_tree.argtypes = [vp, C.c_int32, _dp, _ip, _ip, _dp]
     L.auvp_prrt_grid.argtypes = [vp, C.c_int32, _ip, _ip, _ip]
     L.auvp_prrt_node.argtypes = [vp, C.c_int32, C.c_int32, _dp, _ip, _ip, _dp, C.c_int32]
+    L.auvp_prrt_replan_particles.argtypes = [vp, _dp, C.POINTER(PrrtParams), _dp, _dp, C.c_uint64, C.c_int32]
     L.auvp_prrt_step_log.argtypes = [vp, C.c_int32, _ip]
     L.auvp_prrt_summaries_dev.argtypes = [vp]
     L.auvp_prrt_summaries_dev.restype = C.c_void_p
@@ -76,9 +77,39 @@ class PlannerBatch:
                                                words.ctypes.data_as(C.POINTER(C.c_uint32)), _lib._p(idx, _ip), flags)
         ctx._chk(rc)
 
+    @classmethod
+    def from_particles(cls, ctx, n_episodes, start, rect, max_step, xform, clamp, seed_base, freq=50, cell=2, subs=8,
+                       exp_rate=1, dist_to_end=2, diff_max=0.5, step_log=False):
+        """One episode per particle of the filter batch resident on `ctx` (auvp_prrt_replan_particles): goals are read
+        from the particle state on the device, generators are seeded there as random.seed(seed_base + e)."""
+        self = cls.__new__(cls)
+        self.ctx, self.L, self.E = ctx, _bind(), int(n_episodes)
+        p = PrrtParams()
+        for i in range(4):
+            p.rect[i] = float(rect[i])
+        p.exp_rate, p.dist_to_end, p.diff_max, p.freq = float(exp_rate), float(dist_to_end), float(diff_max), float(freq)
+        p.cell_side_length, p.subsections, p.max_step = float(cell), int(subs), int(max_step)
+        self.max_step = int(max_step)
+        self.rows = int(rect[3] - rect[1]) // int(cell)
+        self.cols = int(rect[2] - rect[0]) // int(cell)
+        self.subs = int(subs)
+        st = _lib._f64((list(start) + [0.0] * 4)[:4])
+        xf = _lib._f64(xform, (-1, 4))
+        cl = _lib._f64(clamp, (4,))
+        ctx._chk(self.L.auvp_prrt_replan_particles(ctx.h, _lib._p(st), C.byref(p), _lib._p(xf), _lib._p(cl), int(seed_base),
+                                                   _lib.FLAG_ITER_LOG if step_log else 0))
+        return self
+
     def plan(self):
         self.ctx._chk(self.L.auvp_prrt_plan(self.ctx.h))
         return self.summaries()
+
+    def goals(self):
+        """the goals of the resident batch (read back from the device)"""
+        out = np.zeros((self.E, 2))
+        self.L.auvp_prrt_goals.argtypes = [C.c_void_p, _dp]
+        self.ctx._chk(self.L.auvp_prrt_goals(self.ctx.h, _lib._p(out)))
+        return out
 
     def step(self, bucket_ids, mt_states=None):
         b = np.ascontiguousarray(np.asarray(bucket_ids, dtype=np.int32).reshape(self.E))

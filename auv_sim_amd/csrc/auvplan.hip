@@ -693,4 +693,5 @@ PrrtState* prrt_of(auvp_handle* h) {
 #include "sog_kernels.h"
 #include "pf_kernel.h"
 #include "pf_host.h"
+#include "compose_host.h"
 #include "gather_host.h"

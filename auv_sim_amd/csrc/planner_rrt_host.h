@@ -52,17 +52,14 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode) {
 
 extern "C" {
 
-int auvp_prrt_create_batch(auvp_handle* h, int32_t E, const double* starts, const double* goals,
-                           const auvp_prrt_params* p, const uint64_t* seeds, const uint32_t* mt, const int32_t* mt_index,
-                           int32_t flags) {
-  if (!h) return AUVP_ERR_ARG;
+// parameters + buffers of a batch of E episodes (everything of auvp_prrt_create_batch that does not depend on where
+// the starts, goals and generator states come from)
+static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_prrt_params* p, int32_t flags) {
   if (!h->have_world) return fail(h, AUVP_ERR_STATE, "auvp_world_set not called (obstacle list)");
-  if (E <= 0 || !starts || !goals || !p || (!seeds && !(mt && mt_index))) return fail(h, AUVP_ERR_ARG, "bad batch arguments");
+  if (E <= 0 || !p) return fail(h, AUVP_ERR_ARG, "bad batch arguments");
   if (h->W.n_obstacles > 16 * 64) return fail(h, AUVP_ERR_ARG, "n_obstacles %d > 1024", h->W.n_obstacles);
   const int ics = (int)p->cell_side_length;
   if (ics <= 0 || p->subsections <= 0 || p->max_step <= 0 || !(p->freq >= 0)) return fail(h, AUVP_ERR_ARG, "bad params");
-  HIPCHK(h, hipSetDevice(h->device));
-  PrrtState& S = *prrt_of(h);
   S.ready = false;
   auvp::PrrtParamsDev& P = S.P;
   for (int i = 0; i < 4; i++) P.rect[i] = p->rect[i];
@@ -96,20 +93,45 @@ int auvp_prrt_create_batch(auvp_handle* h, int32_t E, const double* starts, cons
   HIPCHK(h, S.rng_state.reserve((size_t)E * 4 * sizeof(int32_t)));
   HIPCHK(h, S.summary.reserve((size_t)E * sizeof(auvp::PrrtSummary)));
   HIPCHK(h, S.step_bucket.reserve((size_t)E * sizeof(int32_t)));
+  HIPCHK(h, S.start.reserve((size_t)E * 4 * sizeof(double)));
+  HIPCHK(h, S.goal.reserve((size_t)E * 2 * sizeof(double)));
   B.node_f = S.node_f.as<double>(); B.node_i = S.node_i.as<int32_t>(); B.node_bucket = S.node_bucket.as<int32_t>();
   B.points = S.points.as<double>(); B.occupied = S.occupied.as<int32_t>(); B.bucket_counts = S.bcount.as<int32_t>();
   B.mt = S.mt.as<uint32_t>(); B.rng_state = S.rng_state.as<int32_t>(); B.summary = S.summary.as<auvp::PrrtSummary>();
   B.step_bucket = S.step_bucket.as<int32_t>();
+  B.start = S.start.as<double>(); B.goal = S.goal.as<double>();
   B.st_log = nullptr;
   if (flags & AUVP_FLAG_ITER_LOG) {
     HIPCHK(h, S.st_log.reserve((size_t)E * p->max_step * 8 * sizeof(int32_t)));
     HIPCHK(h, hipMemsetAsync(S.st_log.p, 0xff, (size_t)E * p->max_step * 8 * sizeof(int32_t), h->stream));
     B.st_log = S.st_log.as<int32_t>();
   }
+  return AUVP_OK;
+}
+
+// mps_list = [start]; add_node_to_grid(start)  (:53,:108-159): one thread per episode places the start node with the
+// kernel's own add_node_to_grid arithmetic (starts / goals / generator states are already on the device)
+static int prrt_plant(auvp_handle* h, PrrtState& S, int32_t E) {
+  HIPCHK(h, hipMemsetAsync(S.bcount.p, 0, (size_t)E * S.P.n_buckets * sizeof(int32_t), h->stream));
+  hipLaunchKernelGGL(auvp::prrt_init_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, S.P, S.B, (int)E);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  S.E = E;
+  S.ready = true;
+  return AUVP_OK;
+}
+
+int auvp_prrt_create_batch(auvp_handle* h, int32_t E, const double* starts, const double* goals,
+                           const auvp_prrt_params* p, const uint64_t* seeds, const uint32_t* mt, const int32_t* mt_index,
+                           int32_t flags) {
+  if (!h) return AUVP_ERR_ARG;
+  if (E <= 0 || !starts || !goals || !p || (!seeds && !(mt && mt_index))) return fail(h, AUVP_ERR_ARG, "bad batch arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  PrrtState& S = *prrt_of(h);
   int rc;
+  if ((rc = prrt_configure(h, S, E, p, flags))) return rc;
   if ((rc = upload(h, S.start, starts, (size_t)E * 4))) return rc;
   if ((rc = upload(h, S.goal, goals, (size_t)E * 2))) return rc;
-  B.start = S.start.as<double>(); B.goal = S.goal.as<double>();
   // generator states
   std::vector<uint32_t> words((size_t)E * 624);
   std::vector<int32_t> rs((size_t)E * 4, 0);
@@ -124,15 +146,7 @@ int auvp_prrt_create_batch(auvp_handle* h, int32_t E, const double* starts, cons
   }
   if ((rc = upload(h, S.mt, words.data(), words.size()))) return rc;
   if ((rc = upload(h, S.rng_state, rs.data(), rs.size()))) return rc;
-  // mps_list = [start]; add_node_to_grid(start)  (:53,:108-159) -- done on the host, same arithmetic
-  HIPCHK(h, hipMemsetAsync(S.bcount.p, 0, (size_t)E * P.n_buckets * sizeof(int32_t), h->stream));
-  // one thread per episode places the start node with the kernel's own add_node_to_grid arithmetic
-  hipLaunchKernelGGL(auvp::prrt_init_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, P, B, (int)E);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
-  S.E = E;
-  S.ready = true;
-  return AUVP_OK;
+  return prrt_plant(h, S, E);
 }
 
 int auvp_prrt_plan(auvp_handle* h) {
@@ -170,6 +184,15 @@ int auvp_prrt_summaries(auvp_handle* h, auvp_prrt_summary* out) {
   if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipMemcpy(out, S.B.summary, (size_t)S.E * sizeof(auvp::PrrtSummary), hipMemcpyDeviceToHost));
+  return AUVP_OK;
+}
+
+int auvp_prrt_goals(auvp_handle* h, double* goals2) {
+  if (!h || !goals2) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(goals2, S.B.goal, (size_t)S.E * 2 * sizeof(double), hipMemcpyDeviceToHost));
   return AUVP_OK;
 }
 

@@ -626,6 +626,60 @@ __global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuf
   B.summary[e] = s;
 }
 
+// Config 5 glue: particle (f, p) of a filter batch -> Planner_RRT episode f * N + p.
+//   goal  = clamp(particle.xy * scale_f + offset_f) into a rectangle (filter f's shark frame mapped into the planner's
+//           workspace; the clamp keeps a stray hypothesis inside the boundary)
+//   start = one shared AUV state
+//   generator = CPython random.seed(seed_base + e): init_by_array over the 32-bit limbs of the seed (the same
+//           arithmetic as seed_mt() on the host), one thread per episode
+struct PrrtGoalMap {
+  double start[4];
+  const double* xform;  // [F][4] per filter: gx = x * xform[0] + xform[1];  gy = y * xform[2] + xform[3]
+  double clamp[4];  // x0, y0, x1, y1
+  unsigned long long seed_base;
+  int32_t n_filters, n_particles;
+};
+
+__device__ inline void mt_seed_by_array(unsigned long long seed, uint32_t* mt) {
+  const uint32_t key[2] = {(uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)};
+  const int klen = key[1] ? 2 : 1;
+  mt[0] = 19650218u;
+  for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  int i = 1, j = 0;
+  for (int k = 624; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+    i++; j++;
+    if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    if (j >= klen) j = 0;
+  }
+  for (int k = 623; k; k--) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+    i++;
+    if (i >= 624) { mt[0] = mt[623]; i = 1; }
+  }
+  mt[0] = 0x80000000u;
+}
+
+__global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, PrrtGoalMap M, const double* __restrict__ pf_state,
+                                                                 int n_episodes) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_episodes) return;
+  const int f = e / M.n_particles, p = e - f * M.n_particles;
+  const double* st = pf_state + (size_t)f * 5 * M.n_particles;  // SoA [F][5][N]: x, y, ...
+  const double* xf = M.xform + 4 * (size_t)f;
+  double gx = st[p] * xf[0] + xf[1];
+  double gy = st[(size_t)M.n_particles + p] * xf[2] + xf[3];
+  gx = gx < M.clamp[0] ? M.clamp[0] : (gx > M.clamp[2] ? M.clamp[2] : gx);
+  gy = gy < M.clamp[1] ? M.clamp[1] : (gy > M.clamp[3] ? M.clamp[3] : gy);
+  double* g = const_cast<double*>(B.goal) + 2 * (size_t)e;
+  g[0] = gx; g[1] = gy;
+  double* s = const_cast<double*>(B.start) + 4 * (size_t)e;
+  s[0] = M.start[0]; s[1] = M.start[1]; s[2] = M.start[2]; s[3] = M.start[3];
+  mt_seed_by_array(M.seed_base + (unsigned long long)e, B.mt + (size_t)e * 624);
+  int32_t* rs = B.rng_state + 4 * (size_t)e;
+  rs[0] = 0; rs[1] = 0; rs[2] = 0; rs[3] = 0;  // a freshly seeded generator: nothing generated yet
+}
+
 // RRTEnv's per-step observation arrays (gym_rrt/envs/rrt_env.py:250-295), elementwise over
 // (episode, bucket): [cell.x, cell.y, subsection.theta, len(node_array)], has_node, node counts.
 // The reference rebuilds these three O(#buckets) Python lists after every node.

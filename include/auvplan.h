@@ -142,6 +142,8 @@ int auvp_prrt_plan(auvp_handle* h);
  * continue that generator for this step (the caller's global `random` state) */
 int auvp_prrt_step(auvp_handle* h, const int32_t* bucket_ids, const uint32_t* mt, const int32_t* mt_index);
 int auvp_prrt_summaries(auvp_handle* h, auvp_prrt_summary* out /* [E] */);
+/* the goals of the resident batch, [E,2] (self.goal of every Planner_RRT, :40) */
+int auvp_prrt_goals(auvp_handle* h, double* goals2);
 /* generate_final_course(final_node) (:317-327) in planning()'s return order (goal end first);
  * offsets [E+1] prefix sums of path_len; out [offsets[E],5] = x,y,theta,traj_time_stamp,length */
 int auvp_prrt_paths(auvp_handle* h, const int64_t* offsets, double* out);
@@ -279,6 +281,16 @@ int auvp_rrt_phase_clocks(auvp_handle* h, uint64_t* out);
 /* HIP-event time (ms) of the last batch kernel on the handle's stream, and its launch geometry */
 double auvp_last_kernel_ms(auvp_handle* h);
 int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds_bytes);
+
+/* Config 5 composition (BASELINE.json configs[4]): the particle filter of particleFilter.py:283-317 feeding one
+ * Planner_RRT replan per particle (gym_rrt/envs/rrt_dubins.py:162-248), without leaving the device.
+ * Needs a filter batch on this handle (auvp_pf_create_batch / auvp_pf_run).  Episode e = f * N + p plans from the
+ * shared start4 (x, y, theta, traj_time_stamp) to goal = clamp(particle(f, p).xy * scale_f + offset_f):
+ *   xform [F,4] = sx, ox, sy, oy per filter (gx = x * sx + ox, gy = y * sy + oy);   clamp4 = x0, y0, x1, y1
+ * with the generator of random.seed(seed_base + e), seeded on the device.  Replaces Planner_RRT.__init__ per
+ * particle; follow with auvp_prrt_plan() and the auvp_prrt_* readers. */
+int auvp_prrt_replan_particles(auvp_handle* h, const double* start4, const auvp_prrt_params* params, const double* xform,
+                               const double* clamp4, uint64_t seed_base, int32_t flags);
 
 /* ---------------------------------------------------------------------------------------------------
  * Multi-GPU result gather (SURVEY.md 8(b) "auvp_gather(comm...)", 8(e)).  The reference is single-process;
