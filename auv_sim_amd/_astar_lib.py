@@ -15,7 +15,8 @@ class AstarParams(C.Structure):
 
 
 ASTAR_SUMMARY_DTYPE = np.dtype([(n, "<i4") for n in ("status", "found", "n_nodes", "n_expansions", "n_children", "path_len",
-                                                     "smooth_len", "n_hab_left", "visited_count", "leaf", "_p0", "_p1")])
+                                                     "smooth_len", "n_hab_left", "visited_count", "leaf")] +
+                               [("open_scanned", "<u8")])
 _bound = False
 
 
@@ -34,6 +35,36 @@ def _bind():
     L.auvp_astar_get_visited.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint8)]
     _bound = True
     return L
+
+
+def run_batch_arrays(ctx, variant, starts, goals=None, limits=None, box=(0, 0, 0, 0), velocity=1.0, weights=(0, 0, 0, 0),
+                     cap_nodes=20000):
+    """E searches in one launch + one path-extraction launch; results as arrays (no per-instance Python work):
+    summaries [E], offsets [E+1] and the concatenated path / cost_list / node_path / smooth_path rows."""
+    L = _bind()
+    starts = _lib._f64(starts, (-1, 2))
+    E = len(starts)
+    p = AstarParams()
+    p.variant, p.cap_nodes, p.velocity = VARIANTS[variant], int(cap_nodes), float(velocity)
+    wts = list(weights) + [0.0] * (4 - len(weights))
+    for i in range(4):
+        p.box[i] = float(box[i])
+        p.w[i] = float(wts[i])
+    g = _lib._f64(goals, (-1, 2)) if goals is not None else None
+    lim = _lib._f64(limits).reshape(E) if limits is not None else None
+    ctx._chk(L.auvp_astar_batch(ctx.h, E, _lib._p(starts), _lib._p(g) if g is not None else None,
+                                _lib._p(lim) if lim is not None else None, C.byref(p), 0))
+    batch_ms = ctx.last_kernel_ms()
+    summ = np.zeros(E, dtype=ASTAR_SUMMARY_DTYPE)
+    ctx._chk(L.auvp_astar_summaries(ctx.h, summ.ctypes.data_as(C.c_void_p)))
+    lens = np.where(summ["found"] != 0, summ["path_len"], 0).astype(np.int64)
+    off = np.zeros(E + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    n = max(int(off[-1]), 1)
+    path, cost, npath, smooth = np.zeros((n, 3)), np.zeros(n), np.zeros((n, 8)), np.zeros((n, 3))
+    ctx._chk(L.auvp_astar_paths(ctx.h, off.ctypes.data_as(C.POINTER(C.c_int64)), _lib._p(path), _lib._p(cost), _lib._p(npath),
+                                _lib._p(smooth)))
+    return dict(summ=summ, off=off, path=path, cost_list=cost, node_path=npath, smooth_path=smooth, batch_ms=batch_ms)
 
 
 def run_batch(ctx, variant, starts, goals=None, limits=None, box=(0, 0, 0, 0), velocity=1.0, weights=(0, 0, 0, 0),

@@ -32,12 +32,12 @@ class RRTParams(C.Structure):
 class RRTSummary(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_nodes", C.c_int32), ("n_points", C.c_int32),
                 ("n_leaves", C.c_int32), ("best_leaf", C.c_int32), ("best_path_len", C.c_int32),
-                ("iters_run", C.c_int32), ("_pad", C.c_int32), ("best_cost", C.c_double * 4),
+                ("iters_run", C.c_int32), ("n_candidates", C.c_int32), ("best_cost", C.c_double * 4),
                 ("best_length", C.c_double), ("rng_after", C.c_double), ("leaf_elems", C.c_int64), ("n_draw32", C.c_uint64)]
 
 
 SUMMARY_DTYPE = np.dtype([("status", "<i4"), ("n_nodes", "<i4"), ("n_points", "<i4"), ("n_leaves", "<i4"),
-                          ("best_leaf", "<i4"), ("best_path_len", "<i4"), ("iters_run", "<i4"), ("_pad", "<i4"),
+                          ("best_leaf", "<i4"), ("best_path_len", "<i4"), ("iters_run", "<i4"), ("n_candidates", "<i4"),
                           ("best_cost", "<f8", (4,)), ("best_length", "<f8"), ("rng_after", "<f8"), ("leaf_elems", "<i8"), ("n_draw32", "<u8")])
 assert SUMMARY_DTYPE.itemsize == C.sizeof(RRTSummary)
 

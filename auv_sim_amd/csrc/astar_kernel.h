@@ -51,7 +51,8 @@ struct AstarParamsDev {
 };
 
 struct AstarSummary {  // must match auvp_astar_summary
-  int32_t status, found, n_nodes, n_expansions, n_children, path_len, smooth_len, n_hab_left, visited_count, leaf, _p0, _p1;
+  int32_t status, found, n_nodes, n_expansions, n_children, path_len, smooth_len, n_hab_left, visited_count, leaf;
+  uint32_t open_scanned_lo, open_scanned_hi;  // sum over pops of len(open_list): entries the reference's min-f scan reads
 };
 
 struct AstarBuffers {
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   }
   wave_sync();
   int n_nodes = 1, n_open = 1, n_exp = 0, n_children = 0, status = 0, found = -1, visited_count = 0;
+  unsigned long long open_scanned = 0ull;
   int first_open = 0;  // every node below this index is closed
   double* of_l = s_of[wave];
   int32_t* oi_l = s_oi[wave];
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       wave_sync();
     }
     if (lane == 0) nopen[cur] = 0;
+    open_scanned += (unsigned long long)n_open;
     n_open--;
     if (cur == first_open) first_open++;
     const double cxp = readfirst_f64(nx[cur]), cyp = readfirst_f64(ny[cur]);
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     int L = 0;
     for (int m = found; m >= 0; m = npar[m]) L++;
     s.path_len = L; s.smooth_len = 0; s.n_hab_left = n_hopen; s.visited_count = visited_count; s.leaf = found;
-    s._p0 = 0; s._p1 = 0;
+    s.open_scanned_lo = (uint32_t)(open_scanned & 0xffffffffull); s.open_scanned_hi = (uint32_t)(open_scanned >> 32);
   }
 }
 

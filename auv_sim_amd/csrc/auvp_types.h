@@ -56,7 +56,7 @@ struct RrtParamsDev {
 };
 
 struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h
-  int32_t status, n_nodes, n_points, n_leaves, best_leaf, best_path_len, iters_run, _pad;
+  int32_t status, n_nodes, n_points, n_leaves, best_leaf, best_path_len, iters_run, n_candidates;
   double best_cost[4];
   double best_length;
   double rng_after;

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   int n_nodes = 1, n_points = 0, n_leaves = 0, status = 0, best_leaf = -1, best_L = 0;
   double best_tot = __builtin_inf();
   long long leaf_elems = 0;
-  int it = 0;
+  int it = 0, n_cand = 0;  // n_cand: obstacles that survived the cull (exact tests run), whole episode
   // optional per-phase shader-clock accounting (AUVP_FLAG_PHASE_CLOCKS): select, steer, collision,
   // accept, cost walk
   const bool clk = DIAG && (P.flags & 4) != 0;
@@ -627,6 +627,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = (double)olr[j * 64 + lane];
       const bool cand = !(auvp_fabs(oxj - cxm) > hx + orj || auvp_fabs(oyj - cym) > hy + orj);
       unsigned long long cm = __ballot(cand);
+      n_cand += __popcll(cm);
       while (cm) {
         const int idx = uni(j * 64 + (__ffsll((long long)cm) - 1));
         cm &= cm - 1ull;
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     RrtSummary& s = B.summary[ep];
     if (status == 0 && best_leaf < 0) status = 1;
     s.status = status; s.n_nodes = n_nodes; s.n_points = n_points; s.n_leaves = n_leaves;
-    s.best_leaf = best_leaf; s.best_path_len = best_L; s.iters_run = it; s._pad = 0;
+    s.best_leaf = best_leaf; s.best_path_len = best_L; s.iters_run = it; s.n_candidates = n_cand;
     if (best_leaf < 0) {
       s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;
       s.best_length = 0.0;

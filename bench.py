@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- RRT-Dubins node expansions/s on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path over one batch of synthetic input: E independent
-RRT.exploring episodes (path_planning/rrt_dubins.py:92) x `--iters` expansions each, on the
-256-obstacle 200x200-cell Catalina-like grid of SURVEY.md 8(d) config 2, followed by the extraction
-of every episode's best path and -- for N > 1 -- the RCCL gather of the result records.  Inputs
-(world tables, start states, seeded MT19937 states) are resident in HBM before the timed region.
+A "step" is one pass of the hot path over one batch of synthetic input: E independent RRT.exploring episodes
+(path_planning/rrt_dubins.py:92) x `--iters` expansions each, on the 256-obstacle 200x200-cell Catalina-like grid of
+SURVEY.md 8(d) config 2, followed by the extraction of every episode's best path and -- for N > 1 -- the RCCL gather
+of the result records (libauvplan.so's own auvp_gather entry points, on the planner's HIP stream).  Inputs (world
+tables, start states, seeded MT19937 states) are resident in HBM before the timed region.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: spawns its own N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  value = expansions of ALL ranks / max-over-ranks time.
+Rank 0 prints ONE JSON line.  value = expansions of ALL ranks / max-over-ranks time.  The other configurations of
+BASELINE.json ride along as side measurements in the same line (each with its own step time, kernel time, roofline
+and -- at N = 1 -- CPU baseline); for N > 1 the A* batch (config 3) and the Planner_RRT batch (config 4) are sharded
+over the ranks like the headline and gathered the same way.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,11 +30,15 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+REF_TIMING = os.path.join(REPO, "profiles", "r2_reference_timing.json")
+PMC_FILE = os.path.join(REPO, "profiles", "pmc_latest.json")
 
 
-def algorithmic_bytes(summ, n_iter):
-    """SURVEY.md 8(d) B_exp, evaluated with the launch's own counts (not an estimate):
-    48 parent read + 4 bin-index read per expansion; 52 node write + 8 bin append per accepted node;
+# ----------------------------------------------------------------------------------------------------------------
+# algorithmic bytes, always from the launch's own counters
+# ----------------------------------------------------------------------------------------------------------------
+def rrt_bytes(summ):
+    """B_exp: 48 parent read + 4 bin-index read per expansion; 52 node write + 8 bin append per accepted node;
     56 per stored path point; (24 + 8) per path element walked by the cost function."""
     iters = float(summ["iters_run"].sum())
     nodes = float((summ["n_nodes"] - 1).sum())
@@ -38,9 +47,72 @@ def algorithmic_bytes(summ, n_iter):
     return iters * (48 + 4) + nodes * (52 + 8) + pts * 56 + walked * (24 + 8)
 
 
+def planner_bytes(summ):
+    """Planner_RRT step: 48 parent read + 4 bucket-index read per step; 52 node write + 8 bucket append per accepted
+    node; 56 per stored path point (goal-arc points are transient)."""
+    steps = float(summ["steps"].sum())
+    nodes = float((summ["n_nodes"] - 1).sum())
+    pts = float(summ["n_points"].sum())
+    return steps * (48 + 4) + nodes * (52 + 8) + pts * 56
+
+
+def astar_bytes(summ, variant):
+    """per child cell: node write 68 (44 for astar.py) + visited flag 1 + SOG 16 (cell prob + top-n prefix); per pop:
+    8 bytes per open-list entry the min-f scan reads (sum of len(open_list) over the pops, counted by the kernel)."""
+    cells = float(summ["n_children"].sum())
+    scanned = float(summ["open_scanned"].sum())
+    per_cell = {"astar": 44.0, "astar_real": 44.0, "astar_fixLen": 69.0, "astar_fixLenSOG": 85.0}[variant]
+    return cells * per_cell + scanned * 8.0
+
+
+def roofline(abytes, k_ms, kernel, traffic=None, **extra):
+    ach = abytes / (k_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": traffic, "kernel": kernel, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes}
+    r.update(extra)
+    return r
+
+
+def pmc_traffic(kernel_key, units_now, units_key="units"):
+    """HBM bytes per launch of `kernel_key` from the committed PMC passes (tools/profile_bench.sh -> profiles/pmc_latest.json,
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled as the microarchitecture guide prescribes for
+    gfx950), scaled by the work units when this run's batch differs from the profiled one."""
+    try:
+        pj = json.load(open(PMC_FILE))["kernels"][kernel_key]
+        t = float(pj["hbm_bytes_per_launch"])
+        src = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % json.load(open(PMC_FILE)).get("tag", "?")
+        u0 = float(pj.get(units_key, 0.0))
+        if u0 > 0 and units_now and abs(u0 - units_now) > 0.5:
+            t *= units_now / u0
+            src += ", scaled x%.3f by work units" % (units_now / u0)
+        return t, src
+    except Exception:
+        return None, None
+
+
+def recorded_reference(key):
+    """the reference Python's own timing on this workload, RECORDED in the build container (tests/experiments/ref_timing.py,
+    profiles/r2_reference_timing.json) -- the reference cannot run on the GPU box"""
+    try:
+        return json.load(open(REF_TIMING)).get(key)
+    except Exception:
+        return None
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# worlds
+# ----------------------------------------------------------------------------------------------------------------
+def bench_world(obstacles, grid):
+    from auv_sim_amd import synth
+    half = 0.5 * grid * 10.0
+    return synth.make_world(seed=2, n_obstacles=obstacles, box=(-half, -half, half, half), cell=10.0, n_bins=10, bin_len=50,
+                            n_habitats=10)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baselines (the checker under oracle/, libm build = the restatement pinned to the reference goldens)
+# ----------------------------------------------------------------------------------------------------------------
 def cpu_baseline(world, n_iter, args):
-    """The CPU checker (oracle/, libm build = the restatement pinned to the reference goldens) timed
-    on ONE host core over a bounded sample of the same workload."""
     from oracle import orc
     orc.build()
     w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
@@ -53,13 +125,20 @@ def cpu_baseline(world, n_iter, args):
         t_used += time.perf_counter() - t0
         done += r["iters_run"]
         eps += 1
-    return {"value": done / t_used, "unit": "expansions/s", "cores": 1, "kind": "port",
-            "sample": "%d episodes x %d iterations of the same workload (seeds 0..%d), oracle/ libm build, %.1f s"
-                      % (eps, n_iter, eps - 1, t_used)}
+    out = {"value": done / t_used, "unit": "expansions/s", "cores": 1, "kind": "port",
+           "sample": "%d episodes x %d iterations of the same workload (seeds 0..%d), oracle/ libm build, %.1f s"
+                     % (eps, n_iter, eps - 1, t_used)}
+    ref = recorded_reference("config2_rrt_exploring_o%d" % args.obstacles)
+    if ref:
+        out["reference_recorded"] = {
+            "value": ref["ref_expansions_per_s_1proc"], "unit": "expansions/s", "cores": 1, "kind": "reference",
+            "where": "build container (8 vCPU Xeon 2.1 GHz), NOT this box; tests/experiments/ref_timing.py",
+            "many_cores": {k: v for k, v in ref.items() if k.startswith("ref_expansions_per_s_") and k.endswith("proc")},
+            "port_over_reference_same_container": ref.get("port_over_ref")}
+    return out
 
 
 def _cpu_episode(job):
-    """pool worker: one oracle episode (runs in a forked child that never touches the GPU)"""
     world, seed, n_iter, mode = job
     from oracle import orc
     w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
@@ -68,15 +147,14 @@ def _cpu_episode(job):
 
 
 def cpu_baseline_all_cores(world, n_iter, args):
-    """the same CPU checker on ALL host cores, one episode per core (episodes are the natural
-    parallel unit on the CPU too).  Must be called before this process initialises HIP (it forks)."""
+    """the same checker on ALL usable host cores, one episode per core.  Forks: must precede any HIP initialisation."""
     import multiprocessing as mp
     from oracle import orc
     orc.build()
     cores, how = effective_cores()
     jobs = [(world, 1000 + s, n_iter, args.mode) for s in range(cores)]
     with mp.get_context("fork").Pool(cores) as pool:
-        pool.map(_cpu_episode, [(world, 0, 10, args.mode)] * cores, chunksize=1)  # start the workers, load the library
+        pool.map(_cpu_episode, [(world, 0, 10, args.mode)] * cores, chunksize=1)
         t0 = time.perf_counter()
         done = sum(pool.map(_cpu_episode, jobs, chunksize=1))
         dt = time.perf_counter() - t0
@@ -86,8 +164,6 @@ def cpu_baseline_all_cores(world, n_iter, args):
 
 
 def effective_cores(cap=64):
-    """cores this process may actually use: scheduler affinity, clipped by the cgroup CPU quota, capped so the
-    bounded sample stays bounded"""
     n, how = len(os.sched_getaffinity(0)), "sched_getaffinity"
     try:
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -106,14 +182,111 @@ def effective_cores(cap=64):
     return n, how
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# distributed plumbing
+# ----------------------------------------------------------------------------------------------------------------
+class Ranks:
+    """rank bookkeeping + the result gather.  N = 1: everything is a no-op."""
+
+    def __init__(self, ctx, rank, world, dev):
+        self.ctx, self.rank, self.world, self.dev = ctx, rank, world, dev
+        self.gather, self.gather_note = None, None
+        if world > 1:
+            import torch.distributed as dist
+            from auv_sim_amd import distributed as D
+
+            def exchange(mine):
+                box = [mine]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            try:
+                self.gather = D.RcclGather(ctx, rank, world, exchange)
+            except Exception as e:  # RCCL entry points unusable here: keep measuring with torch.distributed's all-gather
+                self.gather_note = "auvp_gather unavailable (%s)" % e
+            import torch
+            flag = torch.tensor([0 if self.gather is not None else 1], device=dev)
+            dist.all_reduce(flag)
+            if int(flag.item()) != 0:  # every rank uses the same transport
+                if self.gather is not None:
+                    self.gather.close()
+                self.gather = D.TorchGather()
+
+    def sync(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_time(self, dt):
+        if self.world == 1:
+            return dt
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, v):
+        if self.world == 1:
+            return float(v)
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([float(v)], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t)
+        return float(t.item())
+
+    def all(self, obj):
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def gather_records(self, ptr, n, itemsize):
+        """all ranks' fixed-stride records, read straight from the planner's device buffer"""
+        if self.world == 1:
+            return None
+        from auv_sim_amd import distributed as D
+        return self.gather.gather_records(D.device_records(ptr, n, itemsize, self.dev))
+
+    def gather_host_records(self, arr):
+        if self.world == 1:
+            return None
+        from auv_sim_amd import distributed as D
+        return self.gather.gather_records(D.summaries_to_tensor(arr, self.dev))
+
+    def gather_ms(self):
+        return self.gather.take_ms() if self.gather is not None else None
+
+
+def timed_steps(ranks, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    ranks.sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        last = step()
+    ranks.sync()
+    return ranks.max_time(time.perf_counter() - t0), last
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# side measurements
+# ----------------------------------------------------------------------------------------------------------------
+RRT_KW = dict(freq=30, bin_interval=5, v=2, max_traj_time=500.0, weights=(-3, -3, -4))
+
+
 def bench_single_episode(ctx, world, args, reps=3):
     """SURVEY 8(d) config 2 latency test: ONE episode on one GPU (a serial chain: one wavefront busy)."""
     init = np.zeros((1, 6))
     init[0, 0], init[0, 1] = world["start"]
     ms = []
     for i in range(reps + 1):
-        summ = ctx.rrt_explore_batch(init, np.array([7], dtype=np.uint64), args.iters, mode=args.mode, freq=30, bin_interval=5,
-                                     v=2, max_traj_time=500.0, weights=(-3, -3, -4))
+        summ = ctx.rrt_explore_batch(init, np.array([7], dtype=np.uint64), args.iters, mode=args.mode, **RRT_KW)
         if i:
             ms.append(ctx.last_kernel_ms())
     k_ms = float(np.mean(ms))
@@ -121,155 +294,270 @@ def bench_single_episode(ctx, world, args, reps=3):
             "expansions_per_s": float(summ[0]["iters_run"]) / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / float(summ[0]["iters_run"])}
 
 
-def bench_rrt_o64(ctx, args, n_ep=6144, reps=2):
-    """BASELINE configs[1] as written: 64 obstacles (the headline uses 256), same 200x200-cell grid and 10k budget."""
-    from auv_sim_amd import synth
-    half = 0.5 * args.grid * 10.0
-    world = synth.make_world(seed=2, n_obstacles=64, box=(-half, -half, half, half), cell=10.0, n_bins=10, bin_len=50,
-                             n_habitats=10)
+def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0):
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     init = np.zeros((n_ep, 6))
     init[:, 0], init[:, 1] = world["start"]
-    ctx.rrt_prepare(init, np.arange(n_ep, dtype=np.uint64), args.iters, mode=args.mode, freq=30, bin_interval=5, v=2,
-                    max_traj_time=500.0, weights=(-3, -3, -4))
+    ctx.rrt_prepare(init, np.arange(n_ep, dtype=np.uint64), args.iters, mode=args.mode, **RRT_KW)
     ms = []
     for i in range(reps + 1):
         ctx.rrt_run()
         if i:
             ms.append(ctx.last_kernel_ms())
     summ = ctx.summaries()
+    if (summ["status"] < 0).any():
+        return {"error": "episode status %s" % np.unique(summ["status"])}
     k_ms = float(np.mean(ms))
-    return {"metric": "RRT.exploring expansions/s, 64 obstacles", "value": float(summ["iters_run"].sum()) / (k_ms * 1e-3),
-            "unit": "expansions/s", "episodes": n_ep, "kernel_ms": k_ms, "accepted_nodes_per_episode": float((summ["n_nodes"] - 1).mean())}
+    iters = float(summ["iters_run"].sum())
+    out = {"value": iters / (k_ms * 1e-3), "unit": "expansions/s", "episodes": n_ep, "kernel_ms": k_ms,
+           "accept_rate": float((summ["n_nodes"] - 1).sum()) / iters,
+           "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters,
+           "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
+           "roofline": roofline(rrt_bytes(summ), k_ms, "rrt_explore_kernel", bytes_per_expansion=rrt_bytes(summ) / iters)}
+    if cpu_seconds > 0:
+        from oracle import orc
+        w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+        init0 = [world["start"][0], world["start"][1], 0, 0, 0, 0]
+        t0, done, eps = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < cpu_seconds and eps < 16:
+            done += orc.rrt_explore(w, eps, args.iters, mode=args.mode, init=init0, kind="libm", want_path=False)["iters_run"]
+            eps += 1
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": done / dt, "unit": "expansions/s", "cores": 1, "kind": "port",
+                               "sample": "%d episodes x %d iterations (seeds 0..%d), oracle/ libm build, %.1f s" % (eps, args.iters, eps - 1, dt)}
+    return out
 
 
-def bench_config5(ctx, n_ep=12500, max_step=200, reps=2):
-    """every particle hypothesis of a shark position becomes the goal of one
-    Planner_RRT episode with a 200-step budget; 12 500 episodes per GPU (100 000 over 8 GPUs)."""
+def bench_rrt_o64(ctx, args, n_ep=6144):
+    """BASELINE configs[1] as written: 64 obstacles (the headline uses 256), same 200x200-cell grid and 10k budget."""
+    out = _rrt_batch(ctx, bench_world(64, args.grid), n_ep, args)
+    out["metric"] = "RRT.exploring expansions/s, 64 obstacles, %dx%d cells" % (args.grid, args.grid)
+    ref = recorded_reference("config2_rrt_exploring_o64")
+    if ref:
+        out["reference_recorded"] = {"value": ref["ref_expansions_per_s_1proc"], "unit": "expansions/s", "cores": 1,
+                                     "where": "build container, tests/experiments/ref_timing.py"}
+    return out
+
+
+def bench_rrt_dense(ctx, args, with_cpu, n_ep=6144):
+    """Worlds where the exact collision test actually runs (the headline's 256 obstacles in 4 km^2 are sparse: the cull
+    leaves well under one candidate per expansion).  (i) the G3 fixture world: 256 obstacles of r = 1-3 m in a 200 m box,
+    400 cells -- the reference accepts ~56 % there and spends 93 % of its time in check_collision; (ii) a Catalina-sized
+    workspace (path_planning/catalina.py:67-119: ~550 x 345 m): 560 x 350 m, 14 m cells (1 000 cells, the reference's
+    split gives 987), 256 obstacles with the Catalina radii spread (4-26 m obstacles scaled down to stay plannable: 2-8 m)."""
     from auv_sim_amd import synth
-    from auv_sim_amd._prrt_lib import PlannerBatch
-    w = synth.make_rect_world(seed=3, n_obstacles=256)
-    ctx.set_world(obstacles=w["obstacles"])
-    rng = np.random.default_rng(5)
-    starts = np.tile(np.array([w["start"][0], w["start"][1], 0.0, 0.0]), (n_ep, 1))
-    goals = np.clip(np.asarray(w["goal"])[None, :] + rng.normal(0.0, 25.0, size=(n_ep, 2)), w["rect"][0] + 5, w["rect"][2] - 5)
-    seeds = np.arange(n_ep, dtype=np.uint64)
-    ms, steps, done = [], 0, 0
-    for i in range(reps + 1):
-        pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, freq=10, cell=5, subs=1)
-        summ = pb.plan()
-        if i:
-            ms.append(ctx.last_kernel_ms())
-        steps, done = int(summ["steps"].sum()), int(summ["done"].sum())
-        if (summ["status"] < 0).any():
-            return {"error": "episode status %s" % np.unique(summ["status"])}
-    k_ms = float(np.mean(ms))
-    return {"metric": "config 5: Planner_RRT steps/s, one episode per particle hypothesis", "value": steps / (k_ms * 1e-3),
-            "unit": "steps/s", "episodes": n_ep, "max_step": max_step, "steps_per_launch": steps, "episodes_done": done,
-            "kernel_ms": k_ms, "episodes_per_s": n_ep / (k_ms * 1e-3)}
+    out = {}
+    w1 = synth.make_world(seed=2, n_obstacles=256)
+    out["g3_box_200m_o256"] = _rrt_batch(ctx, w1, n_ep, args, cpu_seconds=4.0 if with_cpu else 0.0)
+    out["g3_box_200m_o256"]["world"] = "200 m x 200 m box, 400 cells, 256 obstacles r = 1-3 m (the G3 golden world)"
+    w2 = synth.make_world(seed=5, n_obstacles=256, box=(0.0, 0.0, 560.0, 350.0), cell=14.0, obst_radius=(2.0, 8.0),
+                          hab_radius=(20.0, 55.0))
+    out["catalina_560x350_o256"] = _rrt_batch(ctx, w2, n_ep, args, cpu_seconds=4.0 if with_cpu else 0.0)
+    out["catalina_560x350_o256"]["world"] = "560 m x 350 m, 1 000 cells of 14 m, 256 obstacles r = 2-8 m, habitats r = 20-55 m"
+    return out
 
 
-def bench_astar(ctx, with_cpu, n_inst=1024, reps=3):
-    """BASELINE config 3: 1024 independent astar_fixLenSOG searches (starts on the 10 m lattice,
-    pathLenLimit in {100,200,300}) over one shared world: 64 obstacles, 10 habitats, rectangle polygon,
-    20x20-cell shark grid (the reference's hard-coded 600x600 visited window bounds the workspace).
-    cells/s = neighbour cells that passed the bounds test / time."""
-    from auv_sim_amd import _astar_lib, synth
+def astar_inputs(n_inst):
+    from auv_sim_amd import synth
     w = synth.make_world(seed=12, n_obstacles=64, obst_radius=(2.0, 6.0), n_habitats=10, hab_radius=(10.0, 25.0))
-    ctx.set_world(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
     rng = np.random.default_rng(3)
     starts = np.column_stack([-290.0 + 10.0 * rng.integers(0, 19, n_inst), -90.0 + 10.0 * rng.integers(0, 19, n_inst)])
     limits = rng.choice([100.0, 200.0, 300.0], n_inst)
+    return w, starts, limits
+
+
+def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1):
+    """BASELINE config 3: 1024 independent astar_fixLenSOG searches (starts on the 10 m lattice, pathLenLimit in
+    {100,200,300}) over one shared world: 64 obstacles, 10 habitats, rectangle polygon, 20x20-cell shark grid x 10 bins.
+    A step = the search launch (including whatever reset the batch needs) + the path/smoothing launch + the result
+    download (+ the gather for N > 1); cells/s = child cells evaluated / step time.  For N > 1 the
+    instances are block-sharded over the ranks."""
+    from auv_sim_amd import _astar_lib, distributed as D
+    w, starts, limits = astar_inputs(n_inst)
+    lo, hi = D.shard_range(n_inst, ranks.rank, ranks.world)
+    ctx.set_world(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
     wts = (0, 10, 10, 100)
-    kw = dict(limits=limits, weights=wts, velocity=1.0, cap_nodes=20000)
-    _astar_lib.run_batch(ctx, "astar_fixLenSOG", starts, **kw)
-    ms, cells, exps, found = [], 0, 0, 0
-    for _ in range(reps):
-        res = _astar_lib.run_batch(ctx, "astar_fixLenSOG", starts, **kw)
-        ms.append(ctx.last_kernel_ms())
-        cells = sum(r["n_children"] for r in res)
-        exps = sum(r["n_expansions"] for r in res)
-        found = sum(r["found"] for r in res)
-        bad = [r["status"] for r in res if r["status"] < 0]
-        if bad:
-            return {"error": "instance status %s" % sorted(set(bad))}
-    k_ms = float(np.mean(ms))
-    out = {"metric": "A* cells/s (astar_fixLenSOG, child cells evaluated)", "value": cells / (k_ms * 1e-3), "unit": "cells/s",
-           "instances": n_inst, "cells_per_launch": cells, "expansions_per_launch": exps, "found": found, "kernel_ms": k_ms,
-           "config": "1024 x astar_fixLenSOG, 64 obstacles, 10 habitats, 400-cell grid x 10 bins, limits 100/200/300",
-           # SURVEY 8(d): ~0.1 KB algorithmic HBM bytes per child cell (node write 68 + visited 1 + SOG 16 + scan share)
-           "roofline": {"bound": "hbm", "achieved": cells * 100.0 / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": cells * 100.0 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
-    # SURVEY 8(d) config 3 also asks for the same batch through astar_fixLen (no grid) and astar.astar (start -> goal
-    # pairs on the 50x50 lattice of config 1): reported side by side, labelled
-    def variant(name, st, **k):
-        _astar_lib.run_batch(ctx, name, st, **k)
-        vms, vc, vf = [], 0, 0
-        for _ in range(reps):
-            res = _astar_lib.run_batch(ctx, name, st, **k)
-            vms.append(ctx.last_kernel_ms())
-            vc, vf = sum(r["n_children"] for r in res), sum(r["found"] for r in res)
-            if any(r["status"] < 0 for r in res):
-                return {"error": "instance status %s" % sorted({r["status"] for r in res if r["status"] < 0})}
-        return {"value": vc / (float(np.mean(vms)) * 1e-3), "unit": "cells/s", "cells_per_launch": vc, "found": vf,
-                "kernel_ms": float(np.mean(vms))}
-    out["variants"] = {"astar_fixLen": variant("astar_fixLen", starts, limits=limits, weights=(0, 10, 10), cap_nodes=20000)}
-    lw = synth.make_lattice_world(seed=11, n_obstacles=30, r_range=(10, 22))
-    ctx.set_world(lw["obstacles"], None, None, None, None, None)
-    lst = np.column_stack([10.0 * rng.integers(0, 20, n_inst), 10.0 * rng.integers(0, 20, n_inst)])
-    out["variants"]["astar"] = variant("astar", lst, goals=np.tile([490.0, 490.0], (n_inst, 1)), box=lw["box"], cap_nodes=60000)
+    kms, gms = [], []
+
+    def step():
+        r = _astar_lib.run_batch_arrays(ctx, "astar_fixLenSOG", starts[lo:hi], limits=limits[lo:hi], weights=wts, velocity=1.0,
+                                        cap_nodes=20000)
+        kms.append(r["batch_ms"])
+        if ranks.world > 1:
+            ranks.gather_host_records(r["summ"])
+            gms.append(ranks.gather_ms())
+        return r
+    dt, r = timed_steps(ranks, step, steps, warmup)
+    summ = r["summ"]
+    if (summ["status"] < 0).any():
+        return {"error": "instance status %s" % np.unique(summ["status"][summ["status"] < 0])}
+    cells = ranks.sum(summ["n_children"].sum())
+    k_ms = float(np.mean(kms[-steps:]))
+    abytes = astar_bytes(summ, "astar_fixLenSOG")
+    traffic, tsrc = pmc_traffic("astar_kernel", float(summ["n_children"].sum()))
+    out = {"metric": "A* cells/s (astar_fixLenSOG, child cells evaluated)", "value": cells * steps / dt, "unit": "cells/s",
+           "ms_per_step": 1e3 * dt / steps, "steps": steps, "instances": n_inst, "instances_this_rank": hi - lo,
+           "cells_per_step": cells, "expansions_per_step": ranks.sum(summ["n_expansions"].sum()),
+           "found": int(ranks.sum(summ["found"].sum())),
+           "search_launch_ms": k_ms, "search_launch_ms_per_rank": ranks.all(k_ms),
+           "gather_ms_per_rank": ranks.all(float(np.mean([g for g in gms[-steps:] if g is not None])) if gms and gms[-1] is not None else None),
+           "cells_per_s_search_launch_only": float(summ["n_children"].sum()) / (k_ms * 1e-3),
+           "config": "%d x astar_fixLenSOG, 64 obstacles, 10 habitats, 400-cell grid x 10 bins, limits 100/200/300" % n_inst,
+           "roofline": roofline(abytes, k_ms, "astar_kernel", traffic, traffic_source=tsrc,
+                                bytes_per_cell=abytes / max(float(summ["n_children"].sum()), 1.0),
+                                note="one wave per instance at 1 wave/SIMD: a latency measurement, not a bandwidth one")}
+    if ranks.world == 1:
+        # SURVEY 8(d) config 3 also asks for the same batch through astar_fixLen (no grid) and astar.astar (start -> goal
+        # pairs on the 50x50 lattice of config 1): reported side by side, labelled
+        def variant(name, st, **k):
+            _astar_lib.run_batch_arrays(ctx, name, st, **k)
+            t0 = time.perf_counter()
+            rr = None
+            for _ in range(3):
+                rr = _astar_lib.run_batch_arrays(ctx, name, st, **k)
+            vdt = (time.perf_counter() - t0) / 3
+            s = rr["summ"]
+            if (s["status"] < 0).any():
+                return {"error": "instance status %s" % np.unique(s["status"][s["status"] < 0])}
+            return {"value": float(s["n_children"].sum()) / vdt, "unit": "cells/s", "cells_per_step": int(s["n_children"].sum()),
+                    "found": int(s["found"].sum()), "ms_per_step": 1e3 * vdt, "search_launch_ms": rr["batch_ms"],
+                    "roofline": roofline(astar_bytes(s, name), rr["batch_ms"], "astar_kernel")}
+        from auv_sim_amd import synth
+        out["variants"] = {"astar_fixLen": variant("astar_fixLen", starts, limits=limits, weights=(0, 10, 10), cap_nodes=20000)}
+        lw = synth.make_lattice_world(seed=11, n_obstacles=30, r_range=(10, 22))
+        ctx.set_world(lw["obstacles"], None, None, None, None, None)
+        rng = np.random.default_rng(3)
+        lst = np.column_stack([10.0 * rng.integers(0, 20, n_inst), 10.0 * rng.integers(0, 20, n_inst)])
+        out["variants"]["astar"] = variant("astar", lst, goals=np.tile([490.0, 490.0], (n_inst, 1)), box=lw["box"], cap_nodes=60000)
     if with_cpu:
         from oracle import orc_astar as oa
         t0, c, n = time.perf_counter(), 0, 0
         while time.perf_counter() - t0 < 5.0 and n < n_inst:
-            r = oa.run("astar_fixLenSOG", starts[n], obstacles=w["obstacles"], habitats=w["habitats"], polygon=w["polygon"],
-                       bins=w["bins"], cells=w["cells"], prob=w["prob"], limit=float(limits[n]), weights=wts, velocity=1.0,
-                       cap_nodes=20000, kind="libm")
-            c += r["n_children"]
+            rr = oa.run("astar_fixLenSOG", starts[n], obstacles=w["obstacles"], habitats=w["habitats"], polygon=w["polygon"],
+                        bins=w["bins"], cells=w["cells"], prob=w["prob"], limit=float(limits[n]), weights=wts, velocity=1.0,
+                        cap_nodes=20000, kind="libm")
+            c += rr["n_children"]
             n += 1
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": c / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-                               "sample": "first %d of the %d instances, oracle/ libm build, %.1f s" % (n, n_inst, dt)}
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": c / cdt, "unit": "cells/s", "cores": 1, "kind": "port",
+                               "sample": "first %d of the %d instances, oracle/ libm build, %.1f s" % (n, n_inst, cdt)}
+        ref = recorded_reference("config3_astar_fixLenSOG")
+        if ref:
+            out["cpu_baseline"]["reference_recorded"] = {"value": ref["ref_cells_per_s_1proc"], "unit": "cells/s", "cores": 1,
+                                                         "many_cores": {k: v for k, v in ref.items() if k.startswith("ref_cells_per_s_") and k != "ref_cells_per_s_1proc"},
+                                                         "where": "build container, tests/experiments/ref_timing.py"}
     return out
 
 
-def bench_planner(ctx, with_cpu, n_ep=512, max_step=2000, reps=3):
-    """BASELINE config 4: 512 Planner_RRT.planning(max_step=2000) episodes, 200 m x 200 m rectangle, 256
-    obstacles, cell 5 m, 1 theta subsection, freq 10, start (20,20) -> goal (170,180), seed = episode id."""
-    from auv_sim_amd import synth
-    from auv_sim_amd._prrt_lib import PlannerBatch
+def bench_planner(ctx, ranks, with_cpu, n_ep=512, max_step=2000, steps=5, warmup=1):
+    """BASELINE config 4: 512 Planner_RRT.planning(max_step=2000) episodes, 200 m x 200 m rectangle, 256 obstacles, cell
+    5 m, 1 theta subsection, freq 10, start (20,20) -> goal (170,180), seed = global episode id; block-sharded over the
+    ranks (64 per GPU at N = 8) with the gather of the summary records and final paths.  A step = batch creation
+    (seeding, tree planting) + planning launch + path extraction (+ gather)."""
+    from auv_sim_amd import synth, distributed as D
+    from auv_sim_amd._prrt_lib import PlannerBatch, PRRT_SUMMARY_DTYPE
     w = synth.make_rect_world(seed=3, n_obstacles=256)
     ctx.set_world(obstacles=w["obstacles"])
-    starts = np.tile(np.array([w["start"][0], w["start"][1], 0.0, 0.0]), (n_ep, 1))
-    goals = np.tile(w["goal"], (n_ep, 1))
-    seeds = np.arange(n_ep, dtype=np.uint64)
-    ms, steps, done = [], 0, 0
-    for i in range(reps + 1):
+    lo, hi = D.shard_range(n_ep, ranks.rank, ranks.world)
+    n = hi - lo
+    starts = np.tile(np.array([w["start"][0], w["start"][1], 0.0, 0.0]), (n, 1))
+    goals = np.tile(w["goal"], (n, 1))
+    seeds = np.arange(lo, hi, dtype=np.uint64)
+    kms, gms = [], []
+
+    def step():
         pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, freq=10, cell=5, subs=1)
         summ = pb.plan()
-        if i:
-            ms.append(ctx.last_kernel_ms())
-        steps, done = int(summ["steps"].sum()), int(summ["done"].sum())
-        if (summ["status"] < 0).any():
-            return {"error": "episode status %s" % np.unique(summ["status"])}
-    k_ms = float(np.mean(ms))
-    out = {"metric": "Planner_RRT steps/s (generate_one_node calls)", "value": steps / (k_ms * 1e-3), "unit": "steps/s",
-           "episodes": n_ep, "steps_per_launch": steps, "episodes_done": done, "kernel_ms": k_ms,
-           "config": "512 x Planner_RRT.planning(2000), 200 m env, 256 obstacles, cell 5 m, freq 10",
-           # SURVEY 8(d): ~0.33 KB algorithmic HBM bytes per step
-           "roofline": {"bound": "hbm", "achieved": steps * 330.0 / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": steps * 330.0 / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+        kms.append(ctx.last_kernel_ms())
+        paths = pb.paths(summ)
+        if ranks.world > 1:
+            import torch
+            ranks.gather_records(pb.L.auvp_prrt_summaries_dev(ctx.h), n, PRRT_SUMMARY_DTYPE.itemsize)
+            lens = torch.from_numpy(np.where(summ["done"] != 0, summ["path_len"], 0).astype(np.int64)).to(ranks.dev)
+            flat = torch.from_numpy(np.concatenate(paths) if len(paths) else np.zeros((0, 5))).to(ranks.dev)
+            ranks.gather.gather_paths(flat, lens)
+            gms.append(ranks.gather_ms())
+        return summ
+    dt, summ = timed_steps(ranks, step, steps, warmup)
+    if (summ["status"] < 0).any():
+        return {"error": "episode status %s" % np.unique(summ["status"])}
+    tot_steps = ranks.sum(summ["steps"].sum())
+    k_ms = float(np.mean(kms[-steps:]))
+    abytes = planner_bytes(summ)
+    traffic, tsrc = pmc_traffic("prrt_kernel", float(summ["steps"].sum()))
+    out = {"metric": "Planner_RRT steps/s (generate_one_node calls)", "value": tot_steps * steps / dt, "unit": "steps/s",
+           "ms_per_step": 1e3 * dt / steps, "steps": steps, "episodes": n_ep, "episodes_this_rank": n,
+           "planner_steps_per_step": tot_steps, "episodes_done": int(ranks.sum(summ["done"].sum())),
+           "plan_launch_ms": k_ms, "plan_launch_ms_per_rank": ranks.all(k_ms),
+           "gather_ms_per_rank": ranks.all(float(np.mean([g for g in gms[-steps:] if g is not None])) if gms and gms[-1] is not None else None),
+           "steps_per_s_plan_launch_only": float(summ["steps"].sum()) / (k_ms * 1e-3),
+           "config": "%d x Planner_RRT.planning(2000), 200 m env, 256 obstacles, cell 5 m, freq 10" % n_ep,
+           "roofline": roofline(abytes, k_ms, "prrt_kernel", traffic, traffic_source=tsrc,
+                                bytes_per_step=abytes / max(float(summ["steps"].sum()), 1.0),
+                                note="512 waves on 1 024 SIMDs: a latency measurement")}
     if with_cpu:
         from oracle import orc_planner as op
-        t0, c, n = time.perf_counter(), 0, 0
-        while time.perf_counter() - t0 < 5.0 and n < n_ep:
-            r = op.planning(w["obstacles"], w["rect"], starts[n], goals[n], n, max_step, 10, 5, 1, kind="libm")
+        t0, c, k = time.perf_counter(), 0, 0
+        while time.perf_counter() - t0 < 5.0 and k < n:
+            r = op.planning(w["obstacles"], w["rect"], starts[k], goals[k], int(seeds[k]), max_step, 10, 5, 1, kind="libm")
             c += r["steps"]
-            n += 1
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": c / dt, "unit": "steps/s", "cores": 1, "kind": "port",
-                               "sample": "first %d of the %d episodes, oracle/ libm build, %.1f s" % (n, n_ep, dt)}
+            k += 1
+        cdt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": c / cdt, "unit": "steps/s", "cores": 1, "kind": "port",
+                               "sample": "first %d of the %d episodes, oracle/ libm build, %.1f s" % (k, n_ep, cdt)}
+        ref = recorded_reference("config4_planner_rrt")
+        if ref:
+            out["cpu_baseline"]["reference_recorded"] = {"value": ref["ref_steps_per_s_1proc"], "unit": "steps/s", "cores": 1,
+                                                         "many_cores": {k2: v for k2, v in ref.items() if k2.startswith("ref_steps_per_s_") and k2 != "ref_steps_per_s_1proc"},
+                                                         "where": "build container, tests/experiments/ref_timing.py"}
     return out
+
+
+def bench_config5(ctx, ranks, n_filters=25, n_particles=500, max_step=200, track_steps=6):
+    """BASELINE config 5 as written: particle filters over the reference's recorded shark tracks
+    (data/sharkTrackingData.csv -> tests/golden/shark_tracking_xy.npz), one Planner_RRT replan per particle and tracking
+    step, device resident (auv_sim_amd.tracking).  Per GPU: 25 filters x 500 particles = 12 500 episodes x 200 planner
+    steps per tracking step (100 000 particles over 8 GPUs); filter f of rank r tracks shark (r * 25 + f) mod 32 with
+    np.random.seed(r * 25 + f); episode seeds follow the global episode id."""
+    from auv_sim_amd import synth, tracking
+    path = os.path.join(REPO, "tests", "golden", "shark_tracking_xy.npz")
+    if not os.path.exists(path):
+        return {"error": "tests/golden/shark_tracking_xy.npz missing"}
+    xy = np.load(path)["xy"]
+    w = synth.make_rect_world(seed=3, n_obstacles=256)
+    ctx.set_world(obstacles=w["obstacles"])
+    gf = ranks.rank * n_filters + np.arange(n_filters)
+    E = n_filters * n_particles
+    rp = tracking.ParticleReplanner(ctx, xy[gf % 32, :track_steps + 1], n_particles, w["rect"], w["start"], gf, max_step=max_step,
+                                    episode_offset=ranks.rank * E, episodes_total=ranks.world * E)
+    rp.step(0)  # warm-up (also sizes every buffer)
+    ranks.sync()
+    t0 = time.perf_counter()
+    pf_ms, plan_ms, steps_done, done = [], [], 0, 0
+    for s in range(1, track_steps + 1):
+        summ = rp.step(s)
+        pf_ms.append(rp.pf_ms)
+        plan_ms.append(rp.plan_ms)
+        steps_done += int(summ["steps"].sum())
+        done = int(summ["done"].sum())
+        if ranks.world > 1:
+            from auv_sim_amd._prrt_lib import PRRT_SUMMARY_DTYPE
+            ranks.gather_records(rp.planner.L.auvp_prrt_summaries_dev(ctx.h), E, PRRT_SUMMARY_DTYPE.itemsize)
+        if (summ["status"] < 0).any():
+            return {"error": "episode status %s" % np.unique(summ["status"])}
+    ranks.sync()
+    dt = ranks.max_time(time.perf_counter() - t0)
+    st, _ = rp.filters.status()
+    if (st != 0).any():
+        return {"error": "filter status %s" % np.unique(st)}
+    total = ranks.sum(steps_done)
+    return {"metric": "config 5: Planner_RRT steps/s, one replan per particle hypothesis per tracking step",
+            "value": total / dt, "unit": "steps/s", "ms_per_tracking_step": 1e3 * dt / track_steps,
+            "episodes_per_gpu": E, "filters_per_gpu": n_filters, "particles_per_filter": n_particles, "max_step": max_step,
+            "tracking_steps": track_steps, "episodes_done_last_step": done,
+            "episode_replans_per_s": ranks.world * E * track_steps / dt,
+            "filter_ms": float(np.mean(pf_ms)), "plan_launch_ms": float(np.mean(plan_ms)),
+            "data": "recorded shark tracks of the reference (32 sharks x 815 samples), noise-free range/bearing from two fixed AUVs"}
 
 
 def bench_particle_filter(device, with_cpu, n_filters=4096, n_particles=1000, n_steps=20, n_auv=2, reps=3):
@@ -299,16 +587,13 @@ def bench_particle_filter(device, with_cpu, n_filters=4096, n_particles=1000, n_
         return {"error": "filter status %s" % np.unique(st)}
     k_ms = float(np.mean(ms))
     units = float(F) * N * S
-    # per launch the particle state (5 doubles + 1 id) is read once and written once (it lives in LDS across the
-    # S steps); per step and particle the per-AUV weights make one 8-byte round trip through L2/HBM scratch
     abytes = F * N * (2 * 44.0 + S * A * 24.0) + S * F * A * 40.0
     out = {"metric": "particle filter particle-steps/s (create_and_update + update_weights)", "value": units / (k_ms * 1e-3),
            "unit": "particle-steps/s", "filters": F, "particles": N, "steps": S, "auvs": A, "kernel_ms": k_ms,
            "draws32_per_filter_step": float(nd.mean()) / S,
            "config": "%d filters x %d particles x %d steps, %d AUV measurements per step" % (F, N, S, A),
-           "roofline": {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "state is LDS resident across the steps of a launch: barrier/latency bound, not HBM bound"}}
+           "roofline": roofline(abytes, k_ms, "pf_step_kernel",
+                                note="state is LDS resident across the steps of a launch: barrier/latency bound, not HBM bound")}
     if with_cpu:
         from oracle import orc_pf
         t0, n = time.perf_counter(), 0
@@ -343,17 +628,18 @@ def bench_shark_grid(device, with_cpu, n_side=200, n_sharks=32, n_pts=3000, reps
     k_ms = float(np.mean(ms))
     T, G = grids.shape[0], grids.shape[1] * grids.shape[2]
     units = float(T) * G
-    window = 81  # cells of the radius-5 disc each output cell sums per shark
-    abytes = T * n_sharks * G * (4 + 8.0) + units * (n_sharks * window * 8.0 + 8.0)
+    # compulsory traffic: the points once (24 B), the per-(bin, shark, cell) occupancy written and read once (8 + 8 B; the
+    # 81-cell window re-reads of the disc stencil are cache hits and are NOT counted), the output once (8 B)
+    abytes = len(pts) * 24.0 + T * n_sharks * G * (4.0 + 8.0 + 8.0) + units * 8.0
     out = {"metric": "SharkOccupancyGrid.convert output cells/s", "value": units / (k_ms * 1e-3), "unit": "grid cells/s",
            "bins": int(T), "grid": [int(grids.shape[1]), int(grids.shape[2])], "sharks": n_sharks, "kernel_ms": k_ms,
            "config": "%dx%d cells of 10 m, %d sharks x %d points, %d bins, detect range 50 m" % (n, n, n_sharks, n_pts, T),
-           "roofline": {"bound": "hbm", "achieved": abytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": abytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                        "note": "algorithmic bytes count every window read; they are L2 hits, so achieved can exceed HBM traffic"}}
+           "roofline": roofline(abytes, k_ms, "sog_count/occ/grid_kernel",
+                                note="compulsory bytes only; the 81-cell stencil window is served by L2 (%.0f GB/s of cache reads)"
+                                     % (units * n_sharks * 81 * 8.0 / (k_ms * 1e-3) / 1e9))}
     if with_cpu:
         from oracle import orc_sog
-        sub = 2  # sharks in the CPU sample (the scalar port scans cell_list per point like the reference)
+        sub = 2
         k = sub * n_pts
         t0 = time.perf_counter()
         r = orc_sog.convert(cells, box, cs, 30.0, 50.0, traj_len[:sub], pts[:k], kind="libm")
@@ -365,9 +651,31 @@ def bench_shark_grid(device, with_cpu, n_side=200, n_sharks=32, n_pts=3000, reps
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (fresh children, one per GPU, before
+    anything in this process touches HIP), relay rank 0's JSON line, exit with the worst child's code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--no-extra", action="store_true", help="skip the A* / Planner_RRT side measurements")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements")
+    ap.add_argument("--only", default="", help="comma list of side measurements to run INSTEAD of the headline "
+                                                "(astar, planner_rrt, config5, rrt_dense, ...): profiling passes")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
@@ -382,27 +690,23 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world_size
+    args.gpus = world_size
+    only = [s for s in args.only.split(",") if s]
 
-    from auv_sim_amd import synth
-    half = 0.5 * args.grid * 10.0
-    world = synth.make_world(seed=2, n_obstacles=args.obstacles, box=(-half, -half, half, half), cell=10.0,
-                             n_bins=10, bin_len=50, n_habitats=10)
+    world = bench_world(args.obstacles, args.grid)
+    with_cpu = world_size == 1 and not args.no_cpu
     cpu_all = None
-    if world_size == 1 and not args.no_cpu:
+    if with_cpu and not only:
         cpu_all = cpu_baseline_all_cores(world, args.iters, args)  # forks: must precede any HIP initialisation
 
     import torch
     import torch.distributed as dist
     from auv_sim_amd import _lib
-    from auv_sim_amd import distributed as D
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -411,6 +715,32 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     ctx = _lib.Context(local_rank)
+    ranks = Ranks(ctx, rank, world_size, dev)
+    sides = {
+        "single_episode": lambda: bench_single_episode(ctx, world, args),
+        "rrt_64_obstacles": lambda: bench_rrt_o64(ctx, args),
+        "rrt_dense": lambda: bench_rrt_dense(ctx, args, with_cpu),
+        "astar": lambda: bench_astar(ctx, ranks, with_cpu),
+        "planner_rrt": lambda: bench_planner(ctx, ranks, with_cpu),
+        "config5": lambda: bench_config5(ctx, ranks),
+        "shark_grid": lambda: bench_shark_grid(local_rank, with_cpu),
+        "particle_filter": lambda: bench_particle_filter(local_rank, with_cpu),
+    }
+    sharded = ("astar", "planner_rrt", "config5")  # these run on every rank; the others on rank 0's GPU only
+    if only:
+        out = {}
+        for name in only:
+            if name in sharded or rank == 0:
+                r = sides[name]()
+                if rank == 0:
+                    out[name] = r
+        if rank == 0:
+            print(json.dumps(out))
+        if world_size > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     E = args.episodes
     # the trees need ~17.5 MB of HBM per 10 000-iteration episode: if this GPU has less free than the requested batch
@@ -429,13 +759,13 @@ def main():
     init = np.zeros((E, 6))
     init[:, 0], init[:, 1] = world["start"]
     seeds = np.arange(rank * E, (rank + 1) * E, dtype=np.uint64)  # global episode id = seed
-    ctx.rrt_prepare(init, seeds, args.iters, mode=args.mode, freq=30, bin_interval=5, v=2, max_traj_time=500.0,
-                    weights=(-3, -3, -4))
+    ctx.rrt_prepare(init, seeds, args.iters, mode=args.mode, **RRT_KW)
+    kms, gms = [], []
 
     def step():
         """kernel + best-path extraction (+ RCCL gather of the result records for N > 1)"""
         ctx.rrt_run()
-        ms = ctx.last_kernel_ms()
+        kms.append(ctx.last_kernel_ms())
         summ = ctx.summaries()
         lens = np.where(summ["best_leaf"] >= 0, summ["best_path_len"], 0).astype(np.int64)
         off = np.zeros(E + 1, dtype=np.int64)
@@ -444,58 +774,27 @@ def main():
         paths = torch.empty((max(total, 1), 7), dtype=torch.float64, device=dev)
         ctx.paths_dev(off, paths.data_ptr())  # best paths stay in HBM
         if world_size > 1:
-            # RCCL gather of the fixed-stride result records + the variable-length paths (two-phase)
-            D.gather_records(D.summaries_to_tensor(summ, dev))
-            D.gather_paths(paths[:total], torch.from_numpy(lens).to(dev))
-        return ms, summ
+            # the fixed-stride result records straight from the planner's device buffer + the variable-length paths
+            ranks.gather_records(ctx.L.auvp_rrt_summaries_dev(ctx.h), E, _lib.SUMMARY_DTYPE.itemsize)
+            lens_dev = torch.from_numpy(lens).to(dev)
+            ranks.gather.gather_paths(paths[:total], lens_dev)
+            gms.append(ranks.gather_ms())
+        return summ
 
-    def fence():
-        torch.cuda.synchronize()
-        if world_size > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    kms = []
-    summ = None
-    for _ in range(args.steps):
-        ms, summ = step()
-        kms.append(ms)
-    fence()
-    dt = time.perf_counter() - t0
-    if world_size > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
+    dt, summ = timed_steps(ranks, step, args.steps, args.warmup)
     bad = summ["status"] < 0
     if bad.any():
         sys.exit("device error status in %d episodes: %s" % (int(bad.sum()), np.unique(summ["status"][bad])))
-    iters_per_step = float(summ["iters_run"].sum()) * world_size  # identical budget on every rank
+    iters_local = float(summ["iters_run"].sum())
+    iters_per_step = ranks.sum(iters_local)
     value = iters_per_step * args.steps / dt
+    k_ms = float(np.mean(kms[-args.steps:]))
+    k_all = ranks.all(k_ms)
+    g_all = ranks.all(float(np.mean([g for g in gms[-args.steps:] if g is not None])) if gms and gms[-1] is not None else None)
+    out = None
     if rank == 0:
-        k_ms = float(np.mean(kms))
-        abytes = algorithmic_bytes(summ, args.iters)
-        achieved = abytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        pmc = os.path.join(REPO, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                # PMC passes of tools/profile_bench.sh on the default workload (one wave = one episode, 10 000 iterations);
-                # a different batch is scaled by its number of expansions and says so
-                pj = json.load(open(pmc))
-                waves = float(pj["per_launch"].get("SQ_WAVES", 0.0))
-                traffic = pj.get("hbm_bytes_per_launch")
-                traffic_src = "profiles/%s/pmc_summary.json (FETCH_SIZE + WRITE_SIZE passes)" % pj.get("tag", "?")
-                if traffic is not None and waves > 0 and (int(waves) != E or args.iters != 10000):
-                    scale = (E * args.iters) / (waves * 10000.0)
-                    traffic *= scale
-                    traffic_src += ", scaled x%.3f from %d episodes x 10000 iterations" % (scale, int(waves))
-            except Exception:
-                traffic, traffic_src = None, None
+        abytes = rrt_bytes(summ)
+        traffic, tsrc = pmc_traffic("rrt_explore_kernel", iters_local)
         grid, block, lds = ctx.last_launch()
         out = {
             "metric": "RRT-Dubins node expansions/s (RRT.exploring)", "value": value, "unit": "expansions/s",
@@ -505,32 +804,37 @@ def main():
                                    "%d-iteration budget per episode, %d episodes per GPU per step, %s parent sampling"
                                    % (args.obstacles, args.grid, args.grid, args.iters, E, args.mode),
                        "episodes_per_gpu": E, "iters": args.iters, "obstacles": args.obstacles,
-                       "cells": int(len(world["cells"])), "parallelism": "episodes sharded x%d" % world_size},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "rrt_explore_kernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes,
-                         "bytes_per_expansion": abytes / float(summ["iters_run"].sum()),
-                         "launch": {"grid": grid, "block": block, "lds_bytes": lds},
-                         "note": "fp64-VALU/latency bound at these sizes, not HBM bound (DESIGN.md)"},
-            "expansions_per_s_kernel_only": float(summ["iters_run"].sum()) / (k_ms * 1e-3),
+                       "cells": int(len(world["cells"])), "parallelism": "episodes sharded x%d" % world_size,
+                       "gather": ranks.gather.name if ranks.gather is not None else None, "gather_note": ranks.gather_note},
+            "roofline": roofline(abytes, k_ms, "rrt_explore_kernel", traffic, traffic_source=tsrc,
+                                 bytes_per_expansion=abytes / iters_local,
+                                 launch={"grid": grid, "block": block, "lds_bytes": lds},
+                                 note="fp64-VALU/latency bound at these sizes, not HBM bound (DESIGN.md)"),
+            "expansions_per_s_kernel_only": iters_local / (k_ms * 1e-3),
+            "kernel_ms_per_rank": k_all, "gather_ms_per_rank": g_all,
             "accepted_nodes_per_episode": float((summ["n_nodes"] - 1).mean()),
             "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
+            "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters_local,
         }
-        if world_size == 1 and not args.no_cpu:
+        if with_cpu:
             out["cpu_baseline"] = cpu_baseline(world, args.iters, args)
             out["cpu_baseline_all_cores"] = cpu_all
         else:
             out["cpu_baseline"] = None
-        if not args.no_extra:
-            # the other two planner families of the path, per GPU (rank 0's device), outside the timed region
-            out["single_episode"] = bench_single_episode(ctx, world, args)
-            out["rrt_64_obstacles"] = bench_rrt_o64(ctx, args)
-            out["astar"] = bench_astar(ctx, with_cpu=(world_size == 1 and not args.no_cpu))
-            out["planner_rrt"] = bench_planner(ctx, with_cpu=(world_size == 1 and not args.no_cpu))
-            # the callers either side of the planners
-            out["config5"] = bench_config5(ctx)
-            out["shark_grid"] = bench_shark_grid(local_rank, with_cpu=(world_size == 1 and not args.no_cpu))
-            out["particle_filter"] = bench_particle_filter(local_rank, with_cpu=(world_size == 1 and not args.no_cpu))
+    if not args.no_extra:
+        # the other configurations of the path: configs 3, 4 and 5 on every rank (sharded), the rest on rank 0's GPU
+        for name in ("single_episode", "rrt_64_obstacles", "rrt_dense", "astar", "planner_rrt", "config5", "shark_grid",
+                     "particle_filter"):
+            if name in sharded or rank == 0:
+                try:
+                    r = sides[name]()
+                except Exception as e:  # a side measurement must not cost the headline line
+                    if name in sharded and world_size > 1:
+                        raise
+                    r = {"error": "%s: %s" % (type(e).__name__, e)}
+                if rank == 0:
+                    out[name] = r
+    if rank == 0:
         print(json.dumps(out))
     if world_size > 1:
         dist.barrier()

@@ -69,7 +69,8 @@ typedef struct {
 } auvp_rrt_params;
 
 typedef struct {
-  int32_t status, n_nodes, n_points, n_leaves, best_leaf, best_path_len, iters_run, _pad;
+  int32_t status, n_nodes, n_points, n_leaves, best_leaf, best_path_len, iters_run,
+          n_candidates; /* obstacles that survived the bounding-box cull, whole episode (diagnostic) */
   double best_cost[4]; /* sum, c0, c1, c2 (habitat_shark_cost_func, path_planning/cost.py:145) */
   double best_length;  /* "path length" of the returned dict, rrt_dubins.py:171,176 */
   double rng_after;    /* next random() of the episode's stream (parity probe: same draw count) */
@@ -188,7 +189,8 @@ typedef struct {
   int32_t found;         /* 0: open list ran empty -> the reference returns None */
   int32_t n_nodes, n_expansions;
   int32_t n_children;    /* neighbour cells that passed the bounds test (the "cells/s" unit) */
-  int32_t path_len, smooth_len, n_hab_left, visited_count, leaf, _p0, _p1;
+  int32_t path_len, smooth_len, n_hab_left, visited_count, leaf;
+  uint32_t open_scanned_lo, open_scanned_hi; /* sum over pops of len(open_list) (the min-f scan, astar.py:206-211) */
 } auvp_astar_summary;
 
 /* starts [E,2]; goals [E,2] (variants 0,1) or limits [E] = pathLenLimit (variants 2,3) */
