@@ -43,6 +43,24 @@ struct WorldDev {
   const int32_t* rg_off;    // [2m+2] candidate range of region r: 2i = (bp[i-1], bp[i]), 2i+1 = {bp[i]}
   const double* rg_pm;      // [total] running min of miny along the region's list
   const int32_t* rg_id;     // [total] cell id
+  // separable-grid index: when cell_list is a row-major grid -- cell (r, c) = (X0[c], Y0[r], X1[c], Y1[r]) with all four
+  // arrays non-decreasing -- the first-match scan of cost.py:181-184 factorises: the first row r with Y0[r] <= y and
+  // x <= Y1[r] (sic: x against maxy) and, independently, the first column c with X0[c] <= x <= X1[c]; each is a
+  // lower bound on a sorted array, compared against the table's own doubles (exact).  Takes precedence over the
+  // region index (two dependent reads instead of five).
+  int32_t sg_enabled, sg_ncol, sg_nrow, bins_sorted;  // bins_sorted: t0 and t1 of the time bins are non-decreasing
+  const double* sg_x0;  // [ncol]
+  const double* sg_x1;  // [ncol]
+  const double* sg_y0;  // [nrow]
+  const double* sg_y1;  // [nrow]
+  // the same tables interleaved so that checking a guessed index costs one 32-byte read: entry i = {a1[i-1] (or -inf),
+  // a1[i], a0[i], 0}: i is the lower bound of v in a1 iff entry.x < v <= entry.y
+  const double* sg_col;  // [ncol][4]
+  const double* sg_row;  // [nrow][4]
+  double bins_inv_len;   // 1 / mean spacing of the bins' upper ends (guess only)
+  double sg_x1_0, sg_y1_0, bins_t1_0;  // first entries of X1, Y1 and of the bins' upper ends (origins of the guesses)
+  double sg_inv_dx, sg_inv_dy;  // 1 / mean spacing of X1 / Y1: first guess of the lower bound only
+  double prob_absmax;  // max |prob|: bounds a path element's cost term (approximate-cost error bound of the leaf pass)
   double bb[4];  // polygon bounds xmin,ymin,xmax,ymax (get_random_mps, :334)
   double safe_box[4];    // when the polygon is an axis-aligned rectangle: its corners (strict interior test)
   int32_t has_safe_box, _pad1;
@@ -68,19 +86,21 @@ struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h
 // node: they are read one at a time by the whole wave); path points are 48-B records, a node's run contiguous.
 struct RrtBuffers {
   int32_t cap_nodes, cap_points, bin_cap, cap_leaves;
-  double* node_f;    // [E][cap_nodes][8]  x, y, theta, traj_t, length, -, -, -   (64 B per node)
+  // [E][cap_nodes][8]  x, y, theta, traj_t, length, S, tv, hab   (64 B per node); S/tv/hab: see below
+  double* node_f;
   int32_t* node_i;   // [E][cap_nodes][4]  plan_iter, parent, pt_off, pt_cnt       (16 B per node)
   double* points;    // [E][cap_points][6] x, y, theta, v, traj_t, length
-  // cost-walk acceleration (derived data, never returned):
-  //  * a path element's contribution to habitat_shark_cost_func -- w3*prob of its cell in its time bin, and
-  //    the habitat it lies in -- does not depend on the leaf that walks over it (its bin is always part of
-  //    the leaf's sub-dict), so it is evaluated the first time a walk meets it and kept:
-  //    points in pt_term / pt_hab, nodes in node_f[6] / node_f[7]; hab = -2 marks "not evaluated yet"
-  //  * anc[n] = the node_i records of n's parent, grandparent, ... (4 levels, one 64-B line), so the
-  //    leaf -> root walk follows one dependent load per four ancestors
+  // habitat_shark_cost_func bookkeeping (derived data, never returned).  A path element's contribution to the cost of
+  // a leaf -- w3*prob of its cell in its time bin, and the habitat it lies in -- does not depend on the leaf (its bin
+  // is always part of the leaf's sub-dict), so it is evaluated ONCE, when the node that owns it is accepted:
+  //   pt_term / pt_hab per path point;  node_f[6] / node_f[7] for the node's own state
+  // and summed down the tree:  node_f[5] = S = sum of the terms of every element on the root..node path (any order:
+  // an approximation of the reference's ordered sum with a rigorous bound), node_c = {number of elements inside some
+  // habitat, number of elements, visited-habitat bit set} of that path (exact).  The leaf pass (rrt_leaf_kernel) ranks
+  // the qualifying leaves with these and re-sums in the reference's order only where the bound cannot decide.
   double* pt_term;   // [E][cap_points]
   int8_t* pt_hab;    // [E][cap_points]
-  int32_t* anc;      // [E][cap_nodes][16]
+  int32_t* node_c;   // [E][cap_nodes][4]  hits, elements, visited mask lo, hi
   int32_t* bin_items;                       // [E][K+1][bin_cap]
   int32_t* bin_count;                       // [E][K+1] (copied out of LDS at the end)
   uint32_t* mt;                             // [E][624] generator state in

@@ -49,6 +49,24 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   return v;
 }
 
+// sum over the 64 lanes in a fixed but unspecified order (NOT for sums whose rounding the reference defines): four
+// rotate-and-add steps inside the 16-lane rows on the DPP path (no LDS crossbar), then the four row totals
+__device__ __forceinline__ double wave_sum_any_order(double v) {
+#define AUVP_ROW_ROR_ADD(N)                                                                                 \
+  do {                                                                                                      \
+    const long long b__ = __double_as_longlong(v);                                                          \
+    const int lo__ = __builtin_amdgcn_update_dpp(0, (int)(b__ & 0xffffffffll), 0x120 + (N), 0xf, 0xf, false); \
+    const int hi__ = __builtin_amdgcn_update_dpp(0, (int)(b__ >> 32), 0x120 + (N), 0xf, 0xf, false);         \
+    v = v + __longlong_as_double(((long long)hi__ << 32) | (unsigned int)lo__);                             \
+  } while (0)
+  AUVP_ROW_ROR_ADD(8);
+  AUVP_ROW_ROR_ADD(4);
+  AUVP_ROW_ROR_ADD(2);
+  AUVP_ROW_ROR_ADD(1);
+#undef AUVP_ROW_ROR_ADD
+  return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
+}
+
 // ---------------------------------------------------------------------------------------------
 // CPython-compatible MT19937 stream, state in LDS (624 words per wave), refilled lazily IN PLACE:
 // logical word q overwrites the slot of word q-624 as soon as that one has been consumed, so up to

@@ -49,14 +49,14 @@ struct auvp_handle {
   bool have_world = false;
   WorldDev W{};
   DevBuf d_ox, d_oy, d_ot, d_hab, d_habt, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems, d_xdata, d_rgfirst, d_rgbp, d_rgoff,
-      d_rgpm, d_rgid;
+      d_rgpm, d_rgid, d_sgx0, d_sgx1, d_sgy0, d_sgy1, d_sgcol, d_sgrow;
   // rrt batch
   int E = 0;
   RrtParamsDev P{};
   RrtBuffers B{};
   int max_pts = 0;
   DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_phase, d_pt_term, d_pt_hab, d_anc, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+      d_leaf_c, d_leaf_i, d_phase, d_pt_term, d_pt_hab, d_node_c, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
@@ -296,12 +296,53 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
       std::fill(rfirst.begin(), rfirst.end(), 0);
     }
   }
+  // separable-grid index (auvp_types.h): cell_list row-major over non-decreasing X0/X1 (columns) and Y0/Y1 (rows)
+  std::vector<double> sgx0, sgx1, sgy0, sgy1;
+  int sg_ncol = 0, sg_nrow = 0;
+  if (C > 0) {
+    int nc = 1;
+    while (nc < C && cells[4 * (size_t)nc + 1] == cells[1] && cells[4 * (size_t)nc + 3] == cells[3]) nc++;
+    if (C % nc == 0) {
+      const int nr = C / nc;
+      bool ok = true;
+      sgx0.resize(nc); sgx1.resize(nc); sgy0.resize(nr); sgy1.resize(nr);
+      for (int c = 0; c < nc; c++) { sgx0[c] = cells[4 * (size_t)c]; sgx1[c] = cells[4 * (size_t)c + 2]; }
+      for (int r = 0; r < nr; r++) { sgy0[r] = cells[4 * (size_t)r * nc + 1]; sgy1[r] = cells[4 * (size_t)r * nc + 3]; }
+      for (int r = 0; r < nr && ok; r++)
+        for (int c = 0; c < nc; c++) {
+          const double* cb = cells + 4 * ((size_t)r * nc + c);
+          if (!(cb[0] == sgx0[c] && cb[1] == sgy0[r] && cb[2] == sgx1[c] && cb[3] == sgy1[r])) { ok = false; break; }
+        }
+      for (int c = 1; c < nc && ok; c++) ok = sgx0[c] >= sgx0[c - 1] && sgx1[c] >= sgx1[c - 1];
+      for (int r = 1; r < nr && ok; r++) ok = sgy0[r] >= sgy0[r - 1] && sgy1[r] >= sgy1[r - 1];
+      for (int c = 0; c < nc && ok; c++) ok = std::isfinite(sgx0[c]) && std::isfinite(sgx1[c]);
+      for (int r = 0; r < nr && ok; r++) ok = std::isfinite(sgy0[r]) && std::isfinite(sgy1[r]);
+      if (ok && !getenv("AUVP_NO_GRID_INDEX")) { sg_ncol = nc; sg_nrow = nr; }
+    }
+  }
+  double prob_absmax = 0.0;
+  for (size_t i = 0; i < (size_t)T * C; i++) {
+    const double a = std::fabs(prob[i]);
+    if (a > prob_absmax || a != a) prob_absmax = a;  // a nan poisons the bound: every leaf is then re-summed exactly
+  }
   int rc;
   if ((rc = upload(h, h->d_rgfirst, rfirst.data(), rfirst.size()))) return rc;
   if ((rc = upload(h, h->d_rgbp, bp.data(), bp.size()))) return rc;
   if ((rc = upload(h, h->d_rgoff, roff.data(), roff.size()))) return rc;
   if ((rc = upload(h, h->d_rgpm, rpm.data(), rpm.size()))) return rc;
   if ((rc = upload(h, h->d_rgid, rid.data(), rid.size()))) return rc;
+  if ((rc = upload(h, h->d_sgx0, sgx0.data(), (size_t)sg_ncol))) return rc;
+  if ((rc = upload(h, h->d_sgx1, sgx1.data(), (size_t)sg_ncol))) return rc;
+  if ((rc = upload(h, h->d_sgy0, sgy0.data(), (size_t)sg_nrow))) return rc;
+  if ((rc = upload(h, h->d_sgy1, sgy1.data(), (size_t)sg_nrow))) return rc;
+  {
+    std::vector<double> col((size_t)sg_ncol * 4, 0.0), row((size_t)sg_nrow * 4, 0.0);
+    for (int c = 0; c < sg_ncol; c++) { col[4 * (size_t)c] = c ? sgx1[c - 1] : -INFINITY; col[4 * (size_t)c + 1] = sgx1[c]; col[4 * (size_t)c + 2] = sgx0[c]; }
+    for (int r = 0; r < sg_nrow; r++) { row[4 * (size_t)r] = r ? sgy1[r - 1] : -INFINITY; row[4 * (size_t)r + 1] = sgy1[r]; row[4 * (size_t)r + 2] = sgy0[r]; }
+    if ((rc = upload(h, h->d_sgcol, col.data(), col.size()))) return rc;
+    if ((rc = upload(h, h->d_sgrow, row.data(), row.size()))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   if ((rc = upload(h, h->d_ox, ox.data(), O))) return rc;
   if ((rc = upload(h, h->d_oy, oy.data(), O))) return rc;
   if ((rc = upload(h, h->d_ot, ot.data(), O))) return rc;
@@ -330,6 +371,21 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   W.rg_enabled = rg_enabled; W.n_rg_bp = (int32_t)bp.size();
   W.rg_first = h->d_rgfirst.as<int32_t>(); W.rg_bp = h->d_rgbp.as<double>(); W.rg_off = h->d_rgoff.as<int32_t>();
   W.rg_pm = h->d_rgpm.as<double>(); W.rg_id = h->d_rgid.as<int32_t>();
+  W.sg_enabled = sg_ncol > 0 ? 1 : 0; W.sg_ncol = sg_ncol; W.sg_nrow = sg_nrow;
+  W.sg_col = h->d_sgcol.as<double>(); W.sg_row = h->d_sgrow.as<double>();
+  W.sg_x1_0 = sg_ncol > 0 ? sgx1[0] : 0.0; W.sg_y1_0 = sg_nrow > 0 ? sgy1[0] : 0.0;
+  {
+    bool sorted = T > 0;
+    for (int t = 0; t < T && sorted; t++) sorted = std::isfinite(bins[2 * t]) && std::isfinite(bins[2 * t + 1]);
+    for (int t = 1; t < T && sorted; t++) sorted = bins[2 * t] >= bins[2 * (t - 1)] && bins[2 * t + 1] >= bins[2 * (t - 1) + 1];
+    W.bins_sorted = sorted ? 1 : 0;
+    W.bins_t1_0 = T > 0 ? bins[1] : 0.0;
+    W.bins_inv_len = (sorted && T > 1 && bins[2 * (T - 1) + 1] > bins[1]) ? (double)(T - 1) / (bins[2 * (T - 1) + 1] - bins[1]) : 0.0;
+  }
+  W.sg_x0 = h->d_sgx0.as<double>(); W.sg_x1 = h->d_sgx1.as<double>(); W.sg_y0 = h->d_sgy0.as<double>(); W.sg_y1 = h->d_sgy1.as<double>();
+  W.sg_inv_dx = (sg_ncol > 1 && sgx1[sg_ncol - 1] > sgx1[0]) ? (double)(sg_ncol - 1) / (sgx1[sg_ncol - 1] - sgx1[0]) : 0.0;
+  W.sg_inv_dy = (sg_nrow > 1 && sgy1[sg_nrow - 1] > sgy1[0]) ? (double)(sg_nrow - 1) / (sgy1[sg_nrow - 1] - sgy1[0]) : 0.0;
+  W.prob_absmax = prob_absmax;
   double bb[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
   for (int i = 0; i < V; i++) {
     bb[0] = std::min(bb[0], polygon[2 * i]); bb[1] = std::min(bb[1], polygon[2 * i + 1]);
@@ -438,13 +494,13 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   HIPCHK(h, h->d_summary.reserve((size_t)E * sizeof(RrtSummary)));
   HIPCHK(h, h->d_pt_term.reserve(cpnt * sizeof(double)));
   HIPCHK(h, h->d_pt_hab.reserve(cpnt));
-  HIPCHK(h, h->d_anc.reserve(cn * 16 * sizeof(int32_t)));
+  HIPCHK(h, h->d_node_c.reserve(cn * 4 * sizeof(int32_t)));
   B.node_f = h->d_nodes_f.as<double>();
   B.node_i = h->d_nodes_i.as<int32_t>();
   B.points = h->d_points.as<double>();
   B.pt_term = h->d_pt_term.as<double>();
   B.pt_hab = h->d_pt_hab.as<int8_t>();
-  B.anc = h->d_anc.as<int32_t>();
+  B.node_c = h->d_node_c.as<int32_t>();
   B.bin_items = h->d_bin_items.as<int32_t>();
   B.bin_count = h->d_bin_count.as<int32_t>();
   B.summary = h->d_summary.as<RrtSummary>();
@@ -533,6 +589,16 @@ int auvp_rrt_run(auvp_handle* h) {
   }
 #undef AUVP_LAUNCH_J
   HIPCHK(h, le);
+  // the trees are complete: rank the qualifying leaves (same stream, inside the timed region)
+  RrtParamsDev PL = P;
+  if (const char* e = getenv("AUVP_LEAF_STOP")) PL.flags |= (atoi(e) == 1 ? 256 : (atoi(e) == 2 ? 512 : 0));  // timing experiments
+  {
+    const int gl = rrt_leaf_grid_lds_bytes(h->W.sg_enabled, h->W.sg_ncol, h->W.sg_nrow);
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, gl));
+    hipLaunchKernelGGL(rrt_leaf_kernel, dim3((E + RRT_LEAF_WAVES - 1) / RRT_LEAF_WAVES), dim3(RRT_LEAF_WAVES * 64), gl, h->stream,
+                       h->W, PL, B, (int)E);
+  }
+  HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float ms = 0.f;

@@ -11,9 +11,8 @@
 //   collision    cull: lane = obstacle (J slots of 64) against the path's bounding box; the few candidates that
 //                survive are tested one at a time with lane = path point
 //   polygon      lane = path point
-//   cost         lane = path element; the leaf->root walk only collects element ids (four ancestors per
-//                dependent load), an element's contribution is evaluated once and cached, the shark
-//                term is summed in path order
+//   cost         not here: the qualifying-leaf cost of exploring (:158-171) only decides which leaf is returned, never
+//                how the tree grows, so rrt_leaf_kernel evaluates it on the finished tree (lane = node, all lanes busy)
 // The steer draw count is data dependent (a sub-arc consumes 2 or 3 random() values): the lanes
 // temper a window of the stream, ballot the "taken" predicate for every possible start offset, and
 // a lane-parallel fixed-point iteration resolves where each sub-arc starts.
@@ -80,7 +79,7 @@ __device__ __forceinline__ void rrt_tables_stage(const RrtTables& S, const World
 }
 
 // Per-wave LDS layout (bytes), all sizes multiples of 16:
-//   [scratch]  steer: u[3C+3] | {inc[(C+1)*4], sc[(C+1)*2], phi[C+1]}   cost: elist[192] i32 + term[64] f64
+//   [scratch]  steer: u[3C+3] | {inc[(C+1)*4], sc[(C+1)*2], phi[C+1]}
 //   [mt]       624 u32
 //   [pts]      max_pts * 2 f64
 //   [bins]     (K+2) i32
@@ -97,9 +96,7 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
   const int C = p.chunk;
   int steer_u = (64 + 3 * C + 3) * 8;  // 64 leading random() values + the steer window
   int steer_s = (4 * ((C + 2) & ~1) + (C + 1) * 3 + 4) * 8;  // inc rows (16-byte aligned), sc, phi + path bounding box
-  int cost = RRT_ELIST * 4 + 64 * 8;
   int s = steer_u > steer_s ? steer_u : steer_s;
-  s = s > cost ? s : cost;
   p.scratch = (s + 15) & ~15;
   p.mt = 624 * 4;
   p.pts = ((max_pts * 16) + 15) & ~15;
@@ -146,8 +143,41 @@ __device__ __forceinline__ bool any_point_outside(const double (*poly)[2], int n
 }
 
 // cost.py:181-184 first-match cell scan through the x-bucket index; returns cell id or -1
-__device__ __forceinline__ int cell_lookup(const WorldDev& W, double x, double y) {
+// first index i in [0, n) with a[i] >= v (n if none): lower bound on a non-decreasing table, found from a guess by
+// comparing against the table's own values, so the result is exact whatever the guess
+__device__ __forceinline__ int lower_bound_from(const double* __restrict__ a, int n, double v, int i) {
+  i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+  while (i > 0 && a[i - 1] >= v) i--;
+  while (i < n && a[i] < v) i++;
+  return i;
+}
+
+// `grid_lds`: optional copy of the separable-grid tables in LDS, laid out X1[ncol] X0[ncol] Y1[nrow] Y0[nrow]
+__device__ __forceinline__ int cell_lookup(const WorldDev& W, double x, double y, const double* grid_lds = nullptr) {
   if (W.n_cells == 0) return -1;
+  if (W.sg_enabled && grid_lds) {
+    const double *x1 = grid_lds, *x0 = grid_lds + W.sg_ncol, *y1 = x0 + W.sg_ncol, *y0 = y1 + W.sg_nrow;
+    const int c = lower_bound_from(x1, W.sg_ncol, x, (int)auvp_floor((x - W.sg_x1_0) * W.sg_inv_dx) + 1);
+    const int r = lower_bound_from(y1, W.sg_nrow, x, (int)auvp_floor((x - W.sg_y1_0) * W.sg_inv_dy) + 1);
+    if (c >= W.sg_ncol || r >= W.sg_nrow) return -1;
+    return (x0[c] <= x && y0[r] <= y) ? r * W.sg_ncol + c : -1;
+  }
+  if (W.sg_enabled) {
+    // row-major grid: first row with Y0[r] <= y and x <= Y1[r] (sic, cost.py:182), first column with X0[c] <= x <= X1[c].
+    // Both guesses are checked with one independent 32-byte read each (the usual case: one round trip); a guess that
+    // is off -- rounding next to a cell edge, or a point outside the grid -- falls back to the stepping search.
+    int gc = (int)auvp_floor((x - W.sg_x1_0) * W.sg_inv_dx) + 1, gr = (int)auvp_floor((x - W.sg_y1_0) * W.sg_inv_dy) + 1;
+    gc = gc < 0 ? 0 : (gc > W.sg_ncol - 1 ? W.sg_ncol - 1 : gc);
+    gr = gr < 0 ? 0 : (gr > W.sg_nrow - 1 ? W.sg_nrow - 1 : gr);
+    const double4 cc = reinterpret_cast<const double4*>(W.sg_col)[gc];
+    const double4 rr = reinterpret_cast<const double4*>(W.sg_row)[gr];
+    if (cc.x < x && cc.y >= x && rr.x < x && rr.y >= x) return (cc.z <= x && rr.z <= y) ? gr * W.sg_ncol + gc : -1;
+    const int c = lower_bound_from(W.sg_x1, W.sg_ncol, x, gc);
+    const int r = lower_bound_from(W.sg_y1, W.sg_nrow, x, gr);
+    if (c >= W.sg_ncol || r >= W.sg_nrow) return -1;
+    if (!(W.sg_x0[c] <= x) || !(W.sg_y0[r] <= y)) return -1;
+    return r * W.sg_ncol + c;
+  }
   double fb = auvp_floor((x - W.xb_x0) * W.xb_inv_w);
   int b = fb < 0.0 ? 0 : (fb >= (double)W.n_xbuckets ? W.n_xbuckets - 1 : (int)fb);
   if (W.rg_enabled) {
@@ -183,21 +213,36 @@ struct CostAcc {
 // (0.0 when it has none: x + 0.0 == x, an exact no-op in the ordered sum) and the first habitat that
 // contains it (-1: none).  An element whose time stamp lies in no bin of [bin_lo, bin_hi) is skipped
 // entirely by the reference: (0.0, -1).
+// `hab_near` (wave-uniform): false when the caller knows that no habitat can contain the element (its bounding-box
+// cull), which skips the habitat scan.
 __device__ __forceinline__ void cost_element(const WorldDev& W, const RrtTables& S, int bin_lo, int bin_hi, double w3,
-                                             double x, double y, double t, double& tv, int& hab) {
-  // first matching bin / habitat in table order, scanned backwards without early exits (the last overwrite is the
-  // first match): the table reads (one LDS address for all lanes) are then independent of the compares and
-  // overlap instead of costing one LDS round trip per row
+                                             double x, double y, double t, double& tv, int& hab, bool hab_near = true,
+                                             const double* grid_lds = nullptr) {
   int tb = -1;
-  for (int b = bin_hi - 1; b >= bin_lo; b--) {
-    const double2 r = *reinterpret_cast<const double2*>(&S.bins[b][0]);
-    tb = (t >= r.x && t <= r.y) ? b : tb;
+  if (W.bins_sorted) {
+    // bins with non-decreasing ends: the first match is the first bin whose upper end reaches t, if it starts at or
+    // before t -- a lower bound, checked against the table's own values (LDS)
+    if (bin_hi > bin_lo) {
+      int i = (int)auvp_floor((t - W.bins_t1_0) * W.bins_inv_len) + 1;
+      i = i < bin_lo ? bin_lo : (i > bin_hi - 1 ? bin_hi - 1 : i);
+      while (i > bin_lo && S.bins[i - 1][1] >= t) i--;
+      while (i < bin_hi && S.bins[i][1] < t) i++;
+      if (i < bin_hi && S.bins[i][0] <= t) tb = i;
+    }
+  } else {
+    // first matching bin in table order, scanned backwards without early exits (the last overwrite is the first
+    // match): the table reads (one LDS address for all lanes) are then independent of the compares
+    for (int b = bin_hi - 1; b >= bin_lo; b--) {
+      const double2 r = *reinterpret_cast<const double2*>(&S.bins[b][0]);
+      tb = (t >= r.x && t <= r.y) ? b : tb;
+    }
   }
   tv = 0.0;
   hab = -1;
   if (tb >= 0) {
-    int c = cell_lookup(W, x, y);
+    int c = cell_lookup(W, x, y, grid_lds);
     if (c >= 0) tv = w3 * W.prob[(size_t)tb * W.n_cells + c];
+    if (hab_near)
     for (int h = W.n_habitats - 1; h >= 0; h--) {
       // dist <= size  <=>  d2 <= T(size): same decision as RN(sqrt(d2)) <= size, no sqrt
       const double2 hxy = *reinterpret_cast<const double2*>(&S.hab[h][0]);
@@ -263,8 +308,6 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   double* inc = scratch;                           // [(C+1)*4]   (steer, phase 2: aliases u_win)
   double* sc = scratch + (size_t)4 * ((C + 2) & ~1);  // [(C+1)*2]
   double* phi_l = sc + (size_t)(C + 1) * 2;           // [C+1]
-  int32_t* elist = reinterpret_cast<int32_t*>(wbase);                  // [192]  (cost walk)
-  double* term = reinterpret_cast<double*>(wbase + RRT_ELIST * 4);     // [64]
   uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + plan.scratch);
   double(*pts)[2] = reinterpret_cast<double(*)[2]>(wbase + plan.scratch + plan.mt);
   int32_t* bin_count = reinterpret_cast<int32_t*>(wbase + plan.scratch + plan.mt + plan.pts);
@@ -305,13 +348,10 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   double* nodeF = B.node_f + (size_t)ep * capn * 8;                       // [capn][8] x,y,theta,t,length
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;    // plan_iter,parent,pt_off,pt_cnt
   double* ptF = B.points + (size_t)ep * capp * 6;                         // [capp][6] x,y,theta,v,t,length
-  double* ptTerm = B.pt_term + (size_t)ep * capp;                         // cost-walk cache (auvp_types.h)
-  int8_t* ptHab = B.pt_hab + (size_t)ep * capp;
-  int32_t* anc = B.anc + (size_t)ep * capn * 16;
   int32_t* bin_items = B.bin_items + (size_t)ep * (P.K + 1) * bcap;
   const double* init = B.init + (size_t)ep * 6;
   const int K = P.K;
-  const bool log_it = DIAG && (P.flags & 1) != 0, log_leaf = DIAG && (P.flags & 2) != 0;
+  const bool log_it = DIAG && (P.flags & 1) != 0;
   const size_t logb = (size_t)ep * P.max_iter;
 
   WaveRng rng;
@@ -332,18 +372,12 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   if (lane == 0) {
     nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
     nodeI[0] = make_int4(0, -1, 0, 0);
-    nodeF[7] = -2.0;
     if (MODE == 0) { bin_items[(size_t)(K >= 1 ? 1 : 0) * bcap] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
   }
-  if (lane < 16) anc[lane] = -1;  // the root has no ancestors
   wave_sync();
-  const double init_t = readfirst_f64(init[3]);
-  int n_nodes = 1, n_points = 0, n_leaves = 0, status = 0, best_leaf = -1, best_L = 0;
-  double best_tot = __builtin_inf();
-  long long leaf_elems = 0;
+  int n_nodes = 1, n_points = 0, status = 0;
   int it = 0, n_cand = 0;  // n_cand: obstacles that survived the cull (exact tests run), whole episode
-  // optional per-phase shader-clock accounting (AUVP_FLAG_PHASE_CLOCKS): select, steer, collision,
-  // accept, cost walk
+  // optional per-phase shader-clock accounting (AUVP_FLAG_PHASE_CLOCKS): select, steer, collision, accept
   const bool clk = DIAG && (P.flags & 4) != 0;
   unsigned long long tph[5] = {0, 0, 0, 0, 0}, t_prev = 0;
 #define AUVP_PHASE(i) do { if (clk) { unsigned long long t_now = __builtin_amdgcn_s_memtime(); tph[i] += t_now - t_prev; t_prev = t_now; } } while (0)
@@ -428,11 +462,6 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     }
 
     AUVP_PHASE(0);
-    // the new node's ancestor line = the parent's record + the parent's first three ancestors: requested now,
-    // consumed at accept (the loads overlap the steer)
-    int anc_v = -1;
-    if (lane < 4) anc_v = reinterpret_cast<const int32_t*>(nodeI + par)[lane];
-    else if (lane < 16) anc_v = anc[(size_t)par * 16 + (lane - 4)];
     // ------------------------------------------------------------ steer (:252-295)
     double cx, cy, cth, ctt, clen;
     {
@@ -579,7 +608,6 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
         // not six 8-byte streams whose partly filled lines the L2 writes back early (-17 % HBM write traffic)
         double2* rec = reinterpret_cast<double2*>(ptF + gi * 6);
         rec[0] = make_double2(mx, my); rec[1] = make_double2(myth, vt); rec[2] = make_double2(mt_, ml);
-        ptHab[gi] = -2;  // cost contribution not evaluated yet
         pts[cnt + rank + 1][0] = mx;
         pts[cnt + rank + 1][1] = my;
       }
@@ -661,17 +689,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
 
     // ------------------------------------------------------------ accept (:144-151)
     const int me = n_nodes;
-    if (lane == 0) {
-      double* nf = nodeF + (size_t)me * 8;
-      *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
-      *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
-      nf[4] = clen;
-      nf[7] = -2.0;
-      nodeI[me] = make_int4(it, par, n_points, cnt);
-    }
-    if (lane < 16) anc[(size_t)me * 16 + lane] = anc_v;
-    n_nodes++;
-    n_points += cnt;
+    if (lane == 0) nodeI[me] = make_int4(it, par, n_points, cnt);
     if (MODE == 0) {
       // curr_bin = (t // bin_interval + 1) * bin_interval, exact floor of the true quotient
       double q = auvp_floor(ctt * Q.inv_bin_interval);  // within one of the true floor; the remainder below settles it
@@ -690,134 +708,15 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       wave_sync();
     }
 
-    AUVP_PHASE(3);
-    // ------------------------------------------------------------ qualifying leaf (:158-171)
-    if (ctt >= Q.max_traj_time - 30) {
-      // which bins make up the leaf's sub-dict (:160-165): lane b judges bin b (n_bins <= 64)
-      // (an element's own bin is always one of them -- DESIGN.md -- so only their number is needed, for the
-      // leaf log)
-      int nsel = 0;
-      {
-        bool sel = false;
-        if (lane < W.n_bins) {
-          const double b0 = S.bins[lane][0], b1 = S.bins[lane][1];
-          sel = (init_t >= b0 && init_t <= b1) || (b0 >= init_t && b1 <= ctt) || (ctt >= b0 && ctt <= b1);
-        }
-        nsel = __popcll(__ballot(sel));
-      }
-      CostAcc acc;
-      acc.c2 = 0.0; acc.visited = 0ull; acc.hits = 0;
-      int Lp = 0;
-      // path = [leaf] + reversed(leaf.path) + reversed(parent.path) + ...   (:321-331)
-      // element id: >= 0 path point index, < 0 node ~id.  The walk only collects ids (one 16-B node
-      // record per ancestor); the lookups run over 64 elements at a time.
-      int fill = 0;
-      auto flush = [&]() {
-        // the cached contributions of all (up to three) 64-element passes are requested before the first one is
-        // processed: one global round trip per flush instead of one per pass
-        double tvs[3];
-        int habs[3], ids[3];
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-          tvs[p] = 0.0; habs[p] = -1; ids[p] = 0;
-          if (64 * p + lane < fill) {
-            const int id = elist[64 * p + lane];
-            ids[p] = id;
-            if (id >= 0) { habs[p] = ptHab[id]; tvs[p] = ptTerm[id]; }
-            else {
-              const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)(~id) * 8 + 6);
-              tvs[p] = c.x; habs[p] = (int)c.y;
-            }
-          }
-        }
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-          const int b0 = 64 * p;
-          if (b0 < fill) {
-          const int nv = (fill - b0) < 64 ? (fill - b0) : 64;
-          double tv = tvs[p];
-          int hab = habs[p];
-          const int id = ids[p];
-          const bool need = lane < nv && hab == -2;
-          if (__any(need)) {
-            if (need) {
-              double ex, ey, et;
-              if (id >= 0) {
-                const double* rec = ptF + (size_t)id * 6;
-                const double2 xy = *reinterpret_cast<const double2*>(rec);
-                ex = xy.x; ey = xy.y; et = rec[4];
-              }
-              else {
-                const double* nf = nodeF + (size_t)(~id) * 8;
-                const double2 a = *reinterpret_cast<const double2*>(nf);
-                ex = a.x; ey = a.y; et = nf[3];
-              }
-              cost_element(*S.world, S, 0, S.world->n_bins, Q.w[2], ex, ey, et, tv, hab);
-              if (id >= 0) { ptTerm[id] = tv; ptHab[id] = (int8_t)hab; }
-              else *reinterpret_cast<double2*>(nodeF + (size_t)(~id) * 8 + 6) = make_double2(tv, (double)hab);
-            }
-          }
-          wave_sync();
-          cost_accumulate(nv, tv, hab, term, acc);
-          }
-        }
-        Lp += fill;
-        fill = 0;
-      };
-      if (lane == 0) elist[0] = ~me;
-      fill = 1;
-      int mcnt = cnt, moff = n_points - cnt, mpar = par;
-      // node records of the next ancestors come four at a time out of one 64-B line (lanes 0..15)
-      int cur = me, kanc = 0, av = anc_v;
-      for (;;) {
-        // segment of node m: its appended points last-to-first, then the node it grew from
-        for (int s0 = 0; s0 < mcnt + 1; s0 += 64) {
-          const int seg = (mcnt + 1 - s0) < 64 ? (mcnt + 1 - s0) : 64;
-          if (fill + seg > RRT_ELIST) { wave_sync(); flush(); }
-          int i = s0 + lane;
-          if (lane < seg) elist[fill + lane] = (i < mcnt) ? (moff + (mcnt - 1 - i)) : ~mpar;
-          fill += seg;
-        }
-        if (kanc == 4) {  // `cur` is the fourth ancestor of the previous anchor: continue from its line
-          av = lane < 16 ? anc[(size_t)cur * 16 + lane] : -1;
-          kanc = 0;
-        }
-        const int gp = __builtin_amdgcn_readlane(av, 4 * kanc + 1);
-        if (gp < 0) break;  // mpar is the root: no path of its own
-        mcnt = __builtin_amdgcn_readlane(av, 4 * kanc + 3);
-        moff = __builtin_amdgcn_readlane(av, 4 * kanc + 2);
-        cur = mpar;
-        mpar = gp;
-        kanc++;
-      }
-      wave_sync();
-      flush();
-      double c0 = 0.0, c1 = 0.0, c2 = acc.c2;
-      const double w2 = Q.w[1];
-      if (w2 == auvp_rint(w2) && auvp_fabs(w2) < 1048576.0) c1 = w2 * (double)acc.hits;  // exact
-      else for (int h = 0; h < acc.hits; h++) c1 = c1 + w2;
-      if (ctt > 0) { c1 = c1 / ctt; c2 = c2 / ctt; }
-      if (W.n_habitats != 0) c0 = Q.w[0] * (double)__popcll(acc.visited) / (double)W.n_habitats;
-      double tot = ((0.0 + c0) + c1) + c2;
-      tot = readfirst_f64(tot);
-      if (log_leaf && n_leaves < B.cap_leaves && lane == 0) {
-        double* lc = B.leaf_cost + ((size_t)ep * B.cap_leaves + n_leaves) * 6;
-        lc[0] = tot; lc[1] = c0; lc[2] = c1; lc[3] = c2; lc[4] = (double)Lp; lc[5] = (double)nsel;
-        B.leaf_iter[(size_t)ep * B.cap_leaves + n_leaves] = it;
-      }
-      n_leaves++;
-      leaf_elems += Lp;
-      if (tot < best_tot) {
-        best_tot = tot;
-        best_leaf = me; best_L = Lp;
-        if (lane == 0) {
-          RrtSummary& s = B.summary[ep];
-          s.best_cost[0] = tot; s.best_cost[1] = c0; s.best_cost[2] = c1; s.best_cost[3] = c2;
-          s.best_length = clen;
-        }
-      }
-      AUVP_PHASE(4);
+    if (lane == 0) {
+      double* nf = nodeF + (size_t)me * 8;
+      *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
+      *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
+      nf[4] = clen;
     }
+    n_nodes++;
+    n_points += cnt;
+    AUVP_PHASE(3);
   }
 
   if (clk && lane == 0 && B.phase_clocks) {
@@ -827,15 +726,298 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   double after = rng_next_random(rng);
   for (int i = lane; i < K + 1; i += 64) B.bin_count[(size_t)ep * (K + 1) + i] = bin_count[i];
   if (lane == 0) {
+    // the tree is complete; rrt_leaf_kernel ranks its qualifying leaves and fills in the rest of the record
     RrtSummary& s = B.summary[ep];
-    if (status == 0 && best_leaf < 0) status = 1;
-    s.status = status; s.n_nodes = n_nodes; s.n_points = n_points; s.n_leaves = n_leaves;
-    s.best_leaf = best_leaf; s.best_path_len = best_L; s.iters_run = it; s.n_candidates = n_cand;
-    if (best_leaf < 0) {
-      s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;
-      s.best_length = 0.0;
+    s.status = status; s.n_nodes = n_nodes; s.n_points = n_points; s.n_leaves = 0;
+    s.best_leaf = -1; s.best_path_len = 0; s.iters_run = it; s.n_candidates = n_cand;
+    s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;
+    s.best_length = 0.0;
+    s.rng_after = after; s.leaf_elems = 0; s.n_draw32 = drawn;
+  }
+}
+
+// The qualifying-leaf bookkeeping of exploring (:158-171) for a finished tree, one wavefront per episode.
+//
+// The reference evaluates habitat_shark_cost_func on the path of every accepted node whose traj_time_stamp is within
+// 30 s of max_traj_time, in creation order, and keeps the first strict minimum.  None of that feeds back into the
+// tree, so it runs here, after the expansion kernel, in two sweeps over the nodes in creation order (64 per pass):
+//
+// 1. terms and running sums.  A path element's contribution to a leaf's cost -- w3*prob of its cell in its time bin,
+//    and the habitat it lies in -- does not depend on the leaf (its bin is always part of the leaf's sub-dict), so it
+//    is evaluated once: lane = node, looping over the node's own elements (its appended points, then its state);
+//    terms are kept (pt_term / pt_hab, node_f[6..7]) and summed down the tree, a node's parent always coming earlier:
+//      node_c = {elements inside some habitat, elements, visited-habitat bit set} of the root..node path (exact)
+//      node_f[5] = S = sum of the shark terms of that path, in tree order
+// 2. ranking.  cost[0] and cost[1] of a leaf follow from the exact integers as the reference computes them.  S differs
+//    from the reference's leaf->root ordered sum only by rounding: both add the same L terms, so each is within
+//    gamma_L * sum|term| of the exact sum (gamma_L = L u / (1 - L u), u = 2^-53), and |term| <= |w3| * max|prob|.
+//    That gives every leaf an interval [lo, hi] containing the reference's total.  A leaf whose lo is not below the
+//    smallest hi of the leaves before it cannot be a strict minimum; the others (a handful per episode: the record
+//    setters and exact ties) are re-summed in the reference's order -- leaf, its points last to first, its parent,
+//    ... root, one rounded add per element -- and compared exactly like the reference does.
+//    With the leaf log requested every qualifying leaf is re-summed (the log holds the reference's per-leaf costs).
+constexpr int RRT_LEAF_WAVES = 4;  // episodes per workgroup of the leaf pass (they share the world tables in LDS)
+__host__ __device__ inline int rrt_leaf_grid_lds_bytes(int sg_enabled, int ncol, int nrow) {
+  const long long b = 16LL * ((long long)ncol + nrow);
+  return (sg_enabled && b <= 48 * 1024) ? (int)b : 0;  // bigger grids are looked up in the global copy
+}
+
+__global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
+  __shared__ __align__(16) unsigned char tables[RRT_WORLD_BYTES + RRT_MAX_HAB * 32 + RRT_MAX_POLY * 16 + RRT_MAX_BINS * 16];
+  __shared__ double w_term[RRT_LEAF_WAVES][64];
+  __shared__ double w_S[RRT_LEAF_WAVES][64];
+  __shared__ int32_t w_hits[RRT_LEAF_WAVES][64], w_elems[RRT_LEAF_WAVES][64], w_par[RRT_LEAF_WAVES][64];
+  __shared__ unsigned long long w_vis[RRT_LEAF_WAVES][64];
+  extern __shared__ __align__(16) unsigned char leaf_dyn[];
+  const RrtTables St = rrt_tables_view(tables, W.n_habitats, W.n_poly);
+  const int wave = uni((int)(threadIdx.x >> 6));
+  const int lane = lane_id();
+  rrt_tables_stage(St, W);
+  const double* grid_lds = nullptr;
+  if (rrt_leaf_grid_lds_bytes(W.sg_enabled, W.sg_ncol, W.sg_nrow)) {
+    double* g = reinterpret_cast<double*>(leaf_dyn);
+    for (int i = threadIdx.x; i < W.sg_ncol; i += blockDim.x) { g[i] = W.sg_x1[i]; g[W.sg_ncol + i] = W.sg_x0[i]; }
+    for (int i = threadIdx.x; i < W.sg_nrow; i += blockDim.x) { g[2 * W.sg_ncol + i] = W.sg_y1[i]; g[2 * W.sg_ncol + W.sg_nrow + i] = W.sg_y0[i]; }
+    grid_lds = g;
+  }
+  __syncthreads();
+  const int ep = (int)blockIdx.x * RRT_LEAF_WAVES + wave;
+  if (ep >= n_episodes) return;  // no workgroup barrier after this point
+  double* term = w_term[wave];
+  double* c_S = w_S[wave];
+  int32_t *c_hits = w_hits[wave], *c_elems = w_elems[wave], *c_par = w_par[wave];
+  unsigned long long* c_vis = w_vis[wave];
+  const double (*s_bins)[2] = St.bins;
+  RrtSummary& sum = B.summary[ep];
+  const int status_in = sum.status;
+  if (status_in < 0) return;  // the expansion failed: nothing to rank
+  const int capn = B.cap_nodes;
+  const size_t capp = (size_t)B.cap_points;
+  double* nodeF = B.node_f + (size_t)ep * capn * 8;
+  const int4* nodeI = reinterpret_cast<const int4*>(B.node_i) + (size_t)ep * capn;
+  int4* nodeC = reinterpret_cast<int4*>(B.node_c) + (size_t)ep * capn;
+  double* ptTerm = B.pt_term + (size_t)ep * capp;
+  int8_t* ptHab = B.pt_hab + (size_t)ep * capp;
+  const double* ptF = B.points + (size_t)ep * capp * 6;
+  const int n_nodes = sum.n_nodes;
+  wave_sync();
+  // ---------------------------------------------------------------- sweep 1: terms and running sums
+  // (a) every stored path point, lane = point: 64 independent lookups in flight per pass, coalesced records
+  const int n_points = sum.n_points;
+  for (int p0 = 0; p0 < n_points; p0 += 128) {  // two points per lane and pass: their record / table reads overlap
+    const int pa = p0 + lane, pb = p0 + 64 + lane;
+    const bool va = pa < n_points, vb = pb < n_points;
+    const double* ra = ptF + (size_t)(va ? pa : 0) * 6;
+    const double* rb = ptF + (size_t)(vb ? pb : 0) * 6;
+    const double2 xya = *reinterpret_cast<const double2*>(ra), xyb = *reinterpret_cast<const double2*>(rb);
+    const double ta = ra[4], tb_ = rb[4];
+    double tva = 0.0, tvb = 0.0;
+    int haba = -1, habb = -1;
+    if (va) cost_element(W, St, 0, W.n_bins, P.w[2], xya.x, xya.y, ta, tva, haba, true, grid_lds);
+    if (vb) cost_element(W, St, 0, W.n_bins, P.w[2], xyb.x, xyb.y, tb_, tvb, habb, true, grid_lds);
+    if (va) { ptTerm[pa] = tva; ptHab[pa] = (int8_t)haba; }
+    if (vb) { ptTerm[pb] = tvb; ptHab[pb] = (int8_t)habb; }
+  }
+  if (P.flags & 256) return;  // timing experiments only (AUVP_LEAF_STOP)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  wave_sync();
+  // (b) lane = node, creation order: its own state's term, the sum over its points' terms, then the parent's sums
+  for (int n0 = 0; n0 < n_nodes; n0 += 64) {
+    const int m = n0 + lane;
+    const bool live = m < n_nodes;
+    int4 r = make_int4(0, -1, 0, 0);
+    if (live) r = nodeI[m];
+    double own = 0.0, ntv = 0.0;
+    int own_hits = 0, nhab = -1;
+    unsigned long long own_vis = 0ull;
+    if (live) {
+      const double2 xy = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8);
+      cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, nodeF[(size_t)m * 8 + 3], ntv, nhab, true, grid_lds);
+      for (int k = 0; k < r.w; k += 4) {  // four independent reads in flight per step; any order will do for S
+        double t4[4];
+        int h4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool in = k + j < r.w;
+          const size_t at = (size_t)r.z + (size_t)(in ? k + j : 0);
+          t4[j] = in ? ptTerm[at] : 0.0;
+          h4[j] = in ? (int)ptHab[at] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          own = own + t4[j];
+          if (h4[j] >= 0) { own_hits++; own_vis |= (1ull << h4[j]); }
+        }
+      }
+      own = own + ntv;
+      if (nhab >= 0) { own_hits++; own_vis |= (1ull << nhab); }
     }
-    s.rng_after = after; s.leaf_elems = leaf_elems; s.n_draw32 = drawn;
+    // the parent's sums: from memory when it belongs to an earlier pass, else from the lanes of this one, in order
+    double pS = 0.0;
+    int4 pc = make_int4(0, 0, 0, 0);
+    const bool par_before = live && r.y >= 0 && r.y < n0;
+    if (par_before) { pS = nodeF[(size_t)r.y * 8 + 5]; pc = nodeC[r.y]; }
+    unsigned long long pvis = ((unsigned long long)(uint32_t)pc.w << 32) | (unsigned long long)(uint32_t)pc.z;
+    wave_sync();
+    c_par[lane] = r.y - n0;
+    c_S[lane] = pS + own; c_hits[lane] = pc.x + own_hits; c_elems[lane] = pc.y + r.w + 1; c_vis[lane] = pvis | own_vis;
+    wave_sync();
+    const unsigned long long inpass = __ballot(live && r.y >= n0);
+    if (inpass) {
+      if (lane == 0) {  // creation order: a parent's entry is final before any of its children reads it
+        unsigned long long todo = inpass;
+        while (todo) {
+          const int i = __ffsll((long long)todo) - 1;
+          todo &= todo - 1ull;
+          const int p = c_par[i];
+          c_S[i] = c_S[p] + c_S[i]; c_hits[i] += c_hits[p]; c_elems[i] += c_elems[p]; c_vis[i] |= c_vis[p];
+        }
+      }
+      wave_sync();
+    }
+    if (live) {
+      *reinterpret_cast<double2*>(nodeF + (size_t)m * 8 + 6) = make_double2(ntv, (double)nhab);
+      nodeF[(size_t)m * 8 + 5] = c_S[lane];
+      const unsigned long long v = c_vis[lane];
+      nodeC[m] = make_int4(c_hits[lane], c_elems[lane], (int)(uint32_t)(v & 0xffffffffull), (int)(uint32_t)(v >> 32));
+    }
+    // the next pass reads these sums back through the vector cache: make the stores visible to the whole wave first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wave_sync();
+  }
+  if (P.flags & 512) return;  // timing experiments only (AUVP_LEAF_STOP)
+  // ---------------------------------------------------------------- sweep 2: ranking
+  const bool log_leaf = (P.flags & 2) != 0 && B.leaf_cost != nullptr;
+  const double init_t = B.init[(size_t)ep * 6 + 3];
+  const double w1 = P.w[0], w2 = P.w[1], w3 = P.w[2];
+  const double thresh = P.max_traj_time - 30;
+  const double term_max = auvp_fabs(w3) * W.prob_absmax;  // |shark term of one element| <= this
+  const bool w2_int = (w2 == auvp_rint(w2) && auvp_fabs(w2) < 1048576.0);
+  const int H = W.n_habitats;
+  wave_sync();
+
+  // cost[0], cost[1] and the scaled shark term of a leaf, given the ordered or unordered sum `c2num`
+  auto total_of = [&](int hits, unsigned long long vis, double ctt, double c2num, double& c0, double& c1, double& c2) {
+    c0 = 0.0; c1 = 0.0; c2 = c2num;
+    if (w2_int) c1 = w2 * (double)hits;  // exact: equals `hits` successive rounded additions of an integer weight
+    else for (int h = 0; h < hits; h++) c1 = c1 + w2;
+    if (ctt > 0) { c1 = c1 / ctt; c2 = c2 / ctt; }
+    if (H != 0) c0 = w1 * (double)__popcll(vis) / (double)H;
+    return ((0.0 + c0) + c1) + c2;
+  };
+
+  int n_leaves = 0, best_leaf = -1, best_L = 0;
+  long long leaf_elems = 0;
+  double best_tot = __builtin_inf(), best_c0 = 0.0, best_c1 = 0.0, best_c2 = 0.0, best_len = 0.0;
+  double min_hi = __builtin_inf();  // smallest upper bound among the qualifying leaves seen so far
+  for (int n0 = 1; n0 < n_nodes; n0 += 64) {  // node 0 is the start state: never a leaf candidate (:144-171)
+    const int m = n0 + lane;
+    bool q = false;
+    double lo = __builtin_inf(), hi = __builtin_inf(), ctt = 0.0;
+    int elems = 0;
+    if (m < n_nodes) {
+      const double2 tl = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8 + 3);  // traj_t, length
+      ctt = tl.x;
+      q = ctt >= thresh;
+      if (q) {
+        const int4 c = nodeC[m];
+        elems = c.y;
+        const unsigned long long vis = ((unsigned long long)(uint32_t)c.w << 32) | (unsigned long long)(uint32_t)c.z;
+        double c0, c1, c2;
+        const double S = nodeF[(size_t)m * 8 + 5];
+        const double tot = total_of(c.x, vis, ctt, S, c0, c1, c2);
+        // |S - ordered sum| <= 2 gamma_L L term_max; one more rounding each for the division and the two additions
+        const double L = (double)elems;
+        const double gam = 2.0 * (L + 2.0) * 0x1p-53;
+        double e2 = 2.0 * gam * L * term_max;
+        if (ctt > 0) e2 = e2 / ctt;
+        const double err = 1.25 * e2 + 0x1p-50 * (auvp_fabs(c0) + auvp_fabs(c1) + auvp_fabs(c2) + e2);
+        lo = tot - err; hi = tot + err;
+        if (!(err == err) || !(tot == tot)) { lo = -__builtin_inf(); hi = __builtin_inf(); }  // nan: decide exactly
+      }
+    }
+    const unsigned long long qm = __ballot(q);
+    n_leaves += __popcll(qm);
+    // exclusive prefix minimum of hi over the lanes (creation order), seeded with the earlier chunks
+    double pm = hi;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double t = __shfl_up(pm, o, 64);
+      if (lane >= o) pm = t < pm ? t : pm;
+    }
+    double before = __shfl_up(pm, 1, 64);
+    if (lane == 0) before = __builtin_inf();
+    before = before < min_hi ? before : min_hi;
+    {
+      long long el = q ? (long long)elems : 0ll;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) el += __shfl_xor(el, o, 64);
+      leaf_elems += el;
+    }
+    const bool cand = q && (log_leaf || lo < before);
+    unsigned long long cm = __ballot(cand);
+    min_hi = readlane_f64(pm, 63) < min_hi ? readlane_f64(pm, 63) : min_hi;
+    while (cm) {
+      const int l = __ffsll((long long)cm) - 1;
+      cm &= cm - 1ull;
+      const int leaf = n0 + l;
+      const double lo_l = readlane_f64(lo, l);
+      if (!log_leaf && !(lo_l < best_tot)) continue;  // an exact total found meanwhile already rules it out
+      // ---- the reference's ordered sum: [leaf] + reversed(leaf.path[1:]) + [parent] + reversed(parent.path[1:]) ... root
+      double c2num = 0.0;
+      int mm = leaf;
+      for (;;) {
+        const int4 r = nodeI[mm];
+        const double tvn = nodeF[(size_t)mm * 8 + 6];
+        c2num = c2num + tvn;  // the node's own state comes before the points that led to it
+        if (r.y < 0) break;   // the root has no path of its own
+        for (int k0 = 0; k0 < r.w; k0 += 64) {
+          const int nv = (r.w - k0) < 64 ? (r.w - k0) : 64;
+          wave_sync();
+          term[lane] = (lane < nv) ? ptTerm[(size_t)r.z + (size_t)(r.w - 1 - (k0 + lane))] : 0.0;  // last point first
+          wave_sync();
+          for (int i = 0; i < nv; i++) c2num = c2num + term[i];
+        }
+        mm = r.y;
+      }
+      const int4 c = nodeC[leaf];
+      const unsigned long long vis = ((unsigned long long)(uint32_t)c.w << 32) | (unsigned long long)(uint32_t)c.z;
+      const double2 tl = *reinterpret_cast<const double2*>(nodeF + (size_t)leaf * 8 + 3);
+      double c0, c1, c2;
+      double tot = total_of(c.x, vis, tl.x, c2num, c0, c1, c2);
+      tot = readfirst_f64(tot);
+      if (log_leaf) {
+        // position of this leaf among the qualifying ones = leaves before this chunk + qualifying lanes below l
+        const int pos = n_leaves - __popcll(qm) + __popcll(qm & ((1ull << l) - 1ull));
+        if (pos < B.cap_leaves && lane == 0) {
+          // number of shark-grid bins in the leaf's sub-dict (:160-165)
+          int nsel = 0;
+          for (int b = 0; b < W.n_bins; b++) {
+            const double b0 = s_bins[b][0], b1 = s_bins[b][1];
+            nsel += ((init_t >= b0 && init_t <= b1) || (b0 >= init_t && b1 <= tl.x) || (tl.x >= b0 && tl.x <= b1)) ? 1 : 0;
+          }
+          double* lc = B.leaf_cost + ((size_t)ep * B.cap_leaves + pos) * 6;
+          lc[0] = tot; lc[1] = c0; lc[2] = c1; lc[3] = c2; lc[4] = (double)c.y; lc[5] = (double)nsel;
+          B.leaf_iter[(size_t)ep * B.cap_leaves + pos] = nodeI[leaf].x;
+        }
+      }
+      if (tot < best_tot) {
+        best_tot = tot; best_leaf = leaf; best_L = c.y;
+        best_c0 = c0; best_c1 = c1; best_c2 = c2; best_len = tl.y;
+      }
+    }
+  }
+  if (lane == 0) {
+    sum.n_leaves = n_leaves;
+    sum.leaf_elems = leaf_elems;
+    sum.best_leaf = best_leaf;
+    sum.best_path_len = best_L;
+    if (best_leaf >= 0) {
+      sum.best_cost[0] = best_tot; sum.best_cost[1] = best_c0; sum.best_cost[2] = best_c1; sum.best_cost[3] = best_c2;
+      sum.best_length = best_len;
+    } else if (status_in == 0) {
+      sum.status = 1;  // no qualifying leaf: opt_path stays None (:174)
+    }
   }
 }
 
