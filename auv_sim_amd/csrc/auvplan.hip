@@ -17,6 +17,7 @@
 
 #include "../../include/auvplan.h"
 #include "rrt_explore_kernel.h"
+#include "rrt_rows_kernel.h"
 
 using namespace auvp;
 
@@ -571,9 +572,25 @@ int auvp_rrt_run(auvp_handle* h) {
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipError_t le = hipSuccess;
+  const bool diag = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_LEAF_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
+  // four episodes per wavefront (rrt_rows_kernel.h) where its limits allow; one episode per wavefront otherwise
+  const RowsLdsPlan rp = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins));
+  const bool iter_log = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
+  const char* rows_env = getenv("AUVP_ROWS");
+  const bool use_rows = P.mode == 0 && !iter_log && nfreq <= RW_MAX_FREQ && O_ <= RW_MAX_OBST && P.max_iter < 65534 &&
+                        rp.total <= 160 * 1024 && !(rows_env && atoi(rows_env) == 0);
+  int grid_used = grid, block_used = RRT_X_WAVES * 64, lds_used = (int)lds;
+  if (use_rows) {
+    const int per_wg = RW_WAVES * RW_ROWS;
+    grid_used = (E + per_wg - 1) / per_wg; block_used = RW_WAVES * 64; lds_used = rp.total;
+    le = hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, rp.total);
+    if (le == hipSuccess) {
+      hipLaunchKernelGGL(rrt_rows_kernel, dim3(grid_used), dim3(block_used), rp.total, h->stream, h->W, P, B, (int)E);
+      le = hipGetLastError();
+    }
+  } else {
   // compile-time specialisation: obstacles per lane (J), parent-sampling mode, diagnostics on/off
   const int jsel = O <= 64 ? 0 : (O <= 128 ? 1 : (O <= 256 ? 2 : (O <= 512 ? 3 : 4)));
-  const bool diag = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_LEAF_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
 #define AUVP_LAUNCH_J(JV)                                                                   \
   do {                                                                                      \
     if (P.mode == 0) le = diag ? launch(rrt_explore_kernel<JV, 0, true>) : launch(rrt_explore_kernel<JV, 0, false>); \
@@ -588,6 +605,7 @@ int auvp_rrt_run(auvp_handle* h) {
     default: AUVP_LAUNCH_J(16); break;
   }
 #undef AUVP_LAUNCH_J
+  }
   HIPCHK(h, le);
   // the trees are complete: rank the qualifying leaves (same stream, inside the timed region)
   RrtParamsDev PL = P;
@@ -604,7 +622,7 @@ int auvp_rrt_run(auvp_handle* h) {
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  h->last_grid = grid; h->last_block = RRT_X_WAVES * 64; h->last_lds = (int)lds;
+  h->last_grid = grid_used; h->last_block = block_used; h->last_lds = lds_used;
   h->have_batch = true;
   return AUVP_OK;
 }

@@ -1,0 +1,475 @@
+// rrt_rows_kernel.h -- RRT.exploring (path_planning/rrt_dubins.py:92-176), time-bin sampling, FOUR episodes per
+// wavefront: one 16-lane row (the DPP row) per episode.
+//
+// rrt_explore_kernel gives a whole wavefront to one episode and is bound by vector-instruction issue with ~20 % of
+// the lanes doing useful work (a steer has 14.5 sub-arcs on average, the bookkeeping is one lane's worth).  Here every
+// vector instruction serves four episodes: what was wave-uniform (and lived in scalar registers) becomes row-uniform
+// (the same value in the 16 lanes of a row), ballots are cut into 16-bit row masks, cross-lane reads stay inside a
+// row.  A steer of up to 30 sub-arcs takes two passes of 15 (lane 15 of a row carries the pass-entry angle), the
+// running sums keep the reference's left-to-right order (theta by a DPP row shift chain, x/y/t/length by four lanes
+// per row through LDS).  The results are bit-identical to rrt_explore_kernel's; rrt_leaf_kernel finishes both.
+//
+// LDS per episode: the MT19937 state (2 496 B), one scratch block (the tempered random() window of a pass, then the
+// four running-sum rows: 576 B) and the time-bin counters as u16.  A workgroup is 12 waves = 48 episodes sharing the
+// world tables and the obstacle tile: one workgroup per CU, three waves per SIMD.
+//
+// Limits (the host falls back to rrt_explore_kernel beyond them): time-bin mode, no diagnostics, freq <= 30,
+// <= 256 obstacles, <= 65 534 iterations (u16 bin counters).
+#ifndef AUVP_RRT_ROWS_KERNEL_H
+#define AUVP_RRT_ROWS_KERNEL_H
+#include "rrt_explore_kernel.h"
+
+namespace auvp {
+
+constexpr int RW_WAVES = 12;  // waves per workgroup
+constexpr int RW_ROWS = 4;    // episodes per wave
+constexpr int RW_C = 15;      // sub-arcs per steer pass (lane 15 of the row: pass-entry angle)
+constexpr int RW_MAX_FREQ = 2 * RW_C;
+constexpr int RW_MAX_OBST = 256;
+constexpr int RW_WIN = 3 * RW_C + 3;  // random() values a pass may look at
+
+struct RowsLdsPlan {
+  int tables, mt, scratch, bins, per_ep, obst, total;
+};
+
+__host__ __device__ inline RowsLdsPlan rrt_rows_lds_plan(int K, int n_obst_slots, int tables_bytes) {
+  RowsLdsPlan p;
+  p.tables = (tables_bytes + 15) & ~15;
+  p.mt = 624 * 4;
+  const int win = RW_WIN * 8, inc = 4 * 18 * 8;
+  p.scratch = ((win > inc ? win : inc) + 15) & ~15;
+  p.bins = (((K + 2) * 2) + 15) & ~15;
+  p.per_ep = p.mt + p.scratch + p.bins;
+  p.obst = n_obst_slots * (8 + 8 + 4);  // x, y f64; cull radius f32
+  p.total = p.tables + RW_WAVES * RW_ROWS * p.per_ep + p.obst;
+  return p;
+}
+
+// ---- row helpers (16 lanes = one episode) ----
+__device__ __forceinline__ uint32_t row_ballot(bool pred, int rowbase) {
+  return (uint32_t)((__ballot(pred) >> rowbase) & 0xffffull);
+}
+__device__ __forceinline__ int row_read(int v, int src_lane) { return __shfl(v, src_lane, 64); }
+__device__ __forceinline__ double row_read_f64(double v, int src_lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl((int)(b & 0xffffffffll), src_lane, 64), hi = __shfl((int)(b >> 32), src_lane, 64);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// value of the previous lane of the row (DPP row_shr:1); lane 0 of every row gets `first`
+__device__ __forceinline__ double row_prev_f64(double v, double first) {
+  const long long b = __double_as_longlong(v), f = __double_as_longlong(first);
+  const int lo = __builtin_amdgcn_update_dpp((int)(f & 0xffffffffll), (int)(b & 0xffffffffll), 0x111, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(b >> 32), 0x111, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Per-row view of the MT19937 stream (state in the episode's LDS block, refilled in place like WaveRng, 16 words per
+// round and row).  pslot / avail / drawn are row-uniform.
+struct RowRng {
+  uint32_t* s;
+  uint32_t pslot, avail;
+  unsigned long long drawn;
+};
+
+// make sure every row that asks (`want`) has `need` words generated ahead of its consumer
+__device__ __forceinline__ void rows_ensure(RowRng& r, bool want, uint32_t need, int rl) {
+  for (;;) {
+    const bool go = want && r.avail < need;
+    if (!__any(go)) break;
+    uint32_t n = 624u - r.avail;
+    n = n < 16u ? n : 16u;
+    n = go ? n : 0u;
+    uint32_t k = r.pslot + r.avail + (uint32_t)rl;
+    k = k >= 624u ? k - 624u : k;
+    k = k >= 624u ? k - 624u : k;
+    const uint32_t k1 = (k + 1u == 624u) ? 0u : k + 1u;
+    uint32_t km = k + 397u;
+    km = km >= 624u ? km - 624u : km;
+    const uint32_t a = r.s[k], b = r.s[k1], c = r.s[km];
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    const uint32_t v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    wave_sync();  // every lane's reads are issued before any lane's write
+    if ((uint32_t)rl < n) r.s[k] = v;
+    wave_sync();
+    r.avail += n;
+  }
+}
+__device__ __forceinline__ double rows_random_at(const RowRng& r, uint32_t j) {
+  uint32_t k = r.pslot + 2u * j;
+  k = k >= 624u ? k - 624u : k;
+  const uint32_t k1 = (k + 1u == 624u) ? 0u : k + 1u;
+  const uint32_t a = mt_temper(r.s[k]) >> 5, b = mt_temper(r.s[k1]) >> 6;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ void rows_advance(RowRng& r, bool on, uint32_t nwords) {
+  if (on) {
+    uint32_t p = r.pslot + nwords;
+    while (p >= 624u) p -= 624u;
+    r.pslot = p;
+    r.avail -= nwords;
+    r.drawn += nwords;
+  }
+}
+
+__global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const RrtTables S = rrt_tables_view(smem, W.n_habitats, W.n_poly);
+  const int wave = (int)(threadIdx.x >> 6);
+  const int lane = lane_id();
+  const int row = lane >> 4, rl = lane & 15, rowbase = lane & 48;
+  const int K = P.K;
+  const RowsLdsPlan plan = rrt_rows_lds_plan(K, RW_MAX_OBST, rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins));
+  unsigned char* ebase = smem + plan.tables + (size_t)(wave * RW_ROWS + row) * plan.per_ep;
+  uint32_t* mt = reinterpret_cast<uint32_t*>(ebase);
+  double* win = reinterpret_cast<double*>(ebase + plan.mt);  // [RW_WIN] tempered random() values of a pass
+  double* inc = win;                                         // [4][18] running sums (aliases the window once it is dead)
+  uint16_t* bin_count = reinterpret_cast<uint16_t*>(ebase + plan.mt + plan.scratch);
+
+  rrt_tables_stage(S, W);
+  if (threadIdx.x == 0) *S.params = P;
+  const RrtParamsDev& Q = *S.params;
+  double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)RW_WAVES * RW_ROWS * plan.per_ep);
+  double* oly = olx + RW_MAX_OBST;
+  float* olr = reinterpret_cast<float*>(oly + RW_MAX_OBST);
+  for (int i = threadIdx.x; i < RW_MAX_OBST; i += blockDim.x) {
+    const bool ok = i < W.n_obstacles;
+    const double t = ok ? W.ot[i] : -1.0;
+    olx[i] = ok ? W.ox[i] : 0.0;
+    oly[i] = ok ? W.oy[i] : 0.0;
+    const double rd = t >= 0.0 ? auvp_sqrt(t) * (1.0 + 0x1p-30) + 0x1p-40 : -__builtin_inf();
+    float rf = (float)rd;
+    if ((double)rf < rd) rf = __uint_as_float(__float_as_uint(rf) + 1u);
+    olr[i] = rf;
+  }
+  __syncthreads();
+
+  const int ep = ((int)blockIdx.x * RW_WAVES + wave) * RW_ROWS + row;
+  bool live = ep < n_episodes;  // row-uniform; a row that fails keeps running as a no-op until the wave is done
+  const int eps = live ? ep : 0;
+  if (!__any(live)) return;
+
+  // ---- per-episode views ----
+  const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
+  double* nodeF = B.node_f + (size_t)eps * capn * 8;
+  int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)eps * capn;
+  double* ptF = B.points + (size_t)eps * capp * 6;
+  int32_t* bin_items = B.bin_items + (size_t)eps * (K + 1) * bcap;
+  const double* init = B.init + (size_t)eps * 6;
+
+  RowRng rng;
+  rng.s = mt;
+  for (int i = rl; i < 624; i += 16) mt[i] = B.mt[(size_t)eps * 624 + i];
+  {
+    int idx = B.mt_index ? B.mt_index[eps] : 624;
+    idx = idx < 0 ? 0 : (idx > 624 ? 624 : idx);
+    rng.pslot = idx == 624 ? 0u : (uint32_t)idx;
+    rng.avail = (uint32_t)(624 - idx);
+    rng.drawn = 0ull;
+  }
+  for (int i = rl; i < K + 2; i += 16) bin_count[i] = 0;
+  wave_sync();
+  if (live && rl == 0) {
+    nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
+    nodeI[0] = make_int4(0, -1, 0, 0);
+    bin_items[(size_t)(K >= 1 ? 1 : 0) * bcap] = 0;
+    bin_count[K >= 1 ? 1 : 0] = 1;
+  }
+  wave_sync();
+  int n_nodes = 1, n_points = 0, status = 0, n_cand = 0, iters_run = 0;
+  const int nfreq = (int)Q.freq;
+  const int nv_poly = W.n_poly;
+
+  for (int it = 0; it < P.max_iter; it++) {
+    if (!__any(live)) break;
+    // ------------------------------------------------------------ parent selection (:121-127)
+    // lane rl of a row tries draw rl: ran_bin = int(uniform(1, K+1)) until that bin is non-empty; the first success in
+    // stream order wins, a key beyond K before it is a KeyError.  14 tries per round leave room for the two draws
+    // that follow the successful one.
+    int par = 0, n_total = 0, base = 0;
+    {
+      bool search = live;
+      int fo = 0, rb = 0, cnt = 0;
+      double u = 0.0;
+      for (;;) {
+        rows_ensure(rng, search, 32u, rl);
+        if (search) u = rows_random_at(rng, (uint32_t)rl);
+        const int rbj = (int)py_uniform(1.0, (double)(K + 1), u);
+        const bool cand = search && rl < 14;
+        const bool badkey = cand && rbj > K;
+        const int cj = (cand && !badkey) ? (int)bin_count[rbj] : 0;
+        const uint32_t okm = row_ballot(cj != 0, rowbase), badm = row_ballot(badkey, rowbase);
+        const int f_ok = okm ? (__ffs((int)okm) - 1) : 16, f_bad = badm ? (__ffs((int)badm) - 1) : 16;
+        if (search) {
+          if (f_bad < f_ok) { status = -5; live = false; iters_run = it; search = false; }
+          else if (f_ok < 16) { fo = f_ok; search = false; }
+        }
+        const bool again = search;
+        rows_advance(rng, again, 28u);  // 14 unsuccessful draws
+        const int src = rowbase + (again ? 0 : fo);
+        // rows that just finished pick up the winner's values (rows still searching read garbage they overwrite later)
+        const int rb_n = row_read(rbj, src), cnt_n = row_read(cj, src);
+        if (!again && live && cnt == 0) { rb = rb_n; cnt = cnt_n; }
+        if (!__any(again)) break;
+      }
+      const double u1 = row_read_f64(u, rowbase + fo + 1), u2 = row_read_f64(u, rowbase + fo + 2);
+      if (live) {
+        const int ri = (int)py_uniform(0.0, (double)cnt, u1);
+        par = bin_items[(size_t)rb * bcap + ri];
+        n_total = (int)auvp_floor(py_uniform(0.0, Q.freq, u2) / 1);
+        base = fo + 3;
+      }
+    }
+    // ------------------------------------------------------------ steer (:252-295), passes of RW_C sub-arcs
+    double cx = 0.0, cy = 0.0, cth = 0.0, ctt = 0.0, clen = 0.0;
+    if (live) {
+      const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 8);
+      const double2 b = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 8 + 2);
+      cx = a.x; cy = a.y; cth = b.x; ctt = b.y;
+      clen = nodeF[(size_t)par * 8 + 4];
+    }
+    const double px0 = cx, py0 = cy, clen0 = clen;
+    int cnt = 0;  // appended path points of this row's steer
+    // the lane's own path point of pass 0 / pass 1 (kept for the exact collision and boundary tests)
+    double ptx[2] = {0.0, 0.0}, pty[2] = {0.0, 0.0};
+    bool ptv[2] = {false, false};
+    bool first_pass = true;
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int c0 = pass * RW_C;
+      const bool on = live && c0 < n_total;  // rows with sub-arcs left
+      if (!__any(on)) break;
+      const int n = on ? ((n_total - c0) < RW_C ? (n_total - c0) : RW_C) : 0;
+      const int nwin = 3 * n;
+      const int b0 = first_pass ? base : 0;  // later passes start at the (advanced) head of the stream
+      // window entry j of this pass = random() number b0 + j of the row's stream
+      rows_ensure(rng, on, (uint32_t)(2 * (b0 + nwin)), rl);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int j = rl + 16 * t;
+        if (on && j < nwin) win[j] = rows_random_at(rng, (uint32_t)(b0 + j));
+      }
+      wave_sync();
+      // "taken" predicate for every possible start offset, 48 bits per row
+      unsigned long long tpred = 0ull;
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int j = rl + 16 * t;
+        bool f = false;
+        if (on && j + 1 < nwin) {
+          const double dist = py_uniform(0.0, Q.dist_to_end, win[j]);
+          const double diff = py_uniform(-Q.diff_max, Q.diff_max, win[j + 1]);
+          f = auvp_fabs(dist) > auvp_fabs(diff);
+        }
+        tpred |= (unsigned long long)row_ballot(f, rowbase) << (16 * t);
+      }
+      // where does sub-arc s start?  pos_s = 2s + (#taken among sub-arcs < s): fixed point of
+      //   taken_s = T[2s + c_s],  c_s = popcount(taken below s),  started from "everything taken"
+      const bool active = rl < n;
+      int cbelow = rl;
+      uint32_t tmask;
+      const unsigned long long mywin = tpred >> (2 * rl);
+      for (;;) {
+        const bool tk = active && ((mywin >> cbelow) & 1ull);
+        tmask = row_ballot(tk, rowbase);
+        const int cnew = __popc(tmask & ((1u << rl) - 1u));
+        const bool changed = active && (cnew != cbelow);
+        cbelow = cnew;
+        if (!__any(changed)) break;
+      }
+      const int mypos = 2 * rl + cbelow;
+      const int used = 2 * n + __popc(tmask);
+      const bool taken = (tmask >> rl) & 1u;
+      double radius = 0.0, phi = 0.0, vt = 1.0;
+      if (taken) {
+        const double dist = py_uniform(0.0, Q.dist_to_end, win[mypos]);
+        const double diff = py_uniform(-Q.diff_max, Q.diff_max, win[mypos + 1]);
+        const double s1 = dist + diff, s2 = dist - diff;
+        radius = (s1 + s2) / (-s1 + s2);
+        phi = (s1 + s2) / (2 * radius);
+        vt = py_uniform(0.0, 2 * Q.v, win[mypos + 2]);
+      }
+      wave_sync();  // the window is dead: its LDS becomes the running-sum scratch
+      // theta += phi, left to right: lane s ends with (((theta0 + phi_0) + phi_1) + ... + phi_s); untaken and idle lanes add
+      // an exact 0.0.  One DPP row shift per step; lane s is final after s + 1 steps.
+      double th = phi;
+      {
+        int nmax = 0;  // longest pass among the rows (wave-uniform loop bound)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int nr = __builtin_amdgcn_readlane(n, 16 * r);
+          nmax = nr > nmax ? nr : nmax;
+        }
+        for (int s = 0; s < nmax; s++) th = row_prev_f64(th, cth) + phi;
+      }
+      const double myth = (rl == 15) ? cth : th;  // lane 15: the pass-entry angle
+      double sn, cs;
+      auvp_sincos(myth, &sn, &cs);
+      double dx = 0.0, dy = 0.0, mv = 0.0, dt = 0.0;
+      {
+        const uint32_t below = tmask & ((1u << rl) - 1u);
+        const int prev = below ? (31 - __clz((int)below)) : 15;
+        const double so = row_read_f64(sn, rowbase + prev), co = row_read_f64(cs, rowbase + prev);
+        if (taken) {
+          dx = radius * (sn - so);
+          dy = radius * (-cs + co);
+          mv = auvp_sqrt(dx * dx + dy * dy);
+          dt = mv / vt;
+        }
+      }
+      // x += dx; y += dy; t += dt; length += movement: four serial chains per row, lanes 0..3, 18-double rows in LDS
+      if (rl < 15) { inc[rl] = dx; inc[18 + rl] = dy; inc[36 + rl] = dt; inc[54 + rl] = mv; }
+      else { inc[15] = 0.0; inc[33] = 0.0; inc[51] = 0.0; inc[69] = 0.0; }  // entry 15 pads the last 16-byte pair
+      wave_sync();
+      if (rl < 4 && on) {
+        double acc = rl == 0 ? cx : (rl == 1 ? cy : (rl == 2 ? ctt : clen));
+        double* rowp = inc + rl * 18;
+#pragma unroll 2
+        for (int s = 0; s < n; s += 2) {  // two steps per 16-byte access (entries past n hold exact zeros)
+          double2 v = *reinterpret_cast<double2*>(rowp + s);
+          acc = acc + v.x; v.x = acc;
+          acc = acc + v.y; v.y = acc;
+          *reinterpret_cast<double2*>(rowp + s) = v;
+        }
+      }
+      wave_sync();
+      double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
+      if (active) { mx = inc[rl]; my = inc[18 + rl]; mt_ = inc[36 + rl]; ml = inc[54 + rl]; }
+      const bool app = taken && (mv >= Q.min_dist);
+      const uint32_t amask = row_ballot(app, rowbase);
+      const int napp = __popc(amask);
+      if (on && (n_points + cnt + napp > capp)) { status = -2; live = false; iters_run = it; }
+      const bool wr = app && live;
+      if (wr) {
+        const int rank = __popc(amask & ((1u << rl) - 1u));
+        const size_t gi = (size_t)(n_points + cnt + rank);  // speculative: committed only if the node is accepted
+        double2* rec = reinterpret_cast<double2*>(ptF + gi * 6);
+        rec[0] = make_double2(mx, my); rec[1] = make_double2(myth, vt); rec[2] = make_double2(mt_, ml);
+      }
+      ptx[pass] = mx; pty[pass] = my; ptv[pass] = wr;
+      {
+        // the row's state after this pass = the prefix values of its last sub-arc
+        const int last = n > 0 ? n - 1 : 0;
+        const double th_last = row_read_f64(myth, rowbase + last);
+        if (on) {
+          cnt += napp;
+          cx = inc[last]; cy = inc[18 + last]; ctt = inc[36 + last]; clen = inc[54 + last];
+          cth = th_last;
+        }
+      }
+      rows_advance(rng, on, (uint32_t)(2 * (b0 + used)));
+      first_pass = false;
+      wave_sync();
+    }
+    // a steer without sub-arcs consumed only the selection and n_expand draws
+    rows_advance(rng, live && n_total == 0, (uint32_t)(2 * base));
+
+    // ------------------------------------------------------------ check_collision (:530-549)
+    // conservative cull: the square around the parent's end that holds every prefix position (half-width = the steer's
+    // total movement) against each obstacle's bounding square; survivors get the exact test d2 <= T_i on every point
+    const double reach = clen - clen0;
+    const double bx0 = px0 - reach, by0 = py0 - reach, bx1 = px0 + reach, by1 = py0 + reach;
+    const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + 1.0);
+    const double hx = reach + slack;
+    bool hit = false;
+    for (int j0 = 0; j0 < W.n_obstacles; j0 += 16) {
+      const int oi = j0 + rl;  // the tile is padded to RW_MAX_OBST with entries that never collide
+      const double oxj = olx[oi], oyj = oly[oi], orj = (double)olr[oi];
+      const bool cand = live && !(auvp_fabs(oxj - px0) > hx + orj || auvp_fabs(oyj - py0) > hx + orj);
+      uint32_t cm = row_ballot(cand, rowbase);
+      if (__any(cand)) {
+        n_cand += __popc(cm);
+        while (__any(cm != 0u)) {
+          const bool has = cm != 0u;
+          const int idx = has ? j0 + (__ffs((int)cm) - 1) : 0;
+          cm &= cm - 1u;
+          const double ox = olx[idx], oy = oly[idx], ot = W.ot[idx];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const double ddx = ptx[q] - ox, ddy = pty[q] - oy;
+            hit |= has && ptv[q] && (ddx * ddx + ddy * ddy <= ot);
+          }
+          // the parent's end, path[0], is a path point too
+          if (rl == 15) { const double ddx = px0 - ox, ddy = py0 - oy; hit |= has && (ddx * ddx + ddy * ddy <= ot); }
+        }
+      }
+    }
+    // boundary: strictly inside an axis-aligned rectangle implies Point.within; otherwise the crossing test per point
+    const double* sb = S.world->safe_box;
+    const bool box_inside = W.has_safe_box && bx0 > sb[0] && by0 > sb[1] && bx1 < sb[2] && by1 < sb[3];
+    bool outside = false;
+    if (__any(live && !box_inside)) {
+      // lane = path point (two passes' points + the parent's end on lane 15); edges of the polygon one at a time
+      auto crossing_outside = [&](double x, double y) {
+        if (nv_poly <= 0) return true;
+        int par_ = 0;
+        for (int e = 0; e < nv_poly; e++) {
+          const int ej = e == 0 ? nv_poly - 1 : e - 1;
+          const double xi = S.poly[e][0], yi = S.poly[e][1], xj = S.poly[ej][0], yj = S.poly[ej][1];
+          if ((yi > y) != (yj > y)) par_ ^= (x < (xj - xi) * (y - yi) / (yj - yi) + xi) ? 1 : 0;
+        }
+        return (par_ & 1) == 0;
+      };
+      const bool need = live && !box_inside;
+#pragma unroll
+      for (int q = 0; q < 2; q++)
+        if (need && ptv[q]) outside |= crossing_outside(ptx[q], pty[q]);
+      if (need && rl == 15) outside |= crossing_outside(px0, py0);
+    }
+    const bool bad = row_ballot(hit || outside, rowbase) != 0u;
+    const bool ok = live && !bad;
+    // ------------------------------------------------------------ accept (:144-151)
+    if (ok && n_nodes >= capn) { status = -2; live = false; iters_run = it; }
+    const bool acc_ = ok && live;
+    const int me = n_nodes;
+    if (acc_) {
+      // curr_bin = (t // bin_interval + 1) * bin_interval, exact floor of the true quotient
+      double q = auvp_floor(ctt * Q.inv_bin_interval);
+      const double r = auvp_fma(-q, Q.bin_interval, ctt);
+      if (r < 0.0) q -= 1.0;
+      else if (r >= Q.bin_interval) q += 1.0;
+      const double fi = q + 1.0;
+      const double curr_bin = fi * Q.bin_interval;
+      const bool over = curr_bin > Q.max_traj_time;
+      bool stored = true;
+      if (!over || fi <= (double)K) {
+        const int bi = (int)fi;
+        const int c = over ? 0 : (int)bin_count[bi];  // an overflowing regular key is reset first (:149-151)
+        if (c >= bcap || c >= 65535) { status = -2; live = false; iters_run = it; stored = false; }
+        else if (rl == 0) { bin_items[(size_t)bi * bcap + c] = me; bin_count[bi] = (uint16_t)(c + 1); }
+      }
+      if (stored) {
+        if (rl == 0) {
+          double* nf = nodeF + (size_t)me * 8;
+          *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
+          *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
+          nf[4] = clen;
+          nodeI[me] = make_int4(it, par, n_points, cnt);
+        }
+        n_nodes++;
+        n_points += cnt;
+      }
+    }
+    wave_sync();
+  }
+
+  // ---- epilogue ----
+  const bool valid = ep < n_episodes;
+  if (live) iters_run = P.max_iter;
+  const unsigned long long drawn = rng.drawn;
+  rows_ensure(rng, valid, 2u, rl);
+  const double after = rows_random_at(rng, 0u);
+  if (valid) {
+    for (int i = rl; i < K + 1; i += 16) B.bin_count[(size_t)ep * (K + 1) + i] = (int32_t)bin_count[i];
+    if (rl == 0) {
+      RrtSummary& s = B.summary[ep];
+      s.status = status; s.n_nodes = n_nodes; s.n_points = n_points; s.n_leaves = 0;
+      s.best_leaf = -1; s.best_path_len = 0; s.iters_run = iters_run; s.n_candidates = n_cand;
+      s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;
+      s.best_length = 0.0;
+      s.rng_after = after; s.leaf_elems = 0; s.n_draw32 = drawn;
+    }
+  }
+}
+
+}  // namespace auvp
+#endif
