@@ -61,6 +61,17 @@ struct WorldDev {
   double sg_x1_0, sg_y1_0, bins_t1_0;  // first entries of X1, Y1 and of the bins' upper ends (origins of the guesses)
   double sg_inv_dx, sg_inv_dy;  // 1 / mean spacing of X1 / Y1: first guess of the lower bound only
   double prob_absmax;  // max |prob|: bounds a path element's cost term (approximate-cost error bound of the leaf pass)
+  // the obstacles once more, reordered along a space-filling curve and cut into 16 slots of 16 (rrt_rows_kernel; built
+  // for <= 256 obstacles).  The collision decision is an OR over (point, obstacle) pairs of d2 <= T_i, so the order in
+  // which a kernel looks at them is free once T_i (which encodes the reference's list order) is fixed.
+  //   os_x, os_y, os_t [256]  centre and threshold, padded with entries that never collide
+  //   os_r [256]              cull radius >= sqrt(T) as float, -inf for padding
+  //   os_box [16][4]          per slot: x0, y0, x1, y1 of the union of its obstacles' cull squares (empty slot: inverted)
+  const double* os_x;
+  const double* os_y;
+  const double* os_t;
+  const float* os_r;
+  const double* os_box;
   double bb[4];  // polygon bounds xmin,ymin,xmax,ymax (get_random_mps, :334)
   double safe_box[4];    // when the polygon is an axis-aligned rectangle: its corners (strict interior test)
   int32_t has_safe_box, _pad1;

@@ -50,7 +50,7 @@ struct auvp_handle {
   bool have_world = false;
   WorldDev W{};
   DevBuf d_ox, d_oy, d_ot, d_hab, d_habt, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems, d_xdata, d_rgfirst, d_rgbp, d_rgoff,
-      d_rgpm, d_rgid, d_sgx0, d_sgx1, d_sgy0, d_sgy1, d_sgcol, d_sgrow;
+      d_rgpm, d_rgid, d_sgx0, d_sgx1, d_sgy0, d_sgy1, d_sgcol, d_sgrow, d_osx, d_osy, d_ost, d_osr, d_osbox;
   // rrt batch
   int E = 0;
   RrtParamsDev P{};
@@ -344,6 +344,50 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
     if ((rc = upload(h, h->d_sgrow, row.data(), row.size()))) return rc;
     HIPCHK(h, hipStreamSynchronize(h->stream));
   }
+  {
+    // spatially sorted obstacle tile + slot boxes for rrt_rows_kernel (auvp_types.h)
+    const int NS = 256;
+    std::vector<double> sx(NS, 0.0), sy(NS, 0.0), st(NS, -1.0), box(16 * 4);
+    std::vector<float> sr(NS, -INFINITY);
+    if (O <= NS) {
+      double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+      for (int i = 0; i < O; i++) { x0 = std::min(x0, ox[i]); x1 = std::max(x1, ox[i]); y0 = std::min(y0, oy[i]); y1 = std::max(y1, oy[i]); }
+      auto spread = [](uint32_t v) { uint64_t x = v & 0xffff; x = (x | (x << 8)) & 0x00ff00ff; x = (x | (x << 4)) & 0x0f0f0f0f;
+                                     x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; };
+      std::vector<std::pair<uint64_t, int>> key(O);
+      for (int i = 0; i < O; i++) {
+        const double fx = x1 > x0 ? (ox[i] - x0) / (x1 - x0) : 0.0, fy = y1 > y0 ? (oy[i] - y0) / (y1 - y0) : 0.0;
+        const uint32_t qx = (uint32_t)std::min(65535.0, std::max(0.0, fx * 65535.0)), qy = (uint32_t)std::min(65535.0, std::max(0.0, fy * 65535.0));
+        key[i] = {(std::isfinite(fx) && std::isfinite(fy)) ? (spread(qx) | (spread(qy) << 1)) : 0, i};
+      }
+      std::sort(key.begin(), key.end());
+      for (int k = 0; k < O; k++) {
+        const int i = key[k].second;
+        sx[k] = ox[i]; sy[k] = oy[i]; st[k] = ot[i];
+        const double rd = ot[i] >= 0.0 ? std::sqrt(ot[i]) * (1.0 + 0x1p-30) + 0x1p-40 : -INFINITY;
+        float rf = (float)rd;
+        if ((double)rf < rd) rf = std::nextafter(rf, INFINITY);
+        sr[k] = rf;
+      }
+    }
+    for (int s_ = 0; s_ < 16; s_++) {
+      double b0 = INFINITY, b1 = INFINITY, b2 = -INFINITY, b3 = -INFINITY;
+      for (int k = 16 * s_; k < 16 * s_ + 16; k++) {
+        if (!(sr[k] >= 0.0f) && !std::isnan(sx[k])) continue;  // padding / an obstacle that can never collide
+        const double r = (double)sr[k];
+        if (std::isnan(sx[k]) || std::isnan(sy[k]) || std::isnan(r)) { b0 = b1 = -INFINITY; b2 = b3 = INFINITY; break; }  // never culled
+        b0 = std::min(b0, sx[k] - r); b1 = std::min(b1, sy[k] - r); b2 = std::max(b2, sx[k] + r); b3 = std::max(b3, sy[k] + r);
+      }
+      box[4 * s_] = b0; box[4 * s_ + 1] = b1; box[4 * s_ + 2] = b2; box[4 * s_ + 3] = b3;
+    }
+    int rc2;
+    if ((rc2 = upload(h, h->d_osx, sx.data(), sx.size()))) return rc2;
+    if ((rc2 = upload(h, h->d_osy, sy.data(), sy.size()))) return rc2;
+    if ((rc2 = upload(h, h->d_ost, st.data(), st.size()))) return rc2;
+    if ((rc2 = upload(h, h->d_osr, sr.data(), sr.size()))) return rc2;
+    if ((rc2 = upload(h, h->d_osbox, box.data(), box.size()))) return rc2;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
   if ((rc = upload(h, h->d_ox, ox.data(), O))) return rc;
   if ((rc = upload(h, h->d_oy, oy.data(), O))) return rc;
   if ((rc = upload(h, h->d_ot, ot.data(), O))) return rc;
@@ -365,6 +409,8 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   WorldDev& W = h->W;
   W.n_obstacles = O; W.n_habitats = H; W.n_poly = V; W.n_bins = T; W.n_cells = C; W.n_xbuckets = NB;
   W.ox = h->d_ox.as<double>(); W.oy = h->d_oy.as<double>(); W.ot = h->d_ot.as<double>();
+  W.os_x = h->d_osx.as<double>(); W.os_y = h->d_osy.as<double>(); W.os_t = h->d_ost.as<double>(); W.os_r = h->d_osr.as<float>();
+  W.os_box = h->d_osbox.as<double>();
   W.hab = h->d_hab.as<double>(); W.hab_t = h->d_habt.as<double>(); W.poly = h->d_poly.as<double>(); W.bins = h->d_bins.as<double>();
   W.cells = h->d_cells.as<double>(); W.prob = h->d_prob.as<double>();
   W.xb_off = h->d_xoff.as<int32_t>(); W.xb_items = h->d_xitems.as<int32_t>(); W.xb_data = h->d_xdata.as<double>();

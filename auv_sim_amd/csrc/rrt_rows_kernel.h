@@ -76,20 +76,27 @@ __device__ __forceinline__ void rows_ensure(RowRng& r, bool want, uint32_t need,
   for (;;) {
     const bool go = want && r.avail < need;
     if (!__any(go)) break;
+    // up to 32 words per row and round, two per lane (words 227 apart are independent, so any 32 consecutive are)
     uint32_t n = 624u - r.avail;
-    n = n < 16u ? n : 16u;
+    n = n < 32u ? n : 32u;
     n = go ? n : 0u;
-    uint32_t k = r.pslot + r.avail + (uint32_t)rl;
-    k = k >= 624u ? k - 624u : k;
-    k = k >= 624u ? k - 624u : k;
-    const uint32_t k1 = (k + 1u == 624u) ? 0u : k + 1u;
-    uint32_t km = k + 397u;
-    km = km >= 624u ? km - 624u : km;
-    const uint32_t a = r.s[k], b = r.s[k1], c = r.s[km];
-    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-    const uint32_t v = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    uint32_t v2[2], kk[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      uint32_t k = r.pslot + r.avail + (uint32_t)rl + 16u * (uint32_t)h;
+      k = k >= 624u ? k - 624u : k;
+      k = k >= 624u ? k - 624u : k;
+      const uint32_t k1 = (k + 1u == 624u) ? 0u : k + 1u;
+      uint32_t km = k + 397u;
+      km = km >= 624u ? km - 624u : km;
+      const uint32_t a = r.s[k], b = r.s[k1], c = r.s[km];
+      const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+      v2[h] = c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      kk[h] = k;
+    }
     wave_sync();  // every lane's reads are issued before any lane's write
-    if ((uint32_t)rl < n) r.s[k] = v;
+    if ((uint32_t)rl < n) r.s[kk[0]] = v2[0];
+    if ((uint32_t)rl + 16u < n) r.s[kk[1]] = v2[1];
     wave_sync();
     r.avail += n;
   }
@@ -131,16 +138,8 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)RW_WAVES * RW_ROWS * plan.per_ep);
   double* oly = olx + RW_MAX_OBST;
   float* olr = reinterpret_cast<float*>(oly + RW_MAX_OBST);
-  for (int i = threadIdx.x; i < RW_MAX_OBST; i += blockDim.x) {
-    const bool ok = i < W.n_obstacles;
-    const double t = ok ? W.ot[i] : -1.0;
-    olx[i] = ok ? W.ox[i] : 0.0;
-    oly[i] = ok ? W.oy[i] : 0.0;
-    const double rd = t >= 0.0 ? auvp_sqrt(t) * (1.0 + 0x1p-30) + 0x1p-40 : -__builtin_inf();
-    float rf = (float)rd;
-    if ((double)rf < rd) rf = __uint_as_float(__float_as_uint(rf) + 1u);
-    olr[i] = rf;
-  }
+  // the spatially sorted tile (WorldDev::os_*): slot s = obstacles 16 s .. 16 s + 15
+  for (int i = threadIdx.x; i < RW_MAX_OBST; i += blockDim.x) { olx[i] = W.os_x[i]; oly[i] = W.os_y[i]; olr[i] = W.os_r[i]; }
   __syncthreads();
 
   const int ep = ((int)blockIdx.x * RW_WAVES + wave) * RW_ROWS + row;
@@ -176,6 +175,8 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   }
   wave_sync();
   int n_nodes = 1, n_points = 0, status = 0, n_cand = 0, iters_run = 0;
+  // lane rl keeps the bounding box of obstacle slot rl: one compare round tells which slots a steer can touch
+  const double4 sbox = reinterpret_cast<const double4*>(W.os_box)[rl];
   const int nfreq = (int)Q.freq;
   const int nv_poly = W.n_poly;
 
@@ -321,15 +322,17 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       else { inc[15] = 0.0; inc[33] = 0.0; inc[51] = 0.0; inc[69] = 0.0; }  // entry 15 pads the last 16-byte pair
       wave_sync();
       if (rl < 4 && on) {
+        // entries past n hold exact zeros, so all 16 steps can run: eight independent 16-byte reads up front, sixteen
+        // chained additions, eight writes -- no loop, no round trip per step
         double acc = rl == 0 ? cx : (rl == 1 ? cy : (rl == 2 ? ctt : clen));
-        double* rowp = inc + rl * 18;
-#pragma unroll 2
-        for (int s = 0; s < n; s += 2) {  // two steps per 16-byte access (entries past n hold exact zeros)
-          double2 v = *reinterpret_cast<double2*>(rowp + s);
-          acc = acc + v.x; v.x = acc;
-          acc = acc + v.y; v.y = acc;
-          *reinterpret_cast<double2*>(rowp + s) = v;
-        }
+        double2* rowp = reinterpret_cast<double2*>(inc + rl * 18);
+        double2 v[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2++) v[s2] = rowp[s2];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2++) { acc = acc + v[s2].x; v[s2].x = acc; acc = acc + v[s2].y; v[s2].y = acc; }
+#pragma unroll
+        for (int s2 = 0; s2 < 8; s2++) rowp[s2] = v[s2];
       }
       wave_sync();
       double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
@@ -371,18 +374,24 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
     const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + 1.0);
     const double hx = reach + slack;
     bool hit = false;
-    for (int j0 = 0; j0 < W.n_obstacles; j0 += 16) {
-      const int oi = j0 + rl;  // the tile is padded to RW_MAX_OBST with entries that never collide
-      const double oxj = olx[oi], oyj = oly[oi], orj = (double)olr[oi];
-      const bool cand = live && !(auvp_fabs(oxj - px0) > hx + orj || auvp_fabs(oyj - py0) > hx + orj);
-      uint32_t cm = row_ballot(cand, rowbase);
-      if (__any(cand)) {
+    {
+      const double hs = hx + slack;
+      const bool slot_hit = live && !(sbox.z < px0 - hs || sbox.x > px0 + hs || sbox.w < py0 - hs || sbox.y > py0 + hs);
+      uint32_t sm = row_ballot(slot_hit, rowbase);
+      while (__any(sm != 0u)) {  // slots some row has to look into (none at all for most steers of a sparse world)
+        const bool hs_ = sm != 0u;
+        const int j0 = hs_ ? 16 * (__ffs((int)sm) - 1) : 0;
+        sm &= sm - 1u;
+        const int oi = j0 + rl;
+        const double oxj = olx[oi], oyj = oly[oi], orj = (double)olr[oi];
+        const bool cand = hs_ && !(auvp_fabs(oxj - px0) > hx + orj || auvp_fabs(oyj - py0) > hx + orj);
+        uint32_t cm = row_ballot(cand, rowbase);
         n_cand += __popc(cm);
         while (__any(cm != 0u)) {
           const bool has = cm != 0u;
           const int idx = has ? j0 + (__ffs((int)cm) - 1) : 0;
           cm &= cm - 1u;
-          const double ox = olx[idx], oy = oly[idx], ot = W.ot[idx];
+          const double ox = olx[idx], oy = oly[idx], ot = W.os_t[idx];
 #pragma unroll
           for (int q = 0; q < 2; q++) {
             const double ddx = ptx[q] - ox, ddy = pty[q] - oy;

@@ -8,7 +8,7 @@ R=os.environ["GRAFT_REPO_ROOT"]
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(R+"/gpurun_out/q?/**/*counter_collection.csv",recursive=True):
     for r in csv.DictReader(open(f)):
-        k="explore" if "rrt_explore" in r["Kernel_Name"] else ("leaf" if "rrt_leaf" in r["Kernel_Name"] else None)
+        k="explore" if "rrt_explore" in r["Kernel_Name"] or "rrt_rows" in r["Kernel_Name"] else ("leaf" if "rrt_leaf" in r["Kernel_Name"] else None)
         if k: acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc:
     print(k)
