@@ -833,20 +833,20 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     if (live) {
       const double2 xy = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8);
       cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, nodeF[(size_t)m * 8 + 3], ntv, nhab, true, grid_lds);
-      for (int k = 0; k < r.w; k += 4) {  // four independent reads in flight per step; any order will do for S
-        double t4[4];
-        int h4[4];
+      for (int k = 0; k < r.w; k += 16) {  // sixteen independent reads in flight per step; any order will do for S
+        double t16[16];
+        int h16[16];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 16; j++) {
           const bool in = k + j < r.w;
           const size_t at = (size_t)r.z + (size_t)(in ? k + j : 0);
-          t4[j] = in ? ptTerm[at] : 0.0;
-          h4[j] = in ? (int)ptHab[at] : -1;
+          t16[j] = in ? ptTerm[at] : 0.0;
+          h16[j] = in ? (int)ptHab[at] : -1;
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          own = own + t4[j];
-          if (h4[j] >= 0) { own_hits++; own_vis |= (1ull << h4[j]); }
+        for (int j = 0; j < 16; j++) {
+          own = own + t16[j];
+          if (h16[j] >= 0) { own_hits++; own_vis |= (1ull << h16[j]); }
         }
       }
       own = own + ntv;
@@ -862,18 +862,21 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     c_par[lane] = r.y - n0;
     c_S[lane] = pS + own; c_hits[lane] = pc.x + own_hits; c_elems[lane] = pc.y + r.w + 1; c_vis[lane] = pvis | own_vis;
     wave_sync();
-    const unsigned long long inpass = __ballot(live && r.y >= n0);
-    if (inpass) {
-      if (lane == 0) {  // creation order: a parent's entry is final before any of its children reads it
-        unsigned long long todo = inpass;
-        while (todo) {
-          const int i = __ffsll((long long)todo) - 1;
-          todo &= todo - 1ull;
-          const int p = c_par[i];
-          c_S[i] = c_S[p] + c_S[i]; c_hits[i] += c_hits[p]; c_elems[i] += c_elems[p]; c_vis[i] |= c_vis[p];
-        }
-      }
+    // parents inside this pass: a lane is ready once its parent's entry is final (a parent always has the smaller
+    // index, so the lowest pending lane is ready in every round); all ready lanes add their parent's sums at once
+    unsigned long long pending = __ballot(live && r.y >= n0);
+    while (pending) {
+      const int p = c_par[lane];
+      const bool mine = (pending >> lane) & 1ull;
+      const bool ready = mine && !((pending >> (p & 63)) & 1ull);
+      double aS = 0.0;
+      int aH = 0, aE = 0;
+      unsigned long long aV = 0ull;
+      if (ready) { aS = c_S[p]; aH = c_hits[p]; aE = c_elems[p]; aV = c_vis[p]; }
       wave_sync();
+      if (ready) { c_S[lane] = aS + c_S[lane]; c_hits[lane] += aH; c_elems[lane] += aE; c_vis[lane] |= aV; }
+      wave_sync();
+      pending &= ~__ballot(ready);
     }
     if (live) {
       *reinterpret_cast<double2*>(nodeF + (size_t)m * 8 + 6) = make_double2(ntv, (double)nhab);
