@@ -111,6 +111,7 @@ def load():
     L.auvp_last_kernel_ms.argtypes = [vp]
     L.auvp_last_kernel_ms.restype = C.c_double
     L.auvp_last_launch.argtypes = [vp, _ip, _ip, _ip]
+    L.auvp_rrt_last_launch_parts.argtypes = [vp, _dp, _dp, _ip]
     _lib = L
     return L
 
@@ -302,6 +303,12 @@ class Context:
 
     def last_kernel_ms(self):
         return float(self.L.auvp_last_kernel_ms(self.h))
+
+    def last_launch_parts(self):
+        """(expansion ms, leaf-pass ms, episodes per wavefront) of the last rrt_run"""
+        a, b, k = C.c_double(), C.c_double(), C.c_int32()
+        self._chk(self.L.auvp_rrt_last_launch_parts(self.h, C.byref(a), C.byref(b), C.byref(k)))
+        return a.value, b.value, k.value
 
     def last_launch(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -44,7 +44,9 @@ struct DevBuf {
 struct auvp_handle {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
+  double last_expand_ms = 0.0, last_leaf_ms = 0.0;
+  int last_rows = 0;
   std::string err;
   // world
   bool have_world = false;
@@ -149,7 +151,7 @@ int auvp_create(int device, auvp_handle** out) {
   auvp_handle* h = new auvp_handle();
   h->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev_mid) != hipSuccess) {
     delete h;
     return AUVP_ERR_HIP;
   }
@@ -167,6 +169,7 @@ void auvp_destroy(auvp_handle* h) {
   if (h->comm && h->comm_free) h->comm_free(h->comm);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -654,6 +657,7 @@ int auvp_rrt_run(auvp_handle* h) {
   }
   HIPCHK(h, le);
   // the trees are complete: rank the qualifying leaves (same stream, inside the timed region)
+  HIPCHK(h, hipEventRecord(h->ev_mid, h->stream));
   RrtParamsDev PL = P;
   if (const char* e = getenv("AUVP_LEAF_STOP")) PL.flags |= (atoi(e) == 1 ? 256 : (atoi(e) == 2 ? 512 : 0));  // timing experiments
   {
@@ -668,6 +672,11 @@ int auvp_rrt_run(auvp_handle* h) {
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev_mid));
+  h->last_expand_ms = ms;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev_mid, h->ev1));
+  h->last_leaf_ms = ms;
+  h->last_rows = use_rows ? 1 : 0;
   h->last_grid = grid_used; h->last_block = block_used; h->last_lds = lds_used;
   h->have_batch = true;
   return AUVP_OK;
@@ -793,6 +802,15 @@ int auvp_rrt_phase_clocks(auvp_handle* h, uint64_t* out) {
 }
 
 double auvp_last_kernel_ms(auvp_handle* h) { return h ? h->last_ms : -1.0; }
+
+int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_ms, int32_t* episodes_per_wave) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->have_batch) return fail(h, AUVP_ERR_STATE, "no batch has run");
+  if (expand_ms) *expand_ms = h->last_expand_ms;
+  if (leaf_ms) *leaf_ms = h->last_leaf_ms;
+  if (episodes_per_wave) *episodes_per_wave = h->last_rows ? 4 : 1;
+  return AUVP_OK;
+}
 
 int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds_bytes) {
   if (!h) return AUVP_ERR_ARG;

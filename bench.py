@@ -760,12 +760,13 @@ def main():
     init[:, 0], init[:, 1] = world["start"]
     seeds = np.arange(rank * E, (rank + 1) * E, dtype=np.uint64)  # global episode id = seed
     ctx.rrt_prepare(init, seeds, args.iters, mode=args.mode, **RRT_KW)
-    kms, gms = [], []
+    kms, gms, parts = [], [], []
 
     def step():
-        """kernel + best-path extraction (+ RCCL gather of the result records for N > 1)"""
+        """expansion + leaf pass + best-path extraction (+ RCCL gather of the result records for N > 1)"""
         ctx.rrt_run()
         kms.append(ctx.last_kernel_ms())
+        parts.append(ctx.last_launch_parts())
         summ = ctx.summaries()
         lens = np.where(summ["best_leaf"] >= 0, summ["best_path_len"], 0).astype(np.int64)
         off = np.zeros(E + 1, dtype=np.int64)
@@ -794,8 +795,12 @@ def main():
     out = None
     if rank == 0:
         abytes = rrt_bytes(summ)
-        traffic, tsrc = pmc_traffic("rrt_explore_kernel", iters_local)
+        traffic, tsrc = pmc_traffic("rrt_exploring", iters_local)
         grid, block, lds = ctx.last_launch()
+        exp_ms = float(np.mean([p[0] for p in parts[-args.steps:]]))
+        leaf_ms = float(np.mean([p[1] for p in parts[-args.steps:]]))
+        per_wave = parts[-1][2]
+        kname = "rrt_rows_kernel" if per_wave == 4 else "rrt_explore_kernel"
         out = {
             "metric": "RRT-Dubins node expansions/s (RRT.exploring)", "value": value, "unit": "expansions/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -806,11 +811,15 @@ def main():
                        "episodes_per_gpu": E, "iters": args.iters, "obstacles": args.obstacles,
                        "cells": int(len(world["cells"])), "parallelism": "episodes sharded x%d" % world_size,
                        "gather": ranks.gather.name if ranks.gather is not None else None, "gather_note": ranks.gather_note},
-            "roofline": roofline(abytes, k_ms, "rrt_explore_kernel", traffic, traffic_source=tsrc,
+            # one pass of the path = two launches on the handle's stream: the tree expansion and the leaf pass (cost terms,
+            # ranking); kernel_ms is the HIP-event time around both, the algorithmic bytes are those of the whole pass
+            "roofline": roofline(abytes, k_ms, kname + " + rrt_leaf_kernel", traffic, traffic_source=tsrc,
                                  bytes_per_expansion=abytes / iters_local,
+                                 kernels_ms={kname: exp_ms, "rrt_leaf_kernel": leaf_ms}, episodes_per_wavefront=per_wave,
                                  launch={"grid": grid, "block": block, "lds_bytes": lds},
-                                 note="fp64-VALU/latency bound at these sizes, not HBM bound (DESIGN.md)"),
+                                 note="the expansion is fp64-VALU issue bound, the leaf pass HBM bound (DESIGN.md)"),
             "expansions_per_s_kernel_only": iters_local / (k_ms * 1e-3),
+            "expansions_per_s_expansion_kernel_only": iters_local / (exp_ms * 1e-3),
             "kernel_ms_per_rank": k_all, "gather_ms_per_rank": g_all,
             "accepted_nodes_per_episode": float((summ["n_nodes"] - 1).mean()),
             "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),

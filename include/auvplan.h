@@ -282,6 +282,9 @@ int auvp_random_stream_dev(auvp_handle* h, uint64_t seed, int32_t n, double* out
 int auvp_rrt_phase_clocks(auvp_handle* h, uint64_t* out);
 /* HIP-event time (ms) of the last batch kernel on the handle's stream, and its launch geometry */
 double auvp_last_kernel_ms(auvp_handle* h);
+/* of the last auvp_rrt_run: HIP-event times of its two launches (tree expansion; leaf ranking) and which expansion
+ * kernel ran (4 = four episodes per wavefront, rrt_rows_kernel; 1 = rrt_explore_kernel) */
+int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_ms, int32_t* episodes_per_wave);
 int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds_bytes);
 
 /* Config 5 composition (BASELINE.json configs[4]): the particle filter of particleFilter.py:283-317 feeding one

@@ -28,7 +28,10 @@ for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")) + glob.glob(
     shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 
 # (kernel key, substring of the kernel name, pass-directory prefix, bench json of that pass, path to its work units)
-KERNELS = [("rrt_explore_kernel", "rrt_explore_kernel", "pmc_", None),
+# the headline pass is two launches: the expansion kernel (rows or one-episode variant) and the leaf pass; their counters
+# are summed into "rrt_exploring" (what bench.py's roofline.traffic refers to) and kept separately as well
+KERNELS = [("rrt_rows_kernel", "rrt_rows_kernel", "pmc_", None), ("rrt_explore_kernel", "rrt_explore_kernel", "pmc_", None),
+           ("rrt_leaf_kernel", "rrt_leaf_kernel", "pmc_", None),
            ("astar_kernel", "astar_kernel", "pmc_astar_", "astar"),
            ("prrt_kernel", "prrt_kernel", "pmc_planner_rrt_", "planner_rrt")]
 out = {"tag": tag, "kernels": {}}
@@ -73,9 +76,22 @@ for key, needle, prefix, side in KERNELS:
             if c in summary:
                 rec[c.lower() + "_per_unit"] = summary[c] / rec["units"]
     if "SQ_THREAD_CYCLES_VALU" in summary and "SQ_ACTIVE_INST_VALU" in summary and summary["SQ_ACTIVE_INST_VALU"] > 0:
-        # active lanes per VALU instruction: thread-cycles / (instruction quad-cycles x 4) out of 64
-        rec["valu_lane_occupancy"] = summary["SQ_THREAD_CYCLES_VALU"] / (summary["SQ_ACTIVE_INST_VALU"] * 4.0 * 64.0)
+        # lanes enabled in the exec mask per VALU instruction, out of 64 (normalisation checked on a plain copy kernel,
+        # which reads 0.96): exec-mask occupancy, an upper bound of the lanes doing useful work
+        rec["valu_exec_mask_occupancy"] = summary["SQ_THREAD_CYCLES_VALU"] / (summary["SQ_ACTIVE_INST_VALU"] * 64.0)
     out["kernels"][key] = rec
+parts = [out["kernels"][k] for k in ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel") if k in out["kernels"]]
+if parts:
+    tot = {"per_launch": {}, "kernels": [k for k in ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel") if k in out["kernels"]]}
+    for c in set().union(*[p["per_launch"].keys() for p in parts]):
+        tot["per_launch"][c] = sum(p["per_launch"].get(c, 0.0) for p in parts)
+    for f in ("hbm_read_bytes_raw", "hbm_write_bytes", "hbm_bytes_per_launch_raw", "hbm_bytes_per_launch"):
+        if all(f in p for p in parts):
+            tot[f] = sum(p[f] for p in parts)
+    for f in ("units", "algorithmic_bytes_per_launch"):
+        if f in parts[0]:
+            tot[f] = parts[0][f]
+    out["kernels"]["rrt_exploring"] = tot
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(REPO, "profiles", "pmc_latest.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
