@@ -359,7 +359,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
           cth = th_last;
         }
       }
-      rows_advance(rng, on, (uint32_t)(2 * (b0 + used)));
+      rows_advance(rng, on && live, (uint32_t)(2 * (b0 + used)));  // (a row that just failed keeps its stream position, like the one-episode kernel)
       first_pass = false;
       wave_sync();
     }

@@ -23,10 +23,15 @@ def _fields_equal(a, b, skip=()):
     return all(np.array_equal(a[n], b[n]) for n in a.dtype.names if n not in skip)
 
 
-def test_rrt_exploring_full_budget(ctx, orc):
+@pytest.mark.parametrize("n_obstacles,rows", [(256, "1"), (256, "0"), (64, "1")])
+def test_rrt_exploring_full_budget(ctx, orc, n_obstacles, rows, monkeypatch):
+    """the headline world (256 obstacles) through both expansion kernels -- four episodes per wavefront
+    (rrt_rows_kernel, AUVP_ROWS=1, the default) and one (rrt_explore_kernel) -- and BASELINE configs[1] as written
+    (64 obstacles), all at the full 10 000-iteration budget on the 200x200-cell grid"""
     from auv_sim_amd import synth
+    monkeypatch.setenv("AUVP_ROWS", rows)
     n_iter, E = 10000, 512
-    world = synth.make_world(seed=2, n_obstacles=256, box=(-1000.0, -1000.0, 1000.0, 1000.0), cell=10.0, n_bins=10,
+    world = synth.make_world(seed=2, n_obstacles=n_obstacles, box=(-1000.0, -1000.0, 1000.0, 1000.0), cell=10.0, n_bins=10,
                              bin_len=50, n_habitats=10)
     assert len(world["cells"]) == 40000
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
@@ -60,6 +65,7 @@ def test_rrt_exploring_full_budget(ctx, orc):
     pick = np.array([0, 3, 200, 511])
     s3 = ctx.rrt_explore_batch(init[pick], seeds[pick], n_iter, **kw)
     assert _fields_equal(s1[pick], s3)
+    assert ctx.last_launch_parts()[2] == (4 if rows == "1" else 1)  # the kernel the case names really ran
     for k, e in enumerate(pick):
         assert np.array_equal(ctx.paths(s3)[k], paths1[e])
     # -- the checker on a sample, bit for bit
