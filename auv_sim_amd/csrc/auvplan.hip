@@ -625,16 +625,29 @@ int auvp_rrt_run(auvp_handle* h) {
   // four episodes per wavefront (rrt_rows_kernel.h) where its limits allow; one episode per wavefront otherwise
   const RowsLdsPlan rp = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins));
   const bool iter_log = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
+  // ... and where it pays: a batch that gives the one-episode kernel fewer waves than it can keep resident (6 per SIMD)
+  // runs faster there -- below ~8 k episodes the rows kernel would leave the SIMDs with one or two waves
+  // (measured on MI355X: 6 144 episodes 586 vs 567 M expansions/s, 12 288 episodes 670 vs 881 M).  AUVP_ROWS=1 / 0 force it
+  // on (limits permitting) / off.
   const char* rows_env = getenv("AUVP_ROWS");
-  const bool use_rows = P.mode == 0 && !iter_log && nfreq <= RW_MAX_FREQ && O_ <= RW_MAX_OBST && P.max_iter < 65534 &&
-                        rp.total <= 160 * 1024 && !(rows_env && atoi(rows_env) == 0);
+  const bool rows_ok = P.mode == 0 && !iter_log && nfreq <= RW_MAX_FREQ && O_ <= RW_MAX_OBST && P.max_iter < 65534 &&
+                       rp.total <= 160 * 1024;
+  const bool use_rows = rows_ok && (rows_env ? atoi(rows_env) != 0 : E >= 8192);
   int grid_used = grid, block_used = RRT_X_WAVES * 64, lds_used = (int)lds;
   if (use_rows) {
-    const int per_wg = RW_WAVES * RW_ROWS;
-    grid_used = (E + per_wg - 1) / per_wg; block_used = RW_WAVES * 64; lds_used = rp.total;
+    // a workgroup of up to 12 waves (48 episodes) fills one CU; a batch that cannot give every CU such a workgroup is
+    // spread over all CUs with fewer waves per workgroup instead of leaving CUs idle
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+    if (n_cu <= 0) n_cu = 256;
+    int wg_waves = (E + RW_ROWS * n_cu - 1) / (RW_ROWS * n_cu);
+    wg_waves = wg_waves < 1 ? 1 : (wg_waves > RW_WAVES ? RW_WAVES : wg_waves);
+    const RowsLdsPlan rq = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), wg_waves);
+    const int per_wg = wg_waves * RW_ROWS;
+    grid_used = (E + per_wg - 1) / per_wg; block_used = wg_waves * 64; lds_used = rq.total;
     le = hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, rp.total);
     if (le == hipSuccess) {
-      hipLaunchKernelGGL(rrt_rows_kernel, dim3(grid_used), dim3(block_used), rp.total, h->stream, h->W, P, B, (int)E);
+      hipLaunchKernelGGL(rrt_rows_kernel, dim3(grid_used), dim3(block_used), rq.total, h->stream, h->W, P, B, (int)E);
       le = hipGetLastError();
     }
   } else {

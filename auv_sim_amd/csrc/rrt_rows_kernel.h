@@ -21,7 +21,7 @@
 
 namespace auvp {
 
-constexpr int RW_WAVES = 12;  // waves per workgroup
+constexpr int RW_WAVES = 12;  // most waves per workgroup (48 episodes: one workgroup fills a CU's LDS); small batches use fewer
 constexpr int RW_ROWS = 4;    // episodes per wave
 constexpr int RW_C = 15;      // sub-arcs per steer pass (lane 15 of the row: pass-entry angle)
 constexpr int RW_MAX_FREQ = 2 * RW_C;
@@ -32,7 +32,7 @@ struct RowsLdsPlan {
   int tables, mt, scratch, bins, per_ep, obst, total;
 };
 
-__host__ __device__ inline RowsLdsPlan rrt_rows_lds_plan(int K, int n_obst_slots, int tables_bytes) {
+__host__ __device__ inline RowsLdsPlan rrt_rows_lds_plan(int K, int n_obst_slots, int tables_bytes, int waves = RW_WAVES) {
   RowsLdsPlan p;
   p.tables = (tables_bytes + 15) & ~15;
   p.mt = 624 * 4;
@@ -41,7 +41,7 @@ __host__ __device__ inline RowsLdsPlan rrt_rows_lds_plan(int K, int n_obst_slots
   p.bins = (((K + 2) * 2) + 15) & ~15;
   p.per_ep = p.mt + p.scratch + p.bins;
   p.obst = n_obst_slots * (8 + 8 + 4);  // x, y f64; cull radius f32
-  p.total = p.tables + RW_WAVES * RW_ROWS * p.per_ep + p.obst;
+  p.total = p.tables + waves * RW_ROWS * p.per_ep + p.obst;
   return p;
 }
 
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   const int lane = lane_id();
   const int row = lane >> 4, rl = lane & 15, rowbase = lane & 48;
   const int K = P.K;
-  const RowsLdsPlan plan = rrt_rows_lds_plan(K, RW_MAX_OBST, rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins));
+  const int wg_waves = (int)(blockDim.x >> 6);
+  const RowsLdsPlan plan = rrt_rows_lds_plan(K, RW_MAX_OBST, rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins), wg_waves);
   unsigned char* ebase = smem + plan.tables + (size_t)(wave * RW_ROWS + row) * plan.per_ep;
   uint32_t* mt = reinterpret_cast<uint32_t*>(ebase);
   double* win = reinterpret_cast<double*>(ebase + plan.mt);  // [RW_WIN] tempered random() values of a pass
@@ -135,14 +136,14 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   rrt_tables_stage(S, W);
   if (threadIdx.x == 0) *S.params = P;
   const RrtParamsDev& Q = *S.params;
-  double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)RW_WAVES * RW_ROWS * plan.per_ep);
+  double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)wg_waves * RW_ROWS * plan.per_ep);
   double* oly = olx + RW_MAX_OBST;
   float* olr = reinterpret_cast<float*>(oly + RW_MAX_OBST);
   // the spatially sorted tile (WorldDev::os_*): slot s = obstacles 16 s .. 16 s + 15
   for (int i = threadIdx.x; i < RW_MAX_OBST; i += blockDim.x) { olx[i] = W.os_x[i]; oly[i] = W.os_y[i]; olr[i] = W.os_r[i]; }
   __syncthreads();
 
-  const int ep = ((int)blockIdx.x * RW_WAVES + wave) * RW_ROWS + row;
+  const int ep = ((int)blockIdx.x * wg_waves + wave) * RW_ROWS + row;
   bool live = ep < n_episodes;  // row-uniform; a row that fails keeps running as a no-op until the wave is done
   const int eps = live ? ep : 0;
   if (!__any(live)) return;
@@ -384,14 +385,15 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
         sm &= sm - 1u;
         const int oi = j0 + rl;
         const double oxj = olx[oi], oyj = oly[oi], orj = (double)olr[oi];
+        const double otj = W.os_t[oi];  // this lane's obstacle of the slot: one coalesced read, handed out below
         const bool cand = hs_ && !(auvp_fabs(oxj - px0) > hx + orj || auvp_fabs(oyj - py0) > hx + orj);
         uint32_t cm = row_ballot(cand, rowbase);
         n_cand += __popc(cm);
         while (__any(cm != 0u)) {
           const bool has = cm != 0u;
-          const int idx = has ? j0 + (__ffs((int)cm) - 1) : 0;
+          const int cl = has ? (__ffs((int)cm) - 1) : 0;
           cm &= cm - 1u;
-          const double ox = olx[idx], oy = oly[idx], ot = W.os_t[idx];
+          const double ox = row_read_f64(oxj, rowbase + cl), oy = row_read_f64(oyj, rowbase + cl), ot = row_read_f64(otj, rowbase + cl);
 #pragma unroll
           for (int q = 0; q < 2; q++) {
             const double ddx = ptx[q] - ox, ddy = pty[q] - oy;

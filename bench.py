@@ -328,9 +328,9 @@ def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0):
     return out
 
 
-def bench_rrt_o64(ctx, args, n_ep=6144):
+def bench_rrt_o64(ctx, args, n_ep=None):
     """BASELINE configs[1] as written: 64 obstacles (the headline uses 256), same 200x200-cell grid and 10k budget."""
-    out = _rrt_batch(ctx, bench_world(64, args.grid), n_ep, args)
+    out = _rrt_batch(ctx, bench_world(64, args.grid), n_ep or args.episodes_fit, args)
     out["metric"] = "RRT.exploring expansions/s, 64 obstacles, %dx%d cells" % (args.grid, args.grid)
     ref = recorded_reference("config2_rrt_exploring_o64")
     if ref:
@@ -339,7 +339,7 @@ def bench_rrt_o64(ctx, args, n_ep=6144):
     return out
 
 
-def bench_rrt_dense(ctx, args, with_cpu, n_ep=6144):
+def bench_rrt_dense(ctx, args, with_cpu, n_ep=None):
     """Worlds where the exact collision test actually runs (the headline's 256 obstacles in 4 km^2 are sparse: the cull
     leaves well under one candidate per expansion).  (i) the G3 fixture world: 256 obstacles of r = 1-3 m in a 200 m box,
     400 cells -- the reference accepts ~56 % there and spends 93 % of its time in check_collision; (ii) a Catalina-sized
@@ -347,6 +347,7 @@ def bench_rrt_dense(ctx, args, with_cpu, n_ep=6144):
     split gives 987), 256 obstacles with the Catalina radii spread (4-26 m obstacles scaled down to stay plannable: 2-8 m)."""
     from auv_sim_amd import synth
     out = {}
+    n_ep = n_ep or args.episodes_fit
     w1 = synth.make_world(seed=2, n_obstacles=256)
     out["g3_box_200m_o256"] = _rrt_batch(ctx, w1, n_ep, args, cpu_seconds=4.0 if with_cpu else 0.0)
     out["g3_box_200m_o256"]["world"] = "200 m x 200 m box, 400 cells, 256 obstacles r = 1-3 m (the G3 golden world)"
@@ -697,6 +698,7 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world_size
     only = [s for s in args.only.split(",") if s]
+    args.episodes_fit = args.episodes
 
     world = bench_world(args.obstacles, args.grid)
     with_cpu = world_size == 1 and not args.no_cpu
@@ -756,6 +758,7 @@ def main():
         print("bench: %d episodes per GPU do not fit the free HBM (%.0f GB); running %d" % (E, free_b / 1e9, int(e_fit.item())),
               file=sys.stderr)
         E = int(e_fit.item())
+    args.episodes_fit = E  # the side measurements that fill the GPU use the same batch size
     init = np.zeros((E, 6))
     init[:, 0], init[:, 1] = world["start"]
     seeds = np.arange(rank * E, (rank + 1) * E, dtype=np.uint64)  # global episode id = seed
