@@ -740,22 +740,28 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
 //
 // The reference evaluates habitat_shark_cost_func on the path of every accepted node whose traj_time_stamp is within
 // 30 s of max_traj_time, in creation order, and keeps the first strict minimum.  None of that feeds back into the
-// tree, so it runs here, after the expansion kernel, in two sweeps over the nodes in creation order (64 per pass):
+// tree, so it runs here, after the expansion kernel, in ONE sweep over the nodes in creation order, 64 per pass:
 //
-// 1. terms and running sums.  A path element's contribution to a leaf's cost -- w3*prob of its cell in its time bin,
-//    and the habitat it lies in -- does not depend on the leaf (its bin is always part of the leaf's sub-dict), so it
-//    is evaluated once: lane = node, looping over the node's own elements (its appended points, then its state);
-//    terms are kept (pt_term / pt_hab, node_f[6..7]) and summed down the tree, a node's parent always coming earlier:
+// 1. terms.  A path element's contribution to a leaf's cost -- w3*prob of its cell in its time bin, and the habitat it
+//    lies in -- does not depend on the leaf (its bin is always part of the leaf's sub-dict), so it is evaluated once.
+//    The path points of the 64 nodes of a pass are one contiguous run of records: lane = point (two per lane in flight,
+//    coalesced reads); each term is added to its owner's slot in LDS (the owner = the last node of the pass whose
+//    pt_off is <= the point index: a 6-step search over the pass's offsets; LDS atomics).  Then lane = node: its own
+//    state's term.
+// 2. running sums down the tree (a node's parent always comes earlier; parents inside the pass are resolved in rounds):
 //      node_c = {elements inside some habitat, elements, visited-habitat bit set} of the root..node path (exact)
 //      node_f[5] = S = sum of the shark terms of that path, in tree order
-// 2. ranking.  cost[0] and cost[1] of a leaf follow from the exact integers as the reference computes them.  S differs
+// 3. ranking.  cost[0] and cost[1] of a leaf follow from the exact integers as the reference computes them.  S differs
 //    from the reference's leaf->root ordered sum only by rounding: both add the same L terms, so each is within
 //    gamma_L * sum|term| of the exact sum (gamma_L = L u / (1 - L u), u = 2^-53), and |term| <= |w3| * max|prob|.
 //    That gives every leaf an interval [lo, hi] containing the reference's total.  A leaf whose lo is not below the
 //    smallest hi of the leaves before it cannot be a strict minimum; the others (a handful per episode: the record
 //    setters and exact ties) are re-summed in the reference's order -- leaf, its points last to first, its parent,
-//    ... root, one rounded add per element -- and compared exactly like the reference does.
-//    With the leaf log requested every qualifying leaf is re-summed (the log holds the reference's per-leaf costs).
+//    ... root, one rounded add per element, the terms evaluated again from the records -- and compared exactly like
+//    the reference does.  With the leaf log requested every qualifying leaf is re-summed (the log holds the
+//    reference's per-leaf costs).
+// The order in which the LDS atomics add a node's terms is not defined; S only steers which leaves are re-summed, every
+// reported number comes from the exact integers and the ordered re-summation.
 constexpr int RRT_LEAF_WAVES = 4;  // episodes per workgroup of the leaf pass (they share the world tables in LDS)
 __host__ __device__ inline int rrt_leaf_grid_lds_bytes(int sg_enabled, int ncol, int nrow) {
   const long long b = 16LL * ((long long)ncol + nrow);
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   __shared__ __align__(16) unsigned char tables[RRT_WORLD_BYTES + RRT_MAX_HAB * 32 + RRT_MAX_POLY * 16 + RRT_MAX_BINS * 16];
   __shared__ double w_term[RRT_LEAF_WAVES][64];
   __shared__ double w_S[RRT_LEAF_WAVES][64];
-  __shared__ int32_t w_hits[RRT_LEAF_WAVES][64], w_elems[RRT_LEAF_WAVES][64], w_par[RRT_LEAF_WAVES][64];
+  __shared__ int32_t w_hits[RRT_LEAF_WAVES][64], w_elems[RRT_LEAF_WAVES][64], w_par[RRT_LEAF_WAVES][64], w_off[RRT_LEAF_WAVES][64];
   __shared__ unsigned long long w_vis[RRT_LEAF_WAVES][64];
   extern __shared__ __align__(16) unsigned char leaf_dyn[];
   const RrtTables St = rrt_tables_view(tables, W.n_habitats, W.n_poly);
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   if (ep >= n_episodes) return;  // no workgroup barrier after this point
   double* term = w_term[wave];
   double* c_S = w_S[wave];
-  int32_t *c_hits = w_hits[wave], *c_elems = w_elems[wave], *c_par = w_par[wave];
+  int32_t *c_hits = w_hits[wave], *c_elems = w_elems[wave], *c_par = w_par[wave], *c_off = w_off[wave];
   unsigned long long* c_vis = w_vis[wave];
   const double (*s_bins)[2] = St.bins;
   RrtSummary& sum = B.summary[ep];
@@ -796,100 +802,8 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   double* nodeF = B.node_f + (size_t)ep * capn * 8;
   const int4* nodeI = reinterpret_cast<const int4*>(B.node_i) + (size_t)ep * capn;
   int4* nodeC = reinterpret_cast<int4*>(B.node_c) + (size_t)ep * capn;
-  double* ptTerm = B.pt_term + (size_t)ep * capp;
-  int8_t* ptHab = B.pt_hab + (size_t)ep * capp;
   const double* ptF = B.points + (size_t)ep * capp * 6;
   const int n_nodes = sum.n_nodes;
-  wave_sync();
-  // ---------------------------------------------------------------- sweep 1: terms and running sums
-  // (a) every stored path point, lane = point: 64 independent lookups in flight per pass, coalesced records
-  const int n_points = sum.n_points;
-  for (int p0 = 0; p0 < n_points; p0 += 128) {  // two points per lane and pass: their record / table reads overlap
-    const int pa = p0 + lane, pb = p0 + 64 + lane;
-    const bool va = pa < n_points, vb = pb < n_points;
-    const double* ra = ptF + (size_t)(va ? pa : 0) * 6;
-    const double* rb = ptF + (size_t)(vb ? pb : 0) * 6;
-    const double2 xya = *reinterpret_cast<const double2*>(ra), xyb = *reinterpret_cast<const double2*>(rb);
-    const double ta = ra[4], tb_ = rb[4];
-    double tva = 0.0, tvb = 0.0;
-    int haba = -1, habb = -1;
-    if (va) cost_element(W, St, 0, W.n_bins, P.w[2], xya.x, xya.y, ta, tva, haba, true, grid_lds);
-    if (vb) cost_element(W, St, 0, W.n_bins, P.w[2], xyb.x, xyb.y, tb_, tvb, habb, true, grid_lds);
-    if (va) { ptTerm[pa] = tva; ptHab[pa] = (int8_t)haba; }
-    if (vb) { ptTerm[pb] = tvb; ptHab[pb] = (int8_t)habb; }
-  }
-  if (P.flags & 256) return;  // timing experiments only (AUVP_LEAF_STOP)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  wave_sync();
-  // (b) lane = node, creation order: its own state's term, the sum over its points' terms, then the parent's sums
-  for (int n0 = 0; n0 < n_nodes; n0 += 64) {
-    const int m = n0 + lane;
-    const bool live = m < n_nodes;
-    int4 r = make_int4(0, -1, 0, 0);
-    if (live) r = nodeI[m];
-    double own = 0.0, ntv = 0.0;
-    int own_hits = 0, nhab = -1;
-    unsigned long long own_vis = 0ull;
-    if (live) {
-      const double2 xy = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8);
-      cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, nodeF[(size_t)m * 8 + 3], ntv, nhab, true, grid_lds);
-      for (int k = 0; k < r.w; k += 16) {  // sixteen independent reads in flight per step; any order will do for S
-        double t16[16];
-        int h16[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          const bool in = k + j < r.w;
-          const size_t at = (size_t)r.z + (size_t)(in ? k + j : 0);
-          t16[j] = in ? ptTerm[at] : 0.0;
-          h16[j] = in ? (int)ptHab[at] : -1;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          own = own + t16[j];
-          if (h16[j] >= 0) { own_hits++; own_vis |= (1ull << h16[j]); }
-        }
-      }
-      own = own + ntv;
-      if (nhab >= 0) { own_hits++; own_vis |= (1ull << nhab); }
-    }
-    // the parent's sums: from memory when it belongs to an earlier pass, else from the lanes of this one, in order
-    double pS = 0.0;
-    int4 pc = make_int4(0, 0, 0, 0);
-    const bool par_before = live && r.y >= 0 && r.y < n0;
-    if (par_before) { pS = nodeF[(size_t)r.y * 8 + 5]; pc = nodeC[r.y]; }
-    unsigned long long pvis = ((unsigned long long)(uint32_t)pc.w << 32) | (unsigned long long)(uint32_t)pc.z;
-    wave_sync();
-    c_par[lane] = r.y - n0;
-    c_S[lane] = pS + own; c_hits[lane] = pc.x + own_hits; c_elems[lane] = pc.y + r.w + 1; c_vis[lane] = pvis | own_vis;
-    wave_sync();
-    // parents inside this pass: a lane is ready once its parent's entry is final (a parent always has the smaller
-    // index, so the lowest pending lane is ready in every round); all ready lanes add their parent's sums at once
-    unsigned long long pending = __ballot(live && r.y >= n0);
-    while (pending) {
-      const int p = c_par[lane];
-      const bool mine = (pending >> lane) & 1ull;
-      const bool ready = mine && !((pending >> (p & 63)) & 1ull);
-      double aS = 0.0;
-      int aH = 0, aE = 0;
-      unsigned long long aV = 0ull;
-      if (ready) { aS = c_S[p]; aH = c_hits[p]; aE = c_elems[p]; aV = c_vis[p]; }
-      wave_sync();
-      if (ready) { c_S[lane] = aS + c_S[lane]; c_hits[lane] += aH; c_elems[lane] += aE; c_vis[lane] |= aV; }
-      wave_sync();
-      pending &= ~__ballot(ready);
-    }
-    if (live) {
-      *reinterpret_cast<double2*>(nodeF + (size_t)m * 8 + 6) = make_double2(ntv, (double)nhab);
-      nodeF[(size_t)m * 8 + 5] = c_S[lane];
-      const unsigned long long v = c_vis[lane];
-      nodeC[m] = make_int4(c_hits[lane], c_elems[lane], (int)(uint32_t)(v & 0xffffffffull), (int)(uint32_t)(v >> 32));
-    }
-    // the next pass reads these sums back through the vector cache: make the stores visible to the whole wave first
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    wave_sync();
-  }
-  if (P.flags & 512) return;  // timing experiments only (AUVP_LEAF_STOP)
-  // ---------------------------------------------------------------- sweep 2: ranking
   const bool log_leaf = (P.flags & 2) != 0 && B.leaf_cost != nullptr;
   const double init_t = B.init[(size_t)ep * 6 + 3];
   const double w1 = P.w[0], w2 = P.w[1], w3 = P.w[2];
@@ -913,22 +827,104 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   long long leaf_elems = 0;
   double best_tot = __builtin_inf(), best_c0 = 0.0, best_c1 = 0.0, best_c2 = 0.0, best_len = 0.0;
   double min_hi = __builtin_inf();  // smallest upper bound among the qualifying leaves seen so far
-  for (int n0 = 1; n0 < n_nodes; n0 += 64) {  // node 0 is the start state: never a leaf candidate (:144-171)
+  for (int n0 = 0; n0 < n_nodes; n0 += 64) {
     const int m = n0 + lane;
+    const bool live = m < n_nodes;
+    const int nlive = (n_nodes - n0) < 64 ? (n_nodes - n0) : 64;
+    int4 r = make_int4(0, -1, 0, 0);
+    if (live) r = nodeI[m];
+    // ---------------------------------------------------------------- 1. terms of the pass's path elements
+    c_off[lane] = live ? r.z : 0x7fffffff;
+    c_S[lane] = 0.0; c_hits[lane] = 0; c_vis[lane] = 0ull;
+    const int p_first = __builtin_amdgcn_readlane(r.z, 0);
+    const int p_end = __builtin_amdgcn_readlane(r.z, nlive - 1) + __builtin_amdgcn_readlane(r.w, nlive - 1);
+    wave_sync();
+    for (int p0 = p_first; p0 < p_end; p0 += 128) {  // two points per lane and pass: their record reads overlap
+      const int pa = p0 + lane, pb = p0 + 64 + lane;
+      const bool va = pa < p_end, vb = pb < p_end;
+      const double* ra = ptF + (size_t)(va ? pa : p_first) * 6;
+      const double* rb = ptF + (size_t)(vb ? pb : p_first) * 6;
+      const double2 xya = *reinterpret_cast<const double2*>(ra), xyb = *reinterpret_cast<const double2*>(rb);
+      const double ta = ra[4], tb_ = rb[4];
+      double tva = 0.0, tvb = 0.0;
+      int haba = -1, habb = -1;
+      if (va) cost_element(W, St, 0, W.n_bins, P.w[2], xya.x, xya.y, ta, tva, haba, true, grid_lds);
+      if (vb) cost_element(W, St, 0, W.n_bins, P.w[2], xyb.x, xyb.y, tb_, tvb, habb, true, grid_lds);
+      // owner = last node of the pass whose pt_off is <= the point index (nodes without points share their
+      // successor's offset and are skipped by "last")
+      int oa = 0, ob = 0;
+#pragma unroll
+      for (int st = 32; st >= 1; st >>= 1) {
+        if (oa + st < 64 && c_off[oa + st] <= pa) oa += st;
+        if (ob + st < 64 && c_off[ob + st] <= pb) ob += st;
+      }
+      if (va) {
+        if (tva != 0.0) atomicAdd(&c_S[oa], tva);
+        if (haba >= 0) { atomicAdd(&c_hits[oa], 1); atomicOr(&c_vis[oa], 1ull << haba); }
+      }
+      if (vb) {
+        if (tvb != 0.0) atomicAdd(&c_S[ob], tvb);
+        if (habb >= 0) { atomicAdd(&c_hits[ob], 1); atomicOr(&c_vis[ob], 1ull << habb); }
+      }
+    }
+    wave_sync();
+    double own = c_S[lane], ntv = 0.0, ctt = 0.0, nlen = 0.0;
+    int own_hits = c_hits[lane], nhab = -1;
+    unsigned long long own_vis = c_vis[lane];
+    if (live) {
+      const double2 xy = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8);
+      const double2 tl = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8 + 3);  // traj_t, length (unaligned pair)
+      ctt = tl.x; nlen = tl.y;
+      cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, ctt, ntv, nhab, true, grid_lds);
+      own = own + ntv;
+      if (nhab >= 0) { own_hits++; own_vis |= (1ull << nhab); }
+    }
+    // ---------------------------------------------------------------- 2. running sums down the tree
+    // the parent's sums: from memory when it belongs to an earlier pass, else from the lanes of this one
+    double pS = 0.0;
+    int4 pc = make_int4(0, 0, 0, 0);
+    const bool par_before = live && r.y >= 0 && r.y < n0;
+    if (par_before) { pS = nodeF[(size_t)r.y * 8 + 5]; pc = nodeC[r.y]; }
+    const unsigned long long pvis = ((unsigned long long)(uint32_t)pc.w << 32) | (unsigned long long)(uint32_t)pc.z;
+    wave_sync();
+    c_par[lane] = r.y - n0;
+    c_S[lane] = pS + own; c_hits[lane] = pc.x + own_hits; c_elems[lane] = pc.y + r.w + 1; c_vis[lane] = pvis | own_vis;
+    wave_sync();
+    // parents inside this pass: a lane is ready once its parent's entry is final (a parent always has the smaller
+    // index, so the lowest pending lane is ready in every round); all ready lanes add their parent's sums at once
+    unsigned long long pending = __ballot(live && r.y >= n0);
+    while (pending) {
+      const int p = c_par[lane];
+      const bool mine = (pending >> lane) & 1ull;
+      const bool ready = mine && !((pending >> (p & 63)) & 1ull);
+      double aS = 0.0;
+      int aH = 0, aE = 0;
+      unsigned long long aV = 0ull;
+      if (ready) { aS = c_S[p]; aH = c_hits[p]; aE = c_elems[p]; aV = c_vis[p]; }
+      wave_sync();
+      if (ready) { c_S[lane] = aS + c_S[lane]; c_hits[lane] += aH; c_elems[lane] += aE; c_vis[lane] |= aV; }
+      wave_sync();
+      pending &= ~__ballot(ready);
+    }
+    const double S = c_S[lane];
+    const int hits = c_hits[lane], elems = c_elems[lane];
+    const unsigned long long vis = c_vis[lane];
+    if (live) {
+      *reinterpret_cast<double2*>(nodeF + (size_t)m * 8 + 6) = make_double2(ntv, (double)nhab);
+      nodeF[(size_t)m * 8 + 5] = S;
+      nodeC[m] = make_int4(hits, elems, (int)(uint32_t)(vis & 0xffffffffull), (int)(uint32_t)(vis >> 32));
+    }
+    // later passes (parents) and the re-summation below read these back: make the stores visible to the wave first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    wave_sync();
+    // ---------------------------------------------------------------- 3. ranking of the pass's qualifying leaves
     bool q = false;
-    double lo = __builtin_inf(), hi = __builtin_inf(), ctt = 0.0;
-    int elems = 0;
-    if (m < n_nodes) {
-      const double2 tl = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8 + 3);  // traj_t, length
-      ctt = tl.x;
+    double lo = __builtin_inf(), hi = __builtin_inf();
+    if (live && m >= 1) {  // node 0 is the start state: never a leaf candidate (:144-171)
       q = ctt >= thresh;
       if (q) {
-        const int4 c = nodeC[m];
-        elems = c.y;
-        const unsigned long long vis = ((unsigned long long)(uint32_t)c.w << 32) | (unsigned long long)(uint32_t)c.z;
         double c0, c1, c2;
-        const double S = nodeF[(size_t)m * 8 + 5];
-        const double tot = total_of(c.x, vis, ctt, S, c0, c1, c2);
+        const double tot = total_of(hits, vis, ctt, S, c0, c1, c2);
         // |S - ordered sum| <= 2 gamma_L L term_max; one more rounding each for the division and the two additions
         const double L = (double)elems;
         const double gam = 2.0 * (L + 2.0) * 0x1p-53;
@@ -940,8 +936,9 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
       }
     }
     const unsigned long long qm = __ballot(q);
+    if (qm == 0ull) continue;
     n_leaves += __popcll(qm);
-    // exclusive prefix minimum of hi over the lanes (creation order), seeded with the earlier chunks
+    // exclusive prefix minimum of hi over the lanes (creation order), seeded with the earlier passes
     double pm = hi;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -970,43 +967,51 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
       double c2num = 0.0;
       int mm = leaf;
       for (;;) {
-        const int4 r = nodeI[mm];
+        const int4 rr = nodeI[mm];
         const double tvn = nodeF[(size_t)mm * 8 + 6];
         c2num = c2num + tvn;  // the node's own state comes before the points that led to it
-        if (r.y < 0) break;   // the root has no path of its own
-        for (int k0 = 0; k0 < r.w; k0 += 64) {
-          const int nv = (r.w - k0) < 64 ? (r.w - k0) : 64;
+        if (rr.y < 0) break;  // the root has no path of its own
+        for (int k0 = 0; k0 < rr.w; k0 += 64) {
+          const int nv = (rr.w - k0) < 64 ? (rr.w - k0) : 64;
+          double tvp = 0.0;
+          int habp = -1;
+          if (lane < nv) {  // last point first; the term is evaluated again from the record
+            const double* rec = ptF + ((size_t)rr.z + (size_t)(rr.w - 1 - (k0 + lane))) * 6;
+            const double2 xy = *reinterpret_cast<const double2*>(rec);
+            cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, rec[4], tvp, habp, true, grid_lds);
+          }
           wave_sync();
-          term[lane] = (lane < nv) ? ptTerm[(size_t)r.z + (size_t)(r.w - 1 - (k0 + lane))] : 0.0;  // last point first
+          term[lane] = tvp;
           wave_sync();
           for (int i = 0; i < nv; i++) c2num = c2num + term[i];
         }
-        mm = r.y;
+        mm = rr.y;
       }
-      const int4 c = nodeC[leaf];
-      const unsigned long long vis = ((unsigned long long)(uint32_t)c.w << 32) | (unsigned long long)(uint32_t)c.z;
-      const double2 tl = *reinterpret_cast<const double2*>(nodeF + (size_t)leaf * 8 + 3);
+      const int lhits = __builtin_amdgcn_readlane(hits, l), lelems = __builtin_amdgcn_readlane(elems, l);
+      const unsigned long long lvis = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(vis >> 32), l) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(vis & 0xffffffffull), l);
+      const double lctt = readlane_f64(ctt, l), llen = readlane_f64(nlen, l);
       double c0, c1, c2;
-      double tot = total_of(c.x, vis, tl.x, c2num, c0, c1, c2);
+      double tot = total_of(lhits, lvis, lctt, c2num, c0, c1, c2);
       tot = readfirst_f64(tot);
       if (log_leaf) {
-        // position of this leaf among the qualifying ones = leaves before this chunk + qualifying lanes below l
+        // position of this leaf among the qualifying ones = leaves before this pass + qualifying lanes below l
         const int pos = n_leaves - __popcll(qm) + __popcll(qm & ((1ull << l) - 1ull));
         if (pos < B.cap_leaves && lane == 0) {
           // number of shark-grid bins in the leaf's sub-dict (:160-165)
           int nsel = 0;
           for (int b = 0; b < W.n_bins; b++) {
             const double b0 = s_bins[b][0], b1 = s_bins[b][1];
-            nsel += ((init_t >= b0 && init_t <= b1) || (b0 >= init_t && b1 <= tl.x) || (tl.x >= b0 && tl.x <= b1)) ? 1 : 0;
+            nsel += ((init_t >= b0 && init_t <= b1) || (b0 >= init_t && b1 <= lctt) || (lctt >= b0 && lctt <= b1)) ? 1 : 0;
           }
           double* lc = B.leaf_cost + ((size_t)ep * B.cap_leaves + pos) * 6;
-          lc[0] = tot; lc[1] = c0; lc[2] = c1; lc[3] = c2; lc[4] = (double)c.y; lc[5] = (double)nsel;
+          lc[0] = tot; lc[1] = c0; lc[2] = c1; lc[3] = c2; lc[4] = (double)lelems; lc[5] = (double)nsel;
           B.leaf_iter[(size_t)ep * B.cap_leaves + pos] = nodeI[leaf].x;
         }
       }
       if (tot < best_tot) {
-        best_tot = tot; best_leaf = leaf; best_L = c.y;
-        best_c0 = c0; best_c1 = c1; best_c2 = c2; best_len = tl.y;
+        best_tot = tot; best_leaf = leaf; best_L = lelems;
+        best_c0 = c0; best_c1 = c1; best_c2 = c2; best_len = llen;
       }
     }
   }
