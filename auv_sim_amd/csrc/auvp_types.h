@@ -100,7 +100,9 @@ struct RrtBuffers {
   // [E][cap_nodes][8]  x, y, theta, traj_t, length, S, tv, hab   (64 B per node); S/tv/hab: see below
   double* node_f;
   int32_t* node_i;   // [E][cap_nodes][4]  plan_iter, parent, pt_off, pt_cnt       (16 B per node)
-  double* points;    // [E][cap_points][6] x, y, theta, v, traj_t, length
+  // [E] x { [cap_points][3] x, y, traj_t ; [cap_points][3] theta, v, length }: two 24-byte records per path point -- the
+  // leaf pass reads only the first (half the bytes); a node's points are one contiguous run in both
+  double* points;
   // habitat_shark_cost_func bookkeeping (derived data, never returned).  A path element's contribution to the cost of
   // a leaf -- w3*prob of its cell in its time bin, and the habitat it lies in -- does not depend on the leaf (its bin
   // is always part of the leaf's sub-dict), so it is evaluated ONCE, when the node that owns it is accepted:

@@ -758,11 +758,15 @@ int auvp_rrt_tree(auvp_handle* h, int32_t ep, double* nodes6, int32_t* parent, i
     if (pt_cnt) pt_cnt[i] = ni[4 * (size_t)i + 3];
   }
   if (points7 && NP > 0) {
-    std::vector<double> rec((size_t)NP * 6);
-    const int dst[6] = {0, 1, 2, 3, 4, 6};
-    HIPCHK(h, hipMemcpy(rec.data(), B.points + (size_t)ep * 6 * capp, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (int i = 0; i < NP; i++)
-      for (int c = 0; c < 6; c++) points7[7 * (size_t)i + dst[c]] = rec[6 * (size_t)i + c];
+    // the points live in two 24-byte record arrays per episode: {x, y, traj_t} and {theta, v, length}
+    std::vector<double> ra((size_t)NP * 3), rb((size_t)NP * 3);
+    HIPCHK(h, hipMemcpy(ra.data(), B.points + (size_t)ep * 6 * capp, ra.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(rb.data(), B.points + (size_t)ep * 6 * capp + 3 * capp, rb.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < NP; i++) {
+      double* d = points7 + 7 * (size_t)i;
+      d[0] = ra[3 * (size_t)i]; d[1] = ra[3 * (size_t)i + 1]; d[2] = rb[3 * (size_t)i]; d[3] = rb[3 * (size_t)i + 1];
+      d[4] = ra[3 * (size_t)i + 2]; d[6] = rb[3 * (size_t)i + 2];
+    }
     // plan_time_stamp of a path point = iteration of the node that owns it
     for (int m = 0; m < N; m++) {
       const int off = ni[4 * (size_t)m + 2], cnt = ni[4 * (size_t)m + 3], plan = ni[4 * (size_t)m];

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
   double* nodeF = B.node_f + (size_t)ep * capn * 8;                       // [capn][8] x,y,theta,t,length
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;    // plan_iter,parent,pt_off,pt_cnt
-  double* ptF = B.points + (size_t)ep * capp * 6;                         // [capp][6] x,y,theta,v,t,length
+  double* ptF = B.points + (size_t)ep * capp * 6;                         // [capp][3] x,y,t then [capp][3] theta,v,length
   int32_t* bin_items = B.bin_items + (size_t)ep * (P.K + 1) * bcap;
   const double* init = B.init + (size_t)ep * 6;
   const int K = P.K;
@@ -604,10 +604,11 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       if (app) {
         int rank = __popcll(amask & ((1ull << lane) - 1ull));
         size_t gi = (size_t)(n_points + cnt + rank);  // speculative: committed only if the node is accepted
-        // one 48-byte record per path point: a node's points are one contiguous run (three 16-byte stores per lane),
-        // not six 8-byte streams whose partly filled lines the L2 writes back early (-17 % HBM write traffic)
-        double2* rec = reinterpret_cast<double2*>(ptF + gi * 6);
-        rec[0] = make_double2(mx, my); rec[1] = make_double2(myth, vt); rec[2] = make_double2(mt_, ml);
+        // two 24-byte records per path point (auvp_types.h): what the leaf pass reads, and the rest
+        double* ra = ptF + gi * 3;
+        double* rb = ptF + (size_t)capp * 3 + gi * 3;
+        *reinterpret_cast<double2*>(ra) = make_double2(mx, my); ra[2] = mt_;
+        *reinterpret_cast<double2*>(rb) = make_double2(myth, vt); rb[2] = ml;
         pts[cnt + rank + 1][0] = mx;
         pts[cnt + rank + 1][1] = my;
       }
@@ -842,10 +843,10 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     for (int p0 = p_first; p0 < p_end; p0 += 128) {  // two points per lane and pass: their record reads overlap
       const int pa = p0 + lane, pb = p0 + 64 + lane;
       const bool va = pa < p_end, vb = pb < p_end;
-      const double* ra = ptF + (size_t)(va ? pa : p_first) * 6;
-      const double* rb = ptF + (size_t)(vb ? pb : p_first) * 6;
+      const double* ra = ptF + (size_t)(va ? pa : p_first) * 3;
+      const double* rb = ptF + (size_t)(vb ? pb : p_first) * 3;
       const double2 xya = *reinterpret_cast<const double2*>(ra), xyb = *reinterpret_cast<const double2*>(rb);
-      const double ta = ra[4], tb_ = rb[4];
+      const double ta = ra[2], tb_ = rb[2];
       double tva = 0.0, tvb = 0.0;
       int haba = -1, habb = -1;
       if (va) cost_element(W, St, 0, W.n_bins, P.w[2], xya.x, xya.y, ta, tva, haba, true, grid_lds);
@@ -976,9 +977,9 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
           double tvp = 0.0;
           int habp = -1;
           if (lane < nv) {  // last point first; the term is evaluated again from the record
-            const double* rec = ptF + ((size_t)rr.z + (size_t)(rr.w - 1 - (k0 + lane))) * 6;
+            const double* rec = ptF + ((size_t)rr.z + (size_t)(rr.w - 1 - (k0 + lane))) * 3;
             const double2 xy = *reinterpret_cast<const double2*>(rec);
-            cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, rec[4], tvp, habp, true, grid_lds);
+            cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, rec[2], tvp, habp, true, grid_lds);
           }
           wave_sync();
           term[lane] = tvp;
@@ -1065,9 +1066,10 @@ __global__ __launch_bounds__(64) void rrt_final_course_kernel(RrtBuffers B, cons
       // point k of the node sits k places after the node it grew from
       double* e = o + 7 * (size_t)(pos - cnt + 1 + k);
       size_t gi = (size_t)off + k;
-      const double* rec = ptF + gi * 6;
-      e[0] = rec[0]; e[1] = rec[1]; e[2] = rec[2]; e[3] = rec[3];
-      e[4] = rec[4]; e[5] = (double)r.x; e[6] = rec[5];
+      const double* ra = ptF + gi * 3;
+      const double* rb = ptF + capp * 3 + gi * 3;
+      e[0] = ra[0]; e[1] = ra[1]; e[2] = rb[0]; e[3] = rb[1];
+      e[4] = ra[2]; e[5] = (double)r.x; e[6] = rb[2];
     }
     pos -= cnt;
     if (lane == 0) node_elem(r.y, pos);

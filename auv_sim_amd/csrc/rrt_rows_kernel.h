@@ -346,8 +346,10 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       if (wr) {
         const int rank = __popc(amask & ((1u << rl) - 1u));
         const size_t gi = (size_t)(n_points + cnt + rank);  // speculative: committed only if the node is accepted
-        double2* rec = reinterpret_cast<double2*>(ptF + gi * 6);
-        rec[0] = make_double2(mx, my); rec[1] = make_double2(myth, vt); rec[2] = make_double2(mt_, ml);
+        double* ra = ptF + gi * 3;                       // x, y, traj_t: what the leaf pass reads
+        double* rb = ptF + (size_t)capp * 3 + gi * 3;    // theta, v, length
+        *reinterpret_cast<double2*>(ra) = make_double2(mx, my); ra[2] = mt_;
+        *reinterpret_cast<double2*>(rb) = make_double2(myth, vt); rb[2] = ml;
       }
       ptx[pass] = mx; pty[pass] = my; ptv[pass] = wr;
       {
