@@ -103,16 +103,14 @@ struct RrtBuffers {
   // [E] x { [cap_points][3] x, y, traj_t ; [cap_points][3] theta, v, length }: two 24-byte records per path point -- the
   // leaf pass reads only the first (half the bytes); a node's points are one contiguous run in both
   double* points;
-  // habitat_shark_cost_func bookkeeping (derived data, never returned).  A path element's contribution to the cost of
-  // a leaf -- w3*prob of its cell in its time bin, and the habitat it lies in -- does not depend on the leaf (its bin
-  // is always part of the leaf's sub-dict), so it is evaluated ONCE, when the node that owns it is accepted:
-  //   pt_term / pt_hab per path point;  node_f[6] / node_f[7] for the node's own state
-  // and summed down the tree:  node_f[5] = S = sum of the terms of every element on the root..node path (any order:
-  // an approximation of the reference's ordered sum with a rigorous bound), node_c = {number of elements inside some
-  // habitat, number of elements, visited-habitat bit set} of that path (exact).  The leaf pass (rrt_leaf_kernel) ranks
-  // the qualifying leaves with these and re-sums in the reference's order only where the bound cannot decide.
-  double* pt_term;   // [E][cap_points]
-  int8_t* pt_hab;    // [E][cap_points]
+  // habitat_shark_cost_func bookkeeping (derived data, never returned), filled by rrt_leaf_kernel.  A path element's
+  // contribution to the cost of a leaf -- w3*prob of its cell in its time bin, and the habitat it lies in -- does not
+  // depend on the leaf (its bin is always part of the leaf's sub-dict), so it is evaluated once and summed down the
+  // tree:  node_f[6] / node_f[7] = term and habitat of the node's own state;  node_f[5] = S = sum of the terms of every
+  // element on the root..node path (any order: an approximation of the reference's ordered sum with a rigorous bound);
+  // node_c = {number of elements inside some habitat, number of elements, visited-habitat bit set} of that path
+  // (exact).  The leaf pass ranks the qualifying leaves with these and re-sums in the reference's order only where the
+  // bound cannot decide.
   int32_t* node_c;   // [E][cap_nodes][4]  hits, elements, visited mask lo, hi
   int32_t* bin_items;                       // [E][K+1][bin_cap]
   int32_t* bin_count;                       // [E][K+1] (copied out of LDS at the end)

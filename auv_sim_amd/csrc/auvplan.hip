@@ -59,7 +59,7 @@ struct auvp_handle {
   RrtBuffers B{};
   int max_pts = 0;
   DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_phase, d_pt_term, d_pt_hab, d_node_c, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+      d_leaf_c, d_leaf_i, d_phase, d_node_c, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
@@ -542,14 +542,10 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   HIPCHK(h, h->d_bin_items.reserve((size_t)E * (P.K + 1) * B.bin_cap * sizeof(int32_t)));
   HIPCHK(h, h->d_bin_count.reserve((size_t)E * (P.K + 1) * sizeof(int32_t)));
   HIPCHK(h, h->d_summary.reserve((size_t)E * sizeof(RrtSummary)));
-  HIPCHK(h, h->d_pt_term.reserve(cpnt * sizeof(double)));
-  HIPCHK(h, h->d_pt_hab.reserve(cpnt));
   HIPCHK(h, h->d_node_c.reserve(cn * 4 * sizeof(int32_t)));
   B.node_f = h->d_nodes_f.as<double>();
   B.node_i = h->d_nodes_i.as<int32_t>();
   B.points = h->d_points.as<double>();
-  B.pt_term = h->d_pt_term.as<double>();
-  B.pt_hab = h->d_pt_hab.as<int8_t>();
   B.node_c = h->d_node_c.as<int32_t>();
   B.bin_items = h->d_bin_items.as<int32_t>();
   B.bin_count = h->d_bin_count.as<int32_t>();

@@ -188,10 +188,15 @@ def effective_cores(cap=64):
 class Ranks:
     """rank bookkeeping + the result gather.  N = 1: everything is a no-op."""
 
-    def __init__(self, ctx, rank, world, dev):
+    def __init__(self, ctx, rank, world, dev, use_rccl=True):
         self.ctx, self.rank, self.world, self.dev = ctx, rank, world, dev
         self.gather, self.gather_note = None, None
-        if world > 1:
+        self.cpu_group = not use_rccl  # gloo: collectives on host tensors
+        if world > 1 and not use_rccl:
+            from auv_sim_amd import distributed as D
+            self.gather = _HostGather(D.TorchGather(), dev)
+            self.gather_note = "AUVP_BENCH_ONE_GPU: gloo transport"
+        elif world > 1:
             import torch.distributed as dist
             from auv_sim_amd import distributed as D
 
@@ -211,6 +216,10 @@ class Ranks:
                     self.gather.close()
                 self.gather = D.TorchGather()
 
+    def _t(self, vals, dtype=None):
+        import torch
+        return torch.tensor(vals, dtype=dtype or torch.float64, device="cpu" if self.cpu_group else self.dev)
+
     def sync(self):
         import torch
         torch.cuda.synchronize()
@@ -224,7 +233,7 @@ class Ranks:
             return dt
         import torch
         import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        t = self._t([dt])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -233,7 +242,7 @@ class Ranks:
             return float(v)
         import torch
         import torch.distributed as dist
-        t = torch.tensor([float(v)], dtype=torch.float64, device=self.dev)
+        t = self._t([float(v)])
         dist.all_reduce(t)
         return float(t.item())
 
@@ -260,6 +269,28 @@ class Ranks:
 
     def gather_ms(self):
         return self.gather.take_ms() if self.gather is not None else None
+
+
+class _HostGather:
+    """TorchGather over a CPU process group (gloo) for device tensors: staged through host memory"""
+
+    name = "torch.distributed (gloo, staged through the host)"
+
+    def __init__(self, inner, dev):
+        self.inner, self.dev = inner, dev
+
+    def gather_records(self, records):
+        return [t.to(self.dev) for t in self.inner.gather_records(records.cpu())]
+
+    def gather_paths(self, paths, lengths):
+        lens, blocks = self.inner.gather_paths(paths.cpu(), lengths.cpu())
+        return [l.to(self.dev) for l in lens], [b.to(self.dev) for b in blocks]
+
+    def take_ms(self):
+        return None
+
+    def close(self):
+        pass
 
 
 def timed_steps(ranks, step, steps, warmup):
@@ -681,8 +712,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--episodes", type=int, default=12288,
-                    help="episodes per GPU per step (6144 wavefronts are resident at once, 6 per SIMD: 12288 = two rounds, "
-                         "the second one back-fills as episodes of the first finish; 16.9 MB of tree storage each = 208 GB)")
+                    help="episodes per GPU per step (12288 = one 48-episode workgroup of the four-episodes-per-wavefront kernel "
+                         "on each of the 256 CUs; 14.6 MB of tree storage each = 180 GB)")
     ap.add_argument("--iters", type=int, default=10000, help="expansion budget per episode (10k-node budget)")
     ap.add_argument("--obstacles", type=int, default=256)
     ap.add_argument("--grid", type=int, default=200, help="grid is grid x grid cells of 10 m")
@@ -710,14 +741,22 @@ def main():
     import torch.distributed as dist
     from auv_sim_amd import _lib
 
+    # AUVP_BENCH_ONE_GPU=1 (plumbing test on a single-GPU box): every rank uses GPU 0 and the ranks talk over gloo -- RCCL
+    # cannot put two ranks on one device -- so everything but the RCCL transport itself is exercised
+    one_gpu = os.environ.get("AUVP_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     ctx = _lib.Context(local_rank)
-    ranks = Ranks(ctx, rank, world_size, dev)
+    ranks = Ranks(ctx, rank, world_size, dev, use_rccl=not one_gpu)
     sides = {
         "single_episode": lambda: bench_single_episode(ctx, world, args),
         "rrt_64_obstacles": lambda: bench_rrt_o64(ctx, args),
@@ -745,13 +784,14 @@ def main():
 
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     E = args.episodes
-    # the trees need ~17.5 MB of HBM per 10 000-iteration episode: if this GPU has less free than the requested batch
-    # needs, run the largest whole number of resident rounds (6144 episodes) that fits -- every rank the same
+    # the trees need ~14.6 MB of HBM per 10 000-iteration episode (nodes 1 MB, path points 9.6 MB, time-bin lists 4 MB): if
+    # this GPU has less free than the requested batch needs, run the largest multiple of 6144 episodes that fits -- every
+    # rank the same
     free_b, _total_b = torch.cuda.mem_get_info(dev)
-    fit = int(0.92 * free_b / (17.5e6 * max(args.iters, 1) / 10000.0))
+    fit = int(0.92 * free_b / (15.0e6 * max(args.iters, 1) / 10000.0))
     if fit < E:
         fit = max(6144 * (fit // 6144), min(E, 1024))
-    e_fit = torch.tensor([min(E, fit)], dtype=torch.int64, device=dev)
+    e_fit = ranks._t([min(E, fit)], torch.int64)
     if world_size > 1:
         dist.all_reduce(e_fit, op=dist.ReduceOp.MIN)
     if int(e_fit.item()) < E:
