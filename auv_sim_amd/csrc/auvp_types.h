@@ -61,6 +61,12 @@ struct WorldDev {
   double sg_x1_0, sg_y1_0, bins_t1_0;  // first entries of X1, Y1 and of the bins' upper ends (origins of the guesses)
   double sg_inv_dx, sg_inv_dy;  // 1 / mean spacing of X1 / Y1: first guess of the lower bound only
   double prob_absmax;  // max |prob|: bounds a path element's cost term (approximate-cost error bound of the leaf pass)
+  // habitat mask grid: hg_n x hg_n cells over the bounding box of the habitats' discs; cell -> bit set of the habitats
+  // whose (slightly inflated) bounding square touches it.  A point outside the box, or in a cell with an empty set, lies
+  // in no habitat; otherwise only the set's members are tested, in list order (first match, cost.py:187-191).
+  int32_t hg_n, _pad_hg;
+  double hg_x0, hg_y0, hg_inv_w, hg_inv_h;
+  const unsigned long long* hg_mask;  // [hg_n * hg_n]
   // the obstacles once more, reordered along a space-filling curve and cut into 16 slots of 16 (rrt_rows_kernel; built
   // for <= 256 obstacles).  The collision decision is an OR over (point, obstacle) pairs of d2 <= T_i, so the order in
   // which a kernel looks at them is free once T_i (which encodes the reference's list order) is fixed.
@@ -111,7 +117,7 @@ struct RrtBuffers {
   // node_c = {number of elements inside some habitat, number of elements, visited-habitat bit set} of that path
   // (exact).  The leaf pass ranks the qualifying leaves with these and re-sums in the reference's order only where the
   // bound cannot decide.
-  int32_t* node_c;   // [E][cap_nodes][4]  hits, elements, visited mask lo, hi
+  int32_t* node_c;   // [E][cap_nodes] 32-byte records {S f64, hits i32 | elements i32, visited mask u64, -}
   int32_t* bin_items;                       // [E][K+1][bin_cap]
   int32_t* bin_count;                       // [E][K+1] (copied out of LDS at the end)
   uint32_t* mt;                             // [E][624] generator state in

@@ -52,7 +52,7 @@ struct auvp_handle {
   bool have_world = false;
   WorldDev W{};
   DevBuf d_ox, d_oy, d_ot, d_hab, d_habt, d_poly, d_bins, d_cells, d_prob, d_xoff, d_xitems, d_xdata, d_rgfirst, d_rgbp, d_rgoff,
-      d_rgpm, d_rgid, d_sgx0, d_sgx1, d_sgy0, d_sgy1, d_sgcol, d_sgrow, d_osx, d_osy, d_ost, d_osr, d_osbox;
+      d_rgpm, d_rgid, d_sgx0, d_sgx1, d_sgy0, d_sgy1, d_sgcol, d_sgrow, d_osx, d_osy, d_ost, d_osr, d_osbox, d_hgmask;
   // rrt batch
   int E = 0;
   RrtParamsDev P{};
@@ -134,6 +134,54 @@ template <class T>
 int upload(auvp_handle* h, DevBuf& b, const T* src, size_t n) {
   HIPCHK(h, b.reserve(n * sizeof(T)));
   if (n) HIPCHK(h, hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  return AUVP_OK;
+}
+
+
+// habitat mask grid (auvp_types.h): 32 x 32 cells over the box of the habitats' cull squares; a habitat is entered into
+// every cell its square touches, one cell of margin on each side against rounding in the cell arithmetic
+int build_habitat_grid(auvp_handle* h, const double* habitats, int H) {
+  WorldDev& W = h->W;
+  W.hg_n = 0; W._pad_hg = 0; W.hg_x0 = W.hg_y0 = W.hg_inv_w = W.hg_inv_h = 0.0;
+  W.hg_mask = nullptr;
+  if (H <= 0 || H > 64 || getenv("AUVP_NO_HABITAT_GRID")) return AUVP_OK;
+  const int G = 32;
+  double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
+  std::vector<double> rr(H);
+  for (int i = 0; i < H; i++) {
+    const double t = sq_threshold(habitats[3 * i + 2]);
+    rr[i] = t >= 0.0 ? std::sqrt(t) * (1.0 + 0x1p-30) + 0x1p-40 : -1.0;
+    const double hx = habitats[3 * i], hy = habitats[3 * i + 1];
+    if (!std::isfinite(hx) || !std::isfinite(hy) || !std::isfinite(rr[i])) return AUVP_OK;  // odd input: keep the plain scan
+    if (rr[i] < 0.0) continue;  // can never contain a point
+    x0 = std::min(x0, hx - rr[i]); x1 = std::max(x1, hx + rr[i]);
+    y0 = std::min(y0, hy - rr[i]); y1 = std::max(y1, hy + rr[i]);
+  }
+  std::vector<unsigned long long> mask((size_t)G * G, 0ull);
+  if (x1 >= x0 && y1 >= y0) {
+    // grow the box a little so that every square lies strictly inside it
+    const double mx = 1e-6 * (std::fabs(x0) + std::fabs(x1) + 1.0), my = 1e-6 * (std::fabs(y0) + std::fabs(y1) + 1.0);
+    x0 -= mx; x1 += mx; y0 -= my; y1 += my;
+    const double iw = (double)G / (x1 - x0), ih = (double)G / (y1 - y0);
+    for (int i = 0; i < H; i++) {
+      if (rr[i] < 0.0) continue;
+      const double hx = habitats[3 * i], hy = habitats[3 * i + 1];
+      int cx0 = (int)std::floor((hx - rr[i] - x0) * iw) - 1, cx1 = (int)std::floor((hx + rr[i] - x0) * iw) + 1;
+      int cy0 = (int)std::floor((hy - rr[i] - y0) * ih) - 1, cy1 = (int)std::floor((hy + rr[i] - y0) * ih) + 1;
+      cx0 = std::max(cx0, 0); cy0 = std::max(cy0, 0); cx1 = std::min(cx1, G - 1); cy1 = std::min(cy1, G - 1);
+      for (int cy = cy0; cy <= cy1; cy++)
+        for (int cx = cx0; cx <= cx1; cx++) mask[(size_t)cy * G + cx] |= 1ull << i;
+    }
+    W.hg_x0 = x0; W.hg_y0 = y0; W.hg_inv_w = iw; W.hg_inv_h = ih;
+  } else {
+    W.hg_inv_w = W.hg_inv_h = 0.0;  // no habitat can contain anything: every cell empty (floor(nan/inf) guards below)
+    W.hg_x0 = W.hg_y0 = 0.0;
+  }
+  int rc = upload(h, h->d_hgmask, mask.data(), mask.size());
+  if (rc != AUVP_OK) return rc;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(h, AUVP_ERR_HIP, "habitat grid upload");
+  W.hg_mask = h->d_hgmask.as<unsigned long long>();
+  W.hg_n = G;
   return AUVP_OK;
 }
 
@@ -436,6 +484,7 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   W.sg_inv_dx = (sg_ncol > 1 && sgx1[sg_ncol - 1] > sgx1[0]) ? (double)(sg_ncol - 1) / (sgx1[sg_ncol - 1] - sgx1[0]) : 0.0;
   W.sg_inv_dy = (sg_nrow > 1 && sgy1[sg_nrow - 1] > sgy1[0]) ? (double)(sg_nrow - 1) / (sgy1[sg_nrow - 1] - sgy1[0]) : 0.0;
   W.prob_absmax = prob_absmax;
+  if ((rc = build_habitat_grid(h, habitats, H))) return rc;
   double bb[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
   for (int i = 0; i < V; i++) {
     bb[0] = std::min(bb[0], polygon[2 * i]); bb[1] = std::min(bb[1], polygon[2 * i + 1]);
@@ -481,6 +530,7 @@ int auvp_world_set_habitats(auvp_handle* h, const double* habitats, int32_t H) {
   h->W.n_habitats = H;
   h->W.hab = h->d_hab.as<double>();
   h->W.hab_t = h->d_habt.as<double>();
+  if ((rc = build_habitat_grid(h, habitats, H))) return rc;
   h->w_hab.assign(habitats, habitats + (size_t)H * 3);
   h->world_version++;
   return AUVP_OK;
@@ -542,7 +592,7 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   HIPCHK(h, h->d_bin_items.reserve((size_t)E * (P.K + 1) * B.bin_cap * sizeof(int32_t)));
   HIPCHK(h, h->d_bin_count.reserve((size_t)E * (P.K + 1) * sizeof(int32_t)));
   HIPCHK(h, h->d_summary.reserve((size_t)E * sizeof(RrtSummary)));
-  HIPCHK(h, h->d_node_c.reserve(cn * 4 * sizeof(int32_t)));
+  HIPCHK(h, h->d_node_c.reserve(cn * 8 * sizeof(int32_t)));
   B.node_f = h->d_nodes_f.as<double>();
   B.node_i = h->d_nodes_i.as<int32_t>();
   B.points = h->d_points.as<double>();

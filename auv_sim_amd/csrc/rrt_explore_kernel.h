@@ -242,12 +242,27 @@ __device__ __forceinline__ void cost_element(const WorldDev& W, const RrtTables&
   if (tb >= 0) {
     int c = cell_lookup(W, x, y, grid_lds);
     if (c >= 0) tv = w3 * W.prob[(size_t)tb * W.n_cells + c];
-    if (hab_near)
-    for (int h = W.n_habitats - 1; h >= 0; h--) {
-      // dist <= size  <=>  d2 <= T(size): same decision as RN(sqrt(d2)) <= size, no sqrt
-      const double2 hxy = *reinterpret_cast<const double2*>(&S.hab[h][0]);
-      const double ddx = hxy.x - x, ddy = hxy.y - y;
-      hab = (ddx * ddx + ddy * ddy <= S.hab[h][3]) ? h : hab;
+    if (hab_near) {
+      if (W.hg_n > 0) {
+        // habitat mask grid: the few habitats whose bounding square touches the point's cell, in list order
+        const double fx = auvp_floor((x - W.hg_x0) * W.hg_inv_w), fy = auvp_floor((y - W.hg_y0) * W.hg_inv_h);
+        unsigned long long m = 0ull;
+        if (fx >= 0.0 && fy >= 0.0 && fx < (double)W.hg_n && fy < (double)W.hg_n) m = W.hg_mask[(int)fy * W.hg_n + (int)fx];
+        while (m) {
+          const int h = __ffsll((long long)m) - 1;
+          m &= m - 1ull;
+          const double2 hxy = *reinterpret_cast<const double2*>(&S.hab[h][0]);
+          const double ddx = hxy.x - x, ddy = hxy.y - y;
+          if (ddx * ddx + ddy * ddy <= S.hab[h][3]) { hab = h; break; }
+        }
+      } else {
+        for (int h = W.n_habitats - 1; h >= 0; h--) {
+          // dist <= size  <=>  d2 <= T(size): same decision as RN(sqrt(d2)) <= size, no sqrt
+          const double2 hxy = *reinterpret_cast<const double2*>(&S.hab[h][0]);
+          const double ddx = hxy.x - x, ddy = hxy.y - y;
+          hab = (ddx * ddx + ddy * ddy <= S.hab[h][3]) ? h : hab;
+        }
+      }
     }
   }
 }
@@ -802,7 +817,9 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   const size_t capp = (size_t)B.cap_points;
   double* nodeF = B.node_f + (size_t)ep * capn * 8;
   const int4* nodeI = reinterpret_cast<const int4*>(B.node_i) + (size_t)ep * capn;
-  int4* nodeC = reinterpret_cast<int4*>(B.node_c) + (size_t)ep * capn;
+  // the running sums of a node as one 32-byte record {S, hits | elements, visited mask, -}: a child fetches its parent's
+  // sums with one read
+  double4* nodeC = reinterpret_cast<double4*>(B.node_c) + (size_t)ep * capn;
   const double* ptF = B.points + (size_t)ep * capp * 6;
   const int n_nodes = sum.n_nodes;
   const bool log_leaf = (P.flags & 2) != 0 && B.leaf_cost != nullptr;
@@ -885,8 +902,14 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     double pS = 0.0;
     int4 pc = make_int4(0, 0, 0, 0);
     const bool par_before = live && r.y >= 0 && r.y < n0;
-    if (par_before) { pS = nodeF[(size_t)r.y * 8 + 5]; pc = nodeC[r.y]; }
-    const unsigned long long pvis = ((unsigned long long)(uint32_t)pc.w << 32) | (unsigned long long)(uint32_t)pc.z;
+    unsigned long long pvis = 0ull;
+    if (par_before) {
+      const double4 pr = nodeC[r.y];
+      pS = pr.x;
+      const long long he = __double_as_longlong(pr.y);
+      pc.x = (int)(he & 0xffffffffll); pc.y = (int)(he >> 32);
+      pvis = (unsigned long long)__double_as_longlong(pr.z);
+    }
     wave_sync();
     c_par[lane] = r.y - n0;
     c_S[lane] = pS + own; c_hits[lane] = pc.x + own_hits; c_elems[lane] = pc.y + r.w + 1; c_vis[lane] = pvis | own_vis;
@@ -912,8 +935,8 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     const unsigned long long vis = c_vis[lane];
     if (live) {
       *reinterpret_cast<double2*>(nodeF + (size_t)m * 8 + 6) = make_double2(ntv, (double)nhab);
-      nodeF[(size_t)m * 8 + 5] = S;
-      nodeC[m] = make_int4(hits, elems, (int)(uint32_t)(vis & 0xffffffffull), (int)(uint32_t)(vis >> 32));
+      nodeC[m] = make_double4(S, __longlong_as_double(((long long)elems << 32) | (long long)(uint32_t)hits),
+                              __longlong_as_double((long long)vis), 0.0);
     }
     // later passes (parents) and the re-summation below read these back: make the stores visible to the wave first
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
