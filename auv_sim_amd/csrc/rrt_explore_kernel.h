@@ -157,8 +157,15 @@ __device__ __forceinline__ int cell_lookup(const WorldDev& W, double x, double y
   if (W.n_cells == 0) return -1;
   if (W.sg_enabled && grid_lds) {
     const double *x1 = grid_lds, *x0 = grid_lds + W.sg_ncol, *y1 = x0 + W.sg_ncol, *y0 = y1 + W.sg_nrow;
-    const int c = lower_bound_from(x1, W.sg_ncol, x, (int)auvp_floor((x - W.sg_x1_0) * W.sg_inv_dx) + 1);
-    const int r = lower_bound_from(y1, W.sg_nrow, x, (int)auvp_floor((x - W.sg_y1_0) * W.sg_inv_dy) + 1);
+    int c = (int)auvp_floor((x - W.sg_x1_0) * W.sg_inv_dx) + 1, r = (int)auvp_floor((x - W.sg_y1_0) * W.sg_inv_dy) + 1;
+    c = c < 0 ? 0 : (c > W.sg_ncol - 1 ? W.sg_ncol - 1 : c);
+    r = r < 0 ? 0 : (r > W.sg_nrow - 1 ? W.sg_nrow - 1 : r);
+    // the guess is the lower bound iff a1[g-1] < v <= a1[g]: checked without a loop; the stepping search only runs for
+    // the rare lane whose guess is off (rounding next to an edge, a point outside the grid)
+    const double xc1 = x1[c], xcm = c > 0 ? x1[c - 1] : -__builtin_inf();
+    const double yr1 = y1[r], yrm = r > 0 ? y1[r - 1] : -__builtin_inf();
+    if (!(xcm < x && xc1 >= x)) c = lower_bound_from(x1, W.sg_ncol, x, c);
+    if (!(yrm < x && yr1 >= x)) r = lower_bound_from(y1, W.sg_nrow, x, r);
     if (c >= W.sg_ncol || r >= W.sg_nrow) return -1;
     return (x0[c] <= x && y0[r] <= y) ? r * W.sg_ncol + c : -1;
   }
@@ -225,9 +232,15 @@ __device__ __forceinline__ void cost_element(const WorldDev& W, const RrtTables&
     if (bin_hi > bin_lo) {
       int i = (int)auvp_floor((t - W.bins_t1_0) * W.bins_inv_len) + 1;
       i = i < bin_lo ? bin_lo : (i > bin_hi - 1 ? bin_hi - 1 : i);
-      while (i > bin_lo && S.bins[i - 1][1] >= t) i--;
-      while (i < bin_hi && S.bins[i][1] < t) i++;
-      if (i < bin_hi && S.bins[i][0] <= t) tb = i;
+      const double2 bi = *reinterpret_cast<const double2*>(&S.bins[i][0]);
+      const double pm = i > bin_lo ? S.bins[i - 1][1] : -__builtin_inf();
+      if (pm < t && bi.y >= t) {  // the guess is the lower bound (the usual case: no loop)
+        if (bi.x <= t) tb = i;
+      } else {
+        while (i > bin_lo && S.bins[i - 1][1] >= t) i--;
+        while (i < bin_hi && S.bins[i][1] < t) i++;
+        if (i < bin_hi && S.bins[i][0] <= t) tb = i;
+      }
     }
   } else {
     // first matching bin in table order, scanned backwards without early exits (the last overwrite is the first
