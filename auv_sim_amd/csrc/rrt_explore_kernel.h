@@ -803,6 +803,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   __shared__ double w_S[RRT_LEAF_WAVES][64];
   __shared__ int32_t w_hits[RRT_LEAF_WAVES][64], w_elems[RRT_LEAF_WAVES][64], w_par[RRT_LEAF_WAVES][64], w_off[RRT_LEAF_WAVES][64];
   __shared__ unsigned long long w_vis[RRT_LEAF_WAVES][64];
+  __shared__ uint8_t w_owner[RRT_LEAF_WAVES][2048];  // owner lane of every point of the pass in flight
   extern __shared__ __align__(16) unsigned char leaf_dyn[];
   const RrtTables St = rrt_tables_view(tables, W.n_habitats, W.n_poly);
   const int wave = uni((int)(threadIdx.x >> 6));
@@ -822,6 +823,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   double* c_S = w_S[wave];
   int32_t *c_hits = w_hits[wave], *c_elems = w_elems[wave], *c_par = w_par[wave], *c_off = w_off[wave];
   unsigned long long* c_vis = w_vis[wave];
+  uint8_t* c_owner = w_owner[wave];
   const double (*s_bins)[2] = St.bins;
   RrtSummary& sum = B.summary[ep];
   const int status_in = sum.status;
@@ -869,6 +871,11 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     c_S[lane] = 0.0; c_hits[lane] = 0; c_vis[lane] = 0ull;
     const int p_first = __builtin_amdgcn_readlane(r.z, 0);
     const int p_end = __builtin_amdgcn_readlane(r.z, nlive - 1) + __builtin_amdgcn_readlane(r.w, nlive - 1);
+    // every node marks its own points: owner[point - p_first] = its lane (a pass holds at most 2048 points here; the
+    // binary search below serves longer runs)
+    const bool own_tab = (p_end - p_first) <= 2048;
+    if (own_tab && live)
+      for (int k = 0; k < r.w; k++) c_owner[r.z - p_first + k] = (uint8_t)lane;
     wave_sync();
     for (int p0 = p_first; p0 < p_end; p0 += 128) {  // two points per lane and pass: their record reads overlap
       const int pa = p0 + lane, pb = p0 + 64 + lane;
@@ -881,13 +888,18 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
       int haba = -1, habb = -1;
       if (va) cost_element(W, St, 0, W.n_bins, P.w[2], xya.x, xya.y, ta, tva, haba, true, grid_lds);
       if (vb) cost_element(W, St, 0, W.n_bins, P.w[2], xyb.x, xyb.y, tb_, tvb, habb, true, grid_lds);
-      // owner = last node of the pass whose pt_off is <= the point index (nodes without points share their
-      // successor's offset and are skipped by "last")
+      // owner = the node whose run holds the point: from the table, or -- for a pass with more than 2048 points -- the last
+      // node whose pt_off is <= the point index (nodes without points share their successor's offset and are skipped)
       int oa = 0, ob = 0;
+      if (own_tab) {
+        oa = va ? (int)c_owner[pa - p_first] : 0;
+        ob = vb ? (int)c_owner[pb - p_first] : 0;
+      } else {
 #pragma unroll
-      for (int st = 32; st >= 1; st >>= 1) {
-        if (oa + st < 64 && c_off[oa + st] <= pa) oa += st;
-        if (ob + st < 64 && c_off[ob + st] <= pb) ob += st;
+        for (int st = 32; st >= 1; st >>= 1) {
+          if (oa + st < 64 && c_off[oa + st] <= pa) oa += st;
+          if (ob + st < 64 && c_off[ob + st] <= pb) ob += st;
+        }
       }
       if (va) {
         if (tva != 0.0) atomicAdd(&c_S[oa], tva);
