@@ -110,8 +110,8 @@ __device__ __forceinline__ double rows_random_at(const RowRng& r, uint32_t j) {
 }
 __device__ __forceinline__ void rows_advance(RowRng& r, bool on, uint32_t nwords) {
   if (on) {
-    uint32_t p = r.pslot + nwords;
-    while (p >= 624u) p -= 624u;
+    uint32_t p = r.pslot + nwords;  // nwords < 624: one wrap at most
+    p = p >= 624u ? p - 624u : p;
     r.pslot = p;
     r.avail -= nwords;
     r.drawn += nwords;
