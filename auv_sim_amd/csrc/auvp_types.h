@@ -101,6 +101,8 @@ struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h
 
 // Per-episode tree storage, episode-major.  Nodes are records (one 16-B + one 64-B access per
 // node: they are read one at a time by the whole wave); path points are 48-B records, a node's run contiguous.
+#define AUVP_BIN_HEAD 128
+
 struct RrtBuffers {
   int32_t cap_nodes, cap_points, bin_cap, cap_leaves;
   // [E][cap_nodes][8]  x, y, theta, traj_t, length, S, tv, hab   (64 B per node); S/tv/hab: see below
@@ -118,7 +120,13 @@ struct RrtBuffers {
   // (exact).  The leaf pass ranks the qualifying leaves with these and re-sums in the reference's order only where the
   // bound cannot decide.
   int32_t* node_c;   // [E][cap_nodes] 32-byte records {S f64, hits i32 | elements i32, visited mask u64, -}
-  int32_t* bin_items;                       // [E][K+1][bin_cap]
+  // time-bin member lists, per episode (bin_stride int32 words): the first AUVP_BIN_HEAD members of every bin
+  // direct-mapped [K+1][AUVP_BIN_HEAD]; members beyond that in 64-entry chunks handed out on demand from [bin_over][64],
+  // found through the chunk directory [bin_slots][K+1] (slot s of bin b = members AUVP_BIN_HEAD + 64 s .. of b).  Every
+  // node is in exactly one bin, so bin_over = ceil(cap_nodes / 64) + K + 1 chunks always suffice.
+  int32_t* bin_items;
+  int32_t bin_over, bin_slots;
+  long long bin_stride;
   int32_t* bin_count;                       // [E][K+1] (copied out of LDS at the end)
   uint32_t* mt;                             // [E][624] generator state in
   const int32_t* mt_index;                  // [E] position inside the state (624 = fresh seed)

@@ -584,12 +584,18 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   if (cp > 2.0e9) return fail(h, AUVP_ERR_ARG, "point capacity too large");
   B.cap_points = (int32_t)cp;
   B.bin_cap = P.K > 0 ? B.cap_nodes : 1;
+  // chunked member lists: AUVP_BIN_HEAD direct-mapped members per bin, the rest in 64-entry chunks (auvp_types.h)
+  const bool chunks = B.bin_cap > AUVP_BIN_HEAD;
+  B.bin_over = chunks ? (B.cap_nodes + 63) / 64 + P.K + 1 : 0;
+  B.bin_slots = chunks ? (B.bin_cap - AUVP_BIN_HEAD + 63) / 64 : 0;
+  B.bin_stride = (long long)(P.K + 1) * AUVP_BIN_HEAD + (long long)B.bin_over * 64 + (long long)B.bin_slots * (P.K + 1);
+  if (B.bin_stride >= (1ll << 31)) return fail(h, AUVP_ERR_ARG, "time-bin lists too large (K=%d, max_iter=%d)", P.K, p->max_iter);
   B.cap_leaves = (flags & AUVP_FLAG_LEAF_LOG) ? B.cap_nodes : 1;
   const size_t cn = (size_t)E * B.cap_nodes, cpnt = (size_t)E * B.cap_points;
   HIPCHK(h, h->d_nodes_f.reserve(cn * 8 * sizeof(double)));
   HIPCHK(h, h->d_nodes_i.reserve(cn * 4 * sizeof(int32_t)));
   HIPCHK(h, h->d_points.reserve(cpnt * 6 * sizeof(double)));
-  HIPCHK(h, h->d_bin_items.reserve((size_t)E * (P.K + 1) * B.bin_cap * sizeof(int32_t)));
+  HIPCHK(h, h->d_bin_items.reserve((size_t)E * (size_t)B.bin_stride * sizeof(int32_t)));
   HIPCHK(h, h->d_bin_count.reserve((size_t)E * (P.K + 1) * sizeof(int32_t)));
   HIPCHK(h, h->d_summary.reserve((size_t)E * sizeof(RrtSummary)));
   HIPCHK(h, h->d_node_c.reserve(cn * 8 * sizeof(int32_t)));

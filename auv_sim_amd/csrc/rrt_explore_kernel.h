@@ -210,6 +210,49 @@ __device__ __forceinline__ int cell_lookup(const WorldDev& W, double x, double y
   return -1;
 }
 
+// ---- time-bin member lists (RrtBuffers::bin_items): direct-mapped head + on-demand 64-entry chunks --------------------
+// (every index below fits 32 bits: the host refuses a bin_stride of 2^31 words or more)
+struct BinLists {
+  int32_t* direct;  // [K+1][AUVP_BIN_HEAD]
+  int32_t* over;    // [n_over][64]
+  int32_t* dir;     // [n_slots][K+1]
+  int n_over, k1;
+};
+
+__device__ __forceinline__ BinLists bin_lists(const RrtBuffers& B, size_t episode, int K) {
+  BinLists L;
+  L.n_over = B.bin_over; L.k1 = K + 1;
+  L.direct = B.bin_items + episode * (size_t)B.bin_stride;
+  L.over = L.direct + (size_t)L.k1 * AUVP_BIN_HEAD;
+  L.dir = L.over + (size_t)L.n_over * 64;
+  return L;
+}
+
+// member k of bin b
+__device__ __forceinline__ int bin_member(const BinLists& L, int b, int k) {
+  if (k < AUVP_BIN_HEAD) return L.direct[b * AUVP_BIN_HEAD + k];
+  const int kk = k - AUVP_BIN_HEAD;
+  const int chunk = L.dir[(kk >> 6) * L.k1 + b];
+  return L.over[chunk * 64 + (kk & 63)];
+}
+
+// where member c of bin b goes (nullptr: out of chunks).  The values are uniform over the episode's lanes, every lane
+// keeps its copy of next_chunk; only `writer` touches memory.
+__device__ __forceinline__ int32_t* bin_slot_for_append(const BinLists& L, int b, int c, int& next_chunk, bool writer) {
+  if (c < AUVP_BIN_HEAD) return L.direct + (b * AUVP_BIN_HEAD + c);
+  const int kk = c - AUVP_BIN_HEAD;
+  int32_t* d = L.dir + ((kk >> 6) * L.k1 + b);
+  int chunk;
+  if ((kk & 63) == 0) {
+    if (next_chunk >= L.n_over) return nullptr;
+    chunk = next_chunk++;
+    if (writer) *d = chunk;
+  } else {
+    chunk = *d;
+  }
+  return L.over + (chunk * 64 + (kk & 63));
+}
+
 struct CostAcc {
   double c2;                   // running shark term, summed in path order
   unsigned long long visited;  // habitat bit set
@@ -376,7 +419,8 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   double* nodeF = B.node_f + (size_t)ep * capn * 8;                       // [capn][8] x,y,theta,t,length
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;    // plan_iter,parent,pt_off,pt_cnt
   double* ptF = B.points + (size_t)ep * capp * 6;                         // [capp][3] x,y,t then [capp][3] theta,v,length
-  int32_t* bin_items = B.bin_items + (size_t)ep * (P.K + 1) * bcap;
+  const BinLists bins = bin_lists(B, (size_t)ep, P.K);
+  int next_chunk = 0;
   const double* init = B.init + (size_t)ep * 6;
   const int K = P.K;
   const bool log_it = DIAG && (P.flags & 1) != 0;
@@ -400,7 +444,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   if (lane == 0) {
     nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
     nodeI[0] = make_int4(0, -1, 0, 0);
-    if (MODE == 0) { bin_items[(size_t)(K >= 1 ? 1 : 0) * bcap] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
+    if (MODE == 0) { bins.direct[(K >= 1 ? 1 : 0) * AUVP_BIN_HEAD] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
   }
   wave_sync();
   int n_nodes = 1, n_points = 0, status = 0;
@@ -448,7 +492,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       }
       if (uni(status)) break;  // (uni: the compiler cannot see that status is wave-uniform)
       const int ri = uni((int)py_uniform(0.0, (double)cnt, readlane_f64(u_me, f + 1)));
-      par = uni(bin_items[(size_t)rb * bcap + ri]);
+      par = uni(bin_member(bins, rb, ri));
       base = uni(f + 2);
     } else if (MODE == 1) {
       double u = rng_next_random(rng);
@@ -732,7 +776,9 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
         int bi = uni((int)fi);
         int c = over ? 0 : uni(bin_count[bi]);  // an overflowing regular key is reset first (:149-151)
         if (c >= bcap) { status = -2; break; }
-        if (lane == 0) { bin_items[(size_t)bi * bcap + c] = me; bin_count[bi] = c + 1; }
+        int32_t* slot = bin_slot_for_append(bins, bi, c, next_chunk, lane == 0);
+        if (!slot) { status = -2; break; }
+        if (lane == 0) { *slot = me; bin_count[bi] = c + 1; }
       }
       wave_sync();
     }

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   double* nodeF = B.node_f + (size_t)eps * capn * 8;
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)eps * capn;
   double* ptF = B.points + (size_t)eps * capp * 6;
-  int32_t* bin_items = B.bin_items + (size_t)eps * (K + 1) * bcap;
+  const BinLists bins = bin_lists(B, (size_t)eps, K);
+  int next_chunk = 0;
   const double* init = B.init + (size_t)eps * 6;
 
   RowRng rng;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   if (live && rl == 0) {
     nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
     nodeI[0] = make_int4(0, -1, 0, 0);
-    bin_items[(size_t)(K >= 1 ? 1 : 0) * bcap] = 0;
+    bins.direct[(K >= 1 ? 1 : 0) * AUVP_BIN_HEAD] = 0;
     bin_count[K >= 1 ? 1 : 0] = 1;
   }
   wave_sync();
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       const double u1 = row_read_f64(u, rowbase + fo + 1), u2 = row_read_f64(u, rowbase + fo + 2);
       if (live) {
         const int ri = (int)py_uniform(0.0, (double)cnt, u1);
-        par = bin_items[(size_t)rb * bcap + ri];
+        par = bin_member(bins, rb, ri);
         n_total = (int)auvp_floor(py_uniform(0.0, Q.freq, u2) / 1);
         base = fo + 3;
       }
@@ -447,8 +448,9 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       if (!over || fi <= (double)K) {
         const int bi = (int)fi;
         const int c = over ? 0 : (int)bin_count[bi];  // an overflowing regular key is reset first (:149-151)
-        if (c >= bcap || c >= 65535) { status = -2; live = false; iters_run = it; stored = false; }
-        else if (rl == 0) { bin_items[(size_t)bi * bcap + c] = me; bin_count[bi] = (uint16_t)(c + 1); }
+        int32_t* slot = (c >= bcap || c >= 65535) ? nullptr : bin_slot_for_append(bins, bi, c, next_chunk, rl == 0);
+        if (!slot) { status = -2; live = false; iters_run = it; stored = false; }
+        else if (rl == 0) { *slot = me; bin_count[bi] = (uint16_t)(c + 1); }
       }
       if (stored) {
         if (rl == 0) {

@@ -33,6 +33,12 @@ CASES = {
     "freq1": dict(world=dict(seed=55, n_obstacles=16), E=5, n_iter=300, kw=dict(freq=1)),
     "short_horizon_bin_reset": dict(world=dict(seed=3, n_obstacles=64, n_bins=4), E=7, n_iter=800,
                                     kw=dict(max_traj_time=120.0, bin_interval=7.5, weights=(-0.37, -2.25, -1.7))),
+    # three bins of ~800 members each: the member lists run past their direct-mapped head into the 64-entry chunks
+    "few_bins_chunked_lists": dict(world=dict(seed=59, n_obstacles=32), E=6, n_iter=2500,
+                                   kw=dict(max_traj_time=60.0, bin_interval=20.0)),
+    # 50 / 20: the last regular key (60) is past max_traj_time and is reset to one member at every insertion
+    "few_bins_last_key_reset": dict(world=dict(seed=60, n_obstacles=32), E=5, n_iter=1500,
+                                    kw=dict(max_traj_time=50.0, bin_interval=20.0)),
     "one_episode": dict(world=dict(seed=56, n_obstacles=64), E=1, n_iter=1200, kw={}),
     "no_habitats_no_grid": dict(world=dict(seed=57, n_obstacles=30, n_habitats=0), E=5, n_iter=500, kw={}, strip_grid=True),
     "point_capacity_overflow": dict(world=dict(seed=58, n_obstacles=8), E=6, n_iter=400, kw=dict(points_per_iter=3.0)),
