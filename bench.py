@@ -713,7 +713,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--episodes", type=int, default=12288,
                     help="episodes per GPU per step (12288 = one 48-episode workgroup of the four-episodes-per-wavefront kernel "
-                         "on each of the 256 CUs; 10.9 MB of tree storage each = 134 GB)")
+                         "on each of the 256 CUs; 8.8 MB of tree storage each = 108 GB)")
     ap.add_argument("--iters", type=int, default=10000, help="expansion budget per episode (10k-node budget)")
     ap.add_argument("--obstacles", type=int, default=256)
     ap.add_argument("--grid", type=int, default=200, help="grid is grid x grid cells of 10 m")
@@ -784,11 +784,11 @@ def main():
 
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     E = args.episodes
-    # the trees need ~10.9 MB of HBM per 10 000-iteration episode (nodes 1.1 MB, path points 9.6 MB, time-bin lists 0.2 MB): if
+    # the trees need ~8.8 MB of HBM per 10 000-iteration episode (nodes 1.1 MB, path points 7.5 MB, time-bin lists 0.2 MB): if
     # this GPU has less free than the requested batch needs, run the largest multiple of 6144 episodes that fits -- every
     # rank the same
     free_b, _total_b = torch.cuda.mem_get_info(dev)
-    fit = int(0.92 * free_b / (11.2e6 * max(args.iters, 1) / 10000.0))
+    fit = int(0.92 * free_b / (9.2e6 * max(args.iters, 1) / 10000.0))
     if fit < E:
         fit = max(6144 * (fit // 6144), min(E, 1024))
     e_fit = ranks._t([min(E, fit)], torch.int64)

@@ -65,7 +65,7 @@ typedef struct {
   double w[3];                         /* weights */
   int32_t mode;                        /* AUVP_MODE_*: (plan_time, traj_time_stamp) flags of :121-139 */
   int32_t max_iter;                    /* iteration budget = virtual clock of SURVEY 8(c) */
-  double points_per_iter;              /* device path-point capacity per iteration; 0 -> 0.6*freq+2 */
+  double points_per_iter;              /* device path-point capacity per iteration; 0 -> freq/2 + 8 sigma of the sum */
 } auvp_rrt_params;
 
 typedef struct {
