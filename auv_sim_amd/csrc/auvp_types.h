@@ -120,6 +120,9 @@ struct RrtBuffers {
   // (exact).  The leaf pass ranks the qualifying leaves with these and re-sums in the reference's order only where the
   // bound cannot decide.
   int32_t* node_c;   // [E][cap_nodes] 32-byte records {S f64, hits i32 | elements i32, visited mask u64, -}
+  // [E][cap_nodes] 1 = the node is a qualifying leaf (traj_t >= max_traj_time - 30, :158), written by the expansion
+  // kernels: the leaf pass only visits those and their ancestors
+  uint8_t* node_q;
   // time-bin member lists, per episode (bin_stride int32 words): the first AUVP_BIN_HEAD members of every bin
   // direct-mapped [K+1][AUVP_BIN_HEAD]; members beyond that in 64-entry chunks handed out on demand from [bin_over][64],
   // found through the chunk directory [bin_slots][K+1] (slot s of bin b = members AUVP_BIN_HEAD + 64 s .. of b).  Every

@@ -59,7 +59,7 @@ struct auvp_handle {
   RrtBuffers B{};
   int max_pts = 0;
   DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_phase, d_node_c, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+      d_leaf_c, d_leaf_i, d_phase, d_node_c, d_node_q, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
@@ -607,10 +607,12 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   HIPCHK(h, h->d_bin_count.reserve((size_t)E * (P.K + 1) * sizeof(int32_t)));
   HIPCHK(h, h->d_summary.reserve((size_t)E * sizeof(RrtSummary)));
   HIPCHK(h, h->d_node_c.reserve(cn * 8 * sizeof(int32_t)));
+  HIPCHK(h, h->d_node_q.reserve(cn));
   B.node_f = h->d_nodes_f.as<double>();
   B.node_i = h->d_nodes_i.as<int32_t>();
   B.points = h->d_points.as<double>();
   B.node_c = h->d_node_c.as<int32_t>();
+  B.node_q = h->d_node_q.as<uint8_t>();
   B.bin_items = h->d_bin_items.as<int32_t>();
   B.bin_count = h->d_bin_count.as<int32_t>();
   B.summary = h->d_summary.as<RrtSummary>();
@@ -731,13 +733,15 @@ int auvp_rrt_run(auvp_handle* h) {
   HIPCHK(h, le);
   // the trees are complete: rank the qualifying leaves (same stream, inside the timed region)
   HIPCHK(h, hipEventRecord(h->ev_mid, h->stream));
-  RrtParamsDev PL = P;
-  if (const char* e = getenv("AUVP_LEAF_STOP")) PL.flags |= (atoi(e) == 1 ? 256 : (atoi(e) == 2 ? 512 : 0));  // timing experiments
   {
+    // dynamic LDS of the leaf pass: the separable-grid edge tables + one "ancestor of a qualifying leaf" bit per node
+    // and episode (trees too large for that are swept whole)
     const int gl = rrt_leaf_grid_lds_bytes(h->W.sg_enabled, h->W.sg_ncol, h->W.sg_nrow);
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, gl));
-    hipLaunchKernelGGL(rrt_leaf_kernel, dim3((E + RRT_LEAF_WAVES - 1) / RRT_LEAF_WAVES), dim3(RRT_LEAF_WAVES * 64), gl, h->stream,
-                       h->W, PL, B, (int)E);
+    const int bm_words = rrt_leaf_mark_words(B.cap_nodes);
+    const int dyn = gl + RRT_LEAF_WAVES * bm_words * 4;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    hipLaunchKernelGGL(rrt_leaf_kernel, dim3((E + RRT_LEAF_WAVES - 1) / RRT_LEAF_WAVES), dim3(RRT_LEAF_WAVES * 64), dyn, h->stream,
+                       h->W, P, B, (int)E, bm_words);
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));

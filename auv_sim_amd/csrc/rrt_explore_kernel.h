@@ -418,6 +418,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
   double* nodeF = B.node_f + (size_t)ep * capn * 8;                       // [capn][8] x,y,theta,t,length
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;    // plan_iter,parent,pt_off,pt_cnt
+  uint8_t* nodeQ = B.node_q + (size_t)ep * capn;
   double* ptF = B.points + (size_t)ep * capp * 6;                         // [capp][3] x,y,t then [capp][3] theta,v,length
   const BinLists bins = bin_lists(B, (size_t)ep, P.K);
   int next_chunk = 0;
@@ -444,6 +445,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   if (lane == 0) {
     nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
     nodeI[0] = make_int4(0, -1, 0, 0);
+    nodeQ[0] = 0;  // the start state is never a leaf candidate
     if (MODE == 0) { bins.direct[(K >= 1 ? 1 : 0) * AUVP_BIN_HEAD] = 0; bin_count[K >= 1 ? 1 : 0] = 1; }
   }
   wave_sync();
@@ -788,6 +790,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
       *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
       nf[4] = clen;
+      nodeQ[me] = ctt >= Q.max_traj_time - 30 ? 1 : 0;  // a qualifying leaf (:158); ranked by rrt_leaf_kernel
     }
     n_nodes++;
     n_points += cnt;
@@ -842,12 +845,19 @@ __host__ __device__ inline int rrt_leaf_grid_lds_bytes(int sg_enabled, int ncol,
   const long long b = 16LL * ((long long)ncol + nrow);
   return (sg_enabled && b <= 48 * 1024) ? (int)b : 0;  // bigger grids are looked up in the global copy
 }
+// 32-bit words of the per-episode "ancestor of a qualifying leaf" bit set in LDS (0: the tree is too large, sweep it whole)
+__host__ __device__ inline int rrt_leaf_mark_words(int cap_nodes) {
+  const int w = (cap_nodes + 31) / 32;
+  return w <= 4096 ? w : 0;
+}
 
-__global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
+__global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes,
+                                                                      int mark_words) {
   __shared__ __align__(16) unsigned char tables[RRT_WORLD_BYTES + RRT_MAX_HAB * 32 + RRT_MAX_POLY * 16 + RRT_MAX_BINS * 16];
   __shared__ double w_term[RRT_LEAF_WAVES][64];
   __shared__ double w_S[RRT_LEAF_WAVES][64];
   __shared__ int32_t w_hits[RRT_LEAF_WAVES][64], w_elems[RRT_LEAF_WAVES][64], w_par[RRT_LEAF_WAVES][64], w_off[RRT_LEAF_WAVES][64];
+  __shared__ int32_t w_cpos[RRT_LEAF_WAVES][64], w_ids[RRT_LEAF_WAVES][128];
   __shared__ unsigned long long w_vis[RRT_LEAF_WAVES][64];
   __shared__ uint8_t w_owner[RRT_LEAF_WAVES][2048];  // owner lane of every point of the pass in flight
   extern __shared__ __align__(16) unsigned char leaf_dyn[];
@@ -865,9 +875,13 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   __syncthreads();
   const int ep = (int)blockIdx.x * RRT_LEAF_WAVES + wave;
   if (ep >= n_episodes) return;  // no workgroup barrier after this point
+  uint32_t* mark = mark_words > 0 ? reinterpret_cast<uint32_t*>(leaf_dyn + rrt_leaf_grid_lds_bytes(W.sg_enabled, W.sg_ncol, W.sg_nrow)) +
+                                        (size_t)wave * mark_words
+                                  : nullptr;
   double* term = w_term[wave];
   double* c_S = w_S[wave];
   int32_t *c_hits = w_hits[wave], *c_elems = w_elems[wave], *c_par = w_par[wave], *c_off = w_off[wave];
+  int32_t *c_cpos = w_cpos[wave], *c_ids = w_ids[wave];
   unsigned long long* c_vis = w_vis[wave];
   uint8_t* c_owner = w_owner[wave];
   const double (*s_bins)[2] = St.bins;
@@ -906,47 +920,96 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
   long long leaf_elems = 0;
   double best_tot = __builtin_inf(), best_c0 = 0.0, best_c1 = 0.0, best_c2 = 0.0, best_len = 0.0;
   double min_hi = __builtin_inf();  // smallest upper bound among the qualifying leaves seen so far
-  for (int n0 = 0; n0 < n_nodes; n0 += 64) {
-    const int m = n0 + lane;
-    const bool live = m < n_nodes;
-    const int nlive = (n_nodes - n0) < 64 ? (n_nodes - n0) : 64;
+  // ---------------------------------------------------------------- 0. which nodes matter
+  // Only the qualifying leaves and their ancestors enter any cost (about a quarter of the bench's trees).  Backwards over
+  // the nodes, 64 at a time: a node is marked if it qualifies (node_q, from the expansion) or a child marked it; it
+  // marks its parent.  Children come after their parents, so one backward sweep settles every mark; parents inside the
+  // block in flight are reached by repeating until no lane changes.
+  const uint8_t* nodeQ = B.node_q + (size_t)ep * capn;
+  if (mark) {
+    for (int i = lane; i < mark_words; i += 64) mark[i] = 0u;
+    wave_sync();
+    for (int n0 = ((n_nodes - 1) >> 6) << 6; n0 >= 0; n0 -= 64) {
+      const int m = n0 + lane;
+      const bool live = m < n_nodes;
+      const int par = live ? nodeI[m].y : -1;
+      bool need = live && m >= 1 && nodeQ[m] != 0;
+      bool pushed = false;
+      for (;;) {
+        need = need || (live && ((mark[m >> 5] >> (m & 31)) & 1u));
+        const bool push = need && !pushed && par >= 0;
+        if (push) { atomicOr(&mark[par >> 5], 1u << (par & 31)); pushed = true; }
+        // another round only if some lane just marked a parent inside this block
+        if (!__any(push && par >= n0)) break;
+        wave_sync();
+      }
+      if (need) atomicOr(&mark[m >> 5], 1u << (m & 31));
+      wave_sync();
+    }
+  }
+
+  // ---------------------------------------------------------------- the sweep: marked nodes in creation order, 64 per pass
+  int qn = 0, scan = 0;  // ids waiting in c_ids[0..qn); next block of nodes to look at
+  for (;;) {
+    while (qn < 64 && scan < n_nodes) {
+      const int mm = scan + lane;
+      const bool f = mm < n_nodes && (!mark || ((mark[mm >> 5] >> (mm & 31)) & 1u));
+      const unsigned long long fm = __ballot(f);
+      if (f) c_ids[qn + __popcll(fm & ((1ull << lane) - 1ull))] = mm;
+      qn += __popcll(fm);
+      scan += 64;
+    }
+    wave_sync();
+    if (qn == 0) break;
+    const int nlive = qn < 64 ? qn : 64;
+    const bool live = lane < nlive;
+    const int m = live ? c_ids[lane] : 0x7fffffff;
+    const int first_id = __builtin_amdgcn_readfirstlane(m);
     int4 r = make_int4(0, -1, 0, 0);
     if (live) r = nodeI[m];
     // ---------------------------------------------------------------- 1. terms of the pass's path elements
-    c_off[lane] = live ? r.z : 0x7fffffff;
+    // the runs of the pass's nodes, packed: point slot j of the pass = point c_off[o] + (j - c_cpos[o]) of its owner o
+    int incl = live ? r.w : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    const int cpos = incl - (live ? r.w : 0);
+    const int n_slots = __builtin_amdgcn_readlane(incl, 63);
+    c_cpos[lane] = live ? cpos : 0x7fffffff;
+    c_off[lane] = r.z;
     c_S[lane] = 0.0; c_hits[lane] = 0; c_vis[lane] = 0ull;
-    const int p_first = __builtin_amdgcn_readlane(r.z, 0);
-    const int p_end = __builtin_amdgcn_readlane(r.z, nlive - 1) + __builtin_amdgcn_readlane(r.w, nlive - 1);
-    // every node marks its own points: owner[point - p_first] = its lane (a pass holds at most 2048 points here; the
-    // binary search below serves longer runs)
-    const bool own_tab = (p_end - p_first) <= 2048;
+    // every node marks its own slots: owner[slot] = its lane (2048 slots here; the search below serves longer passes)
+    const bool own_tab = n_slots <= 2048;
     if (own_tab && live)
-      for (int k = 0; k < r.w; k++) c_owner[r.z - p_first + k] = (uint8_t)lane;
+      for (int k = 0; k < r.w; k++) c_owner[cpos + k] = (uint8_t)lane;
     wave_sync();
-    for (int p0 = p_first; p0 < p_end; p0 += 128) {  // two points per lane and pass: their record reads overlap
-      const int pa = p0 + lane, pb = p0 + 64 + lane;
-      const bool va = pa < p_end, vb = pb < p_end;
-      const double* ra = ptF + (size_t)(va ? pa : p_first) * 3;
-      const double* rb = ptF + (size_t)(vb ? pb : p_first) * 3;
+    for (int j0 = 0; j0 < n_slots; j0 += 128) {  // two points per lane and round: their record reads overlap
+      const int ja = j0 + lane, jb = j0 + 64 + lane;
+      const bool va = ja < n_slots, vb = jb < n_slots;
+      // owner = the node whose run holds the slot: from the table, or the last node whose first slot is <= the slot
+      // (nodes without points share their successor's first slot and are skipped)
+      int oa = 0, ob = 0;
+      if (own_tab) {
+        oa = va ? (int)c_owner[ja] : 0;
+        ob = vb ? (int)c_owner[jb] : 0;
+      } else {
+#pragma unroll
+        for (int st = 32; st >= 1; st >>= 1) {
+          if (oa + st < 64 && c_cpos[oa + st] <= ja) oa += st;
+          if (ob + st < 64 && c_cpos[ob + st] <= jb) ob += st;
+        }
+      }
+      const int pa = va ? c_off[oa] + (ja - c_cpos[oa]) : 0, pb = vb ? c_off[ob] + (jb - c_cpos[ob]) : 0;
+      const double* ra = ptF + (size_t)pa * 3;
+      const double* rb = ptF + (size_t)pb * 3;
       const double2 xya = *reinterpret_cast<const double2*>(ra), xyb = *reinterpret_cast<const double2*>(rb);
       const double ta = ra[2], tb_ = rb[2];
       double tva = 0.0, tvb = 0.0;
       int haba = -1, habb = -1;
       if (va) cost_element(W, St, 0, W.n_bins, P.w[2], xya.x, xya.y, ta, tva, haba, true, grid_lds);
       if (vb) cost_element(W, St, 0, W.n_bins, P.w[2], xyb.x, xyb.y, tb_, tvb, habb, true, grid_lds);
-      // owner = the node whose run holds the point: from the table, or -- for a pass with more than 2048 points -- the last
-      // node whose pt_off is <= the point index (nodes without points share their successor's offset and are skipped)
-      int oa = 0, ob = 0;
-      if (own_tab) {
-        oa = va ? (int)c_owner[pa - p_first] : 0;
-        ob = vb ? (int)c_owner[pb - p_first] : 0;
-      } else {
-#pragma unroll
-        for (int st = 32; st >= 1; st >>= 1) {
-          if (oa + st < 64 && c_off[oa + st] <= pa) oa += st;
-          if (ob + st < 64 && c_off[ob + st] <= pb) ob += st;
-        }
-      }
       if (va) {
         if (tva != 0.0) atomicAdd(&c_S[oa], tva);
         if (haba >= 0) { atomicAdd(&c_hits[oa], 1); atomicOr(&c_vis[oa], 1ull << haba); }
@@ -972,7 +1035,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     // the parent's sums: from memory when it belongs to an earlier pass, else from the lanes of this one
     double pS = 0.0;
     int4 pc = make_int4(0, 0, 0, 0);
-    const bool par_before = live && r.y >= 0 && r.y < n0;
+    const bool par_before = live && r.y >= 0 && r.y < first_id;
     unsigned long long pvis = 0ull;
     if (par_before) {
       const double4 pr = nodeC[r.y];
@@ -982,12 +1045,19 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
       pvis = (unsigned long long)__double_as_longlong(pr.z);
     }
     wave_sync();
-    c_par[lane] = r.y - n0;
+    // a parent inside this pass: its lane = its position among the pass's ids (ascending; a marked node's parent is marked)
+    int plane = 0;
+    if (live && r.y >= first_id) {
+#pragma unroll
+      for (int st = 32; st >= 1; st >>= 1)
+        if (plane + st < nlive && c_ids[plane + st] <= r.y) plane += st;
+    }
+    c_par[lane] = plane;
     c_S[lane] = pS + own; c_hits[lane] = pc.x + own_hits; c_elems[lane] = pc.y + r.w + 1; c_vis[lane] = pvis | own_vis;
     wave_sync();
     // parents inside this pass: a lane is ready once its parent's entry is final (a parent always has the smaller
     // index, so the lowest pending lane is ready in every round); all ready lanes add their parent's sums at once
-    unsigned long long pending = __ballot(live && r.y >= n0);
+    unsigned long long pending = __ballot(live && r.y >= first_id);
     while (pending) {
       const int p = c_par[lane];
       const bool mine = (pending >> lane) & 1ull;
@@ -1031,7 +1101,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
       }
     }
     const unsigned long long qm = __ballot(q);
-    if (qm == 0ull) continue;
+    if (qm != 0ull) {
     n_leaves += __popcll(qm);
     // exclusive prefix minimum of hi over the lanes (creation order), seeded with the earlier passes
     double pm = hi;
@@ -1055,7 +1125,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     while (cm) {
       const int l = __ffsll((long long)cm) - 1;
       cm &= cm - 1ull;
-      const int leaf = n0 + l;
+      const int leaf = __builtin_amdgcn_readlane(m, l);
       const double lo_l = readlane_f64(lo, l);
       if (!log_leaf && !(lo_l < best_tot)) continue;  // an exact total found meanwhile already rules it out
       // ---- the reference's ordered sum: [leaf] + reversed(leaf.path[1:]) + [parent] + reversed(parent.path[1:]) ... root
@@ -1109,6 +1179,14 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
         best_c0 = c0; best_c1 = c1; best_c2 = c2; best_len = llen;
       }
     }
+    }  // qm
+    // the ids of the pass are done: the rest of the queue moves to its front
+    wave_sync();
+    const int carry = (lane + 64 < qn) ? c_ids[lane + 64] : 0;
+    wave_sync();
+    if (lane + 64 < qn) c_ids[lane] = carry;
+    qn = qn > 64 ? qn - 64 : 0;
+    wave_sync();
   }
   if (lane == 0) {
     sum.n_leaves = n_leaves;

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
   double* nodeF = B.node_f + (size_t)eps * capn * 8;
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)eps * capn;
+  uint8_t* nodeQ = B.node_q + (size_t)eps * capn;
   double* ptF = B.points + (size_t)eps * capp * 6;
   const BinLists bins = bin_lists(B, (size_t)eps, K);
   int next_chunk = 0;
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   if (live && rl == 0) {
     nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
     nodeI[0] = make_int4(0, -1, 0, 0);
+    nodeQ[0] = 0;  // the start state is never a leaf candidate
     bins.direct[(K >= 1 ? 1 : 0) * AUVP_BIN_HEAD] = 0;
     bin_count[K >= 1 ? 1 : 0] = 1;
   }
@@ -459,6 +461,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
           *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
           nf[4] = clen;
           nodeI[me] = make_int4(it, par, n_points, cnt);
+          nodeQ[me] = ctt >= Q.max_traj_time - 30 ? 1 : 0;  // a qualifying leaf (:158); ranked by rrt_leaf_kernel
         }
         n_nodes++;
         n_points += cnt;
