@@ -344,7 +344,10 @@ def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0):
            "accept_rate": float((summ["n_nodes"] - 1).sum()) / iters,
            "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters,
            "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
-           "roofline": roofline(rrt_bytes(summ), k_ms, "rrt_explore_kernel", bytes_per_expansion=rrt_bytes(summ) / iters)}
+           "roofline": roofline(rrt_bytes(summ), k_ms,
+                                ("rrt_rows_kernel" if ctx.last_launch_parts()[2] == 4 else "rrt_explore_kernel") + " + rrt_leaf_kernel",
+                                bytes_per_expansion=rrt_bytes(summ) / iters,
+                                kernels_ms=dict(zip(("expansion", "leaf"), ctx.last_launch_parts()[:2])))}
     if cpu_seconds > 0:
         from oracle import orc
         w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
@@ -398,7 +401,7 @@ def astar_inputs(n_inst):
     return w, starts, limits
 
 
-def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1):
+def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1, variants=True):
     """BASELINE config 3: 1024 independent astar_fixLenSOG searches (starts on the 10 m lattice, pathLenLimit in
     {100,200,300}) over one shared world: 64 obstacles, 10 habitats, rectangle polygon, 20x20-cell shark grid x 10 bins.
     A step = the search launch (including whatever reset the batch needs) + the path/smoothing launch + the result
@@ -438,7 +441,7 @@ def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1):
            "roofline": roofline(abytes, k_ms, "astar_kernel", traffic, traffic_source=tsrc,
                                 bytes_per_cell=abytes / max(float(summ["n_children"].sum()), 1.0),
                                 note="one wave per instance at 1 wave/SIMD: a latency measurement, not a bandwidth one")}
-    if ranks.world == 1:
+    if ranks.world == 1 and variants:
         # SURVEY 8(d) config 3 also asks for the same batch through astar_fixLen (no grid) and astar.astar (start -> goal
         # pairs on the 50x50 lattice of config 1): reported side by side, labelled
         def variant(name, st, **k):
@@ -461,6 +464,14 @@ def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1):
         rng = np.random.default_rng(3)
         lst = np.column_stack([10.0 * rng.integers(0, 20, n_inst), 10.0 * rng.integers(0, 20, n_inst)])
         out["variants"]["astar"] = variant("astar", lst, goals=np.tile([490.0, 490.0], (n_inst, 1)), box=lw["box"], cap_nodes=60000)
+        # config 3 gives every SIMD ONE wavefront (1 024 instances on 1 024 SIMDs): a latency measurement.  The same search
+        # with the instance list repeated until every CU holds its three workgroups (12 waves) shows what the kernel does
+        # when the chip is full -- labelled, not the config-3 number.
+        n_sat = 12 * n_inst
+        ctx.set_world(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
+        out["variants"]["astar_fixLenSOG_x12_instances"] = variant(
+            "astar_fixLenSOG", np.tile(starts, (12, 1)), limits=np.tile(limits, 12), weights=wts, velocity=1.0, cap_nodes=20000)
+        out["variants"]["astar_fixLenSOG_x12_instances"]["instances"] = n_sat
     if with_cpu:
         from oracle import orc_astar as oa
         t0, c, n = time.perf_counter(), 0, 0
@@ -720,6 +731,7 @@ def main():
     ap.add_argument("--mode", default="timebin", choices=["timebin", "nn", "plantime"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="config 3 only, without the other A* variants (counter passes)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -761,7 +773,7 @@ def main():
         "single_episode": lambda: bench_single_episode(ctx, world, args),
         "rrt_64_obstacles": lambda: bench_rrt_o64(ctx, args),
         "rrt_dense": lambda: bench_rrt_dense(ctx, args, with_cpu),
-        "astar": lambda: bench_astar(ctx, ranks, with_cpu),
+        "astar": lambda: bench_astar(ctx, ranks, with_cpu, variants=not args.no_variants),
         "planner_rrt": lambda: bench_planner(ctx, ranks, with_cpu),
         "config5": lambda: bench_config5(ctx, ranks),
         "shark_grid": lambda: bench_shark_grid(local_rank, with_cpu),

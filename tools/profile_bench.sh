@@ -23,7 +23,7 @@ done
 for SIDE in astar planner_rrt; do
   for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
     N=$(echo $P | cut -d" " -f1)
-    rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_${SIDE}_$N -o pmc -- python3 $R/bench.py --no-cpu --only $SIDE > $OUT/pmc_${SIDE}_$N.json 2> $OUT/pmc_${SIDE}_$N.err
+    rocprofv3 --pmc $P --output-format csv -d $OUT/pmc_${SIDE}_$N -o pmc -- python3 $R/bench.py --no-cpu --no-variants --only $SIDE > $OUT/pmc_${SIDE}_$N.json 2> $OUT/pmc_${SIDE}_$N.err
   done
 done
 find $OUT -name "*.csv" | head -40
