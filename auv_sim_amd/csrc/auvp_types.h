@@ -61,6 +61,8 @@ struct WorldDev {
   double sg_x1_0, sg_y1_0, bins_t1_0;  // first entries of X1, Y1 and of the bins' upper ends (origins of the guesses)
   double sg_inv_dx, sg_inv_dy;  // 1 / mean spacing of X1 / Y1: first guess of the lower bound only
   double prob_absmax;  // max |prob|: bounds a path element's cost term (approximate-cost error bound of the leaf pass)
+  // 1: no two entries of prob differ in sign, so the shark terms of a path all have one sign and sum|term| = |sum|
+  int32_t prob_one_sign, _pad_prob;
   // habitat mask grid: hg_n x hg_n cells over the bounding box of the habitats' discs; cell -> bit set of the habitats
   // whose (slightly inflated) bounding square touches it.  A point outside the box, or in a cell with an empty set, lies
   // in no habitat; otherwise only the set's members are tested, in list order (first match, cost.py:187-191).

@@ -373,9 +373,11 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
     }
   }
   double prob_absmax = 0.0;
+  bool any_pos = false, any_neg = false, any_nan = false;
   for (size_t i = 0; i < (size_t)T * C; i++) {
     const double a = std::fabs(prob[i]);
     if (a > prob_absmax || a != a) prob_absmax = a;  // a nan poisons the bound: every leaf is then re-summed exactly
+    any_pos |= prob[i] > 0; any_neg |= prob[i] < 0; any_nan |= prob[i] != prob[i];
   }
   int rc;
   if ((rc = upload(h, h->d_rgfirst, rfirst.data(), rfirst.size()))) return rc;
@@ -484,6 +486,8 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
   W.sg_inv_dx = (sg_ncol > 1 && sgx1[sg_ncol - 1] > sgx1[0]) ? (double)(sg_ncol - 1) / (sgx1[sg_ncol - 1] - sgx1[0]) : 0.0;
   W.sg_inv_dy = (sg_nrow > 1 && sgy1[sg_nrow - 1] > sgy1[0]) ? (double)(sg_nrow - 1) / (sgy1[sg_nrow - 1] - sgy1[0]) : 0.0;
   W.prob_absmax = prob_absmax;
+  W.prob_one_sign = (!any_nan && !(any_pos && any_neg)) ? 1 : 0;
+  W._pad_prob = 0;
   if ((rc = build_habitat_grid(h, habitats, H))) return rc;
   double bb[4] = {INFINITY, INFINITY, -INFINITY, -INFINITY};
   for (int i = 0; i < V; i++) {

@@ -831,7 +831,9 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
 //      node_f[5] = S = sum of the shark terms of that path, in tree order
 // 3. ranking.  cost[0] and cost[1] of a leaf follow from the exact integers as the reference computes them.  S differs
 //    from the reference's leaf->root ordered sum only by rounding: both add the same L terms, so each is within
-//    gamma_L * sum|term| of the exact sum (gamma_L = L u / (1 - L u), u = 2^-53), and |term| <= |w3| * max|prob|.
+//    gamma_L * sum|term| of the exact sum (gamma_L = L u / (1 - L u), u = 2^-53), and |term| <= |w3| * max|prob|;
+//    when the probabilities all have one sign (they do: they are probabilities) sum|term| is also |exact sum|, i.e.
+//    about |S| -- a path without any shark term has S = 0 exactly, like the reference's sum, and ties stay ties.
 //    That gives every leaf an interval [lo, hi] containing the reference's total.  A leaf whose lo is not below the
 //    smallest hi of the leaves before it cannot be a strict minimum; the others (a handful per episode: the record
 //    setters and exact ties) are re-summed in the reference's order -- leaf, its points last to first, its parent,
@@ -1093,9 +1095,14 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
         // |S - ordered sum| <= 2 gamma_L L term_max; one more rounding each for the division and the two additions
         const double L = (double)elems;
         const double gam = 2.0 * (L + 2.0) * 0x1p-53;
-        double e2 = 2.0 * gam * L * term_max;
+        // sum|term| <= L term_max; with probabilities of one sign also sum|term| = |exact sum| <= |S| / (1 - gamma_L).
+        // The second bound is what separates exact ties: a path without any shark term has S = 0 = the reference's sum.
+        double mag = L * term_max;
+        if (W.prob_one_sign) { const double ms = auvp_fabs(S) * (1.0 + 0x1p-20); mag = ms < mag ? ms : mag; }
+        double e2 = 2.0 * gam * mag;
         if (ctt > 0) e2 = e2 / ctt;
-        const double err = 1.25 * e2 + 0x1p-50 * (auvp_fabs(c0) + auvp_fabs(c1) + auvp_fabs(c2) + e2);
+        // e2 == 0: the sums are the same number, and so is everything computed from them
+        const double err = e2 == 0.0 ? 0.0 : 1.25 * e2 + 0x1p-50 * (auvp_fabs(c0) + auvp_fabs(c1) + auvp_fabs(c2) + e2);
         lo = tot - err; hi = tot + err;
         if (!(err == err) || !(tot == tot)) { lo = -__builtin_inf(); hi = __builtin_inf(); }  // nan: decide exactly
       }

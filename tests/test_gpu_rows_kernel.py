@@ -39,6 +39,13 @@ CASES = {
     # 50 / 20: the last regular key (60) is past max_traj_time and is reset to one member at every insertion
     "few_bins_last_key_reset": dict(world=dict(seed=60, n_obstacles=32), E=5, n_iter=1500,
                                     kw=dict(max_traj_time=50.0, bin_interval=20.0)),
+    # a box in positive coordinates: the reference's `x <= maxy` cell test (cost.py:180) leaves most points without a cell,
+    # many qualifying leaves cost exactly the same, and the FIRST of them must win (strict `<`, rrt_dubins.py:167)
+    "positive_box_exact_cost_ties": dict(world=dict(seed=61, n_obstacles=40, box=(0.0, 0.0, 280.0, 180.0), cell=14.0, n_habitats=0),
+                                         E=6, n_iter=1500, kw=dict(max_traj_time=150.0, weights=(3.0, 3.0, 4.0))),
+    "positive_box_ties_with_habitats": dict(world=dict(seed=62, n_obstacles=40, box=(0.0, 0.0, 280.0, 180.0), cell=14.0,
+                                                       hab_radius=(20.0, 40.0)),
+                                            E=6, n_iter=1500, kw=dict(max_traj_time=150.0)),
     "one_episode": dict(world=dict(seed=56, n_obstacles=64), E=1, n_iter=1200, kw={}),
     "no_habitats_no_grid": dict(world=dict(seed=57, n_obstacles=30, n_habitats=0), E=5, n_iter=500, kw={}, strip_grid=True),
     "point_capacity_overflow": dict(world=dict(seed=58, n_obstacles=8), E=6, n_iter=400, kw=dict(points_per_iter=3.0)),
