@@ -406,6 +406,8 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
           }
           // the parent's end, path[0], is a path point too
           if (rl == 15) { const double ddx = px0 - ox, ddy = py0 - oy; hit |= has && (ddx * ddx + ddy * ddy <= ot); }
+          // a row that has its collision is done with this slot's candidates (they are counted above already)
+          if (row_ballot(hit, rowbase) != 0u) cm = 0u;
         }
       }
     }
