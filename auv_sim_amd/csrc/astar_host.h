@@ -14,7 +14,7 @@ struct AstarState {
   auvp::AstarWorldDev W{};
   auvp::AstarParamsDev P{};
   auvp::AstarBuffers B{};
-  DevBuf ox, oy, ot, hab, poly, bins, rcells, prob, topn;
+  DevBuf ox, oy, ot, hab, poly, bins, rcells, prob, topn, gridtab;
   DevBuf start, goal, limit, nodes, node_i, cellinfo, hab_left, exp_log, summary, off, path, cost, npath, smooth;
   long long visited_set_for = -1;  // entry count of a bitmap uploaded by auvp_astar_set_visited, -1 none
   // epoch of the words in `cellinfo` (astar_kernel.h): bumped per batch instead of clearing 1.4 MB per instance;
@@ -70,7 +70,42 @@ int astar_build_world(auvp_handle* h, AstarState& S) {
     sx += (x0 + x1) * cr;
     sy += (y0 + y1) * cr;
   }
+  // product grid?  row-major list of ncol x nrow cells whose x interval depends on the column only and whose y interval
+  // on the row only, edges ascending, neighbouring intervals touching at most, no degenerate widths (astar_kernel.h)
+  int g_ncol = 0, g_nrow = 0;
+  std::vector<double> gtab;
+  if (C > 0 && !getenv("AUVP_ASTAR_NO_GRID")) {
+    int nc = 1;
+    while (nc < C && rc[4 * (size_t)nc + 1] == rc[1] && rc[4 * (size_t)nc + 3] == rc[3]) nc++;
+    if (C % nc == 0) {
+      const int nr = C / nc;
+      gtab.resize(2 * (size_t)nc + 2 * (size_t)nr);
+      double* X0 = gtab.data(); double* X1 = X0 + nc; double* Y0 = X1 + nc; double* Y1 = Y0 + nr;
+      for (int c = 0; c < nc; c++) { X0[c] = rc[4 * (size_t)c]; X1[c] = rc[4 * (size_t)c + 2]; }
+      for (int r = 0; r < nr; r++) { Y0[r] = rc[4 * (size_t)r * nc + 1]; Y1[r] = rc[4 * (size_t)r * nc + 3]; }
+      bool ok = true;
+      for (int r = 0; r < nr && ok; r++)
+        for (int c = 0; c < nc && ok; c++) {
+          const double* q = &rc[4 * ((size_t)r * nc + c)];
+          ok = q[0] == X0[c] && q[2] == X1[c] && q[1] == Y0[r] && q[3] == Y1[r];
+        }
+      auto axis_ok = [](const double* lo, const double* hi, int n) {
+        double scale = 1.0;
+        for (int i = 0; i < n; i++) {
+          if (!std::isfinite(lo[i]) || !std::isfinite(hi[i])) return false;
+          scale = std::fmax(scale, std::fmax(std::fabs(lo[i]), std::fabs(hi[i])));
+        }
+        for (int i = 0; i < n; i++) {
+          if (!(hi[i] - lo[i] >= 1e-6 * scale)) return false;
+          if (i + 1 < n && !(lo[i + 1] >= hi[i])) return false;
+        }
+        return true;
+      };
+      if (ok && axis_ok(X0, X1, nc) && axis_ok(Y0, Y1, nr)) { g_ncol = nc; g_nrow = nr; }
+    }
+  }
   int rc_;
+  if (g_ncol > 0 && (rc_ = upload(h, S.gridtab, gtab.data(), gtab.size()))) return rc_;
   if ((rc_ = upload(h, S.ox, ox.data(), ox.size()))) return rc_;
   if ((rc_ = upload(h, S.oy, oy.data(), oy.size()))) return rc_;
   if ((rc_ = upload(h, S.ot, ot.data(), ot.size()))) return rc_;
@@ -86,6 +121,15 @@ int astar_build_world(auvp_handle* h, AstarState& S) {
   W.ox = S.ox.as<double>(); W.oy = S.oy.as<double>(); W.ot = S.ot.as<double>(); W.hab = S.hab.as<double>();
   W.poly = S.poly.as<double>(); W.bins = S.bins.as<double>(); W.rcells = S.rcells.as<double>();
   W.prob = S.prob.as<double>(); W.topn = S.topn.as<double>();
+  W.g_ncol = g_ncol; W.g_nrow = g_nrow;
+  W.gx0 = W.gx1 = W.gy0 = W.gy1 = nullptr;
+  W.g_inv_dx = W.g_inv_dy = 0.0;
+  if (g_ncol > 0) {
+    W.gx0 = S.gridtab.as<double>(); W.gx1 = W.gx0 + g_ncol; W.gy0 = W.gx1 + g_ncol; W.gy1 = W.gy0 + g_nrow;
+    const double* X1 = gtab.data() + g_ncol; const double* Y1 = gtab.data() + 2 * (size_t)g_ncol + g_nrow;
+    W.g_inv_dx = g_ncol > 1 ? (g_ncol - 1) / (X1[g_ncol - 1] - X1[0]) : 0.0;
+    W.g_inv_dy = g_nrow > 1 ? (g_nrow - 1) / (Y1[g_nrow - 1] - Y1[0]) : 0.0;
+  }
   W.cx = V > 0 ? sx / (3.0 * a2) : 0.0;
   W.cy = V > 0 ? sy / (3.0 * a2) : 0.0;
   S.world_version = h->world_version;

@@ -38,7 +38,25 @@ struct AstarWorldDev {
   const double* prob;    // [T,C]
   const double* topn;    // [T,C+1] prefix sums of the descending-sorted probabilities (get_top_n_prob)
   double cx, cy;         // polygon centroid (fan apex)
+  // Product grid (detected on the host): cell r * g_ncol + c = [gx0[c], gx1[c]] x [gy0[r], gy1[r]] in list order, both
+  // edge tables ascending, intervals touching at most.  get_cell_prob's first match (:485-514) is then the first
+  // matching row and the first matching column among the three around the lower bounds of the point -- no sweep over
+  // the cells.  g_ncol = 0: any other cell list (the sweep).
+  int32_t g_ncol, g_nrow;
+  const double* gx0;
+  const double* gx1;
+  const double* gy0;
+  const double* gy1;
+  double g_inv_dx, g_inv_dy;  // 1 / mean spacing of gx1 / gy1 (first guess of the lower bound only)
 };
+
+// first index i in [0, n] with a[i] >= v (n if none), searched from the guess g; `a` ascending
+__device__ __forceinline__ int astar_lower_bound(const double* __restrict__ a, int n, double v, int g) {
+  g = g < 0 ? 0 : (g > n ? n : g);
+  while (g > 0 && a[g - 1] >= v) g--;
+  while (g < n && a[g] < v) g++;
+  return g;
+}
 
 struct AstarParamsDev {
   int32_t variant, cap_nodes, cap_exp, flags;
@@ -288,9 +306,32 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       }
     }
     if (V == 3) {
+      // get_cell_prob's cell of every neighbour on a product grid: lane (k8, s8) tests column gc-1+s8 (s8 < 3) or row
+      // gr-4+s8 (3 <= s8 < 6) of neighbour k8 with the reference's own float predicate; the first matching row and the
+      // first matching column give the first matching cell of the list (every (row, column) pair of matches is a match)
+      int key_grid = -1;
+      const bool grid = W.g_ncol > 0;
+      if (grid) {
+        const int gc = astar_lower_bound(W.gx1, W.g_ncol, qx, (int)((qx - W.gx1[0]) * W.g_inv_dx));
+        const int gr = astar_lower_bound(W.gy1, W.g_nrow, qy, (int)((qy - W.gy1[0]) * W.g_inv_dy));
+        const bool colj = s8 < 3;
+        const int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
+        const int n = colj ? W.g_ncol : W.g_nrow;
+        bool m = false;
+        if (s8 < 6 && idx >= 0 && idx < n) {
+          const double a = colj ? W.gx0[idx] : W.gy0[idx], b = colj ? W.gx1[idx] : W.gy1[idx], v = colj ? qx : qy;
+          const double dd = auvp_fabs(a - b);
+          m = auvp_fabs(v - a) <= dd && auvp_fabs(v - b) <= dd;
+        }
+        const unsigned long long bm = __ballot(m);
+        const unsigned g8 = (unsigned)((bm >> (k8 * 8)) & 0xffull);
+        const unsigned cm3 = g8 & 7u, rm3 = (g8 >> 3) & 7u;
+        if (cm3 && rm3) key_grid = (gr - 1 + (__ffs((int)rm3) - 1)) * W.g_ncol + (gc - 1 + (__ffs((int)cm3) - 1));
+      }
       // children of the SOG variant, lane k < 8 = neighbour k: nothing one child does is seen by another (eight
       // distinct lattice points, so eight distinct visited cells), so their table reads go out together
       const int kk = lane & 7;
+      const int key_g = __shfl(key_grid, kk * 8, 64);
       const bool mine = lane < 8 && ((childmask >> kk) & 1);
       const double px = __shfl(qx, kk * 8, 64), py = __shfl(qy, kk * 8, 64);
       const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
@@ -311,8 +352,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       // identifies the point (points are 10 apart), so the key is kept next to it
       const uint32_t ciw = mine ? cellinfo[vi] : 0u;
       const bool ci_live = (ciw & 0xff000000u) == ep_tag;  // written by this batch (or uploaded for it)
-      int key = mine ? (ci_live ? (int)(ciw & 0xffffu) - 1 : -1) : 0;
-      const bool need_key = mine && key < 0;
+      int key = mine ? (grid ? key_g : (ci_live ? (int)(ciw & 0xffffu) - 1 : -1)) : 0;
+      const bool need_key = !grid && mine && key < 0;
     // get_cell_prob (:485-514) for ALL children of this expansion in one sweep over the cells: a lane loads one
     // cell per pass and tests it against the (uniform) positions of the eight neighbours, so the sweep costs
     // ceil(C / 64) independent loads instead of that many dependent round trips per child

@@ -76,6 +76,40 @@ def test_astar_batch_vs_oracle(ctx, orc, variant):
     assert n_found > 0
 
 
+@pytest.mark.parametrize("cells_as", ["product_grid", "shuffled_list", "column_major", "grid_14m_float_starts"])
+def test_sog_cell_lookup_paths(ctx, orc, cells_as):
+    """get_cell_prob (astar_fixLenSOG.py:485-514) = the first cell of the LIST whose closed box holds the point; lattice
+    points sit on cell edges, so up to four cells match and the list order decides.  A row-major product grid takes the
+    arithmetic lookup (three rows and columns around the lower bounds), any other list the sweep over the cells."""
+    from auv_sim_amd import synth
+    from oracle import orc_astar as oa
+    rng = np.random.default_rng(23)
+    cell = 14.0 if cells_as == "grid_14m_float_starts" else 10.0
+    w = synth.make_world(seed=13, n_obstacles=32, obst_radius=(2.0, 6.0), n_habitats=8, hab_radius=(10.0, 25.0), cell=cell)
+    cells, prob = np.array(w["cells"], dtype=np.float64), np.array(w["prob"], dtype=np.float64)
+    if cells_as == "shuffled_list":
+        perm = rng.permutation(len(cells))
+        cells, prob = cells[perm], prob[:, perm]
+    elif cells_as == "column_major":
+        n = int(round(np.sqrt(len(cells))))
+        perm = np.arange(len(cells)).reshape(-1, n).T.ravel() if len(cells) == n * n else rng.permutation(len(cells))
+        cells, prob = cells[perm], prob[:, perm]
+    if cells_as == "grid_14m_float_starts":
+        starts = np.array([(-290.0 + 10.0 * rng.integers(0, 6) + 0.37, -90.0 + 10.0 * rng.integers(0, 6) + 0.21) for _ in range(12)])
+    else:
+        starts = np.array([(-290.0 + 10.0 * rng.integers(0, 6), -90.0 + 10.0 * rng.integers(0, 6)) for _ in range(12)])
+    kw = dict(obstacles=w["obstacles"], polygon=w["polygon"], habitats=w["habitats"], limit=150.0, weights=(0, 10, 10, 100),
+              bins=w["bins"], cells=cells, prob=prob, velocity=1.0)
+    res = _gpu_run(ctx, "astar_fixLenSOG", starts, kw, exp_log=True)
+    for e, r in enumerate(res):
+        o = oa.run("astar_fixLenSOG", starts[e], kind="portable", cap_nodes=20000, **kw)
+        assert r["status"] == o["status"], (e, r["status"], o["status"])
+        assert r["found"] == o["found"] and r["n_nodes"] == o["n_nodes"] and r["n_children"] == o["n_children"]
+        assert np.array_equal(r["expansions"], o["expansions"])
+        assert np.array_equal(r["path"], o["path"]) and np.array_equal(r["cost_list"], o["cost_list"])
+        assert np.array_equal(r["node_path"], o["node_path"]) and np.array_equal(r["smooth_path"], o["smooth_path"])
+
+
 def test_astar_capacity_is_an_error_not_a_truncation(ctx):
     from auv_sim_amd import synth
     w = synth.make_lattice_world(seed=0, n_obstacles=10)
