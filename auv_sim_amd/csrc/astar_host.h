@@ -124,9 +124,11 @@ int astar_build_world(auvp_handle* h, AstarState& S) {
   W.g_ncol = g_ncol; W.g_nrow = g_nrow;
   W.gx0 = W.gx1 = W.gy0 = W.gy1 = nullptr;
   W.g_inv_dx = W.g_inv_dy = 0.0;
+  W.g_x1_0 = W.g_y1_0 = 0.0;
   if (g_ncol > 0) {
     W.gx0 = S.gridtab.as<double>(); W.gx1 = W.gx0 + g_ncol; W.gy0 = W.gx1 + g_ncol; W.gy1 = W.gy0 + g_nrow;
     const double* X1 = gtab.data() + g_ncol; const double* Y1 = gtab.data() + 2 * (size_t)g_ncol + g_nrow;
+    W.g_x1_0 = X1[0]; W.g_y1_0 = Y1[0];
     W.g_inv_dx = g_ncol > 1 ? (g_ncol - 1) / (X1[g_ncol - 1] - X1[0]) : 0.0;
     W.g_inv_dy = g_nrow > 1 ? (g_nrow - 1) / (Y1[g_nrow - 1] - Y1[0]) : 0.0;
   }

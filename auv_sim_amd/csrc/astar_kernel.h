@@ -48,10 +48,12 @@ struct AstarWorldDev {
   const double* gy0;
   const double* gy1;
   double g_inv_dx, g_inv_dy;  // 1 / mean spacing of gx1 / gy1 (first guess of the lower bound only)
+  double g_x1_0, g_y1_0;      // gx1[0], gy1[0]
 };
 
 // first index i in [0, n] with a[i] >= v (n if none), searched from the guess g; `a` ascending
-__device__ __forceinline__ int astar_lower_bound(const double* __restrict__ a, int n, double v, int g) {
+template <typename PtrT>
+__device__ __forceinline__ int astar_lower_bound(PtrT a, int n, double v, int g) {
   g = g < 0 ? 0 : (g > n ? n : g);
   while (g > 0 && a[g - 1] >= v) g--;
   while (g < n && a[g] < v) g++;
@@ -125,6 +127,7 @@ constexpr int ASTAR_WAVES = 4;
 constexpr int ASTAR_MAX_HAB = 64;
 constexpr int ASTAR_OPEN_CAP = 768;
 constexpr int ASTAR_MAX_BINS = 64;
+constexpr int ASTAR_LDS_OBST = 256, ASTAR_LDS_POLY = 64, ASTAR_LDS_GRID = 256;
 
 __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W, AstarParamsDev P, AstarBuffers B, int n_inst) {
   __shared__ int32_t s_hopen[ASTAR_WAVES][ASTAR_MAX_HAB];
@@ -134,13 +137,31 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   // HBM stay authoritative, so an instance that outgrows the list falls back to scanning them
   __shared__ double s_of[ASTAR_WAVES][ASTAR_OPEN_CAP];
   __shared__ int32_t s_oi[ASTAR_WAVES][ASTAR_OPEN_CAP];
-  __shared__ double s_bins[ASTAR_WAVES][ASTAR_MAX_BINS][2];
-  __shared__ double s_hab[ASTAR_WAVES][ASTAR_MAX_HAB][3];  // x, y, T(size) of every habitat
+  // the world is the same for the workgroup's four instances: one copy of its small tables
+  __shared__ double s_bins[ASTAR_MAX_BINS][2];
+  __shared__ double s_hab[ASTAR_MAX_HAB][3];  // x, y, T(size) of every habitat
+  __shared__ double s_obs[3][ASTAR_LDS_OBST];  // x, y, T(size) of the first ASTAR_LDS_OBST obstacles
+  __shared__ double s_poly[ASTAR_LDS_POLY][2];
+  __shared__ double s_grid[ASTAR_LDS_GRID];    // product-grid edge tables gx0 | gx1 | gy0 | gy1 (when they fit)
   __shared__ int32_t s_cov[ASTAR_WAVES][ASTAR_MAX_HAB];     // fixLen: does the child cover habitat h
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   const int ep = (int)blockIdx.x * ASTAR_WAVES + wave;
-  if (ep >= n_inst) return;
+  const int H = W.n_habitats, C = W.n_cells, T = W.n_bins;
+  const bool obs_lds = W.n_obstacles <= ASTAR_LDS_OBST, poly_lds = W.n_poly <= ASTAR_LDS_POLY;
+  const bool grid_lds = W.g_ncol > 0 && 2 * (W.g_ncol + W.g_nrow) <= ASTAR_LDS_GRID;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) {
+    s_hab[i][0] = W.hab[4 * (size_t)i]; s_hab[i][1] = W.hab[4 * (size_t)i + 1]; s_hab[i][2] = W.hab[4 * (size_t)i + 3];
+  }
+  for (int i = threadIdx.x; i < 2 * T && i < 2 * ASTAR_MAX_BINS; i += blockDim.x) (&s_bins[0][0])[i] = W.bins[i];
+  if (obs_lds)
+    for (int i = threadIdx.x; i < W.n_obstacles; i += blockDim.x) { s_obs[0][i] = W.ox[i]; s_obs[1][i] = W.oy[i]; s_obs[2][i] = W.ot[i]; }
+  if (poly_lds)
+    for (int i = threadIdx.x; i < 2 * W.n_poly; i += blockDim.x) (&s_poly[0][0])[i] = W.poly[i];
+  if (grid_lds)
+    for (int i = threadIdx.x; i < 2 * (W.g_ncol + W.g_nrow); i += blockDim.x) s_grid[i] = W.gx0[i];  // one contiguous upload
+  __syncthreads();
+  if (ep >= n_inst) return;  // no workgroup barrier after this point
   const int V = P.variant;
   const int cap = P.cap_nodes;
   double* nd = B.nodes + (size_t)ep * 7 * cap;
@@ -152,7 +173,6 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   const uint32_t ep_tag = P.epoch << 24;
   int32_t* hopen = s_hopen[wave];
   int32_t* hclosed = s_hclosed[wave];
-  const int H = W.n_habitats, C = W.n_cells, T = W.n_bins;
   const double sx = readfirst_f64(B.start[2 * (size_t)ep]), sy = readfirst_f64(B.start[2 * (size_t)ep + 1]);
   double gx = 0.0, gy = 0.0, limit = 0.0;
   if (V <= 1) { gx = readfirst_f64(B.goal[2 * (size_t)ep]); gy = readfirst_f64(B.goal[2 * (size_t)ep + 1]); }
@@ -160,11 +180,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   const double w2 = P.w[1], w3 = P.w[2], w4 = P.w[3];
   const bool logx = (P.flags & 1) != 0 && B.exp_log != nullptr;
 
-  for (int i = lane; i < H; i += 64) {
-    hopen[i] = i;
-    s_hab[wave][i][0] = W.hab[4 * (size_t)i]; s_hab[wave][i][1] = W.hab[4 * (size_t)i + 1]; s_hab[wave][i][2] = W.hab[4 * (size_t)i + 3];
-  }
-  for (int i = lane; i < 2 * T && i < 2 * ASTAR_MAX_BINS; i += 64) (&s_bins[wave][0][0])[i] = W.bins[i];
+  for (int i = lane; i < H; i += 64) hopen[i] = i;
   int n_hopen = H, n_hclosed = 0;
   if (lane == 0) {
     nx[0] = sx; ny[0] = sy; ng[0] = 0.0; nh[0] = 0.0; nf[0] = 0.0; ncost[0] = 0.0; nlen[0] = 0.0;
@@ -251,20 +267,27 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       inb = (qx >= P.box[0] && qx <= P.box[2]) && (qy >= P.box[1] && qy <= P.box[3]);
     } else {
       bool any_tri = false;
-      for (int i = s8; i < W.n_poly; i += 8) {
-        int j = (i != W.n_poly - 1) ? i + 1 : 0;
-        any_tri = any_tri | astar_in_triangle(qx, qy, W.poly[2 * i], W.poly[2 * i + 1], W.poly[2 * j], W.poly[2 * j + 1],
-                                              W.cx, W.cy);
-      }
+      auto fan = [&](const auto* pl) {
+        for (int i = s8; i < W.n_poly; i += 8) {
+          int j = (i != W.n_poly - 1) ? i + 1 : 0;
+          any_tri = any_tri | astar_in_triangle(qx, qy, pl[2 * i], pl[2 * i + 1], pl[2 * j], pl[2 * j + 1], W.cx, W.cy);
+        }
+      };
+      if (poly_lds) fan(&s_poly[0][0]);
+      else fan(W.poly);
       unsigned long long bm = __ballot(any_tri);
       inb = ((bm >> (k8 * 8)) & 0xffull) != 0;
     }
     bool hit = false;
     if (inb) {
-      for (int i = s8; i < W.n_obstacles; i += 8) {
-        double dx = qx - W.ox[i], dy = qy - W.oy[i];
-        hit = hit | (dx * dx + dy * dy <= W.ot[i]);
-      }
+      auto circles = [&](const auto* ox, const auto* oy, const auto* ot) {
+        for (int i = s8; i < W.n_obstacles; i += 8) {
+          double dx = qx - ox[i], dy = qy - oy[i];
+          hit = hit | (dx * dx + dy * dy <= ot[i]);
+        }
+      };
+      if (obs_lds) circles(s_obs[0], s_obs[1], s_obs[2]);
+      else circles(W.ox, W.oy, W.ot);
     }
     const unsigned long long hm = __ballot(hit);
     const unsigned long long im = __ballot(inb && s8 == 0);
@@ -286,8 +309,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         const double px = __shfl(qx, k * 8, 64), py = __shfl(qy, k * 8, 64);
         // which habitats cover this child: one lane per habitat; the list surgery below only reads the flags
         if (lane < H) {
-          const double ddx = px - s_hab[wave][lane][0], ddy = py - s_hab[wave][lane][1];
-          s_cov[wave][lane] = (ddx * ddx + ddy * ddy <= s_hab[wave][lane][2]) ? 1 : 0;
+          const double ddx = px - s_hab[lane][0], ddy = py - s_hab[lane][1];
+          s_cov[wave][lane] = (ddx * ddx + ddy * ddy <= s_hab[lane][2]) ? 1 : 0;
         }
         wave_sync();
         if (lane == 0) {
@@ -312,17 +335,22 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       int key_grid = -1;
       const bool grid = W.g_ncol > 0;
       if (grid) {
-        const int gc = astar_lower_bound(W.gx1, W.g_ncol, qx, (int)((qx - W.gx1[0]) * W.g_inv_dx));
-        const int gr = astar_lower_bound(W.gy1, W.g_nrow, qy, (int)((qy - W.gy1[0]) * W.g_inv_dy));
-        const bool colj = s8 < 3;
-        const int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
-        const int n = colj ? W.g_ncol : W.g_nrow;
+        int gc = 0, gr = 0;
         bool m = false;
-        if (s8 < 6 && idx >= 0 && idx < n) {
-          const double a = colj ? W.gx0[idx] : W.gy0[idx], b = colj ? W.gx1[idx] : W.gy1[idx], v = colj ? qx : qy;
-          const double dd = auvp_fabs(a - b);
-          m = auvp_fabs(v - a) <= dd && auvp_fabs(v - b) <= dd;
-        }
+        auto lookup = [&](const auto* gx0, const auto* gx1, const auto* gy0, const auto* gy1) {
+          gc = astar_lower_bound(gx1, W.g_ncol, qx, (int)((qx - W.g_x1_0) * W.g_inv_dx));
+          gr = astar_lower_bound(gy1, W.g_nrow, qy, (int)((qy - W.g_y1_0) * W.g_inv_dy));
+          const bool colj = s8 < 3;
+          const int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
+          const int n = colj ? W.g_ncol : W.g_nrow;
+          if (s8 < 6 && idx >= 0 && idx < n) {
+            const double a = colj ? gx0[idx] : gy0[idx], b = colj ? gx1[idx] : gy1[idx], v = colj ? qx : qy;
+            const double dd = auvp_fabs(a - b);
+            m = auvp_fabs(v - a) <= dd && auvp_fabs(v - b) <= dd;
+          }
+        };
+        if (grid_lds) lookup(s_grid, s_grid + W.g_ncol, s_grid + 2 * W.g_ncol, s_grid + 2 * W.g_ncol + W.g_nrow);
+        else lookup(W.gx0, W.gx1, W.gy0, W.gy1);
         const unsigned long long bm = __ballot(m);
         const unsigned g8 = (unsigned)((bm >> (k8 * 8)) & 0xffull);
         const unsigned cm3 = g8 & 7u, rm3 = (g8 >> 3) & 7u;
@@ -336,10 +364,10 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       const double px = __shfl(qx, kk * 8, 64), py = __shfl(qy, kk * 8, 64);
       const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
       const double dist_left = auvp_fabs(limit - len_);
-      const int ts_ = (int)(len_ / P.velocity);
+      const int ts_ = (int)(P.velocity == 1.0 ? len_ : len_ / P.velocity);  // x / 1.0 is x: no division on the chain
       int tb = -1;
       for (int t = 0; t < T; t++) {
-        if ((double)ts_ <= s_bins[wave][t][1] && (double)ts_ >= s_bins[wave][t][0]) { tb = t; break; }
+        if ((double)ts_ <= s_bins[t][1] && (double)ts_ >= s_bins[t][0]) { tb = t; break; }
       }
       const int ntop = (int)dist_left;
       int xi = (int)(px + 500), yi = (int)(py + 200);
@@ -428,7 +456,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         bool d2l = false, d3l = false;
         for (int i = lane; i < n_hopen + n_hclosed; i += 64) {
           const bool closed = i >= n_hopen;
-          const double* hb = s_hab[wave][closed ? hclosed[i - n_hopen] : hopen[i]];
+          const double* hb = s_hab[closed ? hclosed[i - n_hopen] : hopen[i]];
           double ddx = px - hb[0], ddy = py - hb[1];
           bool cov = ddx * ddx + ddy * ddy <= hb[2];
           d2l = d2l | cov;
