@@ -226,16 +226,29 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         }
       }
     }
-    // reduce: smaller f wins; on equal f the smaller index wins (list order)
+    // reduce: smaller f wins; on equal f the smaller index wins (list order).  The minimum f first (six min steps),
+    // then the lanes that hold it: almost always one
+    {
+      const bool have = bi != 0x7fffffff;
+      const double fmin = wave_min_f64(have ? bf : __builtin_inf());
+      const unsigned long long eq = __ballot(have && bf == fmin);
+      if (__popcll(eq) == 1) {
+        const int l = __ffsll((long long)eq) - 1;
+        bi = __builtin_amdgcn_readlane(bi, l);
+        bpos = __builtin_amdgcn_readlane(bpos, l);
+      } else {
+        if (eq != 0ull && !((eq >> lane) & 1ull)) bi = 0x7fffffff;  // (eq == 0: a nan among the f values -- the full comparison decides)
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      double of = __shfl_xor(bf, o, 64);
-      int oi = __shfl_xor(bi, o, 64);
-      int op = __shfl_xor(bpos, o, 64);
-      bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || of < bf || (of == bf && oi < bi));
-      bf = take ? of : bf;
-      bi = take ? oi : bi;
-      bpos = take ? op : bpos;
+        for (int o = 32; o >= 1; o >>= 1) {
+          double of = __shfl_xor(bf, o, 64);
+          int oi = __shfl_xor(bi, o, 64);
+          int op = __shfl_xor(bpos, o, 64);
+          bool take = (oi != 0x7fffffff) && (bi == 0x7fffffff || of < bf || (of == bf && oi < bi));
+          bf = take ? of : bf;
+          bi = take ? oi : bi;
+          bpos = take ? op : bpos;
+        }
+      }
     }
     const int cur = uni(bi);
     if (list_ok) {  // the last entry takes the place of the popped one (the order of the list does not matter)
@@ -262,6 +275,17 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     n_exp++;
     // ------------------------------------------------------------ neighbours: bounds, then collision
     const double qx = cxp + (double)offx, qy = cyp + (double)offy;
+    // SOG: the visited/cell-info word of every neighbour is requested now (lane k < 8 = neighbour k), so the read is
+    // under way while the bounds and collision tests run; only the children's words are used
+    uint32_t ciw_early = 0u;
+    double ex = 0.0, ey = 0.0;
+    if (V == 3) { ex = __shfl(qx, (lane & 7) * 8, 64); ey = __shfl(qy, (lane & 7) * 8, 64); }
+    if (V == 3 && lane < 8) {
+      int xi = (int)(ex + 500), yi = (int)(ey + 200);
+      if (xi < 0) xi += P.vx;
+      if (yi < 0) yi += P.vy;
+      if (xi >= 0 && xi < P.vx && yi >= 0 && yi < P.vy) ciw_early = cellinfo[(size_t)xi * P.vy + yi];
+    }
     bool inb;
     if (V == 0) {
       inb = (qx >= P.box[0] && qx <= P.box[2]) && (qy >= P.box[1] && qy <= P.box[3]);
@@ -281,9 +305,20 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     bool hit = false;
     if (inb) {
       auto circles = [&](const auto* ox, const auto* oy, const auto* ot) {
-        for (int i = s8; i < W.n_obstacles; i += 8) {
-          double dx = qx - ox[i], dy = qy - oy[i];
-          hit = hit | (dx * dx + dy * dy <= ot[i]);
+        // four obstacles per trip: their twelve reads are in flight together (the tests are independent)
+        for (int i = s8; i < W.n_obstacles; i += 32) {
+          double x[4], y[4], t[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int iu = i + 8 * u;
+            const int ic = iu < W.n_obstacles ? iu : i;
+            x[u] = ox[ic]; y[u] = oy[ic]; t[u] = ot[ic];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const double dx = qx - x[u], dy = qy - y[u];
+            hit = hit | (dx * dx + dy * dy <= t[u]);  // (a clamped index repeats obstacle i: same answer)
+          }
         }
       };
       if (obs_lds) circles(s_obs[0], s_obs[1], s_obs[2]);
@@ -361,7 +396,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       const int kk = lane & 7;
       const int key_g = __shfl(key_grid, kk * 8, 64);
       const bool mine = lane < 8 && ((childmask >> kk) & 1);
-      const double px = __shfl(qx, kk * 8, 64), py = __shfl(qy, kk * 8, 64);
+      const double px = ex, py = ey;
       const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
       const double dist_left = auvp_fabs(limit - len_);
       const int ts_ = (int)(P.velocity == 1.0 ? len_ : len_ / P.velocity);  // x / 1.0 is x: no division on the chain
@@ -378,7 +413,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       const size_t vi = (size_t)xi * P.vy + yi;
       // the cell of a lattice point is looked up once per search: within one instance the visited-bitmap index
       // identifies the point (points are 10 apart), so the key is kept next to it
-      const uint32_t ciw = mine ? cellinfo[vi] : 0u;
+      const uint32_t ciw = mine ? ciw_early : 0u;  // (same index: lane kk's neighbour is px, py)
       const bool ci_live = (ciw & 0xff000000u) == ep_tag;  // written by this batch (or uploaded for it)
       int key = mine ? (grid ? key_g : (ci_live ? (int)(ciw & 0xffffu) - 1 : -1)) : 0;
       const bool need_key = !grid && mine && key < 0;
