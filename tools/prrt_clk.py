@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic for an instrumented planner build (phase clocks in summary.arc[0..3])."""
+"""Diagnostic for an instrumented planner build (six phase-clock totals in summary.arc[0..5] of the episodes that did
+not finish): AUVPLAN_LIBRARY=<instrumented .so> python tools/prrt_clk.py"""
 import os, sys, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from auv_sim_amd import _lib, synth
@@ -14,5 +15,8 @@ for _ in range(2):
     s = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=np.arange(n_ep, dtype=np.uint64), freq=10, cell=5, subs=1).plan()
 print("kernel %.2f ms" % ctx.last_kernel_ms())
 a = s["arc"][s["done"] == 0]
-for i, n in enumerate(["pick", "steer", "collision+insert", "goal arc"]):
-    print("%-18s %10.0f clk/step" % (n, a[:, i].mean() / max_step))
+names = ["bucket choice (randbelow, occupied/bcount reads)", "node pick (bucket-id scan)", "steer", "collision", "insert", "goal arc"]
+tot = a[:, :6].mean(axis=0).sum()
+for i, n in enumerate(names):
+    print("%-52s %10.0f clk/step  %5.1f %%" % (n, a[:, i].mean() / max_step, 100 * a[:, i].mean() / tot))
+print("episodes not done: %d of %d; total %.0f clk/step" % (len(a), n_ep, tot / max_step))
