@@ -143,7 +143,6 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   __shared__ double s_obs[3][ASTAR_LDS_OBST];  // x, y, T(size) of the first ASTAR_LDS_OBST obstacles
   __shared__ double s_poly[ASTAR_LDS_POLY][2];
   __shared__ double s_grid[ASTAR_LDS_GRID];    // product-grid edge tables gx0 | gx1 | gy0 | gy1 (when they fit)
-  __shared__ int32_t s_cov[ASTAR_WAVES][ASTAR_MAX_HAB];     // fixLen: does the child cover habitat h
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   const int ep = (int)blockIdx.x * ASTAR_WAVES + wave;
@@ -182,6 +181,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
 
   for (int i = lane; i < H; i += 64) hopen[i] = i;
   int n_hopen = H, n_hclosed = 0;
+  unsigned long long closedmask = 0ull;  // bit h: habitat h is in the closed list
   if (lane == 0) {
     nx[0] = sx; ny[0] = sy; ng[0] = 0.0; nh[0] = 0.0; nf[0] = 0.0; ncost[0] = 0.0; nlen[0] = 0.0;
     npar[0] = -1; nts[0] = 0; nopen[0] = 1;
@@ -279,8 +279,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     // under way while the bounds and collision tests run; only the children's words are used
     uint32_t ciw_early = 0u;
     double ex = 0.0, ey = 0.0;
-    if (V == 3) { ex = __shfl(qx, (lane & 7) * 8, 64); ey = __shfl(qy, (lane & 7) * 8, 64); }
-    if (V == 3 && lane < 8) {
+    if (V >= 2) { ex = __shfl(qx, (lane & 7) * 8, 64); ey = __shfl(qy, (lane & 7) * 8, 64); }
+    if (V >= 2 && lane < 8) {
       int xi = (int)(ex + 500), yi = (int)(ey + 200);
       if (xi < 0) xi += P.vx;
       if (yi < 0) yi += P.vy;
@@ -337,22 +337,29 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     const int nch = __popc(childmask);
     if (n_nodes + nch > cap) { status = -2; break; }
     // ------------------------------------------------------------ children, in neighbour order
+    unsigned long long covm_v = 0ull;  // fixLen, lane k: bit set of the habitats that cover child k
     if (V == 2) {
       // first loop of :350-363: habitat coverage update per new node (mutates the lists)
       for (int k = 0; k < 8; k++) {
         if (!((childmask >> k) & 1)) continue;
         const double px = __shfl(qx, k * 8, 64), py = __shfl(qy, k * 8, 64);
-        // which habitats cover this child: one lane per habitat; the list surgery below only reads the flags
+        // which habitats cover this child: one lane per habitat (H <= 64)
+        bool cov = false;
         if (lane < H) {
           const double ddx = px - s_hab[lane][0], ddy = py - s_hab[lane][1];
-          s_cov[wave][lane] = (ddx * ddx + ddy * ddy <= s_hab[lane][2]) ? 1 : 0;
+          cov = ddx * ddx + ddy * ddy <= s_hab[lane][2];
         }
-        wave_sync();
+        const unsigned long long cm = __ballot(cov);
+        if (lane == k) covm_v = cm;
+        if ((cm & ~closedmask) == 0ull) continue;  // no open habitat covers it: the lists stay as they are (most children)
+        unsigned long long removed = 0ull;
         if (lane == 0) {
           // update_habitat_coverage (:182-199): pop(index) while enumerating skips the next element
           for (int idx = 0; idx < n_hopen; idx++) {
-            if (s_cov[wave][hopen[idx]]) {
-              hclosed[n_hclosed++] = hopen[idx];
+            const int hb = hopen[idx];
+            if ((cm >> hb) & 1ull) {
+              hclosed[n_hclosed++] = hb;
+              removed |= 1ull << hb;
               for (int m = idx; m < n_hopen - 1; m++) hopen[m] = hopen[m + 1];
               n_hopen--;
             }
@@ -360,8 +367,56 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         }
         n_hopen = __shfl(n_hopen, 0, 64);
         n_hclosed = __shfl(n_hclosed, 0, 64);
+        closedmask |= ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(removed >> 32), 0, 64) << 32) |
+                      (unsigned long long)(uint32_t)__shfl((int)(uint32_t)(removed & 0xffffffffull), 0, 64);
         wave_sync();
       }
+    }
+    if (V == 2) {
+      // second loop (:364-416), lane k < 8 = child k: with the coverage bit sets nothing a child does is seen by another
+      // (eight distinct lattice points), so costs, visited words, node stores and the open-list append go out together.
+      // cost_of_edge with the lists as they stand after all children were created (:395-400, cost.py:66-101): every
+      // habitat is in exactly one of the two lists and the coverage test is the one of the first loop, so d2 = some
+      // habitat covers the child, d3 = some habitat of the closed list does
+      const int kk = lane & 7;
+      const bool mine = lane < 8 && ((childmask >> kk) & 1);
+      const double px = ex, py = ey;
+      const double d2 = covm_v ? 1.0 : 0.0, d3 = (covm_v & closedmask) ? 1.0 : 0.0;
+      const double g_ = ccost - w2 * d2 - w3 * d3;
+      const double h_ = -w2 * auvp_fabs(limit - 0.0) - w3 * (double)n_hopen;  // child.pathLen is still 0 (:401-403)
+      const double f_ = g_ + h_;
+      const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
+      // visited bitmap (:414-416), numpy index semantics (negative wraps)
+      int xi = (int)(px + 500), yi = (int)(py + 200);
+      if (xi < 0) xi += P.vx;
+      if (yi < 0) yi += P.vy;
+      const bool oob = mine && (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy);
+      if (__any(oob)) { status = -1; break; }
+      const size_t vi = (size_t)xi * P.vy + yi;
+      const uint32_t ciw = mine ? ciw_early : 0u;  // (requested before the bounds test; same index)
+      const bool was = (ciw & 0xff000000u) == ep_tag && (ciw & 0x10000u);
+      const int open_ = was ? 0 : 1;
+      if (mine) {
+        const int c = n_nodes + __popc(childmask & ((1 << kk) - 1));
+        nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = g_; nlen[c] = len_;
+        npar[c] = cur; nts[c] = 0; nopen[c] = open_;
+        if (!was) cellinfo[vi] = ep_tag | 0x10000u;
+      }
+      const unsigned long long om = __ballot(mine && open_);
+      const int opened = __popcll(om);
+      if (list_ok) {
+        if (n_list + opened > ASTAR_OPEN_CAP) list_ok = false;
+        else {
+          if (mine && open_) {
+            const int q = n_list + __popcll(om & ((1ull << lane) - 1ull));
+            of_l[q] = f_; oi_l[q] = n_nodes + __popc(childmask & ((1 << kk) - 1));
+          }
+          n_list += opened;
+        }
+      }
+      n_open += opened;
+      visited_count += opened;
+      wave_sync();
     }
     if (V == 3) {
       // get_cell_prob's cell of every neighbour on a product grid: lane (k8, s8) tests column gc-1+s8 (s8 < 3) or row
@@ -475,7 +530,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       wave_sync();
     }
     int slot = 0;
-    for (int k = 0; k < 8 && status == 0 && V != 3; k++) {
+    for (int k = 0; k < 8 && status == 0 && V <= 1; k++) {
       if (!((childmask >> k) & 1)) continue;
       const int c = n_nodes + slot;
       slot++;
@@ -486,40 +541,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         g_ = cg + astar_sqdist(px, py, cxp, cyp);
         h_ = astar_sqdist(px, py, gx, gy);
         f_ = g_ + h_;
-      } else if (V == 2) {
-        // cost_of_edge with the lists as they stand after all children were created (:395-400, cost.py:66-101)
-        bool d2l = false, d3l = false;
-        for (int i = lane; i < n_hopen + n_hclosed; i += 64) {
-          const bool closed = i >= n_hopen;
-          const double* hb = s_hab[closed ? hclosed[i - n_hopen] : hopen[i]];
-          double ddx = px - hb[0], ddy = py - hb[1];
-          bool cov = ddx * ddx + ddy * ddy <= hb[2];
-          d2l = d2l | cov;
-          d3l = d3l | (cov && closed);
-        }
-        const double d2 = __any(d2l) ? 1.0 : 0.0, d3 = __any(d3l) ? 1.0 : 0.0;
-        g_ = ccost - w2 * d2 - w3 * d3;
-        cost_ = g_;
-        h_ = -w2 * auvp_fabs(limit - 0.0) - w3 * (double)n_hopen;  // child.pathLen is still 0 (:401-403)
-        f_ = g_ + h_;
-        len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
       } else {
-        break;  // V == 3 is handled above (lane-parallel children); not reached
-      }
-      if (V >= 2) {
-        // visited bitmap (:414-416 / :653-657), numpy index semantics (negative wraps)
-        int xi = (int)(px + 500), yi = (int)(py + 200);
-        if (xi < 0) xi += P.vx;
-        if (yi < 0) yi += P.vy;
-        if (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy) { status = -1; break; }
-        const size_t vi = (size_t)xi * P.vy + yi;
-        const uint32_t ciw = (uint32_t)uni((int)cellinfo[vi]);
-        const bool was = (ciw & 0xff000000u) == ep_tag && (ciw & 0x10000u);
-        if (was) open_ = 0;
-        else {
-          if (lane == 0) cellinfo[vi] = ep_tag | 0x10000u;
-          visited_count++;
-        }
+        break;  // V >= 2 is handled above (lane-parallel children); not reached
       }
       if (lane == 0) {
         nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = cost_; nlen[c] = len_;

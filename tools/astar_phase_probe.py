@@ -9,9 +9,11 @@ from auv_sim_amd import _lib, _astar_lib
 ctx = _lib.Context(0)
 w, starts, limits = bench.astar_inputs(1024)
 ctx.set_world(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
+variant = sys.argv[1] if len(sys.argv) > 1 else "astar_fixLenSOG"
+wts = (0, 10, 10, 100) if variant == "astar_fixLenSOG" else (0, 10, 10)
 for _ in range(2):
-    res = _astar_lib.run_batch(ctx, "astar_fixLenSOG", starts, limits=limits, weights=(0, 10, 10, 100), velocity=1.0, cap_nodes=20000,
-                               exp_log=True)
+    res = _astar_lib.run_batch(ctx, variant, starts, limits=limits, weights=wts, velocity=1.0, cap_nodes=20000, exp_log=True)
+print(variant, "launch ms", ctx.last_kernel_ms())
 ms = ctx.last_kernel_ms() if hasattr(ctx, "last_kernel_ms") else float("nan")
 i = int(np.argmax([r["n_expansions"] if "n_expansions" in r else len(r["expansions"]) for r in res]))
 r = res[i]
