@@ -741,7 +741,8 @@ int auvp_rrt_run(auvp_handle* h) {
     // dynamic LDS of the leaf pass: the separable-grid edge tables + one "ancestor of a qualifying leaf" bit per node
     // and episode (trees too large for that are swept whole)
     const int gl = rrt_leaf_grid_lds_bytes(h->W.sg_enabled, h->W.sg_ncol, h->W.sg_nrow);
-    const int bm_words = rrt_leaf_mark_words(B.cap_nodes);
+    // (AUVP_LEAF_SWEEP_ALL=1: no pruning, every node visited -- what trees of more than 131 072 nodes get; for tests)
+    const int bm_words = getenv("AUVP_LEAF_SWEEP_ALL") ? 0 : rrt_leaf_mark_words(B.cap_nodes);
     const int dyn = gl + RRT_LEAF_WAVES * bm_words * 4;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     hipLaunchKernelGGL(rrt_leaf_kernel, dim3((E + RRT_LEAF_WAVES - 1) / RRT_LEAF_WAVES), dim3(RRT_LEAF_WAVES * 64), dyn, h->stream,

@@ -128,3 +128,32 @@ def test_rows_kernel_continues_a_global_random_state(ctx, orc, monkeypatch):
     n = int(res["1"][0]["n_draw32"])
     rnd.getrandbits(32 * n)
     assert rnd.random() == float(res["1"][0]["rng_after"])
+
+
+def test_leaf_pass_without_pruning_gives_the_same_answers(ctx, orc, monkeypatch):
+    """trees too large for the ancestor bit set are swept whole by rrt_leaf_kernel; AUVP_LEAF_SWEEP_ALL forces that path"""
+    from auv_sim_amd import synth
+    world = synth.make_world(seed=63, n_obstacles=64)
+    ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    E, n_iter = 9, 1200
+    init = np.zeros((E, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    seeds = np.arange(7000, 7000 + E, dtype=np.uint64)
+    a = ctx.rrt_explore_batch(init, seeds, n_iter, leaf_log=True).copy()
+    la = [ctx.leaf_log(e, a[e]) for e in range(E)]
+    pa = ctx.paths(a)
+    monkeypatch.setenv("AUVP_LEAF_SWEEP_ALL", "1")
+    b = ctx.rrt_explore_batch(init, seeds, n_iter, leaf_log=True).copy()
+    lb = [ctx.leaf_log(e, b[e]) for e in range(E)]
+    pb = ctx.paths(b)
+    for f in a.dtype.names:
+        assert np.array_equal(a[f], b[f]), f
+    for e in range(E):
+        assert np.array_equal(pa[e], pb[e])
+        assert np.array_equal(la[e][0], lb[e][0]) and np.array_equal(la[e][1], lb[e][1])  # per-leaf costs, creation iteration
+    w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    for e in range(3):
+        r = orc.rrt_explore(w, int(seeds[e]), n_iter, init=init[e], kind="portable")
+        assert (b[e]["status"], b[e]["n_leaves"], b[e]["best_leaf"]) == (r["status"], r["n_leaves"], r["best_leaf"])
+        if r["status"] == 0:
+            assert np.array_equal(np.array(b[e]["best_cost"]), r["best_cost"]) and np.array_equal(pb[e], r["path"])
