@@ -163,10 +163,14 @@ class RRT:
         shark grid's last bin ends.  Returns [committed trajectory, {round: [bucket, habitats at that round]},
         cost of the whole trajectory against the ORIGINAL habitat list].
 
-        The SharkUpdate / SharkOccupancyGrid objects the reference constructs at :67-68 are never read by it
-        and are not constructed here.  The final cost runs on a cost-only device context of its own, so this
-        object's obstacles and boundary stay on the device for later exploring() / check_collision() calls."""
+        Like the reference (:67) the call leaves a `SharkUpdate` over the planner's boundary and cell list in
+        `self.sharkEstimate` (sharkEstimate.py, host arithmetic; nothing here reads it, neither does the reference); the
+        SharkOccupancyGrid of :68 is likewise never read and is not built (its constructor splits polygons with
+        shapely).  The final cost runs on a cost-only device context of its own, so this object's obstacles and
+        boundary stay on the device for later exploring() / check_collision() calls."""
         from .cost import habitat_shark_cost_func
+        from .sharkEstimate import SharkUpdate
+        self.sharkEstimate = SharkUpdate(self.boundary_poly, 10, self.cell_list)
         horizon_end = list(self.sharkGrid.keys())[-1][1]
         round_span = plan_time_budget + replan_time_interval  # also the shark_interval handed to exploring (:80)
         all_habitats = list(habitats)

@@ -1119,8 +1119,97 @@ def g13():
         print(name, "rounds", len(calls), "iters", iters, "traj", len(traj), "habitats left", len(hab_in), "cost", cost[0])
 
 
+# --------------------------------------------------------------------------------------------
+# G14: SharkUpdate (path_planning/sharkEstimate.py:8-207) -- SURVEY 8(f) f3: the grid predictor RRT.replanning
+# constructs at rrt_dubins.py:67.  Inputs are dense row x column grids (lists of lists); recorded: every method's
+# return value AND what it did to its arguments (prediction2 / predictOnAve alias their inputs), plus the exception type
+# update() ends with when it runs a second round on its own [init, result] pair.
+# --------------------------------------------------------------------------------------------
+def g14():
+    import copy
+    refstubs.install()
+    _purge(_SHARED)
+    saved = list(sys.path)
+    sys.path[:0] = [os.path.join(REF, "path_planning"), REF]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            se = importlib.import_module("sharkEstimate")
+    finally:
+        sys.path[:] = saved
+    rng = random.Random(141)
+    out = {"cases": []}
+    specs = [("full_grid", (-300.0, -100.0, -100.0, 100.0), 10.0, None),
+             ("ragged_cells", (0.0, 0.0, 47.0, 33.0), 5.0, 0.7),     # ceil() before the division, cells missing
+             ("one_row", (2.0, 3.0, 26.0, 7.0), 4.0, None)]
+    for name, box, cs, keep in specs:
+        x0, y0, x1, y1 = box
+        ncol, nrow = int(math.floor((x1 - x0) / cs)), int(math.floor((y1 - y0) / cs))
+        cells = [(x0 + c * cs, y0 + r * cs, x0 + (c + 1) * cs, y0 + (r + 1) * cs) for r in range(nrow) for c in range(ncol)]
+        if keep is not None:
+            cells = [c for c in cells if rng.random() < keep]
+            rng.shuffle(cells)                                       # prediction1 depends on the list order
+        cell_objs = [refstubs.CellStub(*c) for c in cells]
+        boundary = refstubs.Polygon([(x0, y0), (x1, y0), (x1, y1), (x0, y1)])
+        upd = se.SharkUpdate(boundary, cs, cell_objs)
+        rows = int(math.ceil(y1 - y0) / cs) + 1
+        cols = int(math.ceil(x1 - x0) / cs) + 1
+        prev = [[0.0 for _ in range(cols)] for _ in range(rows)]
+        for c in cell_objs:
+            r_, c_ = upd.cellToIndex(c)
+            prev[r_][c_] = rng.choice([0.0, 0.0, rng.uniform(0.0, 0.2)])
+        inf = [[rng.uniform(0.0, 0.1) for _ in range(cols)] for _ in range(rows)]
+        parts = [[rng.randrange(0, 40) for _ in range(cols)] for _ in range(rows)]
+        case = {"name": name, "box": list(box), "cell_size": cs, "cells": [list(c) for c in cells], "prev": prev, "inf": inf,
+                "particles": parts, "index": [list(upd.cellToIndex(c)) for c in cell_objs]}
+        case["prediction1"] = upd.prediction1(copy.deepcopy(prev), 0.6)
+        a, b = copy.deepcopy(prev), copy.deepcopy(inf)
+        case["prediction2"] = upd.prediction2(a, 0.1, b)
+        case["prediction2_arg_after"] = a                          # shallow copy: the argument's rows are the result's rows
+        for meth in (1, 2):
+            a = copy.deepcopy(prev)
+            r = upd.predictOnAve(a, False, meth, 0.6, 0.1)
+            case["ave_m%d" % meth] = r
+            case["ave_m%d_arg_after" % meth] = a
+            r = upd.predictOnAve(None, True, meth, 0.6, 0.1)
+            case["ave_exp_m%d" % meth] = r
+            a, b = copy.deepcopy(prev), copy.deepcopy(inf)
+            r = upd.predictOnHist(a, False, meth, b, 0.6, 0.1)
+            case["hist_m%d" % meth] = r
+            a, b = None, copy.deepcopy(inf)
+            r = upd.predictOnHist(a, True, meth, b, 0.6, 0.1)
+            case["hist_exp_m%d" % meth] = r
+            case["hist_exp_m%d_inf_after" % meth] = b
+        case["correction"] = upd.correction(parts, copy.deepcopy(case["prediction1"]))
+        # update(): one round works, the second one feeds the [init, result] pair back in
+        for meth in (["ave", 1], ["ave", 2], ["hist", 1], ["hist", 2]):
+            key = "update_%s%d" % (meth[0], meth[1])
+            grid = {(0, 10): copy.deepcopy(prev)}
+            res = upd.update((0, 10), grid, 10, 10, meth)
+            case[key + "_one_round"] = {"%d,%d" % k: v for k, v in res.items()}
+            grid = {(0, 10): copy.deepcopy(prev)}
+            try:
+                upd.update((0, 10), grid, 20, 10, meth)
+                case[key + "_two_rounds_raises"] = None
+            except Exception as e:  # noqa: BLE001
+                case[key + "_two_rounds_raises"] = type(e).__name__
+        try:
+            upd.predictOnAve(copy.deepcopy(prev), False, 3, 0.6, 0.1)
+            case["ave_m3_raises"] = None
+        except Exception as e:  # noqa: BLE001
+            case["ave_m3_raises"] = type(e).__name__
+        try:
+            upd.correction([[0] * cols for _ in range(rows)], copy.deepcopy(case["prediction1"]))
+            case["correction_zero_raises"] = None
+        except Exception as e:  # noqa: BLE001
+            case["correction_zero_raises"] = type(e).__name__
+        out["cases"].append(case)
+        print("g14", name, "grid", rows, "x", cols, "cells", len(cells), {k: v for k, v in case.items() if k.endswith("raises")})
+    with open(os.path.join(HERE, "g14_shark_update.json"), "w") as f:
+        json.dump(out, f)
+
+
 ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8, "g9": g9,
-       "g10": g10, "g11": g11, "g12": g12, "g13": g13}
+       "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(ALL)
