@@ -81,6 +81,15 @@ class RcclGather:
 
     name = "rccl (auvp_gather, C-ABI)"
 
+    @staticmethod
+    def usable():
+        """can this process reach RCCL through the C-ABI at all?  (every rank asks BEFORE the collective initialisation, so
+        that a rank without it cannot leave the others waiting inside ncclCommInitRank)"""
+        from . import _lib
+        L = _lib.load()
+        L.auvp_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+        return L.auvp_comm_unique_id((C.c_uint8 * 128)()) == 0
+
     def __init__(self, ctx, rank, world, exchange_id):
         from . import _lib
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
@@ -96,11 +105,10 @@ class RcclGather:
         mine = None
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
-            rc = L.auvp_comm_unique_id(buf)
-            if rc != 0:
-                raise _lib.AuvpError(rc, "auvp_comm_unique_id failed (RCCL not loadable?)")
-            mine = bytes(buf)
-        uid = exchange_id(mine)
+            mine = bytes(buf) if L.auvp_comm_unique_id(buf) == 0 else b""
+        uid = exchange_id(mine)  # every rank takes part, also when rank 0 has nothing to hand out
+        if not uid or len(uid) != 128:
+            raise _lib.AuvpError(-6, "auvp_comm_unique_id failed on rank 0 (RCCL not loadable?)")
         arr = (C.c_uint8 * 128).from_buffer_copy(uid)
         ctx._chk(L.auvp_comm_init(ctx.h, self.world, self.rank, arr))
         self.last_ms = None

@@ -204,11 +204,17 @@ class Ranks:
                 box = [mine]
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
-            try:
-                self.gather = D.RcclGather(ctx, rank, world, exchange)
-            except Exception as e:  # RCCL entry points unusable here: keep measuring with torch.distributed's all-gather
-                self.gather_note = "auvp_gather unavailable (%s)" % e
             import torch
+            # pre-flight on every rank, agreed on by all, BEFORE the collective communicator initialisation
+            pre = torch.tensor([0 if D.RcclGather.usable() else 1], device=dev)
+            dist.all_reduce(pre)
+            if int(pre.item()) == 0:
+                try:
+                    self.gather = D.RcclGather(ctx, rank, world, exchange)
+                except Exception as e:  # RCCL entry points unusable here: keep measuring with torch.distributed's all-gather
+                    self.gather_note = "auvp_gather unavailable (%s)" % e
+            else:
+                self.gather_note = "auvp_gather unavailable (RCCL not reachable through the C-ABI on %d rank(s))" % int(pre.item())
             flag = torch.tensor([0 if self.gather is not None else 1], device=dev)
             dist.all_reduce(flag)
             if int(flag.item()) != 0:  # every rank uses the same transport
