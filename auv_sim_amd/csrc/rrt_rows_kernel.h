@@ -225,6 +225,21 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       }
     }
     // ------------------------------------------------------------ steer (:252-295), passes of RW_C sub-arcs
+    // window entry j of a pass = random() number b0 + j of the row's stream
+    auto make_window = [&](bool on, int nwin, int b0) {
+      rows_ensure(rng, on, (uint32_t)(2 * (b0 + nwin)), rl);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int j = rl + 16 * t;
+        if (on && j < nwin) win[j] = rows_random_at(rng, (uint32_t)(b0 + j));
+      }
+      wave_sync();
+    };
+    // the first pass's window needs nothing of the parent: it is generated while the parent's id (and then its record)
+    // is still on its way from memory
+    const bool on0 = live && 0 < n_total;
+    const int n0_ = on0 ? (n_total < RW_C ? n_total : RW_C) : 0;
+    make_window(on0, 3 * n0_, base);
     double cx = 0.0, cy = 0.0, cth = 0.0, ctt = 0.0, clen = 0.0;
     if (live) {
       const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 8);
@@ -246,14 +261,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       const int n = on ? ((n_total - c0) < RW_C ? (n_total - c0) : RW_C) : 0;
       const int nwin = 3 * n;
       const int b0 = first_pass ? base : 0;  // later passes start at the (advanced) head of the stream
-      // window entry j of this pass = random() number b0 + j of the row's stream
-      rows_ensure(rng, on, (uint32_t)(2 * (b0 + nwin)), rl);
-#pragma unroll
-      for (int t = 0; t < 3; t++) {
-        const int j = rl + 16 * t;
-        if (on && j < nwin) win[j] = rows_random_at(rng, (uint32_t)(b0 + j));
-      }
-      wave_sync();
+      if (pass != 0) make_window(on, nwin, b0);
       // "taken" predicate for every possible start offset, 48 bits per row
       unsigned long long tpred = 0ull;
 #pragma unroll
