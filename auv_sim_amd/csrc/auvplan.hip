@@ -691,14 +691,17 @@ int auvp_rrt_run(auvp_handle* h) {
   // four episodes per wavefront (rrt_rows_kernel.h) where its limits allow; one episode per wavefront otherwise
   const RowsLdsPlan rp = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins));
   const bool iter_log = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
-  // ... and where it pays: a batch that gives the one-episode kernel fewer waves than it can keep resident (6 per SIMD)
-  // runs faster there -- below ~8 k episodes the rows kernel would leave the SIMDs with one or two waves
-  // (measured on MI355X: 6 144 episodes 586 vs 567 M expansions/s, 12 288 episodes 670 vs 881 M).  AUVP_ROWS=1 / 0 force it
-  // on (limits permitting) / off.
+  // ... and where it pays: a batch the one-episode kernel can keep resident in one go (6 waves per SIMD = 24 episodes per
+  // CU) runs faster there -- the rows kernel would leave the SIMDs with one or two waves.  Measured on MI355X, M
+  // expansions/s one-episode vs rows: 4 096 episodes 616 vs 507, 6 144 episodes 704 vs 645, 8 192 episodes 699 vs 849,
+  // 10 240 episodes 737 vs 877.  AUVP_ROWS=1 / 0 force it on (limits permitting) / off.
+  int n_cu_ = 256;
+  (void)hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, h->device);
+  if (n_cu_ <= 0) n_cu_ = 256;
   const char* rows_env = getenv("AUVP_ROWS");
   const bool rows_ok = P.mode == 0 && !iter_log && nfreq <= RW_MAX_FREQ && O_ <= RW_MAX_OBST && P.max_iter < 65534 &&
                        rp.total <= 160 * 1024;
-  const bool use_rows = rows_ok && (rows_env ? atoi(rows_env) != 0 : E >= 8192);
+  const bool use_rows = rows_ok && (rows_env ? atoi(rows_env) != 0 : E > 24 * n_cu_);
   int grid_used = grid, block_used = RRT_X_WAVES * 64, lds_used = (int)lds;
   if (use_rows) {
     // a workgroup of up to 12 waves (48 episodes) fills one CU; a batch that cannot give every CU such a workgroup is

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     }
     // ------------------------------------------------------------ parent selection (:121-139)
     if (clk) t_prev = __builtin_amdgcn_s_memtime();
-    int par;
+    int par = 0, par_v = 0;
     // The next 64 random() values of the stream are tempered in one pass (lane j holds number j);
     // the iteration's scalar draws are read out of that window and `base` counts how many of them
     // the selection + n_expand draws consumed.  The steer window continues in the same buffer.
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       }
       if (uni(status)) break;  // (uni: the compiler cannot see that status is wave-uniform)
       const int ri = uni((int)py_uniform(0.0, (double)cnt, readlane_f64(u_me, f + 1)));
-      par = uni(bin_member(bins, rb, ri));
+      par_v = bin_member(bins, rb, ri);  // every lane reads the same word; made uniform when the record is fetched
       base = uni(f + 2);
     } else if (MODE == 1) {
       double u = rng_next_random(rng);
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
         lo = uni(lo); hi = uni(hi);
       }
       par = lo;
+      par_v = par;
       if (nodeF[(size_t)par * 8 + 3] > Q.max_traj_time) continue;
     } else {
       // get_random_mps (:333-343): x, y, theta, size draws; only x,y are used
@@ -532,19 +533,26 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
         cand = t < cand ? t : cand;
       }
       par = uni(cand);
+      par_v = par;
       if (nodeF[(size_t)par * 8 + 3] > Q.max_traj_time) continue;
     }
 
     AUVP_PHASE(0);
     // ------------------------------------------------------------ steer (:252-295)
-    double cx, cy, cth, ctt, clen;
-    {
+    // The parent's record is fetched as late as possible -- right before the first chunk's theta chain: the random
+    // window, the "taken" predicate, the draw-offset fixed point and the arc radii need nothing of it, and run while the
+    // parent's id and then its record are on their way from memory.
+    double cx = 0.0, cy = 0.0, cth = 0.0, ctt = 0.0, clen = 0.0;
+    double px0 = 0.0, py0 = 0.0, clen0 = 0.0;  // the parent's end: centre of the collision cull's box
+    auto fetch_parent = [&]() {
+      par = uni(par_v);
       const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 8);
       const double2 b = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 8 + 2);
       cx = readfirst_f64(a.x); cy = readfirst_f64(a.y); cth = readfirst_f64(b.x); ctt = readfirst_f64(b.y);
       clen = readfirst_f64(nodeF[(size_t)par * 8 + 4]);
-    }
-    const double px0 = cx, py0 = cy, clen0 = clen;  // the parent's end: centre of the collision cull's box
+      px0 = cx; py0 = cy; clen0 = clen;
+      if (lane == 0) { pts[0][0] = cx; pts[0][1] = cy; }
+    };
     if (MODE != 0) {  // modes 1/2 consumed their selection draws one by one; open the window here
       rng_ensure(rng, 128u);
       u_me = rng_random_at(rng, (uint32_t)lane);
@@ -553,7 +561,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     const int n_total = uni((int)auvp_floor(py_uniform(0.0, Q.freq, readlane_f64(u_me, base)) / 1));
     base += 1;
     int cnt = 0;  // appended path points
-    if (lane == 0) { pts[0][0] = cx; pts[0][1] = cy; }
+    if (n_total == 0) fetch_parent();
     bool cap_err = false;
     for (int c0 = 0; c0 < n_total; c0 += C) {
       const int n = (n_total - c0) < C ? (n_total - c0) : C;
@@ -623,6 +631,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
         vt = py_uniform(0.0, 2 * Q.v, uw[mypos + 2]);
       }
       wave_sync();  // the window is dead: its LDS becomes the steer scratch
+      if (c0 == 0) fetch_parent();
       if (lane <= C) phi_l[lane] = phi;  // untaken / idle lanes add an exact 0.0
       wave_sync();
       // theta += phi, left to right, by one lane; prefix angles written back in place

@@ -319,6 +319,7 @@ RRT_KW = dict(freq=30, bin_interval=5, v=2, max_traj_time=500.0, weights=(-3, -3
 
 def bench_single_episode(ctx, world, args, reps=3):
     """SURVEY 8(d) config 2 latency test: ONE episode on one GPU (a serial chain: one wavefront busy)."""
+    ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     init = np.zeros((1, 6))
     init[0, 0], init[0, 1] = world["start"]
     ms = []
