@@ -57,3 +57,27 @@ def golden_world(g):
         h.update(np.ascontiguousarray(w[k]).tobytes())
     assert h.hexdigest() == str(g["world_sha"]), "synth.make_world no longer reproduces the golden's world"
     return {k: w[k] for k in keys}
+
+
+def uneven_grid(world, seed, lo=4.0, hi=17.0):
+    """replace a synth world's uniform cells by a product grid with uneven column widths / row heights over the same box
+    (row-major, prob re-drawn): the lower-bound guesses of the grid indexes are then wrong by several cells"""
+    import random
+    import numpy as np
+    rng = random.Random(seed)
+    x0, y0, x1, y1 = [float(v) for v in world["box"]]
+
+    def edges(a, b):
+        e = [a]
+        while e[-1] < b - 1e-9:
+            e.append(min(b, e[-1] + round(rng.uniform(lo, hi), 2)))
+        if e[-1] - e[-2] < 1.0:  # no sliver at the end
+            e.pop(-2)
+        return e
+    ex, ey = edges(x0, x1), edges(y0, y1)
+    cells = [(ex[c], ey[r], ex[c + 1], ey[r + 1]) for r in range(len(ey) - 1) for c in range(len(ex) - 1)]
+    T = len(world["bins"])
+    w = dict(world)
+    w["cells"] = np.array(cells, dtype=np.float64)
+    w["prob"] = np.array([[rng.uniform(0.0, 0.3) for _ in cells] for _ in range(T)], dtype=np.float64)
+    return w

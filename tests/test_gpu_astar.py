@@ -76,7 +76,7 @@ def test_astar_batch_vs_oracle(ctx, orc, variant):
     assert n_found > 0
 
 
-@pytest.mark.parametrize("cells_as", ["product_grid", "shuffled_list", "column_major", "grid_14m_float_starts"])
+@pytest.mark.parametrize("cells_as", ["product_grid", "shuffled_list", "column_major", "grid_14m_float_starts", "uneven_product_grid"])
 def test_sog_cell_lookup_paths(ctx, orc, cells_as):
     """get_cell_prob (astar_fixLenSOG.py:485-514) = the first cell of the LIST whose closed box holds the point; lattice
     points sit on cell edges, so up to four cells match and the list order decides.  A row-major product grid takes the
@@ -87,6 +87,10 @@ def test_sog_cell_lookup_paths(ctx, orc, cells_as):
     cell = 14.0 if cells_as == "grid_14m_float_starts" else 10.0
     w = synth.make_world(seed=13, n_obstacles=32, obst_radius=(2.0, 6.0), n_habitats=8, hab_radius=(10.0, 25.0), cell=cell)
     cells, prob = np.array(w["cells"], dtype=np.float64), np.array(w["prob"], dtype=np.float64)
+    if cells_as == "uneven_product_grid":
+        from conftest import uneven_grid
+        w2 = uneven_grid(w, 77)
+        cells, prob = w2["cells"], w2["prob"]
     if cells_as == "shuffled_list":
         perm = rng.permutation(len(cells))
         cells, prob = cells[perm], prob[:, perm]

@@ -46,6 +46,8 @@ CASES = {
     "positive_box_ties_with_habitats": dict(world=dict(seed=62, n_obstacles=40, box=(0.0, 0.0, 280.0, 180.0), cell=14.0,
                                                        hab_radius=(20.0, 40.0)),
                                             E=6, n_iter=1500, kw=dict(max_traj_time=150.0)),
+    # a product grid with uneven column widths and row heights: the separable cell index starts from wrong guesses
+    "uneven_product_grid": dict(world=dict(seed=64, n_obstacles=48), E=6, n_iter=900, kw={}, uneven=True),
     "one_episode": dict(world=dict(seed=56, n_obstacles=64), E=1, n_iter=1200, kw={}),
     "no_habitats_no_grid": dict(world=dict(seed=57, n_obstacles=30, n_habitats=0), E=5, n_iter=500, kw={}, strip_grid=True),
     "point_capacity_overflow": dict(world=dict(seed=58, n_obstacles=8), E=6, n_iter=400, kw=dict(points_per_iter=3.0)),
@@ -61,6 +63,9 @@ def test_rows_kernel_equals_one_episode_kernel_and_checker(ctx, orc, name, monke
     if c.get("poly") == "hex":
         x0, y0, x1, y1 = world["box"]
         poly = _hexagon(0.5 * (x0 + x1), 0.5 * (y0 + y1), 0.55 * (x1 - x0))
+    if c.get("uneven"):
+        from conftest import uneven_grid
+        world = uneven_grid(world, 78)
     bins, cells, prob = world["bins"], world["cells"], world["prob"]
     if c.get("strip_grid"):
         bins, cells, prob = None, None, None
