@@ -996,38 +996,50 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     if (own_tab && live)
       for (int k = 0; k < r.w; k++) c_owner[cpos + k] = (uint8_t)lane;
     wave_sync();
-    for (int j0 = 0; j0 < n_slots; j0 += 128) {  // two points per lane and round: their record reads overlap
-      const int ja = j0 + lane, jb = j0 + 64 + lane;
-      const bool va = ja < n_slots, vb = jb < n_slots;
-      // owner = the node whose run holds the slot: from the table, or the last node whose first slot is <= the slot
-      // (nodes without points share their successor's first slot and are skipped)
-      int oa = 0, ob = 0;
-      if (own_tab) {
-        oa = va ? (int)c_owner[ja] : 0;
-        ob = vb ? (int)c_owner[jb] : 0;
-      } else {
+    // the node's own record and its parent's running sums are requested now; they are used after the point rounds
+    double2 n_xy = make_double2(0.0, 0.0), n_tl = make_double2(0.0, 0.0);
+    if (live) {
+      n_xy = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8);
+      n_tl = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8 + 3);  // traj_t, length (unaligned pair)
+    }
+    const bool par_before = live && r.y >= 0 && r.y < first_id;
+    double4 par_rec = make_double4(0.0, 0.0, 0.0, 0.0);
+    if (par_before) par_rec = nodeC[r.y];
+    // Point rounds, two points per lane and round, software-pipelined: the records of round k + 1 are requested before
+    // the terms of round k are evaluated.  owner = the node whose run holds the slot: from the table, or the last node
+    // whose first slot is <= the slot (nodes without points share their successor's first slot and are skipped)
+    struct Slot { bool v; int o; double2 xy; double t; };
+    auto fetch = [&](int j) {
+      Slot q;
+      q.v = j < n_slots;
+      q.o = 0;
+      if (own_tab) q.o = q.v ? (int)c_owner[j] : 0;
+      else {
 #pragma unroll
-        for (int st = 32; st >= 1; st >>= 1) {
-          if (oa + st < 64 && c_cpos[oa + st] <= ja) oa += st;
-          if (ob + st < 64 && c_cpos[ob + st] <= jb) ob += st;
-        }
+        for (int st = 32; st >= 1; st >>= 1)
+          if (q.o + st < 64 && c_cpos[q.o + st] <= j) q.o += st;
       }
-      const int pa = va ? c_off[oa] + (ja - c_cpos[oa]) : 0, pb = vb ? c_off[ob] + (jb - c_cpos[ob]) : 0;
-      const double* ra = ptF + (size_t)pa * 3;
-      const double* rb = ptF + (size_t)pb * 3;
-      const double2 xya = *reinterpret_cast<const double2*>(ra), xyb = *reinterpret_cast<const double2*>(rb);
-      const double ta = ra[2], tb_ = rb[2];
+      const int pidx = q.v ? c_off[q.o] + (j - c_cpos[q.o]) : 0;
+      const double* rec = ptF + (size_t)pidx * 3;
+      q.xy = *reinterpret_cast<const double2*>(rec);
+      q.t = rec[2];
+      return q;
+    };
+    Slot sa = fetch(lane), sb = fetch(64 + lane);
+    for (int j0 = 0; j0 < n_slots; j0 += 128) {
+      const Slot ca = sa, cb = sb;
+      if (j0 + 128 < n_slots) { sa = fetch(j0 + 128 + lane); sb = fetch(j0 + 192 + lane); }
       double tva = 0.0, tvb = 0.0;
       int haba = -1, habb = -1;
-      if (va) cost_element(W, St, 0, W.n_bins, P.w[2], xya.x, xya.y, ta, tva, haba, true, grid_lds);
-      if (vb) cost_element(W, St, 0, W.n_bins, P.w[2], xyb.x, xyb.y, tb_, tvb, habb, true, grid_lds);
-      if (va) {
-        if (tva != 0.0) atomicAdd(&c_S[oa], tva);
-        if (haba >= 0) { atomicAdd(&c_hits[oa], 1); atomicOr(&c_vis[oa], 1ull << haba); }
+      if (ca.v) cost_element(W, St, 0, W.n_bins, P.w[2], ca.xy.x, ca.xy.y, ca.t, tva, haba, true, grid_lds);
+      if (cb.v) cost_element(W, St, 0, W.n_bins, P.w[2], cb.xy.x, cb.xy.y, cb.t, tvb, habb, true, grid_lds);
+      if (ca.v) {
+        if (tva != 0.0) atomicAdd(&c_S[ca.o], tva);
+        if (haba >= 0) { atomicAdd(&c_hits[ca.o], 1); atomicOr(&c_vis[ca.o], 1ull << haba); }
       }
-      if (vb) {
-        if (tvb != 0.0) atomicAdd(&c_S[ob], tvb);
-        if (habb >= 0) { atomicAdd(&c_hits[ob], 1); atomicOr(&c_vis[ob], 1ull << habb); }
+      if (cb.v) {
+        if (tvb != 0.0) atomicAdd(&c_S[cb.o], tvb);
+        if (habb >= 0) { atomicAdd(&c_hits[cb.o], 1); atomicOr(&c_vis[cb.o], 1ull << habb); }
       }
     }
     wave_sync();
@@ -1035,10 +1047,8 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     int own_hits = c_hits[lane], nhab = -1;
     unsigned long long own_vis = c_vis[lane];
     if (live) {
-      const double2 xy = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8);
-      const double2 tl = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8 + 3);  // traj_t, length (unaligned pair)
-      ctt = tl.x; nlen = tl.y;
-      cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, ctt, ntv, nhab, true, grid_lds);
+      ctt = n_tl.x; nlen = n_tl.y;
+      cost_element(W, St, 0, W.n_bins, P.w[2], n_xy.x, n_xy.y, ctt, ntv, nhab, true, grid_lds);
       own = own + ntv;
       if (nhab >= 0) { own_hits++; own_vis |= (1ull << nhab); }
     }
@@ -1046,10 +1056,9 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     // the parent's sums: from memory when it belongs to an earlier pass, else from the lanes of this one
     double pS = 0.0;
     int4 pc = make_int4(0, 0, 0, 0);
-    const bool par_before = live && r.y >= 0 && r.y < first_id;
     unsigned long long pvis = 0ull;
     if (par_before) {
-      const double4 pr = nodeC[r.y];
+      const double4 pr = par_rec;
       pS = pr.x;
       const long long he = __double_as_longlong(pr.y);
       pc.x = (int)(he & 0xffffffffll); pc.y = (int)(he >> 32);
@@ -1147,9 +1156,13 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
       // ---- the reference's ordered sum: [leaf] + reversed(leaf.path[1:]) + [parent] + reversed(parent.path[1:]) ... root
       double c2num = 0.0;
       int mm = leaf;
+      int4 rr = nodeI[mm];
+      double tvn = nodeF[(size_t)mm * 8 + 6];
       for (;;) {
-        const int4 rr = nodeI[mm];
-        const double tvn = nodeF[(size_t)mm * 8 + 6];
+        // the parent's record is requested while this node's points are evaluated (the walk is a chain of dependent reads)
+        int4 rr_up = make_int4(0, -1, 0, 0);
+        double tvn_up = 0.0;
+        if (rr.y >= 0) { rr_up = nodeI[rr.y]; tvn_up = nodeF[(size_t)rr.y * 8 + 6]; }
         c2num = c2num + tvn;  // the node's own state comes before the points that led to it
         if (rr.y < 0) break;  // the root has no path of its own
         for (int k0 = 0; k0 < rr.w; k0 += 64) {
@@ -1166,7 +1179,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
           wave_sync();
           for (int i = 0; i < nv; i++) c2num = c2num + term[i];
         }
-        mm = rr.y;
+        mm = rr.y; rr = rr_up; tvn = tvn_up;
       }
       const int lhits = __builtin_amdgcn_readlane(hits, l), lelems = __builtin_amdgcn_readlane(elems, l);
       const unsigned long long lvis = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(vis >> 32), l) << 32) |
