@@ -85,6 +85,9 @@ struct WorldDev {
   int32_t has_safe_box, _pad1;
 };
 
+// kernel-internal bits of RrtParamsDev::flags (above the public AUVP_FLAG_* bits)
+#define AUVP_KFLAG_TIGHT_CULL 1024
+
 struct RrtParamsDev {
   double dist_to_end, diff_max, freq, min_dist, bin_interval, v, max_traj_time, max_plan_time;
   double w[3];

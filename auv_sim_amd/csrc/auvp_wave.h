@@ -49,6 +49,15 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   return v;
 }
 
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    double t = __shfl_xor(v, o, 64);
+    v = (t > v) ? t : v;
+  }
+  return v;
+}
+
 // sum over the 64 lanes in a fixed but unspecified order (NOT for sums whose rounding the reference defines): four
 // rotate-and-add steps inside the 16-lane rows on the DPP path (no LDS crossbar), then the four row totals
 __device__ __forceinline__ double wave_sum_any_order(double v) {

@@ -725,15 +725,25 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     // it costs nothing to maintain (tracking min/max in the serial chains was 30 instructions per expansion).
     const double reach = clen - clen0;
     const double bx0 = px0 - reach, by0 = py0 - reach, bx1 = px0 + reach, by1 = py0 + reach;
-    const double cxm = px0, cym = py0;
+    double cxm = px0, cym = py0;
     const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + 1.0);
-    const double hx = reach + slack, hy = reach + slack;
+    double hx = reach + slack, hy = reach + slack;
     // lane = path point (the usual steer has < 64 of them): the few obstacles that survive the cull are tested one
     // at a time against every point at once, read back from the tile with a wave-uniform address
     int hit = 0;
     const bool pv0 = lane < P_n;
     double2 q0 = make_double2(0.0, 0.0);
     if (pv0) q0 = *reinterpret_cast<const double2*>(&pts[lane][0]);
+    // Where the host expects dense obstacles (AUVP_KFLAG_TIGHT_CULL, set at launch) the cull box is the tight box of the
+    // path points themselves (the parent's end is pts[0]): four wave reductions, far fewer exact tests
+    if ((P.flags & AUVP_KFLAG_TIGHT_CULL) && P_n <= 64) {
+      const double inf = __builtin_inf();
+      const double mnx = wave_min_f64(pv0 ? q0.x : inf), mxx = wave_max_f64(pv0 ? q0.x : -inf);
+      const double mny = wave_min_f64(pv0 ? q0.y : inf), mxy = wave_max_f64(pv0 ? q0.y : -inf);
+      const double ts = 0x1p-30 * (auvp_fabs(mnx) + auvp_fabs(mxx) + auvp_fabs(mny) + auvp_fabs(mxy) + 1.0);
+      cxm = (mnx + mxx) * 0.5; cym = (mny + mxy) * 0.5;
+      hx = (mxx - mnx) * 0.5 + ts; hy = (mxy - mny) * 0.5 + ts;
+    }
 #pragma unroll
     for (int j = 0; j < J; j++) {
       const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = (double)olr[j * 64 + lane];

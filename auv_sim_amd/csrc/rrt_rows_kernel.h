@@ -17,6 +17,8 @@
 // <= 256 obstacles, <= 65 534 iterations (u16 bin counters).
 #ifndef AUVP_RRT_ROWS_KERNEL_H
 #define AUVP_RRT_ROWS_KERNEL_H
+#include <type_traits>
+
 #include "rrt_explore_kernel.h"
 
 namespace auvp {
@@ -388,10 +390,36 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
     const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + 1.0);
     const double hx = reach + slack;
     bool hit = false;
-    {
+    // Two instances of the same loop, picked by a launch-uniform flag: where the host expects dense obstacles the cull goes
+    // on with the tight box of the row's path points (and the parent's end) instead of the reach square -- the path
+    // wanders inside a fraction of it, and an obstacle can only be hit if its bounding square meets that box.  The
+    // sparse instance is the plain loop (the ~100 instructions of the tight box would cost more than they save there).
+    auto cull_and_test = [&](auto tight_tag) {
+      constexpr bool TIGHT = decltype(tight_tag)::value;
       const double hs = hx + slack;
       const bool slot_hit = live && !(sbox.z < px0 - hs || sbox.x > px0 + hs || sbox.w < py0 - hs || sbox.y > py0 + hs);
       uint32_t sm = row_ballot(slot_hit, rowbase);
+      double tcx = px0, tcy = py0, thx = hx, thy = hx;
+      if (TIGHT && __any(sm != 0u)) {
+        double mnx = px0, mxx = px0, mny = py0, mxy = py0;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          if (ptv[q]) {
+            mnx = __builtin_fmin(mnx, ptx[q]); mxx = __builtin_fmax(mxx, ptx[q]);
+            mny = __builtin_fmin(mny, pty[q]); mxy = __builtin_fmax(mxy, pty[q]);
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          mnx = __builtin_fmin(mnx, __shfl_xor(mnx, o, 16)); mxx = __builtin_fmax(mxx, __shfl_xor(mxx, o, 16));
+          mny = __builtin_fmin(mny, __shfl_xor(mny, o, 16)); mxy = __builtin_fmax(mxy, __shfl_xor(mxy, o, 16));
+        }
+        const double ts = 0x1p-30 * (auvp_fabs(mnx) + auvp_fabs(mxx) + auvp_fabs(mny) + auvp_fabs(mxy) + 1.0);
+        tcx = (mnx + mxx) * 0.5; tcy = (mny + mxy) * 0.5;
+        thx = (mxx - mnx) * 0.5 + ts; thy = (mxy - mny) * 0.5 + ts;
+        const bool tight = slot_hit && !(sbox.z < mnx - ts || sbox.x > mxx + ts || sbox.w < mny - ts || sbox.y > mxy + ts);
+        sm = row_ballot(tight, rowbase);
+      }
       while (__any(sm != 0u)) {  // slots some row has to look into (none at all for most steers of a sparse world)
         const bool hs_ = sm != 0u;
         const int j0 = hs_ ? 16 * (__ffs((int)sm) - 1) : 0;
@@ -399,7 +427,8 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
         const int oi = j0 + rl;
         const double oxj = olx[oi], oyj = oly[oi], orj = (double)olr[oi];
         const double otj = W.os_t[oi];  // this lane's obstacle of the slot: one coalesced read, handed out below
-        const bool cand = hs_ && !(auvp_fabs(oxj - px0) > hx + orj || auvp_fabs(oyj - py0) > hx + orj);
+        const bool cand = hs_ && (TIGHT ? !(auvp_fabs(oxj - tcx) > thx + orj || auvp_fabs(oyj - tcy) > thy + orj)
+                                        : !(auvp_fabs(oxj - px0) > hx + orj || auvp_fabs(oyj - py0) > hx + orj));
         uint32_t cm = row_ballot(cand, rowbase);
         n_cand += __popc(cm);
         while (__any(cm != 0u)) {
@@ -418,7 +447,9 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
           if (row_ballot(hit, rowbase) != 0u) cm = 0u;
         }
       }
-    }
+    };
+    if (P.flags & AUVP_KFLAG_TIGHT_CULL) cull_and_test(std::true_type{});
+    else cull_and_test(std::false_type{});
     // boundary: strictly inside an axis-aligned rectangle implies Point.within; otherwise the crossing test per point
     const double* sb = S.world->safe_box;
     const bool box_inside = W.has_safe_box && bx0 > sb[0] && by0 > sb[1] && bx1 < sb[2] && by1 < sb[3];

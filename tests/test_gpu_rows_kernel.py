@@ -90,6 +90,11 @@ def test_rows_kernel_equals_one_episode_kernel_and_checker(ctx, orc, name, monke
         # an episode that stopped with a capacity error reports where it stopped; the position of its random stream at
         # that moment depends on how the kernel cuts a steer into passes and is not part of the contract
         keep = ~failed if f in ("rng_after", "n_draw32") else np.ones(E, bool)
+        if f == "n_candidates":
+            # a diagnostic (obstacles that passed the conservative cull): the four-episode kernel culls dense worlds with the
+            # tight box of the path points, the one-episode kernel with the reach square -- never fewer candidates there
+            assert (sa[f] <= sb[f]).all()
+            continue
         assert np.array_equal(sa[f][keep], sb[f][keep]), f
     for e in range(E):
         for k in ("nodes", "parent", "pt_off", "pt_cnt", "points"):
@@ -129,7 +134,8 @@ def test_rows_kernel_continues_a_global_random_state(ctx, orc, monkeypatch):
         monkeypatch.setenv("AUVP_ROWS", rows)
         res[rows] = ctx.rrt_explore_batch(init, (words, idx), 700).copy()
     for f in res["1"].dtype.names:
-        assert np.array_equal(res["1"][f], res["0"][f]), f
+        if f != "n_candidates":  # (cull diagnostic: depends on the kernel's cull box, see above)
+            assert np.array_equal(res["1"][f], res["0"][f]), f
     n = int(res["1"][0]["n_draw32"])
     rnd.getrandbits(32 * n)
     assert rnd.random() == float(res["1"][0]["rng_after"])
