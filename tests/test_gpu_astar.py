@@ -76,7 +76,8 @@ def test_astar_batch_vs_oracle(ctx, orc, variant):
     assert n_found > 0
 
 
-@pytest.mark.parametrize("cells_as", ["product_grid", "shuffled_list", "column_major", "grid_14m_float_starts", "uneven_product_grid"])
+@pytest.mark.parametrize("cells_as", ["product_grid", "shuffled_list", "column_major", "grid_14m_float_starts", "uneven_product_grid",
+                                      "fine_grid_tables_in_hbm"])
 def test_sog_cell_lookup_paths(ctx, orc, cells_as):
     """get_cell_prob (astar_fixLenSOG.py:485-514) = the first cell of the LIST whose closed box holds the point; lattice
     points sit on cell edges, so up to four cells match and the list order decides.  A row-major product grid takes the
@@ -84,7 +85,8 @@ def test_sog_cell_lookup_paths(ctx, orc, cells_as):
     from auv_sim_amd import synth
     from oracle import orc_astar as oa
     rng = np.random.default_rng(23)
-    cell = 14.0 if cells_as == "grid_14m_float_starts" else 10.0
+    # (80 x 80 cells of 2.5 m: the edge tables no longer fit the kernel's LDS budget and are read from memory)
+    cell = 14.0 if cells_as == "grid_14m_float_starts" else (2.5 if cells_as == "fine_grid_tables_in_hbm" else 10.0)
     w = synth.make_world(seed=13, n_obstacles=32, obst_radius=(2.0, 6.0), n_habitats=8, hab_radius=(10.0, 25.0), cell=cell)
     cells, prob = np.array(w["cells"], dtype=np.float64), np.array(w["prob"], dtype=np.float64)
     if cells_as == "uneven_product_grid":
@@ -102,6 +104,8 @@ def test_sog_cell_lookup_paths(ctx, orc, cells_as):
         starts = np.array([(-290.0 + 10.0 * rng.integers(0, 6) + 0.37, -90.0 + 10.0 * rng.integers(0, 6) + 0.21) for _ in range(12)])
     else:
         starts = np.array([(-290.0 + 10.0 * rng.integers(0, 6), -90.0 + 10.0 * rng.integers(0, 6)) for _ in range(12)])
+    if cells_as == "fine_grid_tables_in_hbm":
+        starts = starts[:5]
     kw = dict(obstacles=w["obstacles"], polygon=w["polygon"], habitats=w["habitats"], limit=150.0, weights=(0, 10, 10, 100),
               bins=w["bins"], cells=cells, prob=prob, velocity=1.0)
     res = _gpu_run(ctx, "astar_fixLenSOG", starts, kw, exp_log=True)
