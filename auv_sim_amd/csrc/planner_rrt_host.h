@@ -12,7 +12,7 @@ struct PrrtState {
   int E = 0;
   auvp::PrrtParamsDev P{};
   auvp::PrrtBuffers B{};
-  DevBuf node_f, node_i, node_bucket, points, occupied, bcount, mt, rng_state, start, goal, step_bucket, summary, st_log,
+  DevBuf node_f, node_i, node_bucket, points, occupied, bcount, bhead, nnext, mt, rng_state, start, goal, step_bucket, summary, st_log,
       tmp_off, tmp_out;
 };
 
@@ -89,6 +89,8 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
   HIPCHK(h, S.points.reserve((size_t)E * B.cap_points * 4 * sizeof(double)));
   HIPCHK(h, S.occupied.reserve(cn * sizeof(int32_t)));
   HIPCHK(h, S.bcount.reserve((size_t)E * P.n_buckets * sizeof(int32_t)));
+  HIPCHK(h, S.bhead.reserve((size_t)E * P.n_buckets * sizeof(int32_t)));
+  HIPCHK(h, S.nnext.reserve(cn * sizeof(int32_t)));
   HIPCHK(h, S.mt.reserve((size_t)E * 624 * sizeof(uint32_t)));
   HIPCHK(h, S.rng_state.reserve((size_t)E * 4 * sizeof(int32_t)));
   HIPCHK(h, S.summary.reserve((size_t)E * sizeof(auvp::PrrtSummary)));
@@ -97,6 +99,7 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
   HIPCHK(h, S.goal.reserve((size_t)E * 2 * sizeof(double)));
   B.node_f = S.node_f.as<double>(); B.node_i = S.node_i.as<int32_t>(); B.node_bucket = S.node_bucket.as<int32_t>();
   B.points = S.points.as<double>(); B.occupied = S.occupied.as<int32_t>(); B.bucket_counts = S.bcount.as<int32_t>();
+  B.bucket_head = S.bhead.as<int32_t>(); B.node_next = S.nnext.as<int32_t>();
   B.mt = S.mt.as<uint32_t>(); B.rng_state = S.rng_state.as<int32_t>(); B.summary = S.summary.as<auvp::PrrtSummary>();
   B.step_bucket = S.step_bucket.as<int32_t>();
   B.start = S.start.as<double>(); B.goal = S.goal.as<double>();

@@ -44,6 +44,11 @@ struct PrrtBuffers {
   double* points;        // [E][4][cap_points] SoA x, y, theta, traj_t
   int32_t* occupied;     // [E][cap_nodes]
   int32_t* bucket_counts;  // [E][n_buckets]
+  // member lists of the buckets, newest first: bucket_head[b] = the last node added to bucket b (valid while its count
+  // is > 0), node_next[m] = the member added before m (-1: m was the first).  Member k of the reference's node_array
+  // (creation order) is count - 1 - k steps from the head.
+  int32_t* bucket_head;    // [E][n_buckets]
+  int32_t* node_next;      // [E][cap_nodes]
   uint32_t* mt;          // [E][624] generator words (lazy in-place format between launches)
   int32_t* rng_state;    // [E][4] pslot, avail, drawn_lo, drawn_hi
   const double* start;   // [E][4] x, y, theta, traj_t
@@ -168,6 +173,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
   double* ptF = B.points + (size_t)ep * capp * 4;
   int32_t* occupied = B.occupied + (size_t)ep * capn;
   int32_t* bcount = B.bucket_counts + (size_t)ep * P.n_buckets;
+  int32_t* bhead = B.bucket_head + (size_t)ep * P.n_buckets;
+  int32_t* nnext = B.node_next + (size_t)ep * capn;
   PrrtSummary& sum = B.summary[ep];
   const double gx = readfirst_f64(B.goal[2 * (size_t)ep]), gy = readfirst_f64(B.goal[2 * (size_t)ep + 1]);
   const bool logst = (P.flags & 1) != 0 && B.st_log != nullptr;
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       b = uni(occupied[rng_randbelow(rng, (uint32_t)n_occ)]);
     }
     const int cnt_b = uni(bcount[b]);
+    const int head_b = bhead[b];  // (requested with the count; used only when the bucket is not empty)
     last_accepted = 0; last_new = -1;
     if (cnt_b == 0) {  // generate_one_node on an empty bucket: (False, None) (:214-220, input() not reproduced)
       if (logst && lane == 0) {
@@ -214,8 +222,15 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
     }
     const int rsel = (int)rng_randbelow(rng, (uint32_t)cnt_b);
     int par = -1;
-    // the rsel-th node (list order) whose bucket is b: 256 bucket ids are requested at a time so their loads
-    // overlap (one dependent round trip per 256 nodes instead of per 64)
+    // the rsel-th node (list order) whose bucket is b.  A few steps along the bucket's member list when the node is
+    // near its head ...
+    const int hops = cnt_b - 1 - rsel;
+    if (hops <= 6) {
+      par = uni(head_b);
+      for (int q = 0; q < hops; q++) par = uni(nnext[par]);
+    }
+    // ... else a scan of the bucket ids: 256 are requested at a time so their loads overlap (one dependent round trip per
+    // 256 nodes instead of per 64)
     for (int base = 0, seen = 0; base < n_nodes && par < 0; base += 256) {
       int v[4];
 #pragma unroll
@@ -378,6 +393,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
       if (__any(idx_err)) { status = -1; break; }
       bk = uni(bk);
       const int c_before = bk >= 0 ? uni(bcount[bk]) : -1;
+      const int h_before = bk >= 0 ? uni(bhead[bk]) : -1;
       if (lane == 0) {
         double* nf = nodeF + (size_t)me * 4;
         *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
@@ -385,6 +401,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) vo
         nodeI[me] = make_int4(step, par, n_points, cnt);
         nbucket[me] = bk;
         if (bk >= 0) {
+          nnext[me] = c_before > 0 ? h_before : -1;
+          bhead[bk] = me;
           bcount[bk] = c_before + 1;
           if (c_before == 0) occupied[n_occ] = bk;  // first node of the bucket (:157-159)
         }
@@ -617,7 +635,9 @@ __global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuf
   if (bk >= 0) {
     B.bucket_counts[(size_t)e * P.n_buckets + bk] = 1;
     B.occupied[(size_t)e * B.cap_nodes] = bk;
+    B.bucket_head[(size_t)e * P.n_buckets + bk] = 0;
   }
+  B.node_next[(size_t)e * B.cap_nodes] = -1;
   PrrtSummary s;
   s.status = err ? -1 : 0; s.n_nodes = 1; s.n_points = 0; s.n_occ = bk >= 0 ? 1 : 0; s.steps = 0; s.done = 0;
   s.path_len = 0; s.last_node = 0; s.last_accepted = 0; s.last_new_node = -1; s.n_arc = 0; s._pad = 0;
