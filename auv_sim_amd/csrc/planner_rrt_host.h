@@ -33,11 +33,25 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode) {
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipError_t le;
-  if (O <= 64) le = launch(auvp::prrt_kernel<1>);
-  else if (O <= 128) le = launch(auvp::prrt_kernel<2>);
-  else if (O <= 256) le = launch(auvp::prrt_kernel<4>);
-  else if (O <= 512) le = launch(auvp::prrt_kernel<8>);
-  else le = launch(auvp::prrt_kernel<16>);
+  // latency run (at most two waves per SIMD on this GPU) or throughput run: the register budget differs (planner_rrt_kernel.h)
+  int n_cu_l = 256;
+  (void)hipDeviceGetAttribute(&n_cu_l, hipDeviceAttributeMultiprocessorCount, h->device);
+  if (n_cu_l <= 0) n_cu_l = 256;
+  const char* lenv = getenv("AUVP_PRRT_LAT");
+  const bool lat = lenv ? atoi(lenv) != 0 : S.E <= 8 * n_cu_l;
+  if (lat) {
+    if (O <= 64) le = launch(auvp::prrt_kernel<1, true>);
+    else if (O <= 128) le = launch(auvp::prrt_kernel<2, true>);
+    else if (O <= 256) le = launch(auvp::prrt_kernel<4, true>);
+    else if (O <= 512) le = launch(auvp::prrt_kernel<8, true>);
+    else le = launch(auvp::prrt_kernel<16, true>);
+  } else {
+    if (O <= 64) le = launch(auvp::prrt_kernel<1, false>);
+    else if (O <= 128) le = launch(auvp::prrt_kernel<2, false>);
+    else if (O <= 256) le = launch(auvp::prrt_kernel<4, false>);
+    else if (O <= 512) le = launch(auvp::prrt_kernel<8, false>);
+    else le = launch(auvp::prrt_kernel<16, false>);
+  }
   HIPCHK(h, le);
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

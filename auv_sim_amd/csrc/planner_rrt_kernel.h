@@ -125,9 +125,11 @@ __device__ __forceinline__ bool prrt_hits(const double (&ox)[J], const double (&
   return __any(hit != 0);
 }
 
-template <int J>
-// (five waves per SIMD = 96 VGPRs, two spilled; six or eight spill 35+ and measure slower)
-__global__ __launch_bounds__(RRT_WAVES * 64, (J <= 4 ? 5 : (J <= 8 ? 2 : 1))) void prrt_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
+// Two register budgets per J: batches that fill the chip run five waves per SIMD (96 VGPRs, a few spilled; six or eight
+// spill 35+ and measure slower); batches that leave most SIMDs with one wave (config 4: 512 episodes) are latency runs
+// and take the whole register file (LAT: no spills, no scalar spills into vector lanes).
+template <int J, bool LAT>
+__global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 2 : 1)))) void prrt_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
