@@ -207,7 +207,12 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
     B.exp_log = S.exp_log.as<double>();
   }
   const int grid = (E + auvp::ASTAR_WAVES - 1) / auvp::ASTAR_WAVES;
-  hipLaunchKernelGGL(auvp::astar_kernel, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E);
+  switch (P.variant) {
+    case 0: hipLaunchKernelGGL(auvp::astar_kernel<0>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
+    case 1: hipLaunchKernelGGL(auvp::astar_kernel<1>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
+    case 2: hipLaunchKernelGGL(auvp::astar_kernel<2>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
+    default: hipLaunchKernelGGL(auvp::astar_kernel<3>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
+  }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -129,6 +129,8 @@ constexpr int ASTAR_OPEN_CAP = 768;
 constexpr int ASTAR_MAX_BINS = 64;
 constexpr int ASTAR_LDS_OBST = 256, ASTAR_LDS_POLY = 64, ASTAR_LDS_GRID = 256;
 
+// one instantiation per variant (VARIANT = AstarParamsDev::variant): the other variants' state and branches are gone
+template <int VARIANT>
 __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W, AstarParamsDev P, AstarBuffers B, int n_inst) {
   __shared__ int32_t s_hopen[ASTAR_WAVES][ASTAR_MAX_HAB];
   __shared__ int32_t s_hclosed[ASTAR_WAVES][ASTAR_MAX_HAB];
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     for (int i = threadIdx.x; i < 2 * (W.g_ncol + W.g_nrow); i += blockDim.x) s_grid[i] = W.gx0[i];  // one contiguous upload
   __syncthreads();
   if (ep >= n_inst) return;  // no workgroup barrier after this point
-  const int V = P.variant;
+  constexpr int V = VARIANT;
   const int cap = P.cap_nodes;
   double* nd = B.nodes + (size_t)ep * 7 * cap;
   double *nx = nd, *ny = nd + cap, *ng = nd + 2 * (size_t)cap, *nh = nd + 3 * (size_t)cap, *nf = nd + 4 * (size_t)cap,
