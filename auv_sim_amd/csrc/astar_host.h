@@ -170,8 +170,8 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
   if (p->variant <= 1) { if ((rc = upload(h, S.goal, goals, (size_t)E * 2))) return rc; B.goal = S.goal.as<double>(); }
   else { if ((rc = upload(h, S.limit, limits, (size_t)E))) return rc; B.limit = S.limit.as<double>(); }
   const size_t cn = (size_t)E * p->cap_nodes;
-  HIPCHK(h, S.nodes.reserve(cn * 7 * sizeof(double)));
-  HIPCHK(h, S.node_i.reserve(cn * 3 * sizeof(int32_t)));
+  HIPCHK(h, S.nodes.reserve(cn * 9 * sizeof(double)));
+  HIPCHK(h, S.node_i.reserve(cn * sizeof(int32_t)));
   HIPCHK(h, S.summary.reserve((size_t)E * sizeof(auvp::AstarSummary)));
   const int H = S.W.n_habitats;
   HIPCHK(h, S.hab_left.reserve((size_t)E * (H > 0 ? H : 1) * sizeof(int32_t)));

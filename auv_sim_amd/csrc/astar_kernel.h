@@ -79,8 +79,11 @@ struct AstarBuffers {
   const double* start;   // [E,2]
   const double* goal;    // [E,2]   (variants 0,1)
   const double* limit;   // [E]     (variants 2,3)
-  double* nodes;         // [E][7][cap_nodes] SoA x, y, g, h, f, cost, pathLen
-  int32_t* node_i;       // [E][3][cap_nodes] parent, time_stamp, open
+  // [E][cap_nodes][8] node records {x, y, g, h | f, cost, pathLen, parent i32 : time_stamp i32} (64 B: one line per node --
+  // a pop reads one line, a child is four 16-byte stores), then [E][cap_nodes] f once more, contiguous, for the variants
+  // whose pop scans every open node
+  double* nodes;
+  int32_t* node_i;       // [E][cap_nodes] open flag
   // [E][vx*vy] one word per entry of the reference's visited_nodes array (variants 2,3):
   //   bits 31..24  epoch of the batch that wrote the word; a word of another epoch reads as "never touched", so a new
   //                batch needs no 360 KB-per-instance clear (the host bumps the epoch; a full clear every 255 batches)
@@ -165,11 +168,16 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   if (ep >= n_inst) return;  // no workgroup barrier after this point
   constexpr int V = VARIANT;
   const int cap = P.cap_nodes;
-  double* nd = B.nodes + (size_t)ep * 7 * cap;
-  double *nx = nd, *ny = nd + cap, *ng = nd + 2 * (size_t)cap, *nh = nd + 3 * (size_t)cap, *nf = nd + 4 * (size_t)cap,
-         *ncost = nd + 5 * (size_t)cap, *nlen = nd + 6 * (size_t)cap;
-  int32_t* ni = B.node_i + (size_t)ep * 3 * cap;
-  int32_t *npar = ni, *nts = ni + cap, *nopen = ni + 2 * (size_t)cap;
+  double4* rec = reinterpret_cast<double4*>(B.nodes + (size_t)ep * 8 * cap);  // two per node; 64-byte aligned
+  // f once more, contiguous, behind the records of all instances (the scan of the variants without an open list in LDS)
+  double* nf = B.nodes + (size_t)n_inst * 8 * cap + (size_t)ep * cap;
+  int32_t* nopen = B.node_i + (size_t)ep * cap;
+  auto put_node = [&](int c, double x, double y, double g, double hh, double f, double cost, double len, int par, int ts, int open) {
+    rec[2 * (size_t)c] = make_double4(x, y, g, hh);
+    rec[2 * (size_t)c + 1] = make_double4(f, cost, len, __longlong_as_double(((long long)ts << 32) | (long long)(uint32_t)par));
+    nf[c] = f;
+    nopen[c] = open;
+  };
   uint32_t* cellinfo = B.cellinfo ? B.cellinfo + (size_t)ep * P.vx * P.vy : nullptr;
   const uint32_t ep_tag = P.epoch << 24;
   int32_t* hopen = s_hopen[wave];
@@ -185,8 +193,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   int n_hopen = H, n_hclosed = 0;
   unsigned long long closedmask = 0ull;  // bit h: habitat h is in the closed list
   if (lane == 0) {
-    nx[0] = sx; ny[0] = sy; ng[0] = 0.0; nh[0] = 0.0; nf[0] = 0.0; ncost[0] = 0.0; nlen[0] = 0.0;
-    npar[0] = -1; nts[0] = 0; nopen[0] = 1;
+    put_node(0, sx, sy, 0.0, 0.0, 0.0, 0.0, 0.0, -1, 0, 1);
   }
   wave_sync();
   int n_nodes = 1, n_open = 1, n_exp = 0, n_children = 0, status = 0, found = -1, visited_count = 0;
@@ -263,8 +270,9 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     open_scanned += (unsigned long long)n_open;
     n_open--;
     if (cur == first_open) first_open++;
-    const double cxp = readfirst_f64(nx[cur]), cyp = readfirst_f64(ny[cur]);
-    const double cg = readfirst_f64(ng[cur]), ccost = readfirst_f64(ncost[cur]), clen = readfirst_f64(nlen[cur]);
+    const double4 cur_a = rec[2 * (size_t)cur], cur_b = rec[2 * (size_t)cur + 1];  // one line
+    const double cxp = readfirst_f64(cur_a.x), cyp = readfirst_f64(cur_a.y);
+    const double cg = readfirst_f64(cur_a.z), ccost = readfirst_f64(cur_b.y), clen = readfirst_f64(cur_b.z);
     bool stop;
     if (V == 0) stop = (cxp == gx && cyp == gy);
     else if (V == 1) stop = astar_sqdist(cxp, cyp, gx, gy) <= 100;
@@ -272,7 +280,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     if (stop) { found = cur; break; }
     if (logx && n_exp < P.cap_exp && lane == 0) {
       double* e = B.exp_log + ((size_t)ep * P.cap_exp + n_exp) * 8;
-      e[0] = cxp; e[1] = cyp; e[2] = cg; e[3] = nh[cur]; e[4] = nf[cur]; e[5] = ccost; e[6] = clen; e[7] = (double)nts[cur];
+      e[0] = cxp; e[1] = cyp; e[2] = cg; e[3] = cur_a.w; e[4] = cur_b.x; e[5] = ccost; e[6] = clen;
+      e[7] = (double)(int)(__double_as_longlong(cur_b.w) >> 32);
     }
     n_exp++;
     // ------------------------------------------------------------ neighbours: bounds, then collision
@@ -400,8 +409,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       const int open_ = was ? 0 : 1;
       if (mine) {
         const int c = n_nodes + __popc(childmask & ((1 << kk) - 1));
-        nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = g_; nlen[c] = len_;
-        npar[c] = cur; nts[c] = 0; nopen[c] = open_;
+        put_node(c, px, py, g_, h_, f_, g_, len_, cur, 0, open_);
         if (!was) cellinfo[vi] = ep_tag | 0x10000u;
       }
       const unsigned long long om = __ballot(mine && open_);
@@ -511,8 +519,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       const int open_ = was ? 0 : 1;
       if (mine) {
         const int c = n_nodes + __popc(childmask & ((1 << kk) - 1));
-        nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = g_; nlen[c] = len_;
-        npar[c] = cur; nts[c] = ts_; nopen[c] = open_;
+        put_node(c, px, py, g_, h_, f_, g_, len_, cur, ts_, open_);
         if (!was || need_key) cellinfo[vi] = ep_tag | 0x10000u | (uint32_t)(key + 1);  // visited from now on, key kept
       }
       const unsigned long long om = __ballot(mine && open_);
@@ -547,8 +554,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         break;  // V >= 2 is handled above (lane-parallel children); not reached
       }
       if (lane == 0) {
-        nx[c] = px; ny[c] = py; ng[c] = g_; nh[c] = h_; nf[c] = f_; ncost[c] = cost_; nlen[c] = len_;
-        npar[c] = cur; nts[c] = ts_; nopen[c] = open_;
+        put_node(c, px, py, g_, h_, f_, cost_, len_, cur, ts_, open_);
       }
       if (list_ok && open_) {
         if (n_list + 1 > ASTAR_OPEN_CAP) list_ok = false;
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     AstarSummary& s = B.summary[ep];
     s.status = status; s.found = found >= 0 ? 1 : 0; s.n_nodes = n_nodes; s.n_expansions = n_exp; s.n_children = n_children;
     int L = 0;
-    for (int m = found; m >= 0; m = npar[m]) L++;
+    for (int m = found; m >= 0; m = (int)(__double_as_longlong(rec[2 * (size_t)m + 1].w) & 0xffffffffll)) L++;
     s.path_len = L; s.smooth_len = 0; s.n_hab_left = n_hopen; s.visited_count = visited_count; s.leaf = found;
     s.open_scanned_lo = (uint32_t)(open_scanned & 0xffffffffull); s.open_scanned_hi = (uint32_t)(open_scanned >> 32);
   }
@@ -585,20 +591,21 @@ __global__ __launch_bounds__(64) void astar_path_kernel(AstarWorldDev W, AstarPa
   AstarSummary& s = B.summary[ep];
   if (!s.found || s.path_len <= 0) return;
   const int cap = P.cap_nodes, L = s.path_len;
-  const double* nd = B.nodes + (size_t)ep * 7 * cap;
-  const int32_t* ni = B.node_i + (size_t)ep * 3 * cap;
+  const double4* rec = reinterpret_cast<const double4*>(B.nodes + (size_t)ep * 8 * cap);
   const size_t o = (size_t)offsets[ep];
   double* pth = path + 3 * o;
   if (lane == 0) {
     int k = 0;
-    for (int m = s.leaf; m >= 0; m = ni[m], k++) {
-      cost_list[o + k] = nd[5 * (size_t)cap + m];
+    for (int m = s.leaf; m >= 0; k++) {
+      const double4 a = rec[2 * (size_t)m], b = rec[2 * (size_t)m + 1];
+      const long long pk = __double_as_longlong(b.w);
+      const int par = (int)(pk & 0xffffffffll), ts = (int)(pk >> 32);
+      cost_list[o + k] = b.y;
       double* e = pth + 3 * (size_t)(L - 1 - k);
-      e[0] = nd[m]; e[1] = nd[cap + m]; e[2] = (double)ni[cap + m];  // round(int, 2) == int
+      e[0] = a.x; e[1] = a.y; e[2] = (double)ts;  // round(int, 2) == int
       double* q = node_path + 8 * (o + (size_t)(L - 1 - k));
-      q[0] = nd[m]; q[1] = nd[cap + m]; q[2] = nd[2 * (size_t)cap + m]; q[3] = nd[3 * (size_t)cap + m];
-      q[4] = nd[4 * (size_t)cap + m]; q[5] = nd[5 * (size_t)cap + m]; q[6] = nd[6 * (size_t)cap + m];
-      q[7] = (double)ni[cap + m];
+      q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = (double)ts;
+      m = par;
     }
   }
   __threadfence_block();
