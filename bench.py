@@ -879,7 +879,7 @@ def main():
                                  bytes_per_expansion=abytes / iters_local,
                                  kernels_ms={kname: exp_ms, "rrt_leaf_kernel": leaf_ms}, episodes_per_wavefront=per_wave,
                                  launch={"grid": grid, "block": block, "lds_bytes": lds},
-                                 note="the expansion is fp64-VALU issue bound, the leaf pass HBM bound (DESIGN.md)"),
+                                 note="the expansion (94 % of the pass) is fp64-VALU issue bound, the leaf pass latency bound (DESIGN.md)"),
             "expansions_per_s_kernel_only": iters_local / (k_ms * 1e-3),
             "expansions_per_s_expansion_kernel_only": iters_local / (exp_ms * 1e-3),
             "kernel_ms_per_rank": k_all, "gather_ms_per_rank": g_all,
