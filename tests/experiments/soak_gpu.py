@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised GPU-vs-checker soak (run by hand on a GPU box: python tests/experiments/soak_gpu.py [n_cases] [seed]).
+"""Randomised GPU-vs-checker soak (run by hand on a GPU box: python tests/experiments/soak_gpu.py [n_cases] [seed] [big]).
 Every case draws a world and planner parameters at random and compares, bit for bit, the four-episode-per-wavefront
 kernel, the one-episode kernel and the CPU checker (RRT.exploring), the astar_fixLenSOG / astar_fixLen searches and
 Planner_RRT.planning with the checker.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
@@ -16,6 +16,7 @@ from oracle import orc, orc_astar as oa, orc_planner as op  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"  # fewer, longer RRT episodes (member-list chunks, thousands of leaves)
 ctx = _lib.Context(0)
 fails = 0
 
@@ -34,7 +35,7 @@ def rrt_case(i):
               min_dist=rng.choice([0.0, 0.5, 1.5]), bin_interval=rng.choice([2.5, 5.0, 20.0]), v=rng.choice([0.7, 2.0]),
               max_traj_time=rng.choice([40.0, 120.0, 500.0]),
               weights=(rng.choice([-3.0, 0.0, 2.5]), rng.choice([-3.0, -0.37, 4.0]), rng.choice([-4.0, 0.0, 1.7])))
-    E, n_iter = rng.choice([1, 5, 9]), rng.choice([200, 700, 1500])
+    E, n_iter = (rng.choice([1, 5, 9]), rng.choice([200, 700, 1500])) if not BIG else (2, rng.choice([4000, 8000]))
     ctx.set_world(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
     init = np.zeros((E, 6)); init[:, 0], init[:, 1] = w["start"]; init[:, 2] = np.linspace(-3, 3, E)
     seeds = np.array([rng.randrange(2 ** 40) for _ in range(E)], dtype=np.uint64)
