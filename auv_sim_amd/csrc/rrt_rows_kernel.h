@@ -73,22 +73,26 @@ struct RowRng {
   unsigned long long drawn;
 };
 
-// make sure every row that asks (`want`) has `need` words generated ahead of its consumer
+// make sure every row that asks (`want`) has `need` words generated ahead of its consumer.  The generation frontier
+// pslot + avail is kept a multiple of 16 (624 = 39 x 16; it starts at 624 = 0): whole 16-word blocks are regenerated, so
+// a block never wraps and lane rl's word is block + rl.
 __device__ __forceinline__ void rows_ensure(RowRng& r, bool want, uint32_t need, int rl) {
   for (;;) {
     const bool go = want && r.avail < need;
     if (!__any(go)) break;
     // up to 32 words per row and round, two per lane (words 227 apart are independent, so any 32 consecutive are)
-    uint32_t n = 624u - r.avail;
+    uint32_t n = (624u - r.avail) & ~15u;
     n = n < 32u ? n : 32u;
     n = go ? n : 0u;
+    uint32_t f0 = r.pslot + r.avail;
+    f0 = f0 >= 624u ? f0 - 624u : f0;
     uint32_t v2[2], kk[2];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      uint32_t k = r.pslot + r.avail + (uint32_t)rl + 16u * (uint32_t)h;
-      k = k >= 624u ? k - 624u : k;
-      k = k >= 624u ? k - 624u : k;
-      const uint32_t k1 = (k + 1u == 624u) ? 0u : k + 1u;
+      uint32_t fh = f0 + 16u * (uint32_t)h;
+      fh = fh >= 624u ? fh - 624u : fh;
+      const uint32_t k = fh + (uint32_t)rl;
+      const uint32_t k1 = (k == 623u) ? 0u : k + 1u;
       uint32_t km = k + 397u;
       km = km >= 624u ? km - 624u : km;
       const uint32_t a = r.s[k], b = r.s[k1], c = r.s[km];
@@ -97,8 +101,8 @@ __device__ __forceinline__ void rows_ensure(RowRng& r, bool want, uint32_t need,
       kk[h] = k;
     }
     wave_sync();  // every lane's reads are issued before any lane's write
-    if ((uint32_t)rl < n) r.s[kk[0]] = v2[0];
-    if ((uint32_t)rl + 16u < n) r.s[kk[1]] = v2[1];
+    if (n >= 16u) r.s[kk[0]] = v2[0];
+    if (n >= 32u) r.s[kk[1]] = v2[1];
     wave_sync();
     r.avail += n;
   }
