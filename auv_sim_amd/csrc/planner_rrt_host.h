@@ -21,9 +21,15 @@ PrrtState* prrt_of(auvp_handle* h);
 int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode) {
   S.P.step_mode = step_mode;
   const int nfreq = (int)std::floor(S.P.freq);
-  const size_t lds = (size_t)auvp::RRT_WAVES * auvp::prrt_lds_per_wave(S.B.max_pts, nfreq);
-  if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB", lds);
   const int grid = (S.E + auvp::RRT_WAVES - 1) / auvp::RRT_WAVES;
+  // latency run (at most two waves per SIMD on this GPU) or throughput run: register budget and steer differ (planner_rrt_kernel.h)
+  int n_cu_l = 256;
+  (void)hipDeviceGetAttribute(&n_cu_l, hipDeviceAttributeMultiprocessorCount, h->device);
+  if (n_cu_l <= 0) n_cu_l = 256;
+  const char* lenv = getenv("AUVP_PRRT_LAT");
+  const bool lat = lenv ? atoi(lenv) != 0 : S.E <= 8 * n_cu_l;
+  const size_t lds = (size_t)auvp::RRT_WAVES * auvp::prrt_lds_per_wave(S.B.max_pts, nfreq, lat);
+  if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB", lds);
   const int O = h->W.n_obstacles;
   auto launch = [&](auto kern) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -33,12 +39,6 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode) {
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipError_t le;
-  // latency run (at most two waves per SIMD on this GPU) or throughput run: the register budget differs (planner_rrt_kernel.h)
-  int n_cu_l = 256;
-  (void)hipDeviceGetAttribute(&n_cu_l, hipDeviceAttributeMultiprocessorCount, h->device);
-  if (n_cu_l <= 0) n_cu_l = 256;
-  const char* lenv = getenv("AUVP_PRRT_LAT");
-  const bool lat = lenv ? atoi(lenv) != 0 : S.E <= 8 * n_cu_l;
   if (lat) {
     if (O <= 64) le = launch(auvp::prrt_kernel<1, true>);
     else if (O <= 128) le = launch(auvp::prrt_kernel<2, true>);

@@ -58,9 +58,14 @@ struct PrrtBuffers {
   int32_t* st_log;       // optional [E][max_step][8]: bucket, picked, accepted, done, npath, arc_n, arc_free, -
 };
 
-__host__ __device__ inline int prrt_lds_per_wave(int max_pts, int nfreq) {
-  (void)nfreq;  // the steer works across lanes: LDS holds the generator state and the path points only
-  return 624 * 4 + ((max_pts * 16 + 15) & ~15);
+// LDS per wave: the generator state and the path points; the throughput instantiation adds its steer scratch
+__host__ __device__ inline int prrt_lds_per_wave(int max_pts, int nfreq, bool lat) {
+  const int base = 624 * 4 + ((max_pts * 16 + 15) & ~15);
+  if (lat) return base;
+  const int C = nfreq < 1 ? 1 : (nfreq > 63 ? 63 : nfreq);
+  const int u = (2 * C + 2) * 8;
+  const int sb = ((C + 1) * 6 + 4) * 8;  // inc[(C+1)*3], sc[(C+1)*2], phi[C+1], path bounding box [4]
+  return base + (((u > sb ? u : sb) + 15) & ~15);
 }
 
 // angle_wrap (:425-433)
@@ -137,10 +142,18 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
   if (ep >= n_episodes) return;
   const int nfreq = (int)P.freq;
   const int C = nfreq < 1 ? 1 : (nfreq > 63 ? 63 : nfreq);
-  const int per_wave = prrt_lds_per_wave(B.max_pts, nfreq);
+  const int per_wave = prrt_lds_per_wave(B.max_pts, nfreq, LAT);
   unsigned char* wbase = smem + (size_t)wave * per_wave;
   uint32_t* mt = reinterpret_cast<uint32_t*>(wbase);
   double(*pts)[2] = reinterpret_cast<double(*)[2]>(wbase + 624 * 4);
+  // steer scratch of the throughput instantiation, behind the path points
+  double* scratch = reinterpret_cast<double*>(wbase + 624 * 4 + ((B.max_pts * 16 + 15) & ~15));
+  double* u_win = scratch;                        // [2C+2]
+  double* inc = scratch;                          // [(C+1)*3]  aliases u_win
+  double* sc = scratch + (size_t)(C + 1) * 3;     // [(C+1)*2]
+  double* phi_l = scratch + (size_t)(C + 1) * 5;  // [C+1]
+  double* bbox_l = scratch + (size_t)(C + 1) * 6;  // [4] xmin, ymin, xmax, ymax of the steer
+  (void)u_win; (void)inc; (void)sc; (void)phi_l; (void)bbox_l;
 
   const int step_bucket = P.step_mode ? uni(B.step_bucket[ep]) : 0;
   if (P.step_mode && step_bucket < 0) return;
@@ -269,68 +282,158 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
       const int lo = __shfl((int)(bits & 0xffffffffll), src, 64), hi = __shfl((int)(bits >> 32), src, 64);
       return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
     };
-    for (int c0 = 0; c0 < n_total; c0 += C) {
-      const int n = (n_total - c0) < C ? (n_total - c0) : C;
-      rng_ensure(rng, (uint32_t)(4 * n));
-      // sub-arc s draws random() numbers 2s (dist) and 2s + 1 (diff) of the chunk: every lane tempers its own two
-      const bool active = lane < n;
-      double radius = 0.0, phi = 0.0;
-      bool taken = false;
-      if (active) {
-        double dist = py_uniform(0.0, P.dist_to_end, rng_random_at(rng, (uint32_t)(2 * lane)));
-        double diff = py_uniform(-P.diff_max, P.diff_max, rng_random_at(rng, (uint32_t)(2 * lane + 1)));
-        taken = auvp_fabs(dist) > auvp_fabs(diff);
-        if (taken) {
-          double s1 = dist + diff, s2 = dist - diff;
-          radius = (s1 + s2) / (-s1 + s2);
-          phi = (s1 + s2) / (2 * radius);
+    if constexpr (LAT) {
+      // latency runs: nothing staged in LDS -- every lane tempers its own two draws, the theta and x/y/t chains are
+      // uniform loops over cross-lane reads
+      for (int c0 = 0; c0 < n_total; c0 += C) {
+        const int n = (n_total - c0) < C ? (n_total - c0) : C;
+        rng_ensure(rng, (uint32_t)(4 * n));
+        // sub-arc s draws random() numbers 2s (dist) and 2s + 1 (diff) of the chunk: every lane tempers its own two
+        const bool active = lane < n;
+        double radius = 0.0, phi = 0.0;
+        bool taken = false;
+        if (active) {
+          double dist = py_uniform(0.0, P.dist_to_end, rng_random_at(rng, (uint32_t)(2 * lane)));
+          double diff = py_uniform(-P.diff_max, P.diff_max, rng_random_at(rng, (uint32_t)(2 * lane + 1)));
+          taken = auvp_fabs(dist) > auvp_fabs(diff);
+          if (taken) {
+            double s1 = dist + diff, s2 = dist - diff;
+            radius = (s1 + s2) / (-s1 + s2);
+            phi = (s1 + s2) / (2 * radius);
+          }
         }
-      }
-      const unsigned long long tmask = __ballot(taken);
-      // theta = angle_wrap(theta + phi) for the taken sub-arcs only, left to right: a uniform loop over the sub-arcs (phi of
-      // lane s read across the wave); lane s keeps the angle after its step, idle lanes the chunk-entry angle
-      double th = cth, myth = cth;
-      for (int s = 0; s < n; s++) {
-        if ((tmask >> s) & 1ull) th = prrt_angle_wrap(th + readlane_f64(phi, s));
-        if (lane == s) myth = th;
-      }
-      double sn, cs;
-      auvp_sincos(myth, &sn, &cs);
-      double dx = 0.0, dy = 0.0, dt = 0.0;
-      {
-        // sin / cos of the previous TAKEN sub-arc's angle (lane C is idle: it holds the chunk-entry angle)
-        const unsigned long long below = tmask & ((1ull << lane) - 1ull);
-        const int prev = below ? (63 - __clzll((long long)below)) : C;
-        const double so = lane_f64(sn, prev), co = lane_f64(cs, prev);
+        const unsigned long long tmask = __ballot(taken);
+        // theta = angle_wrap(theta + phi) for the taken sub-arcs only, left to right: a uniform loop over the sub-arcs (phi of
+        // lane s read across the wave); lane s keeps the angle after its step, idle lanes the chunk-entry angle
+        double th = cth, myth = cth;
+        for (int s = 0; s < n; s++) {
+          if ((tmask >> s) & 1ull) th = prrt_angle_wrap(th + readlane_f64(phi, s));
+          if (lane == s) myth = th;
+        }
+        double sn, cs;
+        auvp_sincos(myth, &sn, &cs);
+        double dx = 0.0, dy = 0.0, dt = 0.0;
+        {
+          // sin / cos of the previous TAKEN sub-arc's angle (lane C is idle: it holds the chunk-entry angle)
+          const unsigned long long below = tmask & ((1ull << lane) - 1ull);
+          const int prev = below ? (63 - __clzll((long long)below)) : C;
+          const double so = lane_f64(sn, prev), co = lane_f64(cs, prev);
+          if (taken) {
+            dx = radius * (sn - so);
+            dy = radius * (-cs + co);
+            dt = auvp_sqrt(dx * dx + dy * dy) / 1;
+          }
+        }
+        // x += dx; y += dy; t += dt, left to right (untaken sub-arcs add an exact 0.0): the same uniform loop
+        double mx = 0.0, my = 0.0, mt_ = 0.0;
+        for (int s = 0; s < n; s++) {
+          cx = cx + readlane_f64(dx, s);
+          cy = cy + readlane_f64(dy, s);
+          ctt = ctt + readlane_f64(dt, s);
+          bbx0 = __builtin_fmin(cx, bbx0); bbx1 = __builtin_fmax(cx, bbx1);  // (nothing here is NaN)
+          bby0 = __builtin_fmin(cy, bby0); bby1 = __builtin_fmax(cy, bby1);
+          if (lane == s) { mx = cx; my = cy; mt_ = ctt; }
+        }
+        cth = th;
+        const int napp = __popcll(tmask);
+        if (n_points + cnt + napp > (int)capp || cnt + napp + 2 > B.max_pts) { cap_err = true; break; }
         if (taken) {
+          int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+          size_t gi = (size_t)(n_points + cnt + rank);
+          ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * capp + gi] = myth; ptF[3 * capp + gi] = mt_;
+          pts[cnt + rank + 1][0] = mx;
+          pts[cnt + rank + 1][1] = my;
+        }
+        cnt += napp;
+        rng_advance_words(rng, (uint32_t)(4 * n));
+        wave_sync();
+      }
+    } else {
+      // throughput runs: the round-1 steer (draw window, theta chain on one lane, x/y/t chains on three lanes, all through
+      // the wave's LDS scratch): fewer instructions per step, more latency
+      for (int c0 = 0; c0 < n_total; c0 += C) {
+        const int n = (n_total - c0) < C ? (n_total - c0) : C;
+        rng_ensure(rng, (uint32_t)(4 * n));
+        for (int jj = lane; jj < 2 * n; jj += 64) u_win[jj] = rng_random_at(rng, (uint32_t)jj);
+        wave_sync();
+        const bool active = lane < n;
+        double radius = 0.0, phi = 0.0;
+        bool taken = false;
+        if (active) {
+          double dist = py_uniform(0.0, P.dist_to_end, u_win[2 * lane]);
+          double diff = py_uniform(-P.diff_max, P.diff_max, u_win[2 * lane + 1]);
+          taken = auvp_fabs(dist) > auvp_fabs(diff);
+          if (taken) {
+            double s1 = dist + diff, s2 = dist - diff;
+            radius = (s1 + s2) / (-s1 + s2);
+            phi = (s1 + s2) / (2 * radius);
+          }
+        }
+        const unsigned long long tmask = __ballot(taken);
+        wave_sync();
+        if (lane <= C) phi_l[lane] = phi;
+        wave_sync();
+        // theta = angle_wrap(theta + phi) for the taken sub-arcs only, left to right, one lane
+        if (lane == 0) {
+          double th = cth;
+          for (int s = 0; s < n; s++) {
+            if ((tmask >> s) & 1ull) th = prrt_angle_wrap(th + phi_l[s]);
+            phi_l[s] = th;
+          }
+        }
+        wave_sync();
+        const double myth = active ? phi_l[lane] : cth;
+        double sn, cs;
+        auvp_sincos(myth, &sn, &cs);
+        if (lane <= C) { sc[2 * lane] = sn; sc[2 * lane + 1] = cs; }
+        wave_sync();
+        double dx = 0.0, dy = 0.0, dt = 0.0;
+        if (taken) {
+          unsigned long long below = tmask & ((1ull << lane) - 1ull);
+          int prev = below ? (63 - __clzll((long long)below)) : C;
+          double so = sc[2 * prev], co = sc[2 * prev + 1];
           dx = radius * (sn - so);
           dy = radius * (-cs + co);
           dt = auvp_sqrt(dx * dx + dy * dy) / 1;
         }
+        if (active) { inc[3 * lane] = dx; inc[3 * lane + 1] = dy; inc[3 * lane + 2] = dt; }
+        wave_sync();
+        if (lane < 3) {
+          double acc = lane == 0 ? cx : (lane == 1 ? cy : ctt);
+          // lanes 0/1 also track the extent of x / y over every prefix position (= the path points and their parent)
+          double bmin = acc, bmax = acc;
+          if (c0 != 0 && lane < 2) { bmin = bbox_l[lane]; bmax = bbox_l[2 + lane]; }
+  #pragma unroll 4
+          for (int s = 0; s < n; s++) {
+            acc = acc + inc[3 * s + lane];
+            inc[3 * s + lane] = acc;
+            bmin = __builtin_fmin(acc, bmin);  // v_min_f64 / v_max_f64; nothing here is NaN
+            bmax = __builtin_fmax(acc, bmax);
+          }
+          if (lane < 2) { bbox_l[lane] = bmin; bbox_l[2 + lane] = bmax; }
+        }
+        wave_sync();
+        double mx = 0.0, my = 0.0, mt_ = 0.0;
+        if (active) { mx = inc[3 * lane]; my = inc[3 * lane + 1]; mt_ = inc[3 * lane + 2]; }
+        const int napp = __popcll(tmask);
+        if (n_points + cnt + napp > (int)capp || cnt + napp + 2 > B.max_pts) { cap_err = true; break; }
+        if (taken) {
+          int rank = __popcll(tmask & ((1ull << lane) - 1ull));
+          size_t gi = (size_t)(n_points + cnt + rank);
+          ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * capp + gi] = myth; ptF[3 * capp + gi] = mt_;
+          pts[cnt + rank + 1][0] = mx;
+          pts[cnt + rank + 1][1] = my;
+        }
+        cnt += napp;
+        if (n > 0) {
+          cx = readlane_f64(mx, n - 1); cy = readlane_f64(my, n - 1); ctt = readlane_f64(mt_, n - 1);
+          cth = readlane_f64(myth, n - 1);
+        }
+        rng_advance_words(rng, (uint32_t)(4 * n));
+        wave_sync();
       }
-      // x += dx; y += dy; t += dt, left to right (untaken sub-arcs add an exact 0.0): the same uniform loop
-      double mx = 0.0, my = 0.0, mt_ = 0.0;
-      for (int s = 0; s < n; s++) {
-        cx = cx + readlane_f64(dx, s);
-        cy = cy + readlane_f64(dy, s);
-        ctt = ctt + readlane_f64(dt, s);
-        bbx0 = __builtin_fmin(cx, bbx0); bbx1 = __builtin_fmax(cx, bbx1);  // (nothing here is NaN)
-        bby0 = __builtin_fmin(cy, bby0); bby1 = __builtin_fmax(cy, bby1);
-        if (lane == s) { mx = cx; my = cy; mt_ = ctt; }
-      }
-      cth = th;
-      const int napp = __popcll(tmask);
-      if (n_points + cnt + napp > (int)capp || cnt + napp + 2 > B.max_pts) { cap_err = true; break; }
-      if (taken) {
-        int rank = __popcll(tmask & ((1ull << lane) - 1ull));
-        size_t gi = (size_t)(n_points + cnt + rank);
-        ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * capp + gi] = myth; ptF[3 * capp + gi] = mt_;
-        pts[cnt + rank + 1][0] = mx;
-        pts[cnt + rank + 1][1] = my;
-      }
-      cnt += napp;
-      rng_advance_words(rng, (uint32_t)(4 * n));
       wave_sync();
+      if (n_total > 0) { bbx0 = bbox_l[0]; bby0 = bbox_l[1]; bbx1 = bbox_l[2]; bby1 = bbox_l[3]; }
     }
     if (cap_err) { status = -2; break; }
     wave_sync();
