@@ -250,7 +250,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
           const int c = __popcll(bal);
           if (seen + c > rsel) {
             const int want = rsel - seen;
-            const unsigned long long sel = __ballot(is && __popcll(bal & ((1ull << lane) - 1ull)) == want);
+            const unsigned long long sel = __ballot(is && (int)__popcll(bal & ((1ull << lane) - 1ull)) == want);
             par = base + 64 * k + (__ffsll((long long)sel) - 1);
           }
           seen += c;

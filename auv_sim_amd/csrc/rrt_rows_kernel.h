@@ -187,7 +187,6 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   int n_nodes = 1, n_points = 0, status = 0, n_cand = 0, iters_run = 0;
   // lane rl keeps the bounding box of obstacle slot rl: one compare round tells which slots a steer can touch
   const double4 sbox = reinterpret_cast<const double4*>(W.os_box)[rl];
-  const int nfreq = (int)Q.freq;
   const int nv_poly = W.n_poly;
 
   for (int it = 0; it < P.max_iter; it++) {
