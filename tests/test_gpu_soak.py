@@ -1,0 +1,18 @@
+"""A short run of the randomised GPU-vs-checker sweep (tests/experiments/soak_gpu.py): random worlds and planner parameters
+through every RRT.exploring kernel / cull variant, astar_fixLenSOG / astar_fixLen and Planner_RRT.planning, bit for bit."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_random_cases_match_the_checker(seed):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "experiments", "soak_gpu.py"), "10", str(seed)],
+                       cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
