@@ -380,6 +380,14 @@ def bench_rrt_o64(ctx, args, n_ep=None):
     return out
 
 
+def bench_rrt_replicas(ctx, args, n_ep=1024):
+    """SURVEY 8(d) config 2, throughput test: 1 024 replicas of the 64-obstacle episode (seeds 0..1023) -- one wavefront per
+    SIMD, so this is the one-episode kernel running as many latency chains as the chip has SIMDs."""
+    out = _rrt_batch(ctx, bench_world(64, args.grid), n_ep, args)
+    out["metric"] = "RRT.exploring expansions/s, %d replicas, 64 obstacles, %dx%d cells" % (n_ep, args.grid, args.grid)
+    return out
+
+
 def bench_rrt_dense(ctx, args, with_cpu, n_ep=None):
     """Worlds where the exact collision test actually runs (the headline's 256 obstacles in 4 km^2 are sparse: the cull
     leaves well under one candidate per expansion).  (i) the G3 fixture world: 256 obstacles of r = 1-3 m in a 200 m box,
@@ -779,6 +787,7 @@ def main():
     sides = {
         "single_episode": lambda: bench_single_episode(ctx, world, args),
         "rrt_64_obstacles": lambda: bench_rrt_o64(ctx, args),
+        "rrt_1024_replicas": lambda: bench_rrt_replicas(ctx, args),
         "rrt_dense": lambda: bench_rrt_dense(ctx, args, with_cpu),
         "astar": lambda: bench_astar(ctx, ranks, with_cpu, variants=not args.no_variants),
         "planner_rrt": lambda: bench_planner(ctx, ranks, with_cpu),
@@ -894,7 +903,7 @@ def main():
             out["cpu_baseline"] = None
     if not args.no_extra:
         # the other configurations of the path: configs 3, 4 and 5 on every rank (sharded), the rest on rank 0's GPU
-        for name in ("single_episode", "rrt_64_obstacles", "rrt_dense", "astar", "planner_rrt", "config5", "shark_grid",
+        for name in ("single_episode", "rrt_64_obstacles", "rrt_1024_replicas", "rrt_dense", "astar", "planner_rrt", "config5", "shark_grid",
                      "particle_filter"):
             if name in sharded or rank == 0:
                 try:
