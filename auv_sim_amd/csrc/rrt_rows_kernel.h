@@ -397,13 +397,15 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
     // on with the tight box of the row's path points (and the parent's end) instead of the reach square -- the path
     // wanders inside a fraction of it, and an obstacle can only be hit if its bounding square meets that box.  The
     // sparse instance is the plain loop (the ~100 instructions of the tight box would cost more than they save there).
+    // (the extent used by the boundary test below: the reach square, or the tight box once the dense instance has it)
+    double ex0 = bx0, ey0 = by0, ex1 = bx1, ey1 = by1;
     auto cull_and_test = [&](auto tight_tag) {
       constexpr bool TIGHT = decltype(tight_tag)::value;
       const double hs = hx + slack;
       const bool slot_hit = live && !(sbox.z < px0 - hs || sbox.x > px0 + hs || sbox.w < py0 - hs || sbox.y > py0 + hs);
       uint32_t sm = row_ballot(slot_hit, rowbase);
       double tcx = px0, tcy = py0, thx = hx, thy = hx;
-      if (TIGHT && __any(sm != 0u)) {
+      if (TIGHT) {  // (dense worlds: nearly every steer has a slot within reach, and the boundary test profits as well)
         double mnx = px0, mxx = px0, mny = py0, mxy = py0;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -422,6 +424,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
         thx = (mxx - mnx) * 0.5 + ts; thy = (mxy - mny) * 0.5 + ts;
         const bool tight = slot_hit && !(sbox.z < mnx - ts || sbox.x > mxx + ts || sbox.w < mny - ts || sbox.y > mxy + ts);
         sm = row_ballot(tight, rowbase);
+        ex0 = mnx; ey0 = mny; ex1 = mxx; ey1 = mxy;
       }
       while (__any(sm != 0u)) {  // slots some row has to look into (none at all for most steers of a sparse world)
         const bool hs_ = sm != 0u;
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
     else cull_and_test(std::false_type{});
     // boundary: strictly inside an axis-aligned rectangle implies Point.within; otherwise the crossing test per point
     const double* sb = S.world->safe_box;
-    const bool box_inside = W.has_safe_box && bx0 > sb[0] && by0 > sb[1] && bx1 < sb[2] && by1 < sb[3];
+    const bool box_inside = W.has_safe_box && ex0 > sb[0] && ey0 > sb[1] && ex1 < sb[2] && ey1 < sb[3];
     bool outside = false;
     if (__any(live && !box_inside)) {
       // lane = path point (two passes' points + the parent's end on lane 15); edges of the polygon one at a time
