@@ -507,6 +507,43 @@ def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1, variants=T
     return out
 
 
+def bench_rrt_env(local_rank, n_env=512, n_steps=60):
+    """the batched RRTEnv (gym_rrt/envs/rrt_env.py:182-295) -- n_env environments of config 4's world stepped
+    together with a random occupied-bucket policy; one step = bucket upload + generate_one_node launch + observation kernel +
+    the observation dict on the HOST (rrt_grid [E, buckets, 4] f64, has_node, node counts: ~39 MB per step at 512 x 1 600
+    buckets, i.e. a PCIe figure), and the same with the observation left on the device (observation_to_device)."""
+    import torch
+    from auv_sim_amd import synth
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    from auv_sim_amd.rrt_env import RRTEnvBatch, R_CREATE_NODE
+    w = synth.make_rect_world(seed=3, n_obstacles=256)
+    obstacles = [MPS(o[0], o[1], size=o[2]) for o in w["obstacles"].tolist()]
+    bnd = [MPS(float(w["rect"][0]), float(w["rect"][1])), MPS(float(w["rect"][2]), float(w["rect"][3]))]
+    auv, shark = MPS(float(w["start"][0]), float(w["start"][1]), z=-5.0), MPS(float(w["goal"][0]), float(w["goal"][1]), z=-5.0)
+    env = RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=list(range(n_env)), max_nodes=n_steps + 8, freq=10, device=local_rank)
+    rng = np.random.default_rng(5)
+
+    def policy(st):
+        # a random bucket among those that hold a node (what an agent that respects the action mask does)
+        has = st["has_node"] != 0
+        return np.array([rng.choice(np.flatnonzero(h)) if h.any() else 0 for h in has], dtype=np.int64)
+    st = env.reset()
+    st, _, _, _ = env.step(policy(st))  # warm-up (allocations)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    created = 0
+    for _ in range(n_steps):
+        st, reward, done, _ = env.step(policy(st))
+        created += int((reward == R_CREATE_NODE).sum())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nb = env.n_buckets
+    return {"metric": "RRTEnv steps/s (batched env, host observation dict)", "value": n_env * n_steps / dt, "unit": "env-steps/s",
+            "envs": n_env, "steps": n_steps, "ms_per_batched_step": 1e3 * dt / n_steps, "buckets": nb,
+            "observation_bytes_per_step": int(n_env * nb * (32 + 8 + 8)), "nodes_created": created,
+            "note": "includes the numpy policy on the host and the download of the full observation arrays"}
+
+
 def bench_planner(ctx, ranks, with_cpu, n_ep=512, max_step=2000, steps=5, warmup=1):
     """BASELINE config 4: 512 Planner_RRT.planning(max_step=2000) episodes, 200 m x 200 m rectangle, 256 obstacles, cell
     5 m, 1 theta subsection, freq 10, start (20,20) -> goal (170,180), seed = global episode id; block-sharded over the
@@ -790,7 +827,8 @@ def main():
         "rrt_1024_replicas": lambda: bench_rrt_replicas(ctx, args),
         "rrt_dense": lambda: bench_rrt_dense(ctx, args, with_cpu),
         "astar": lambda: bench_astar(ctx, ranks, with_cpu, variants=not args.no_variants),
-        "planner_rrt": lambda: bench_planner(ctx, ranks, with_cpu),
+"rrt_env": lambda: bench_rrt_env(local_rank),
+                "planner_rrt": lambda: bench_planner(ctx, ranks, with_cpu),
         "config5": lambda: bench_config5(ctx, ranks),
         "shark_grid": lambda: bench_shark_grid(local_rank, with_cpu),
         "particle_filter": lambda: bench_particle_filter(local_rank, with_cpu),
@@ -903,7 +941,7 @@ def main():
             out["cpu_baseline"] = None
     if not args.no_extra:
         # the other configurations of the path: configs 3, 4 and 5 on every rank (sharded), the rest on rank 0's GPU
-        for name in ("single_episode", "rrt_64_obstacles", "rrt_1024_replicas", "rrt_dense", "astar", "planner_rrt", "config5", "shark_grid",
+        for name in ("single_episode", "rrt_64_obstacles", "rrt_1024_replicas", "rrt_dense", "astar", "planner_rrt", "rrt_env", "config5", "shark_grid",
                      "particle_filter"):
             if name in sharded or rank == 0:
                 try:
