@@ -33,12 +33,14 @@ class RRTSummary(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_nodes", C.c_int32), ("n_points", C.c_int32),
                 ("n_leaves", C.c_int32), ("best_leaf", C.c_int32), ("best_path_len", C.c_int32),
                 ("iters_run", C.c_int32), ("n_candidates", C.c_int32), ("best_cost", C.c_double * 4),
-                ("best_length", C.c_double), ("rng_after", C.c_double), ("leaf_elems", C.c_int64), ("n_draw32", C.c_uint64)]
+                ("best_length", C.c_double), ("rng_after", C.c_double), ("leaf_elems", C.c_int64), ("n_draw32", C.c_uint64),
+                ("nn_scanned", C.c_uint64)]
 
 
 SUMMARY_DTYPE = np.dtype([("status", "<i4"), ("n_nodes", "<i4"), ("n_points", "<i4"), ("n_leaves", "<i4"),
                           ("best_leaf", "<i4"), ("best_path_len", "<i4"), ("iters_run", "<i4"), ("n_candidates", "<i4"),
-                          ("best_cost", "<f8", (4,)), ("best_length", "<f8"), ("rng_after", "<f8"), ("leaf_elems", "<i8"), ("n_draw32", "<u8")])
+                          ("best_cost", "<f8", (4,)), ("best_length", "<f8"), ("rng_after", "<f8"), ("leaf_elems", "<i8"), ("n_draw32", "<u8"),
+                          ("nn_scanned", "<u8")])
 assert SUMMARY_DTYPE.itemsize == C.sizeof(RRTSummary)
 
 MODES = {"timebin": 0, "plantime": 1, "nn": 2}
@@ -106,6 +108,7 @@ def load():
     L.auvp_check_collision_batch.argtypes = [vp, C.c_int32, _ip, _dp, _bp]
     L.auvp_cost_paths.argtypes = [vp, C.c_int32, _ip, _dp, _ip, _ip, _dp, _dp, _dp]
     L.auvp_sincos_dev.argtypes = [vp, C.c_int32, _dp, _dp, _dp]
+    L.auvp_nn_closest_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _ip, _ip]
     L.auvp_random_stream_dev.argtypes = [vp, C.c_uint64, C.c_int32, _dp]
     L.auvp_rrt_phase_clocks.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.auvp_last_kernel_ms.argtypes = [vp]
@@ -284,6 +287,13 @@ class Context:
         out = np.zeros((n, 4))
         self._chk(self.L.auvp_cost_paths(self.h, n, _p(off, _ip), _p(pts), _p(lo, _ip), _p(hi, _ip), _p(tt), _p(w), _p(out)))
         return out
+
+    def nn_closest(self, xy, queries, force_exact=False):
+        """get_closest_mps (rrt_dubins.py:505-513) of every query point against the node list xy -> (index, slow-path flag)"""
+        xy, q = _f64(xy, (-1, 2)), _f64(queries, (-1, 2))
+        idx, slow = np.zeros(len(q), np.int32), np.zeros(len(q), np.int32)
+        self._chk(self.L.auvp_nn_closest_batch(self.h, len(xy), _p(xy), len(q), _p(q), 1 if force_exact else 0, _p(idx, _ip), _p(slow, _ip)))
+        return idx, slow.astype(bool)
 
     def sincos(self, x):
         x = _f64(x).ravel()

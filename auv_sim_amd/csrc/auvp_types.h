@@ -87,6 +87,7 @@ struct WorldDev {
 
 // kernel-internal bits of RrtParamsDev::flags (above the public AUVP_FLAG_* bits)
 #define AUVP_KFLAG_TIGHT_CULL 1024
+#define AUVP_KFLAG_NN_EXACT 2048  // nearest-neighbour scan: always rank the reference's way (sqrt per node); tests
 
 struct RrtParamsDev {
   double dist_to_end, diff_max, freq, min_dist, bin_interval, v, max_traj_time, max_plan_time;
@@ -102,6 +103,7 @@ struct RrtSummary {  // must match auvp_rrt_summary in include/auvplan.h
   double rng_after;
   long long leaf_elems;
   unsigned long long n_draw32;
+  unsigned long long nn_scanned;  // nearest-neighbour mode: sum over the iterations of len(mps_list) (16 B of x,y each)
 };
 
 // Per-episode tree storage, episode-major.  Nodes are records (one 16-B + one 64-B access per
@@ -113,6 +115,11 @@ struct RrtBuffers {
   // [E][cap_nodes][8]  x, y, theta, traj_t, length, S, tv, hab   (64 B per node); S/tv/hab: see below
   double* node_f;
   int32_t* node_i;   // [E][cap_nodes][4]  plan_iter, parent, pt_off, pt_cnt       (16 B per node)
+  // nearest-neighbour mode only: contiguous mirror of the nodes' x, y (16 B per node; what get_closest_mps :505-513 reads
+  // of every node, every iteration), [E][xy_stride] with xy_stride = cap_nodes rounded up to a whole scan block; entries
+  // past the tree's end hold +inf (never the nearest)
+  double* node_xy;
+  long long xy_stride;
   // [E] x { [cap_points][3] x, y, traj_t ; [cap_points][3] theta, v, length }: two 24-byte records per path point -- the
   // leaf pass reads only the first (half the bytes); a node's points are one contiguous run in both
   double* points;

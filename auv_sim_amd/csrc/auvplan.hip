@@ -60,7 +60,7 @@ struct auvp_handle {
   RrtBuffers B{};
   int max_pts = 0;
   DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_phase, d_node_c, d_node_q, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+      d_leaf_c, d_leaf_i, d_phase, d_node_c, d_node_q, d_node_xy, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
@@ -623,6 +623,14 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   B.points = h->d_points.as<double>();
   B.node_c = h->d_node_c.as<int32_t>();
   B.node_q = h->d_node_q.as<uint8_t>();
+  // nearest-neighbour sampling scans a contiguous x,y mirror of the nodes (auvp_types.h); the other modes never touch it
+  B.node_xy = nullptr;
+  B.xy_stride = 0;
+  if (p->mode == AUVP_MODE_NN) {
+    B.xy_stride = rrt_nn_stride(B.cap_nodes);
+    HIPCHK(h, h->d_node_xy.reserve((size_t)E * (size_t)B.xy_stride * 2 * sizeof(double)));
+    B.node_xy = h->d_node_xy.as<double>();
+  }
   B.bin_items = h->d_bin_items.as<int32_t>();
   B.bin_count = h->d_bin_count.as<int32_t>();
   B.summary = h->d_summary.as<RrtSummary>();
@@ -688,6 +696,7 @@ int auvp_rrt_run(auvp_handle* h) {
     const double lam = h->obst_area > 0.0 ? 4.0 * reach * reach * (double)O_ / h->obst_area : (O_ > 0 ? 1e9 : 0.0);
     const char* tenv = getenv("AUVP_TIGHT_CULL");
     if (tenv ? atoi(tenv) != 0 : lam > 0.5) PR.flags |= AUVP_KFLAG_TIGHT_CULL;
+    if (const char* ne = getenv("AUVP_NN_EXACT")) if (atoi(ne) != 0) PR.flags |= AUVP_KFLAG_NN_EXACT;
   }
   const int jslots = (O_ <= 64 ? 1 : (O_ <= 128 ? 2 : (O_ <= 256 ? 4 : (O_ <= 512 ? 8 : 16)))) * 64;
   const size_t lds = (size_t)rrt_lds_plan(P.K, h->max_pts, nfreq, jslots,

@@ -66,6 +66,17 @@ __global__ __launch_bounds__(64) void cost_probe_kernel(WorldDev W, int n_paths,
   }
 }
 
+// get_closest_mps (path_planning/rrt_dubins.py:505-513): one wave per query against one padded x,y table
+__global__ __launch_bounds__(64) void nn_probe_kernel(const double2* __restrict__ xy, int n_nodes, int n_queries,
+                                                      const double* __restrict__ q, int force_exact, int32_t* __restrict__ out,
+                                                      int32_t* __restrict__ slow) {
+  const int i = blockIdx.x;
+  if (i >= n_queries) return;
+  int sl = 0;
+  const int r = nn_closest(xy, n_nodes, readfirst_f64(q[2 * i]), readfirst_f64(q[2 * i + 1]), force_exact != 0, &sl);
+  if (lane_id() == 0) { out[i] = r; slow[i] = sl; }
+}
+
 __global__ void sincos_probe_kernel(int n, const double* __restrict__ x, double* __restrict__ s, double* __restrict__ c) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) auvp_sincos(x[i], &s[i], &c[i]);
@@ -137,6 +148,28 @@ int auvp_cost_paths(auvp_handle* h, int32_t n_paths, const int32_t* off, const d
                      h->d_tmp5.as<double>(), h->d_leaf_c.as<double>());
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(out4, h->d_leaf_c.p, (size_t)n_paths * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_nn_closest_batch(auvp_handle* h, int32_t n_nodes, const double* xy, int32_t n_queries, const double* q, int32_t force_exact,
+                          int32_t* out_index, int32_t* out_slow) {
+  if (!h || n_nodes <= 0 || n_queries < 0 || !xy || !q || !out_index) return AUVP_ERR_ARG;
+  if (n_queries == 0) return AUVP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t stride = (size_t)rrt_nn_stride(n_nodes);
+  std::vector<double> pad(stride * 2, INFINITY);  // the scan reads whole blocks: +inf past the end, as in the planner
+  memcpy(pad.data(), xy, (size_t)n_nodes * 2 * sizeof(double));
+  int rc;
+  if ((rc = upload(h, h->d_tmp0, pad.data(), pad.size()))) return rc;
+  if ((rc = upload(h, h->d_tmp1, q, (size_t)n_queries * 2))) return rc;
+  HIPCHK(h, h->d_tmp2.reserve((size_t)n_queries * sizeof(int32_t)));
+  HIPCHK(h, h->d_tmp3.reserve((size_t)n_queries * sizeof(int32_t)));
+  hipLaunchKernelGGL(nn_probe_kernel, dim3(n_queries), dim3(64), 0, h->stream, h->d_tmp0.as<double2>(), (int)n_nodes, (int)n_queries,
+                     h->d_tmp1.as<double>(), (int)force_exact, h->d_tmp2.as<int32_t>(), h->d_tmp3.as<int32_t>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out_index, h->d_tmp2.p, (size_t)n_queries * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+  if (out_slow) HIPCHK(h, hipMemcpyAsync(out_slow, h->d_tmp3.p, (size_t)n_queries * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return AUVP_OK;
 }

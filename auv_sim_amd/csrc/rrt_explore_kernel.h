@@ -363,8 +363,78 @@ __device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtTables& S,
   cost_accumulate(n_valid, tv, hab, term, acc);
 }
 
+// ---- get_closest_mps (path_planning/rrt_dubins.py:505-513) as a streaming scan ------------------------------------------
+// The reference walks mps_list and keeps the FIRST node with the smallest dist = RN(sqrt(dx**2 + dy**2)) (strict <).  The
+// scan reads the episode's contiguous x,y mirror (16 B per node: one global_load_dwordx4 per lane, RRT_NN_UNROLL of them in
+// flight per lane, 1 KB per wave-instruction) and ranks by the SQUARED distance -- sqrt is monotone, so the minimum of
+// RN(sqrt(d2)) is taken where d2 is smallest -- with two running minima per lane:
+//   bd / bt  smallest d2 of the lane's nodes and the block it first appeared in (strict <: the first of equal values)
+//   sd       second smallest d2 of the lane's nodes (counting multiplicity)
+// Afterwards gmin = wave minimum of bd.  Two different d2 can still round to the same sqrt; such a value lies within a few
+// ulps above gmin.  If no lane's bd or sd falls in (gmin, gmin (1 + 2^-49)] -- a lane's third smallest value cannot be
+// there unless its second is -- every node with RN(sqrt(d2)) == RN(sqrt(gmin)) has d2 == gmin exactly, and the answer is
+// the smallest index among them (duplicated positions are common: a steer with zero sub-arcs copies its parent).
+// Otherwise (never observed: it needs two nodes equidistant from the sample to 1e-15) the scan is repeated the reference's
+// way, sqrt per node.  Entries past the tree's end hold +inf: a block is always read whole.
+constexpr int RRT_NN_UNROLL = 8;
+constexpr int RRT_NN_BLOCK = 64 * RRT_NN_UNROLL;
+__host__ __device__ inline long long rrt_nn_stride(int cap_nodes) {
+  return ((long long)cap_nodes + RRT_NN_BLOCK - 1) / RRT_NN_BLOCK * RRT_NN_BLOCK;
+}
+
+// `force_exact` (wave-uniform): take the sqrt-per-node path regardless (tests); `*slow` reports which path ran.
+__device__ __forceinline__ int nn_closest(const double2* __restrict__ xy, int n_nodes, double rx, double ry, bool force_exact = false,
+                                          int* slow = nullptr) {
+  const int lane = lane_id();
+  const double inf = __builtin_inf();
+  double bd = inf, sd = inf;
+  int bt = 0;
+  for (int base = 0; base < n_nodes; base += RRT_NN_BLOCK) {
+    double2 q[RRT_NN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < RRT_NN_UNROLL; u++) q[u] = xy[base + u * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < RRT_NN_UNROLL; u++) {
+      const double ddx = rx - q[u].x, ddy = ry - q[u].y;
+      const double d2 = ddx * ddx + ddy * ddy;
+      const bool lt = d2 < bd;
+      sd = __builtin_fmin(sd, __builtin_fmax(bd, d2));  // the larger of {old minimum, newcomer} competes for second place
+      bd = lt ? d2 : bd;
+      bt = lt ? base + u * 64 : bt;
+    }
+  }
+  const double gmin = wave_min_f64(bd);
+  const double band = gmin + gmin * 0x1p-49;
+  const bool suspect = (bd > gmin && bd <= band) || (sd > gmin && sd <= band);
+  int cand = 0x7fffffff;
+  const bool exact = __any(suspect) || force_exact;
+  if (slow) *slow = exact ? 1 : 0;
+  if (!exact) {
+    const unsigned long long em = __ballot(bd == gmin);
+    if (__popcll(em) == 1) return uni(__builtin_amdgcn_readlane(bt, __ffsll((long long)em) - 1) + (__ffsll((long long)em) - 1));
+    cand = (bd == gmin) ? bt + lane : 0x7fffffff;
+  } else {
+    // the reference's own ranking
+    double bs = inf;
+    for (int m = lane; m < n_nodes; m += 64) {
+      const double2 q = xy[m];
+      const double ddx = rx - q.x, ddy = ry - q.y;
+      const double d = auvp_sqrt(ddx * ddx + ddy * ddy);
+      if (d < bs) { bs = d; cand = m; }
+    }
+    const double smin = wave_min_f64(bs);
+    cand = (bs == smin) ? cand : 0x7fffffff;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const int t = __shfl_xor(cand, o, 64);
+    cand = t < cand ? t : cand;
+  }
+  return uni(cand);
+}
+
 template <int J, int MODE, bool DIAG>
-__global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
+__global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 4 : 2) : (J <= 4 ? 6 : 2))) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
                                                                      int n_episodes, int max_pts) {
   extern __shared__ __align__(16) unsigned char smem[];
   const RrtTables S = rrt_tables_view(smem, W.n_habitats, W.n_poly);
@@ -419,6 +489,8 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   double* nodeF = B.node_f + (size_t)ep * capn * 8;                       // [capn][8] x,y,theta,t,length
   int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;    // plan_iter,parent,pt_off,pt_cnt
   uint8_t* nodeQ = B.node_q + (size_t)ep * capn;
+  double2* nodeXY = MODE == 2 ? reinterpret_cast<double2*>(B.node_xy) + (size_t)ep * (size_t)B.xy_stride : nullptr;
+  unsigned long long nn_scanned = 0ull;
   double* ptF = B.points + (size_t)ep * capp * 6;                         // [capp][3] x,y,t then [capp][3] theta,v,length
   const BinLists bins = bin_lists(B, (size_t)ep, P.K);
   int next_chunk = 0;
@@ -441,8 +513,13 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
   for (int i = lane; i < K + 2; i += 64) bin_count[i] = 0;
   wave_sync();
 
+  if (MODE == 2) {  // the x,y mirror starts out as +inf everywhere (a scan block is always read whole)
+    const double inf = __builtin_inf();
+    for (long long i = lane; i < B.xy_stride; i += 64) nodeXY[i] = make_double2(inf, inf);
+  }
   // mps_list = [initial]; time_bin[bin_interval].append(initial)  (:105,:114)
   if (lane == 0) {
+    if (MODE == 2) nodeXY[0] = make_double2(init[0], init[1]);
     nodeF[0] = init[0]; nodeF[1] = init[1]; nodeF[2] = init[2]; nodeF[3] = init[3]; nodeF[4] = init[5];
     nodeI[0] = make_int4(0, -1, 0, 0);
     nodeQ[0] = 0;  // the start state is never a leaf candidate
@@ -516,23 +593,9 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       double rx = py_uniform(W.bb[0], W.bb[2], rng_random_at(rng, 0));
       double ry = py_uniform(W.bb[1], W.bb[3], rng_random_at(rng, 1));
       rng_advance_words(rng, 8);
-      // get_closest_mps (:505-513): first index with the smallest RN(sqrt(d2))
-      double bd = __builtin_inf();
-      int bi = 0x7fffffff;
-      for (int m = lane; m < n_nodes; m += 64) {
-        const double2 xy = *reinterpret_cast<const double2*>(nodeF + (size_t)m * 8);
-        double ddx = rx - xy.x, ddy = ry - xy.y;
-        double d = auvp_sqrt(ddx * ddx + ddy * ddy);
-        if (d < bd) { bd = d; bi = m; }
-      }
-      double gmin = wave_min_f64(bd);
-      int cand = (bd == gmin) ? bi : 0x7fffffff;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) {
-        int t = __shfl_xor(cand, o, 64);
-        cand = t < cand ? t : cand;
-      }
-      par = uni(cand);
+      // get_closest_mps (:505-513): first index with the smallest RN(sqrt(d2)), a streaming scan of the x,y mirror
+      nn_scanned += (unsigned long long)n_nodes;
+      par = nn_closest(nodeXY, n_nodes, readfirst_f64(rx), readfirst_f64(ry), (P.flags & AUVP_KFLAG_NN_EXACT) != 0);
       par_v = par;
       if (nodeF[(size_t)par * 8 + 3] > Q.max_traj_time) continue;
     }
@@ -809,6 +872,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
       *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
       *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
       nf[4] = clen;
+      if (MODE == 2) nodeXY[me] = make_double2(cx, cy);
       nodeQ[me] = ctt >= Q.max_traj_time - 30 ? 1 : 0;  // a qualifying leaf (:158); ranked by rrt_leaf_kernel
     }
     n_nodes++;
@@ -829,7 +893,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (J <= 4 ? 6 : 2)) void rrt_explor
     s.best_leaf = -1; s.best_path_len = 0; s.iters_run = it; s.n_candidates = n_cand;
     s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;
     s.best_length = 0.0;
-    s.rng_after = after; s.leaf_elems = 0; s.n_draw32 = drawn;
+    s.rng_after = after; s.leaf_elems = 0; s.n_draw32 = drawn; s.nn_scanned = nn_scanned;
   }
 }
 

@@ -531,7 +531,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       s.best_leaf = -1; s.best_path_len = 0; s.iters_run = iters_run; s.n_candidates = n_cand;
       s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;
       s.best_length = 0.0;
-      s.rng_after = after; s.leaf_elems = 0; s.n_draw32 = drawn;
+      s.rng_after = after; s.leaf_elems = 0; s.n_draw32 = drawn; s.nn_scanned = 0ull;
     }
   }
 }

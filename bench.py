@@ -39,12 +39,15 @@ PMC_FILE = os.path.join(REPO, "profiles", "pmc_latest.json")
 # ----------------------------------------------------------------------------------------------------------------
 def rrt_bytes(summ):
     """B_exp: 48 parent read + 4 bin-index read per expansion; 52 node write + 8 bin append per accepted node;
-    56 per stored path point; (24 + 8) per path element walked by the cost function."""
+    56 per stored path point; (24 + 8) per path element walked by the cost function; nearest-neighbour sampling adds
+    16 B (x, y) per node of mps_list per iteration ("NN mode adds 16 N per iteration"), counted by the
+    kernel as the sum of len(mps_list) over its scans."""
     iters = float(summ["iters_run"].sum())
     nodes = float((summ["n_nodes"] - 1).sum())
     pts = float(summ["n_points"].sum())
     walked = float(summ["leaf_elems"].sum())
-    return iters * (48 + 4) + nodes * (52 + 8) + pts * 56 + walked * (24 + 8)
+    scanned = float(summ["nn_scanned"].sum())
+    return iters * (48 + 4) + nodes * (52 + 8) + pts * 56 + walked * (24 + 8) + scanned * 16
 
 
 def planner_bytes(summ):
@@ -332,11 +335,13 @@ def bench_single_episode(ctx, world, args, reps=3):
             "expansions_per_s": float(summ[0]["iters_run"]) / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / float(summ[0]["iters_run"])}
 
 
-def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0):
+def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0, mode=None, kw=None):
+    mode = mode or args.mode
+    kw = kw or RRT_KW
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     init = np.zeros((n_ep, 6))
     init[:, 0], init[:, 1] = world["start"]
-    ctx.rrt_prepare(init, np.arange(n_ep, dtype=np.uint64), args.iters, mode=args.mode, **RRT_KW)
+    ctx.rrt_prepare(init, np.arange(n_ep, dtype=np.uint64), args.iters, mode=mode, **kw)
     ms = []
     for i in range(reps + 1):
         ctx.rrt_run()
@@ -347,7 +352,7 @@ def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0):
         return {"error": "episode status %s" % np.unique(summ["status"])}
     k_ms = float(np.mean(ms))
     iters = float(summ["iters_run"].sum())
-    out = {"value": iters / (k_ms * 1e-3), "unit": "expansions/s", "episodes": n_ep, "kernel_ms": k_ms,
+    out = {"value": iters / (k_ms * 1e-3), "unit": "expansions/s", "episodes": n_ep, "kernel_ms": k_ms, "mode": mode,
            "accept_rate": float((summ["n_nodes"] - 1).sum()) / iters,
            "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters,
            "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
@@ -361,7 +366,7 @@ def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0):
         init0 = [world["start"][0], world["start"][1], 0, 0, 0, 0]
         t0, done, eps = time.perf_counter(), 0, 0
         while time.perf_counter() - t0 < cpu_seconds and eps < 16:
-            done += orc.rrt_explore(w, eps, args.iters, mode=args.mode, init=init0, kind="libm", want_path=False)["iters_run"]
+            done += orc.rrt_explore(w, eps, args.iters, mode=mode, init=init0, kind="libm", want_path=False, **kw)["iters_run"]
             eps += 1
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": done / dt, "unit": "expansions/s", "cores": 1, "kind": "port",
@@ -385,6 +390,38 @@ def bench_rrt_replicas(ctx, args, n_ep=1024):
     SIMD, so this is the one-episode kernel running as many latency chains as the chip has SIMDs."""
     out = _rrt_batch(ctx, bench_world(64, args.grid), n_ep, args)
     out["metric"] = "RRT.exploring expansions/s, %d replicas, 64 obstacles, %dx%d cells" % (n_ep, args.grid, args.grid)
+    return out
+
+
+def bench_rrt_nn(ctx, args, with_cpu, n_ep=4096, long_horizon=False):
+    """The nearest-neighbour parent selection of RRT.exploring (plan_time=False: get_random_mps + get_closest_mps,
+    rrt_dubins.py:333-343,505-513) at the full 10 000-iteration budget on the headline world: every iteration reads x, y of
+    every node of the episode's tree (16 B each) -- the part of the path that streams memory.
+      rrt_nn               the headline's parameters (max_traj_time = 500 s): the parent's time stamp rule (:138-139) rejects
+                           ~94 % of the samples, the trees stop at ~550 nodes, so the x,y mirrors of all episodes (36 MB)
+                           are served by L2 / Infinity Cache
+      rrt_nn_long_horizon  max_traj_time = 20 000 s: the 10k-node budget is what ends the tree (~9 600 nodes, ~77 KB per
+                           scan on average); n_ep x 160 KB of x,y mirror = 0.66 GB >> the 256 MB Infinity Cache: HBM"""
+    world = bench_world(args.obstacles, args.grid)
+    kw = dict(RRT_KW, max_traj_time=20000.0) if long_horizon else RRT_KW
+    out = _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=6.0 if with_cpu else 0.0, mode="nn", kw=kw)
+    if "error" in out:
+        return out
+    out["metric"] = "RRT.exploring expansions/s, nearest-neighbour sampling, %d obstacles, %dx%d cells, max_traj_time %g s" % (
+        args.obstacles, args.grid, args.grid, kw["max_traj_time"])
+    summ = ctx.summaries()
+    scanned = float(summ["nn_scanned"].sum())
+    out["nodes_per_tree"] = float(summ["n_nodes"].mean())
+    out["nodes_scanned_per_iteration"] = scanned / float(summ["iters_run"].sum())
+    out["scan_bytes_per_launch"] = 16.0 * scanned
+    out["xy_mirror_working_set_bytes"] = 16.0 * float(summ["n_nodes"].sum())
+    out["scan_GBps"] = 16.0 * scanned / (ctx.last_launch_parts()[0] * 1e-3) / 1e9
+    traffic, tsrc = pmc_traffic("rrt_nn_long_horizon" if long_horizon else "rrt_nn", float(summ["iters_run"].sum()))
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic, tsrc
+    ref = recorded_reference(("rrt_exploring_nn_long_o%d" if long_horizon else "rrt_exploring_nn_o%d") % args.obstacles)
+    if ref:
+        out["reference_recorded"] = {"value": ref["ref_expansions_per_s_1proc"], "unit": "expansions/s", "cores": 1,
+                                     "where": "build container, tests/experiments/ref_timing.py", "sample": ref.get("sample")}
     return out
 
 
@@ -826,9 +863,11 @@ def main():
         "rrt_64_obstacles": lambda: bench_rrt_o64(ctx, args),
         "rrt_1024_replicas": lambda: bench_rrt_replicas(ctx, args),
         "rrt_dense": lambda: bench_rrt_dense(ctx, args, with_cpu),
+        "rrt_nn": lambda: bench_rrt_nn(ctx, args, with_cpu),
+        "rrt_nn_long_horizon": lambda: bench_rrt_nn(ctx, args, with_cpu, long_horizon=True),
         "astar": lambda: bench_astar(ctx, ranks, with_cpu, variants=not args.no_variants),
-"rrt_env": lambda: bench_rrt_env(local_rank),
-                "planner_rrt": lambda: bench_planner(ctx, ranks, with_cpu),
+        "rrt_env": lambda: bench_rrt_env(local_rank),
+        "planner_rrt": lambda: bench_planner(ctx, ranks, with_cpu),
         "config5": lambda: bench_config5(ctx, ranks),
         "shark_grid": lambda: bench_shark_grid(local_rank, with_cpu),
         "particle_filter": lambda: bench_particle_filter(local_rank, with_cpu),
@@ -941,7 +980,7 @@ def main():
             out["cpu_baseline"] = None
     if not args.no_extra:
         # the other configurations of the path: configs 3, 4 and 5 on every rank (sharded), the rest on rank 0's GPU
-        for name in ("single_episode", "rrt_64_obstacles", "rrt_1024_replicas", "rrt_dense", "astar", "planner_rrt", "rrt_env", "config5", "shark_grid",
+        for name in ("single_episode", "rrt_64_obstacles", "rrt_1024_replicas", "rrt_dense", "rrt_nn", "rrt_nn_long_horizon", "astar", "planner_rrt", "rrt_env", "config5", "shark_grid",
                      "particle_filter"):
             if name in sharded or rank == 0:
                 try:

@@ -76,6 +76,7 @@ typedef struct {
   double rng_after;    /* next random() of the episode's stream (parity probe: same draw count) */
   int64_t leaf_elems;  /* sum over qualifying leaves of len(path) (cost-walk reads; bench byte count) */
   uint64_t n_draw32;   /* 32-bit MT19937 outputs consumed: lets the host advance Python's global `random` */
+  uint64_t nn_scanned; /* nearest-neighbour sampling: sum over iterations of len(mps_list) scanned by get_closest_mps */
 } auvp_rrt_summary;
 
 /* RRT.exploring (path_planning/rrt_dubins.py:92-176) for E independent episodes, one wavefront
@@ -272,6 +273,12 @@ int auvp_check_collision_batch(auvp_handle* h, int32_t n_paths, const int32_t* o
 int auvp_cost_paths(auvp_handle* h, int32_t n_paths, const int32_t* off, const double* pts_xyt,
                     const int32_t* bin_lo, const int32_t* bin_hi, const double* total_traj_time,
                     const double* weights3, double* out4);
+/* RRT.get_closest_mps (path_planning/rrt_dubins.py:505-513) for n_queries sample points against one node list xy
+ * [n_nodes,2]: index of the FIRST node with the smallest RN(sqrt(dx**2 + dy**2)), by the planner's streaming scan.
+ * force_exact != 0 ranks with a sqrt per node (the scan's fallback path); out_slow (optional) reports per query whether
+ * that path ran */
+int auvp_nn_closest_batch(auvp_handle* h, int32_t n_nodes, const double* xy, int32_t n_queries, const double* q,
+                          int32_t force_exact, int32_t* out_index, int32_t* out_slow);
 /* portable sin/cos evaluated on the device (bit-exactness probe for auvp_math.h) */
 int auvp_sincos_dev(auvp_handle* h, int32_t n, const double* x, double* s, double* c);
 /* CPython random() stream of `seed` generated by the wave-level device MT19937 */

@@ -80,6 +80,46 @@ def test_rrt_exploring_full_budget(ctx, orc, n_obstacles, rows, monkeypatch):
         assert np.array_equal(paths1[e], r["path"])
 
 
+def test_rrt_exploring_nn_full_budget(ctx, orc):
+    """nearest-neighbour parent sampling (plan_time=False, rrt_dubins.py:333-343,505-513) at the full 10 000-iteration
+    budget on the headline world: every iteration scans the whole tree (streaming x,y mirror)"""
+    from auv_sim_amd import synth
+    n_iter, E = 10000, 320
+    world = synth.make_world(seed=2, n_obstacles=256, box=(-1000.0, -1000.0, 1000.0, 1000.0), cell=10.0, n_bins=10,
+                             bin_len=50, n_habitats=10)
+    ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    init = np.zeros((E, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    seeds = np.arange(E, dtype=np.uint64)
+    kw = dict(mode="nn", freq=30, bin_interval=5, v=2, max_traj_time=500.0, weights=(-3, -3, -4))
+    s1 = ctx.rrt_explore_batch(init, seeds, n_iter, **kw).copy()
+    trees = {e: ctx.tree(e, s1[e]) for e in (1, 319)}
+    assert (s1["status"] >= 0).all() and (s1["iters_run"] == n_iter).all()
+    assert (s1["n_nodes"] >= 2).all() and (s1["n_nodes"] <= n_iter + 1).all()
+    # len(mps_list) summed over the scans is bounded by the final tree size and by the triangle of a tree that accepts everything
+    assert (s1["nn_scanned"] <= s1["n_nodes"].astype(np.uint64) * n_iter).all()
+    assert (s1["nn_scanned"] >= s1["n_nodes"].astype(np.uint64) * (s1["n_nodes"].astype(np.uint64) - 1) // 2).all()
+    for e, t in trees.items():
+        n = len(t["parent"])
+        assert t["parent"][0] == -1 and (t["parent"][1:] < np.arange(1, n)).all() and (t["parent"][1:] >= 0).all()
+        assert (t["nodes"][t["parent"][1:], 3] <= 500.0).all()                      # no parent beyond max_traj_time (:138)
+        plan_it = t["nodes"][1:, 4]
+        assert int(s1[e]["nn_scanned"]) == int(n_iter + (n_iter - 1 - plan_it).sum())
+    s2 = ctx.rrt_explore_batch(init, seeds, n_iter, **kw)
+    assert _fields_equal(s1, s2)
+    pick = np.array([1, 100, 319])
+    s3 = ctx.rrt_explore_batch(init[pick], seeds[pick], n_iter, **kw)
+    assert _fields_equal(s1[pick], s3)
+    w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    for e in (1, 319):
+        r = orc.rrt_explore(w, int(seeds[e]), n_iter, mode="nn", init=init[e], kind="portable", max_traj_time=500.0)
+        s = s1[e]
+        assert (s["status"], s["n_nodes"], s["n_points"], s["n_leaves"]) == (r["status"], r["n_nodes"], r["n_points"], r["n_leaves"])
+        assert s["rng_after"] == r["rng_after"] and int(s["n_draw32"]) == int(r["n_draw32"])
+        assert np.array_equal(np.array(s["best_cost"]), r["best_cost"]) and s["best_length"] == r["best_length"]
+        assert np.array_equal(trees[e]["parent"], r["parent"]) and np.array_equal(trees[e]["nodes"], r["nodes"])
+
+
 def test_planner_rrt_config4(ctx, orc):
     from auv_sim_amd import synth
     from auv_sim_amd._prrt_lib import PlannerBatch

@@ -16,15 +16,15 @@ def test_rccl_gather_single_rank_round_trip():
     ctx = _lib.Context(0)
     g = D.RcclGather(ctx, 0, 1, lambda mine: mine)
     dev = torch.device("cuda", 0)
-    rec = torch.arange(7 * 104, dtype=torch.uint8, device=dev).reshape(7, 104)
+    rec = torch.arange(7 * 112, dtype=torch.uint8, device=dev).reshape(7, 112)
     out = g.gather_records(rec)
     assert len(out) == 1 and torch.equal(out[0], rec)
     lens = torch.tensor([3, 0, 5], dtype=torch.int64, device=dev)
     paths = torch.arange(8 * 7, dtype=torch.float64, device=dev).reshape(8, 7)
     all_len, blocks = g.gather_paths(paths, lens)
     assert torch.equal(all_len[0], lens) and torch.equal(blocks[0], paths)
-    empty = g.gather_records(torch.zeros((0, 104), dtype=torch.uint8, device=dev))
-    assert empty[0].shape == (0, 104)
+    empty = g.gather_records(torch.zeros((0, 112), dtype=torch.uint8, device=dev))
+    assert empty[0].shape == (0, 112)
     assert g.take_ms() is not None
     # fixed-size entry point + device-resident summaries view
     init = np.zeros((4, 6))
