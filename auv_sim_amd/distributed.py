@@ -86,22 +86,41 @@ class RcclGather:
         """can this process reach RCCL through the C-ABI at all?  (every rank asks BEFORE the collective initialisation, so
         that a rank without it cannot leave the others waiting inside ncclCommInitRank)"""
         from . import _lib
-        L = _lib.load()
-        L.auvp_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
-        return L.auvp_comm_unique_id((C.c_uint8 * 128)()) == 0
+        return _lib.load().auvp_comm_available() == 1  # binds the library only: no bootstrap root is started
 
-    def __init__(self, ctx, rank, world, exchange_id):
+    @staticmethod
+    def library():
+        """path of the RCCL image the C-ABI bound (or why none could be)"""
+        from . import _lib
+        L = _lib.load()
+        L.auvp_comm_library.restype = C.c_char_p
+        return (L.auvp_comm_library() or b"").decode()
+
+    def __init__(self, ctx, rank, world, exchange_id, L=None):
+        """`L`: the bound C-ABI (default: libauvplan.so); the CPU tests pass a stand-in with the same entry points"""
         from . import _lib
         self.ctx, self.rank, self.world = ctx, int(rank), int(world)
+        if L is not None:
+            self.L = L
+            self._join(exchange_id)
+            return
         L = _lib.load()
         L.auvp_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
         L.auvp_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_uint8)]
         L.auvp_comm_destroy.argtypes = [C.c_void_p]
         L.auvp_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.auvp_gather_var.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.auvp_gather_counts.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.auvp_gather_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.auvp_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.auvp_last_gather_ms.argtypes = [C.c_void_p]
         L.auvp_last_gather_ms.restype = C.c_double
         self.L = L
+        self._join(exchange_id)
+
+    def _join(self, exchange_id):
+        from . import _lib
+        L = self.L
         mine = None
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
@@ -110,8 +129,14 @@ class RcclGather:
         if not uid or len(uid) != 128:
             raise _lib.AuvpError(-6, "auvp_comm_unique_id failed on rank 0 (RCCL not loadable?)")
         arr = (C.c_uint8 * 128).from_buffer_copy(uid)
-        ctx._chk(L.auvp_comm_init(ctx.h, self.world, self.rank, arr))
+        self.ctx._chk(L.auvp_comm_init(self.ctx.h, self.world, self.rank, arr))
         self.last_ms = None
+
+    def info(self):
+        """(world size given, rank and rank count as the communicator itself reports them)"""
+        w, r, n = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        self.ctx._chk(self.L.auvp_comm_info(self.ctx.h, C.byref(w), C.byref(r), C.byref(n)))
+        return int(w.value), int(r.value), int(n.value)
 
     def close(self):
         if self.ctx is not None and getattr(self.ctx, "h", None):
@@ -123,13 +148,16 @@ class RcclGather:
         t = t.contiguous()
         nbytes = t.numel() * t.element_size()
         counts = (C.c_int64 * self.world)()
-        self.ctx._chk(self.L.auvp_gather_var(self.ctx.h, C.c_void_p(t.data_ptr()), nbytes, None, 0, counts))
+        # one count exchange, then the payload: the caller sizes its buffer in between (auvp_gather_counts / _blocks)
+        self.ctx._chk(self.L.auvp_gather_counts(self.ctx.h, nbytes, counts))
+        ms = float(self.L.auvp_last_gather_ms(self.ctx.h))
         total = sum(counts)
         out = torch.empty(max(total, 1), dtype=torch.uint8, device=t.device)
-        self.ctx._chk(self.L.auvp_gather_var(self.ctx.h, C.c_void_p(t.data_ptr()), nbytes, C.c_void_p(out.data_ptr()),
-                                             total, counts))
-        self.last_ms = (self.last_ms or 0.0) + float(self.L.auvp_last_gather_ms(self.ctx.h))
-        return list(counts), out
+        if total > 0:
+            self.ctx._chk(self.L.auvp_gather_blocks(self.ctx.h, C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), total, counts))
+            ms += float(self.L.auvp_last_gather_ms(self.ctx.h))
+        self.last_ms = (self.last_ms or 0.0) + ms
+        return list(counts), out[:total]
 
     def gather_records(self, records):
         records = records.contiguous()

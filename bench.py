@@ -30,7 +30,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-REF_TIMING = os.path.join(REPO, "profiles", "r2_reference_timing.json")
+REF_TIMING = [os.path.join(REPO, "profiles", f) for f in ("r3_reference_timing.json", "r2_reference_timing.json")]
 PMC_FILE = os.path.join(REPO, "profiles", "pmc_latest.json")
 
 
@@ -69,37 +69,53 @@ def astar_bytes(summ, variant):
 
 
 def roofline(abytes, k_ms, kernel, traffic=None, **extra):
+    """`traffic`: the dict pmc_traffic() returns (or None)"""
     ach = abytes / (k_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-         "traffic": traffic, "kernel": kernel, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes}
+         "traffic": None, "kernel": kernel, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes}
+    r.update(traffic or {})
     r.update(extra)
     return r
 
 
-def pmc_traffic(kernel_key, units_now, units_key="units"):
-    """HBM bytes per launch of `kernel_key` from the committed PMC passes (tools/profile_bench.sh -> profiles/pmc_latest.json,
-    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH doubled as the microarchitecture guide prescribes for
-    gfx950), scaled by the work units when this run's batch differs from the profiled one."""
+def pmc_traffic(meas, kernels_ran, units_now):
+    """HBM bytes per launch of measurement `meas` from the committed PMC passes (tools/profile_bench.sh ->
+    profiles/pmc_latest.json; FETCH_SIZE and WRITE_SIZE collected in separate passes), scaled by the work units when this
+    run's batch differs from the profiled one.  Returns {"traffic": 2 x FETCH_SIZE + WRITE_SIZE (the microarchitecture
+    guide's gfx950 correction, calibrated for 16-B/lane streaming reads), "traffic_raw": FETCH_SIZE + WRITE_SIZE,
+    "traffic_source": ...}; all None when the profiled launch ran other kernels than this one (`kernels_ran`)."""
+    none = {"traffic": None, "traffic_raw": None, "traffic_source": None}
     try:
-        pj = json.load(open(PMC_FILE))["kernels"][kernel_key]
-        t = float(pj["hbm_bytes_per_launch"])
-        src = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate passes)" % json.load(open(PMC_FILE)).get("tag", "?")
-        u0 = float(pj.get(units_key, 0.0))
+        pj = json.load(open(PMC_FILE))
+        m = pj["measurements"][meas]
+        if set(kernels_ran) != set(m["kernels"].keys()):
+            none["traffic_source"] = "profiles/%s profiled %s, this launch ran %s: not comparable" % (
+                pj.get("tag", "?"), sorted(m["kernels"].keys()), sorted(kernels_ran))
+            return none
+        x2, raw = float(m["hbm_bytes_fetch_x2"]), float(m["hbm_bytes_raw"])
+        src = "profiles/%s pmc@%s (traffic = 2 x FETCH_SIZE + WRITE_SIZE, traffic_raw = FETCH_SIZE + WRITE_SIZE; separate passes)" % (
+            pj.get("tag", "?"), meas)
+        u0 = float(m.get("units") or 0.0)
         if u0 > 0 and units_now and abs(u0 - units_now) > 0.5:
-            t *= units_now / u0
+            x2 *= units_now / u0
+            raw *= units_now / u0
             src += ", scaled x%.3f by work units" % (units_now / u0)
-        return t, src
+        return {"traffic": x2, "traffic_raw": raw, "traffic_source": src}
     except Exception:
-        return None, None
+        return none
 
 
 def recorded_reference(key):
     """the reference Python's own timing on this workload, RECORDED in the build container (tests/experiments/ref_timing.py,
-    profiles/r2_reference_timing.json) -- the reference cannot run on the GPU box"""
-    try:
-        return json.load(open(REF_TIMING)).get(key)
-    except Exception:
-        return None
+    profiles/r2_reference_timing.json, r3_reference_timing.json) -- the reference cannot run on the GPU box"""
+    for f in REF_TIMING:
+        try:
+            r = json.load(open(f)).get(key)
+            if r:
+                return r
+        except Exception:
+            pass
+    return None
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -194,6 +210,7 @@ class Ranks:
     def __init__(self, ctx, rank, world, dev, use_rccl=True):
         self.ctx, self.rank, self.world, self.dev = ctx, rank, world, dev
         self.gather, self.gather_note = None, None
+        self.rccl_info, self.rccl_library = None, None
         self.cpu_group = not use_rccl  # gloo: collectives on host tensors
         if world > 1 and not use_rccl:
             from auv_sim_amd import distributed as D
@@ -214,8 +231,14 @@ class Ranks:
             if int(pre.item()) == 0:
                 try:
                     self.gather = D.RcclGather(ctx, rank, world, exchange)
-                except Exception as e:  # RCCL entry points unusable here: keep measuring with torch.distributed's all-gather
-                    self.gather_note = "auvp_gather unavailable (%s)" % e
+                except Exception as e:
+                    # every rank agreed that RCCL is reachable, so the others are inside (or about to enter)
+                    # ncclCommInitRank: falling back on this rank alone would leave them waiting there.  End the job: the
+                    # launcher (spawn_ranks below / torchrun) takes the other ranks down and reports the failure.
+                    print("bench: rank %d: communicator initialisation failed (%s); aborting the job" % (rank, e), file=sys.stderr, flush=True)
+                    os._exit(3)
+                self.rccl_info = self.gather.info()
+                self.rccl_library = D.RcclGather.library()
             else:
                 self.gather_note = "auvp_gather unavailable (RCCL not reachable through the C-ABI on %d rank(s))" % int(pre.item())
             flag = torch.tensor([0 if self.gather is not None else 1], device=dev)
@@ -416,8 +439,9 @@ def bench_rrt_nn(ctx, args, with_cpu, n_ep=4096, long_horizon=False):
     out["scan_bytes_per_launch"] = 16.0 * scanned
     out["xy_mirror_working_set_bytes"] = 16.0 * float(summ["n_nodes"].sum())
     out["scan_GBps"] = 16.0 * scanned / (ctx.last_launch_parts()[0] * 1e-3) / 1e9
-    traffic, tsrc = pmc_traffic("rrt_nn_long_horizon" if long_horizon else "rrt_nn", float(summ["iters_run"].sum()))
-    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = traffic, tsrc
+    out["iters_per_launch"] = float(summ["iters_run"].sum())
+    out["roofline"].update(pmc_traffic("rrt_nn_long_horizon" if long_horizon else "rrt_nn", ["rrt_explore_kernel", "rrt_leaf_kernel"],
+                                       out["iters_per_launch"]))
     ref = recorded_reference(("rrt_exploring_nn_long_o%d" if long_horizon else "rrt_exploring_nn_o%d") % args.obstacles)
     if ref:
         out["reference_recorded"] = {"value": ref["ref_expansions_per_s_1proc"], "unit": "expansions/s", "cores": 1,
@@ -481,7 +505,7 @@ def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1, variants=T
     cells = ranks.sum(summ["n_children"].sum())
     k_ms = float(np.mean(kms[-steps:]))
     abytes = astar_bytes(summ, "astar_fixLenSOG")
-    traffic, tsrc = pmc_traffic("astar_kernel", float(summ["n_children"].sum()))
+    traffic = pmc_traffic("astar", ["astar_kernel"], float(summ["n_children"].sum()))
     out = {"metric": "A* cells/s (astar_fixLenSOG, child cells evaluated)", "value": cells * steps / dt, "unit": "cells/s",
            "ms_per_step": 1e3 * dt / steps, "steps": steps, "instances": n_inst, "instances_this_rank": hi - lo,
            "cells_per_step": cells, "expansions_per_step": ranks.sum(summ["n_expansions"].sum()),
@@ -490,7 +514,7 @@ def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1, variants=T
            "gather_ms_per_rank": ranks.all(float(np.mean([g for g in gms[-steps:] if g is not None])) if gms and gms[-1] is not None else None),
            "cells_per_s_search_launch_only": float(summ["n_children"].sum()) / (k_ms * 1e-3),
            "config": "%d x astar_fixLenSOG, 64 obstacles, 10 habitats, 400-cell grid x 10 bins, limits 100/200/300" % n_inst,
-           "roofline": roofline(abytes, k_ms, "astar_kernel", traffic, traffic_source=tsrc,
+           "roofline": roofline(abytes, k_ms, "astar_kernel", traffic,
                                 bytes_per_cell=abytes / max(float(summ["n_children"].sum()), 1.0),
                                 note="one wave per instance at 1 wave/SIMD: a latency measurement, not a bandwidth one")}
     if ranks.world == 1 and variants:
@@ -616,7 +640,7 @@ def bench_planner(ctx, ranks, with_cpu, n_ep=512, max_step=2000, steps=5, warmup
     tot_steps = ranks.sum(summ["steps"].sum())
     k_ms = float(np.mean(kms[-steps:]))
     abytes = planner_bytes(summ)
-    traffic, tsrc = pmc_traffic("prrt_kernel", float(summ["steps"].sum()))
+    traffic = pmc_traffic("planner_rrt", ["prrt_kernel"], float(summ["steps"].sum()))
     out = {"metric": "Planner_RRT steps/s (generate_one_node calls)", "value": tot_steps * steps / dt, "unit": "steps/s",
            "ms_per_step": 1e3 * dt / steps, "steps": steps, "episodes": n_ep, "episodes_this_rank": n,
            "planner_steps_per_step": tot_steps, "episodes_done": int(ranks.sum(summ["done"].sum())),
@@ -624,7 +648,7 @@ def bench_planner(ctx, ranks, with_cpu, n_ep=512, max_step=2000, steps=5, warmup
            "gather_ms_per_rank": ranks.all(float(np.mean([g for g in gms[-steps:] if g is not None])) if gms and gms[-1] is not None else None),
            "steps_per_s_plan_launch_only": float(summ["steps"].sum()) / (k_ms * 1e-3),
            "config": "%d x Planner_RRT.planning(2000), 200 m env, 256 obstacles, cell 5 m, freq 10" % n_ep,
-           "roofline": roofline(abytes, k_ms, "prrt_kernel", traffic, traffic_source=tsrc,
+           "roofline": roofline(abytes, k_ms, "prrt_kernel", traffic,
                                 bytes_per_step=abytes / max(float(summ["steps"].sum()), 1.0),
                                 note="512 waves on 1 024 SIMDs: a latency measurement")}
     if with_cpu:
@@ -797,9 +821,20 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # a rank that dies (e.g. its communicator initialisation failed) must not leave the others waiting inside a
+    # collective: the first non-zero exit ends the job (these are our own children: exact PIDs, no patterns)
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(r))
+            if r != 0:
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
     sys.exit(rc)
 
 
@@ -940,15 +975,16 @@ def main():
     k_ms = float(np.mean(kms[-args.steps:]))
     k_all = ranks.all(k_ms)
     g_all = ranks.all(float(np.mean([g for g in gms[-args.steps:] if g is not None])) if gms and gms[-1] is not None else None)
+    rccl_info_all = ranks.all(ranks.rccl_info) if world_size > 1 else None
     out = None
     if rank == 0:
         abytes = rrt_bytes(summ)
-        traffic, tsrc = pmc_traffic("rrt_exploring", iters_local)
         grid, block, lds = ctx.last_launch()
         exp_ms = float(np.mean([p[0] for p in parts[-args.steps:]]))
         leaf_ms = float(np.mean([p[1] for p in parts[-args.steps:]]))
         per_wave = parts[-1][2]
         kname = "rrt_rows_kernel" if per_wave == 4 else "rrt_explore_kernel"
+        traffic = pmc_traffic("headline", [kname, "rrt_leaf_kernel"], iters_local)
         out = {
             "metric": "RRT-Dubins node expansions/s (RRT.exploring)", "value": value, "unit": "expansions/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -958,10 +994,14 @@ def main():
                                    % (args.obstacles, args.grid, args.grid, args.iters, E, args.mode),
                        "episodes_per_gpu": E, "iters": args.iters, "obstacles": args.obstacles,
                        "cells": int(len(world["cells"])), "parallelism": "episodes sharded x%d" % world_size,
-                       "gather": ranks.gather.name if ranks.gather is not None else None, "gather_note": ranks.gather_note},
+                       "gather": ranks.gather.name if ranks.gather is not None else None, "gather_note": ranks.gather_note,
+                       # self-check of a multi-GPU run: (world size given, rank, RANK COUNT AS THE RCCL COMMUNICATOR REPORTS IT)
+                       # of every rank, and the RCCL image the C-ABI bound
+                       "rccl_comm_info_per_rank": rccl_info_all, "rccl_ranks_seen": (rccl_info_all[0][2] if rccl_info_all and rccl_info_all[0] else None),
+                       "rccl_library": ranks.rccl_library},
             # one pass of the path = two launches on the handle's stream: the tree expansion and the leaf pass (cost terms,
             # ranking); kernel_ms is the HIP-event time around both, the algorithmic bytes are those of the whole pass
-            "roofline": roofline(abytes, k_ms, kname + " + rrt_leaf_kernel", traffic, traffic_source=tsrc,
+            "roofline": roofline(abytes, k_ms, kname + " + rrt_leaf_kernel", traffic,
                                  bytes_per_expansion=abytes / iters_local,
                                  kernels_ms={kname: exp_ms, "rrt_leaf_kernel": leaf_ms}, episodes_per_wavefront=per_wave,
                                  launch={"grid": grid, "block": block, "lds_bytes": lds},

@@ -315,7 +315,18 @@ int auvp_prrt_replan_particles(auvp_handle* h, const double* start4, const auvp_
  *   auvp_gather          all-gather of equally sized blocks: recv_dev [world][bytes_per_rank]
  *   auvp_gather_var      variable-size blocks, two-phase: counts_out[world] always receives every rank's byte
  *                        count; with recv_dev == NULL only that (size query), else the blocks are written back
- *                        to back in rank order (AUVP_ERR_CAPACITY if recv_cap_bytes is too small)
+ *                        to back in rank order.  Whether the payload phase runs is decided COLLECTIVELY (every rank
+ *                        also publishes its capacity): it runs only if every rank passed a buffer that holds
+ *                        sum(counts); otherwise every rank returns after the counts (AUVP_ERR_CAPACITY on the ranks
+ *                        that passed a buffer), none is left waiting
+ *   auvp_gather_counts / auvp_gather_blocks   the two phases as separate calls, for a caller that sizes its
+ *                        buffer between them (one count exchange instead of two); counts must be the array
+ *                        auvp_gather_counts returned, unchanged, on every rank
+ *   auvp_comm_available  1 if an RCCL can be bound in this process (no communicator, no bootstrap thread is created)
+ *   auvp_comm_library    path of the RCCL image that was bound (an already mapped one -- PyTorch's -- is preferred
+ *                        over opening a second image), or the reason none could be
+ *   auvp_comm_info       communicator facts for self-checking runs: world size given, rank and rank count as RCCL
+ *                        reports them (ncclCommUserRank, ncclCommCount)
  *   auvp_last_gather_ms  HIP-event time of the last gather on the handle's stream */
 #define AUVP_COMM_ID_BYTES 128
 int auvp_comm_unique_id(uint8_t* id_out /* [AUVP_COMM_ID_BYTES] */);
@@ -324,6 +335,12 @@ int auvp_comm_destroy(auvp_handle* h);
 int auvp_gather(auvp_handle* h, const void* send_dev, size_t bytes_per_rank, void* recv_dev);
 int auvp_gather_var(auvp_handle* h, const void* send_dev, int64_t send_bytes, void* recv_dev, int64_t recv_cap_bytes,
                     int64_t* counts_out);
+int auvp_gather_counts(auvp_handle* h, int64_t send_bytes, int64_t* counts_out /* [world] */);
+int auvp_gather_blocks(auvp_handle* h, const void* send_dev, void* recv_dev, int64_t recv_cap_bytes,
+                       const int64_t* counts /* [world] */);
+int auvp_comm_available(void);
+const char* auvp_comm_library(void);
+int auvp_comm_info(auvp_handle* h, int32_t* world_size, int32_t* rank, int32_t* rccl_ranks_seen);
 double auvp_last_gather_ms(auvp_handle* h);
 
 #ifdef __cplusplus

@@ -46,7 +46,8 @@ def bench_world(obstacles):
 
 # ---------------------------------------------------------------- config 2
 def ref_exploring(job):
-    obstacles, seed, n_iter = job
+    obstacles, seed, n_iter = job[:3]
+    mode, max_traj = (job[3], job[4]) if len(job) > 3 else ("timebin", 500.0)
     mg = _mg()
     world = bench_world(obstacles)
     rrt_mod, mpsm, _ = mg.import_rrt()
@@ -59,8 +60,8 @@ def ref_exploring(job):
     t0 = time.perf_counter()
     with contextlib.redirect_stdout(io.StringIO()):
         try:
-            res = rrt.exploring(start, habitats, float(n_iter), 5, 2, 50, traj_time_stamp=True, max_plan_time=float(n_iter),
-                                max_traj_time=500.0, plan_time=True, weights=[-3, -3, -4])
+            res = rrt.exploring(start, habitats, float(n_iter), 5, 2, 50, traj_time_stamp=(mode == "timebin"),
+                                max_plan_time=float(n_iter), max_traj_time=max_traj, plan_time=(mode != "nn"), weights=[-3, -3, -4])
             cost = float(res["cost"][0])
         except TypeError:
             cost = None
@@ -69,13 +70,14 @@ def ref_exploring(job):
 
 
 def port_exploring(job):
-    obstacles, seed, n_iter = job
+    obstacles, seed, n_iter = job[:3]
+    mode, max_traj = (job[3], job[4]) if len(job) > 3 else ("timebin", 500.0)
     from oracle import orc
     world = bench_world(obstacles)
     w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     init = [world["start"][0], world["start"][1], 0, 0, 0, 0]
     t0 = time.perf_counter()
-    r = orc.rrt_explore(w, seed, n_iter, init=init, kind="libm", want_path=False)
+    r = orc.rrt_explore(w, seed, n_iter, mode=mode, init=init, kind="libm", want_path=False, max_traj_time=max_traj)
     dt = time.perf_counter() - t0
     return {"seconds": dt, "iters": r["iters_run"], "nodes": r["n_nodes"], "cost": float(r["best_cost"][0]), "seed": seed}
 
@@ -200,7 +202,7 @@ def main():
            "procs_many": P}
     if os.path.exists(args.out):
         try:
-            out.update({k: v for k, v in json.load(open(args.out)).items() if k.startswith("config")})
+            out.update({k: v for k, v in json.load(open(args.out)).items() if k.startswith("config") or k.startswith("rrt_")})
         except Exception:
             pass
     only = args.only.split(",")
@@ -258,6 +260,21 @@ def main():
                 pmany, tp_many = pool_map(port_exploring, [(O, s, n_iter) for s in range(P)], P)
                 rec["port_expansions_per_s_%dproc" % P] = sum(x["iters"] for x in pmany) / tp_many
                 print(key, "many", rec, flush=True)
+    if "nn" in only:
+        # round 3: nearest-neighbour parent sampling (plan_time=False, traj_time_stamp=False) on the headline world, at the
+        # headline's max_traj_time and with a horizon long enough for the 10k-node budget to end the tree (bench.py rrt_nn*)
+        n_iter = args.c2_iters
+        for key, max_traj in (("rrt_exploring_nn_o256", 500.0), ("rrt_exploring_nn_long_o256", 20000.0)):
+            one, _ = pool_map(ref_exploring, [(256, 7, n_iter, "nn", max_traj)], 1)
+            pone, _ = pool_map(port_exploring, [(256, 7, n_iter, "nn", max_traj)], 1)
+            rec = {"iters": n_iter, "sample": "seed 7, %d iterations, max_traj_time %g" % (n_iter, max_traj),
+                   "ref_expansions_per_s_1proc": n_iter / one[0]["seconds"], "ref_seconds_1proc": one[0]["seconds"],
+                   "port_expansions_per_s_1proc": pone[0]["iters"] / pone[0]["seconds"],
+                   "ref_nodes": one[0]["nodes"], "port_nodes": pone[0]["nodes"], "ref_cost": one[0]["cost"], "port_cost": pone[0]["cost"]}
+            rec["port_over_ref"] = rec["port_expansions_per_s_1proc"] / rec["ref_expansions_per_s_1proc"]
+            out[key] = rec
+            print(key, rec, flush=True)
+            json.dump(out, open(args.out, "w"), indent=1)
     json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out))
 

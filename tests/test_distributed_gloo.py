@@ -112,3 +112,164 @@ def test_two_rank_gather_gloo(E_total):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RcclGather's own Python (count exchange, buffer sizing, slicing of the gathered blocks, path gather) with two ranks:
+# the C-ABI entry points it calls are replaced by a stand-in with the same signatures and semantics that moves the bytes
+# over gloo, so everything above the C boundary runs exactly as on the GPUs.
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeCtx:
+    h = 1
+
+    def _chk(self, rc):
+        assert rc == 0, rc
+
+
+class _FakeAbi:
+    """auvp_comm_* / auvp_gather_* of include/auvplan.h over torch.distributed (gloo), host pointers"""
+
+    def __init__(self):
+        self.world = self.rank = None
+        self.calls = []
+
+    def auvp_comm_unique_id(self, buf):
+        for i in range(128):
+            buf[i] = (i * 7 + 3) % 256
+        return 0
+
+    def auvp_comm_init(self, h, world, rank, arr):
+        assert bytes(arr) == bytes((i * 7 + 3) % 256 for i in range(128))  # rank 0's id reached this rank
+        self.world, self.rank = world, rank
+        return 0
+
+    def auvp_comm_destroy(self, h):
+        return 0
+
+    def auvp_comm_info(self, h, w, r, n):
+        import ctypes as C
+        C.cast(w, C.POINTER(C.c_int32))[0] = self.world
+        C.cast(r, C.POINTER(C.c_int32))[0] = self.rank
+        C.cast(n, C.POINTER(C.c_int32))[0] = dist.get_world_size()
+        return 0
+
+    def auvp_last_gather_ms(self, h):
+        return 0.25
+
+    def auvp_gather_counts(self, h, nbytes, counts):
+        self.calls.append("counts")
+        mine = torch.tensor([int(nbytes)], dtype=torch.int64)
+        allc = torch.empty(self.world, dtype=torch.int64)
+        dist.all_gather_into_tensor(allc, mine)
+        for r in range(self.world):
+            counts[r] = int(allc[r])
+        return 0
+
+    def auvp_gather_blocks(self, h, send, recv, cap, counts):
+        import ctypes as C
+        self.calls.append("blocks")
+        cs = [int(counts[r]) for r in range(self.world)]
+        if sum(cs) > cap:
+            return -3
+        off = 0
+        for r in range(self.world):  # one broadcast per rank, like the grouped ncclBroadcast of the library
+            if cs[r] > 0:
+                t = torch.empty(cs[r], dtype=torch.uint8)
+                if r == self.rank:
+                    C.memmove(t.data_ptr(), send.value, cs[r])
+                dist.broadcast(t, src=r)
+                C.memmove(recv.value + off, t.data_ptr(), cs[r])
+            off += cs[r]
+        return 0
+
+
+def _rccl_python_worker(rank, world, port, E_total, q):
+    import sys
+    sys.path.insert(0, REPO)
+    from auv_sim_amd import _lib, distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def exchange(mine):
+        box = [mine]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    abi = _FakeAbi()
+    G = D.RcclGather(_FakeCtx(), rank, world, exchange, L=abi)
+    ok = G.info() == (world, rank, world)
+    lo, hi = D.shard_range(E_total, rank, world)
+    n = hi - lo
+    summ = np.zeros(n, dtype=_lib.SUMMARY_DTYPE)
+    for i in range(n):
+        summ[i]["best_leaf"] = lo + i
+        summ[i]["best_path_len"] = 2 + ((lo + i) % 4)
+        summ[i]["nn_scanned"] = 1000 + lo + i
+    rec = G.gather_records(D.summaries_to_tensor(summ, "cpu"))
+    lens = torch.from_numpy(summ["best_path_len"].astype(np.int64))
+    paths = torch.zeros((int(lens.sum()) + 3, 7), dtype=torch.float64)  # slack rows past sum(lengths) are not sent
+    pos = 0
+    for i in range(n):
+        L = int(lens[i])
+        paths[pos:pos + L, 0] = lo + i
+        paths[pos:pos + L, 6] = torch.arange(L, dtype=torch.float64)
+        pos += L
+    all_len, blocks = G.gather_paths(paths, lens)
+    seen = []
+    for r in range(world):
+        rlo, rhi = D.shard_range(E_total, r, world)
+        rs = D.tensor_to_summaries(rec[r], _lib.SUMMARY_DTYPE)
+        ok &= rec[r].shape == (rhi - rlo, _lib.SUMMARY_DTYPE.itemsize) and len(all_len[r]) == rhi - rlo
+        pos = 0
+        for i in range(rhi - rlo):
+            e = rlo + i
+            ok &= int(rs[i]["best_leaf"]) == e and int(rs[i]["nn_scanned"]) == 1000 + e
+            L = int(all_len[r][i])
+            ok &= L == 2 + (e % 4)
+            seg = blocks[r][pos:pos + L]
+            ok &= bool((seg[:, 0] == e).all()) and bool((seg[:, 6] == torch.arange(L, dtype=torch.float64)).all())
+            pos += L
+            seen.append(e)
+        ok &= pos == blocks[r].shape[0]
+    ok &= seen == list(range(E_total))
+    # one count exchange per gather (not two), and no payload call when nobody has anything to send
+    ok &= abi.calls.count("counts") == 3
+    empty = G.gather_records(torch.zeros((0, 16), dtype=torch.uint8))
+    ok &= all(e.shape == (0, 16) for e in empty) and abi.calls[-1] == "counts"
+    ok &= G.take_ms() is not None and G.take_ms() is None
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("E_total", [9, 8, 1])  # uneven, even, one rank with an empty shard
+def test_rccl_gather_python_two_ranks(E_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_python_worker, args=(r, 2, port, E_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_rccl_unloadable_is_an_error_code_not_a_crash():
+    """AUVP_RCCL_LIBRARY pointing nowhere: auvp_comm_available() == 0, auvp_comm_unique_id -> AUVP_ERR_COMM, and the reason is
+    readable (the round-2 build dereferenced a null dlerror() here)"""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, os, sys\n"
+        "L = C.CDLL(os.path.join(%r, 'auv_sim_amd', 'libauvplan.so'))\n"
+        "L.auvp_comm_library.restype = C.c_char_p\n"
+        "assert L.auvp_comm_available() == 0\n"
+        "assert L.auvp_comm_unique_id((C.c_uint8 * 128)()) == -6\n"
+        "msg = L.auvp_comm_library().decode()\n"
+        "assert 'cannot load RCCL' in msg and 'no_such_rccl' in msg, msg\n"
+        "print('ok')\n" % REPO)
+    env = dict(os.environ, AUVP_RCCL_LIBRARY="/nonexistent/libno_such_rccl.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)

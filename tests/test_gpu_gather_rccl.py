@@ -14,7 +14,13 @@ def test_rccl_gather_single_rank_round_trip():
     import torch
     from auv_sim_amd import _lib, distributed as D
     ctx = _lib.Context(0)
+    assert D.RcclGather.usable()
     g = D.RcclGather(ctx, 0, 1, lambda mine: mine)
+    assert g.info() == (1, 0, 1)  # world size given; rank and rank count as the communicator reports them
+    # ONE RCCL per process: torch (imported above) has mapped its bundled librccl, and the C-ABI must have bound that image
+    lib = D.RcclGather.library()
+    mapped = [l.split()[-1] for l in open("/proc/self/maps") if "librccl.so" in l]
+    assert lib and mapped and lib in mapped and len(set(mapped)) == 1, (lib, sorted(set(mapped)))
     dev = torch.device("cuda", 0)
     rec = torch.arange(7 * 112, dtype=torch.uint8, device=dev).reshape(7, 112)
     out = g.gather_records(rec)

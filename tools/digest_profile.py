@@ -2,10 +2,16 @@
 """Copy the judged summaries of a tools/profile_bench.sh run from gpurun_out/prof_<tag>/ into profiles/<tag>/ (tracked)
 and refresh profiles/pmc_latest.json (read by bench.py for roofline.traffic).
 
-Per kernel: the mean of every counter over the kernel's dispatches in the counter passes, and HBM bytes per launch =
-2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  The x2 is MI355X_MICROARCH.md's gfx950 correction (FETCH_SIZE tallies
-128-B requests at 64 B); the guide calibrates it for 16-B-per-lane streaming reads and calls other widths
-uncalibrated, so the raw sum is kept next to it."""
+Per measurement (the headline and every profiled side measurement): the counters of the kernels that measurement
+launches, averaged over the dispatches of its counter passes and summed over its kernels, and the HBM bytes per launch in
+two explicitly named forms:
+  hbm_bytes_raw        FETCH_SIZE + WRITE_SIZE (KiB -> bytes), as the counters read
+  hbm_bytes_fetch_x2   2 x FETCH_SIZE + WRITE_SIZE: MI355X_MICROARCH.md's gfx950 correction (FETCH_SIZE tallies 128-B
+                       requests at 64 B).  The guide calibrates it for 16-B-per-lane streaming reads (the nearest-neighbour
+                       scan is exactly that) and calls other access widths uncalibrated (the tree kernels' 8-B scattered
+                       reads): bench.py reports both.
+A measurement records the kernel names its counters came from; bench.py only attaches the traffic to a roofline whose
+launch ran the same kernels."""
 import collections
 import csv
 import glob
@@ -19,79 +25,88 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 dst = os.path.join(REPO, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(os.path.join(src, "trace_main", "*kernel_stats.csv")):
-    shutil.copy(f, os.path.join(dst, os.path.basename(f)))
-for f in ("bench.json", "trace_bench.json", "trace_main_bench.json"):
-    if os.path.exists(os.path.join(src, f)):
-        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
-for f in glob.glob(os.path.join(src, "trace", "*kernel_stats.csv")) + glob.glob(os.path.join(src, "trace", "*domain_stats.csv")):
-    shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+for d in glob.glob(os.path.join(src, "trace*")):
+    if os.path.isdir(d):
+        for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True) + glob.glob(os.path.join(d, "**", "*domain_stats.csv"), recursive=True):
+            shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+for f in glob.glob(os.path.join(src, "*.json")):
+    if os.path.basename(f).startswith(("bench", "trace")):
+        shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 
-# (kernel key, substring of the kernel name, pass-directory prefix, bench json of that pass, path to its work units)
-# the headline pass is two launches: the expansion kernel (rows or one-episode variant) and the leaf pass; their counters
-# are summed into "rrt_exploring" (what bench.py's roofline.traffic refers to) and kept separately as well
-KERNELS = [("rrt_rows_kernel", "rrt_rows_kernel", "pmc_", None), ("rrt_explore_kernel", "rrt_explore_kernel", "pmc_", None),
-           ("rrt_leaf_kernel", "rrt_leaf_kernel", "pmc_", None),
-           ("astar_kernel", "astar_kernel", "pmc_astar_", "astar"),
-           ("prrt_kernel", "prrt_kernel", "pmc_planner_rrt_", "planner_rrt")]
-out = {"tag": tag, "kernels": {}}
-for key, needle, prefix, side in KERNELS:
-    pmc = collections.defaultdict(list)
-    for d in glob.glob(os.path.join(src, prefix + "*")):
+# measurement key (= pass-directory name pmc@<key>@<counter>; "headline" or the side's name in the bench JSON) ->
+#   (kernel-name needles, field of the side's JSON holding its work units)
+RRT = ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel")
+MEAS = {
+    "headline": (RRT, None),
+    "astar": (("astar_kernel",), "cells_per_step"),
+    "planner_rrt": (("prrt_kernel", "prrt_rows_kernel"), "planner_steps_per_step"),
+    "rrt_nn": (RRT, "iters_per_launch"),
+    "rrt_nn_long_horizon": (RRT, "iters_per_launch"),
+    "config5": (("prrt_kernel", "prrt_rows_kernel"), "planner_steps_per_tracking_step"),
+}
+
+
+def short(name):
+    for n in ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel", "astar_kernel", "astar_path_kernel", "prrt_rows_kernel",
+              "prrt_kernel", "prrt_from_particles_kernel", "pf_step_kernel", "pf_create_kernel"):
+        if n in name:
+            return n
+    return name.split("(")[0][:60]
+
+
+out = {"tag": tag, "measurements": {}}
+for key, (needles, units_field) in MEAS.items():
+    side = None if key == "headline" else key
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+    for d in sorted(glob.glob(os.path.join(src, "pmc@%s@*" % key))):
         if not os.path.isdir(d):
-            continue
-        base = os.path.basename(d)[len(prefix):]
-        if side is None and (base.startswith("astar_") or base.startswith("planner_rrt_")):
             continue
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if needle in r["Kernel_Name"]:
-                    pmc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    if not pmc:
+                if any(n in r["Kernel_Name"] for n in needles):
+                    per_kernel[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if not per_kernel:
         continue
-    # the headline pass launches the kernel once (--steps 1 --warmup 0); the side passes launch it warm-up + steps
-    # times with identical work, so the mean is the per-launch figure either way
-    summary = {k: sum(v) / len(v) for k, v in pmc.items()}
-    rec = {"per_launch": summary, "dispatches_seen": {k: len(v) for k, v in pmc.items()}}
-    if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
-        rd, wr = summary["FETCH_SIZE"] * 1024.0, summary["WRITE_SIZE"] * 1024.0
-        rec["hbm_read_bytes_raw"] = rd
-        rec["hbm_write_bytes"] = wr
-        rec["hbm_bytes_per_launch_raw"] = rd + wr
-        rec["hbm_bytes_per_launch"] = 2 * rd + wr
-    # work units of the profiled launch, so bench.py can scale the traffic to a different batch
+    rec = {"kernels": {}, "per_launch": collections.defaultdict(float)}
+    for kn, ctrs in per_kernel.items():
+        # launches per measurement step: a kernel that runs L times per step shows L x (warm-up + steps) dispatches; the
+        # mean per dispatch x L would need L -- every kernel here runs once per launch of its measurement
+        km = {c: sum(v) / len(v) for c, v in ctrs.items()}
+        rec["kernels"][kn] = {"per_launch": km, "dispatches_seen": {c: len(v) for c, v in ctrs.items()}}
+        for c, v in km.items():
+            rec["per_launch"][c] += v
+    rec["per_launch"] = dict(rec["per_launch"])
+    s = rec["per_launch"]
+    if "FETCH_SIZE" in s and "WRITE_SIZE" in s:
+        rd, wr = s["FETCH_SIZE"] * 1024.0, s["WRITE_SIZE"] * 1024.0
+        rec["hbm_read_bytes_raw"], rec["hbm_write_bytes"] = rd, wr
+        rec["hbm_bytes_raw"] = rd + wr
+        rec["hbm_bytes_fetch_x2"] = 2 * rd + wr
     try:
         if side is None:
-            j = json.loads(open(os.path.join(src, "pmc_FETCH_SIZE.json")).read().strip().splitlines()[-1])
+            j = json.loads(open(os.path.join(src, "pmc@headline@FETCH_SIZE.json")).read().strip().splitlines()[-1])
             rec["units"] = j["expansions_per_s_kernel_only"] * j["roofline"]["kernel_ms"] * 1e-3
             rec["algorithmic_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
         else:
-            j = json.loads(open(os.path.join(src, prefix + "FETCH_SIZE.json")).read().strip().splitlines()[-1])[side]
-            rec["units"] = j["cells_per_step"] if side == "astar" else j["planner_steps_per_step"]
-            rec["algorithmic_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
+            j = json.loads(open(os.path.join(src, "pmc@%s@FETCH_SIZE.json" % key)).read().strip().splitlines()[-1])[side]
+            rec["units"] = j[units_field]
+            if "roofline" in j:
+                rec["algorithmic_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
     except Exception as e:
-        rec["units_error"] = str(e)
-    if "SQ_INSTS_VALU" in summary and rec.get("units"):
+        rec["units_error"] = "%s: %s" % (type(e).__name__, e)
+    if "SQ_INSTS_VALU" in s and rec.get("units"):
         for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"):
-            if c in summary:
-                rec[c.lower() + "_per_unit"] = summary[c] / rec["units"]
-    if "SQ_THREAD_CYCLES_VALU" in summary and "SQ_ACTIVE_INST_VALU" in summary and summary["SQ_ACTIVE_INST_VALU"] > 0:
-        # lanes enabled in the exec mask per VALU instruction, out of 64 (normalisation checked on a plain copy kernel,
-        # which reads 0.96): exec-mask occupancy, an upper bound of the lanes doing useful work
-        rec["valu_exec_mask_occupancy"] = summary["SQ_THREAD_CYCLES_VALU"] / (summary["SQ_ACTIVE_INST_VALU"] * 64.0)
-    out["kernels"][key] = rec
-parts = [out["kernels"][k] for k in ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel") if k in out["kernels"]]
-if parts:
-    tot = {"per_launch": {}, "kernels": [k for k in ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel") if k in out["kernels"]]}
-    for c in set().union(*[p["per_launch"].keys() for p in parts]):
-        tot["per_launch"][c] = sum(p["per_launch"].get(c, 0.0) for p in parts)
-    for f in ("hbm_read_bytes_raw", "hbm_write_bytes", "hbm_bytes_per_launch_raw", "hbm_bytes_per_launch"):
-        if all(f in p for p in parts):
-            tot[f] = sum(p[f] for p in parts)
-    for f in ("units", "algorithmic_bytes_per_launch"):
-        if f in parts[0]:
-            tot[f] = parts[0][f]
-    out["kernels"]["rrt_exploring"] = tot
+            if c in s:
+                rec[c.lower() + "_per_unit"] = s[c] / rec["units"]
+    for kn, kr in rec["kernels"].items():
+        km = kr["per_launch"]
+        if "SQ_THREAD_CYCLES_VALU" in km and km.get("SQ_ACTIVE_INST_VALU", 0) > 0:
+            # lanes enabled in the exec mask per VALU instruction, out of 64 (a plain copy kernel reads 0.96)
+            kr["valu_exec_mask_occupancy"] = km["SQ_THREAD_CYCLES_VALU"] / (km["SQ_ACTIVE_INST_VALU"] * 64.0)
+        if "SQ_INSTS_VALU" in km and rec.get("units"):
+            kr["sq_insts_valu_per_unit"] = km["SQ_INSTS_VALU"] / rec["units"]
+    out["measurements"][key] = rec
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(REPO, "profiles", "pmc_latest.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+print(json.dumps({k: {f: v.get(f) for f in ("hbm_bytes_raw", "hbm_bytes_fetch_x2", "algorithmic_bytes_per_launch", "units", "sq_insts_valu_per_unit")}
+                  for k, v in out["measurements"].items()}, indent=1))
