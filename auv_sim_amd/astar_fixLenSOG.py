@@ -12,6 +12,22 @@ from .motion_plan_state import Motion_plan_state
 from .rrt_dubins import pack_shark_grid
 
 
+def createSharkGrid(filepath, cell_list):
+    """CSV -> {(t0,t1): {cell.bounds: prob}}, this module's twin of the loader (astar_fixLenSOG.py:31-49): same wire format
+    as rrt_dubins.createSharkGrid (header `time bin,grid`, one row per bin: "(t0, t1)","[p0, p1, ...]"), but the LAST value
+    of every row is dropped (`range(len(temp)-1)`, :46 -- "changed to fix outofindex error"), so a 987-value row yields 986
+    cells."""
+    import csv
+    out = {}
+    with open(filepath, newline="") as f:
+        for row in csv.DictReader(f):
+            a, b = row["time bin"].split(", ")
+            key = (int(a[1:]), int(b[:-1]))
+            vals = row["grid"][1:-1].split(", ")
+            out[key] = {cell_list[i].bounds: float(vals[i]) for i in range(len(vals) - 1)}
+    return out
+
+
 class astar:
     def __init__(self, start, obstacleList, boundaryList, habitatList, sharkGrid, shark_dict, AUV_velocity,
                  cap_nodes=200000, device=0):

@@ -1208,7 +1208,45 @@ def g14():
         json.dump(out, f)
 
 
-ALL = {"g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8, "g9": g9,
+def g15():
+    """createSharkGrid, both twins (path_planning/rrt_dubins.py:612-630 and astar_fixLenSOG.py:31-49, which drops the last
+    value of every row, :46), run by the reference itself on its own shark_data/*.csv with `.bounds` stand-in
+    cells.  Inputs: the reference's DATA files, stored gzip-compressed under tests/golden/shark_data/ (no source).  Outputs:
+    per file and twin the bin keys, the number of cells per bin, every probability, the first / last cell key."""
+    import gzip
+    import shutil
+    rrt_mod, _, _ = import_rrt()
+    sog_mod, _ = import_astar("astar_fixLenSOG")
+
+    class Cell:
+        def __init__(self, i):
+            self.bounds = (float(i), 0.5 * i, float(i) + 1.0, 0.5 * i + 1.0)
+    cell_list = [Cell(i) for i in range(1200)]
+    src = os.path.join(REF, "path_planning", "shark_data")
+    dst = os.path.join(HERE, "shark_data")
+    os.makedirs(dst, exist_ok=True)
+    out = {}
+    for name in sorted(os.listdir(src)):
+        if not name.endswith(".csv"):
+            continue
+        with open(os.path.join(src, name), "rb") as fi, gzip.GzipFile(os.path.join(dst, name + ".gz"), "wb", mtime=0) as fo:
+            shutil.copyfileobj(fi, fo)
+        stem = name[:-4]
+        for twin, fn in (("rrt", rrt_mod.createSharkGrid), ("sog", sog_mod.createSharkGrid)):
+            g = fn(os.path.join(src, name), cell_list)
+            keys = list(g.keys())
+            lens = [len(g[k]) for k in keys]
+            vals = np.concatenate([np.array(list(g[k].values()), dtype=np.float64) for k in keys])
+            out["%s_%s_keys" % (stem, twin)] = np.array(keys, dtype=np.int64).reshape(-1, 2)
+            out["%s_%s_lens" % (stem, twin)] = np.array(lens, dtype=np.int64)
+            out["%s_%s_vals" % (stem, twin)] = vals
+            out["%s_%s_first_cell" % (stem, twin)] = np.array(list(g[keys[0]].keys())[0])
+            out["%s_%s_last_cell" % (stem, twin)] = np.array(list(g[keys[-1]].keys())[-1])
+            print("g15", stem, twin, "bins", len(keys), "cells per bin", sorted(set(lens)), "sum", float(vals.sum()))
+    np.savez_compressed(os.path.join(HERE, "g15_shark_grid_csv.npz"), **out)
+
+
+ALL = {"g15": g15, "g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8, "g9": g9,
        "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14}
 
 if __name__ == "__main__":

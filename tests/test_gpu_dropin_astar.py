@@ -83,3 +83,44 @@ def test_astar_fixlen_solver_reuse_keeps_visited_bitmap():
         if res is not None:
             assert [(p.x, p.y) for p in res[0]] == [tuple(r) for r in g["path%d" % k].tolist()]
         assert int(solver.visited_nodes.sum()) == int(g["visited_count%d" % k])
+
+
+@pytest.mark.parametrize("stem", ["AUVGrid_prob_500_straight", "AUVGrid_prob_500_turn"])
+def test_astar_fixlen_sog_on_the_reference_shark_csv(tmp_path, stem, orc):
+    """row a12 end to end: the reference's shark_data CSV -> this module's createSharkGrid (drops each row's last value,
+    astar_fixLenSOG.py:46) -> astar_fixLenSOG on the GPU, against the checker run on arrays built from what the REFERENCE's
+    loader returned for the same file (G15) -- a non-grid cell list (the last row is one cell short), so the search takes the
+    cell sweep"""
+    import gzip
+    from auv_sim_amd.astar_fixLenSOG import astar, createSharkGrid
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    from oracle import orc_astar as oa
+    g = np.load(os.path.join(GOLDEN, "g15_shark_grid_csv.npz"))
+    p = tmp_path / (stem + ".csv")
+    p.write_bytes(gzip.open(os.path.join(GOLDEN, "shark_data", stem + ".csv.gz")).read())
+
+    class Cell:
+        def __init__(self, b):
+            self.bounds = b
+    # 987 = 47 x 21 cells of 10 m over the window the hard-coded visited bitmap covers (astar_fixLenSOG.py:281-282)
+    cells = [Cell((-300.0 + 10.0 * c, -100.0 + 10.0 * r, -290.0 + 10.0 * c, -90.0 + 10.0 * r)) for r in range(21) for c in range(47)]
+    shark = createSharkGrid(str(p), cells)
+    pre = stem + "_sog_"
+    n = int(g[pre + "lens"][0])
+    assert all(len(v) == n for v in shark.values()) and n in (986, 985)
+    rng = np.random.default_rng(8)
+    obstacles = np.column_stack([rng.uniform(-280, 150, 24), rng.uniform(-80, 90, 24), rng.uniform(2, 6, 24)])
+    habitats = np.column_stack([rng.uniform(-280, 150, 8), rng.uniform(-80, 90, 8), rng.uniform(10, 25, 8)])
+    poly = [(-300.0, -100.0), (170.0, -100.0), (170.0, 110.0), (-300.0, 110.0)]
+    bins = g[pre + "keys"].astype(np.float64)
+    cell_arr = np.array([c.bounds for c in cells[:n]])
+    prob = g[pre + "vals"].reshape(len(bins), n)
+    obs, hab, bnd = _mps(obstacles.tolist()), _mps(habitats.tolist()), [MPS(x, y) for x, y in poly]
+    for start, limit in (((-250.0, -50.0), 200.0), ((100.0, 60.0), 300.0), ((-100.0, 0.0), 100.0)):
+        res = astar(start, obs, bnd, hab, shark, {}, 1.0).astar(limit, [0, 10, 10, 100], {})
+        o = oa.run("astar_fixLenSOG", np.array(start), obstacles=obstacles, habitats=habitats, polygon=np.array(poly), bins=bins,
+                   cells=cell_arr, prob=prob, limit=limit, weights=(0, 10, 10, 100), velocity=1.0, cap_nodes=200000, kind="portable")
+        assert (res is not None) == o["found"]
+        if res is not None:
+            assert [[q.x, q.y, q.traj_time_stamp] for q in res["path"]] == o["smooth_path"].tolist()
+            assert res["cost list"] == o["cost_list"].tolist()

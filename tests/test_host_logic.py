@@ -25,6 +25,34 @@ def test_create_shark_grid_roundtrip(tmp_path):
     assert cl.shape == (5, 4) and prob.shape == (2, 5) and prob[1, 4] == 1.0
 
 
+@pytest.mark.parametrize("stem", ["AUVGrid_prob_200_straight", "AUVGrid_prob_500_straight", "AUVGrid_prob_500_turn"])
+@pytest.mark.parametrize("twin", ["rrt", "sog"])
+def test_create_shark_grid_matches_the_reference_on_its_own_csv(tmp_path, stem, twin):
+    """both createSharkGrid twins (rrt_dubins.py:612-630; astar_fixLenSOG.py:31-49 drops the last value of each row) on the
+    reference's own shark_data/*.csv, against what the reference's loaders returned for them (G15)"""
+    import gzip
+    from conftest import GOLDEN
+    from auv_sim_amd import astar_fixLenSOG, rrt_dubins
+    g = np.load(os.path.join(GOLDEN, "g15_shark_grid_csv.npz"))
+    p = tmp_path / (stem + ".csv")
+    p.write_bytes(gzip.open(os.path.join(GOLDEN, "shark_data", stem + ".csv.gz")).read())
+    cells = [_Cell((float(i), 0.5 * i, float(i) + 1.0, 0.5 * i + 1.0)) for i in range(1200)]  # the stand-ins G15 used
+    fn = rrt_dubins.createSharkGrid if twin == "rrt" else astar_fixLenSOG.createSharkGrid
+    got = fn(str(p), cells)
+    pre = "%s_%s_" % (stem, twin)
+    keys = list(got.keys())
+    assert np.array_equal(np.array(keys, dtype=np.int64).reshape(-1, 2), g[pre + "keys"])
+    assert [len(got[k]) for k in keys] == g[pre + "lens"].tolist()
+    assert np.array_equal(np.concatenate([np.array(list(got[k].values())) for k in keys]), g[pre + "vals"])
+    assert list(got[keys[0]].keys())[0] == tuple(g[pre + "first_cell"]) and list(got[keys[-1]].keys())[-1] == tuple(g[pre + "last_cell"])
+    n = int(g[pre + "lens"][0])
+    assert n == {"AUVGrid_prob_200_straight": 987, "AUVGrid_prob_500_straight": 987, "AUVGrid_prob_500_turn": 986}[stem] - (twin == "sog")
+    # and the packed arrays the device tables are built from
+    bins, cl, prob = rrt_dubins.pack_shark_grid(got)
+    assert bins.shape == (len(keys), 2) and cl.shape == (n, 4) and prob.shape == (len(keys), n)
+    assert np.array_equal(prob.ravel(), g[pre + "vals"])
+
+
 def test_pack_shark_grid_rejects_inconsistent_cell_order():
     from auv_sim_amd.rrt_dubins import pack_shark_grid
     a, b = (0.0, 0.0, 1.0, 1.0), (1.0, 0.0, 2.0, 1.0)
