@@ -1,0 +1,467 @@
+// planner_rows_kernel.h -- Planner_RRT (gym_rrt/envs/rrt_dubins.py:162-289,374-423) for throughput batches: FOUR episodes
+// per wavefront, one 16-lane DPP row each, rows fed from a work counter.
+//
+// prrt_kernel gives a wavefront to one episode; at freq <= 15 (the environment's planner runs freq = 10, rrt_env.py:28) a
+// steer has at most 15 sub-arcs and everything between the bucket draw and the goal arc is one lane's worth of
+// bookkeeping.  Here, as in rrt_rows_kernel, what was wave-uniform is row-uniform: every vector instruction serves four
+// episodes, ballots are cut into 16-bit row masks, cross-lane reads stay inside a row.
+//   bucket / node choice   random.choice = _randbelow (:186,:223): lanes 0..7 of a row temper eight tries at once; the
+//                          picked node is reached along the bucket's member list (newest first)
+//   steer (:251-289)       lane s = sub-arc s (two draws each, no data-dependent offsets); theta with its angle_wrap and
+//                          x / y / t are left-to-right DPP row-shift chains (lane s is final after s + 1 steps): no LDS
+//                          scratch at all -- the only LDS an episode owns is its MT19937 state
+//   collision (:435-458)   the obstacles cut into 16 slots of 16 along a space-filling curve (WorldDev::os_*): lane rl
+//                          keeps slot rl's bounding box, hit slots get the per-obstacle cull against the tight box of the
+//                          path points, survivors the exact d2 <= T_i test (lane = path point, lane 15 = the parent's end)
+//   goal arc (:374-423)    16 samples per row and pass, same cull, early exit at the first pass that is not free
+// Rows are persistent: a row whose episode is finished (goal connected, step budget used, error) stores it and takes
+// the next episode id from a device counter, so rows do not wait for their neighbours' episodes and a batch that is
+// not a multiple of the resident capacity has no second round.
+//
+// Bit-identical to prrt_kernel (tree, bucket lists, counters, generator position).  Limits (the host falls back to
+// prrt_kernel beyond them): freq <= 15, <= 256 obstacles, no step log.
+#ifndef AUVP_PLANNER_ROWS_KERNEL_H
+#define AUVP_PLANNER_ROWS_KERNEL_H
+#include "planner_rrt_kernel.h"
+#include "rrt_rows_kernel.h"
+
+namespace auvp {
+
+constexpr int PRW_WAVES = 4;       // waves per workgroup (16 episodes in flight per workgroup)
+constexpr int PRW_MAX_FREQ = 15;   // sub-arcs of a steer: lanes 0..14 of the row (lane 15: the parent's end / entry angle)
+constexpr int PRW_LDS_PER_EP = 624 * 4;
+
+__device__ __forceinline__ uint32_t rows_word(const RowRng& r, uint32_t j) {
+  uint32_t k = r.pslot + j;  // pslot < 624, j < avail <= 624: one wrap
+  k = k >= 624u ? k - 624u : k;
+  return mt_temper(r.s[k]);
+}
+
+__global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes,
+                                                                      int* __restrict__ work_counter) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int wave = (int)(threadIdx.x >> 6);
+  const int lane = lane_id();
+  const int row = lane >> 4, rl = lane & 15, rowbase = lane & 48;
+  uint32_t* mt = reinterpret_cast<uint32_t*>(smem + (size_t)(wave * RW_ROWS + row) * PRW_LDS_PER_EP);
+  const int capn = B.cap_nodes;
+  const size_t capp = (size_t)B.cap_points;
+  const double4 sbox = reinterpret_cast<const double4*>(W.os_box)[rl];  // lane rl: bounding box of obstacle slot rl
+  const int nfreq = (int)P.freq;
+
+  RowRng rng;
+  rng.s = mt; rng.pslot = 0u; rng.avail = 0u; rng.drawn = 0ull;
+  // ---- the row's episode (row-uniform) ----
+  int ep = -1;
+  bool live = false, more = true;
+  int n_nodes = 0, n_points = 0, n_occ = 0, step = 0, done = 0, status = 0, last_accepted = 0, last_new = -1;
+  int prev_n_arc = -1, step_end = 0, step_bucket = 0;
+  bool have_prev_arc = false;
+  double gx = 0.0, gy = 0.0;
+
+  for (;;) {
+    // ---------------------------------------------------------------- rows without an episode take the next one
+    if (__any(!live && more)) {
+      const bool need = !live && more;
+      int e = 0;
+      if (need && rl == 0) e = atomicAdd(work_counter, 1);
+      e = row_read(e, rowbase);
+      bool skip = false;
+      if (need) {
+        if (e >= n_episodes) { more = false; }
+        else {
+          ep = e;
+          step_bucket = P.step_mode ? B.step_bucket[e] : 0;
+          // step mode: an episode whose bucket is < 0 is not touched at all
+          skip = P.step_mode && step_bucket < 0;
+        }
+      }
+      const bool load = need && more && !skip;
+      if (__any(load)) {
+        wave_sync();
+        if (load) {
+          const uint32_t* src = B.mt + (size_t)ep * 624;
+          for (int i = rl; i < 624; i += 16) mt[i] = src[i];
+          const int4 rs = *reinterpret_cast<const int4*>(B.rng_state + 4 * (size_t)ep);
+          rng.pslot = (uint32_t)rs.x; rng.avail = (uint32_t)rs.y;
+          rng.drawn = ((unsigned long long)(uint32_t)rs.z) | ((unsigned long long)(uint32_t)rs.w << 32);
+          const PrrtSummary& sm = B.summary[ep];
+          n_nodes = sm.n_nodes; n_points = sm.n_points; n_occ = sm.n_occ; step = sm.steps; done = sm.done; status = sm.status;
+          last_accepted = 0; last_new = -1; prev_n_arc = -1; have_prev_arc = false;
+          step_end = P.step_mode ? step + 1 : P.max_step;
+          gx = B.goal[2 * (size_t)ep]; gy = B.goal[2 * (size_t)ep + 1];
+          // whole 16-word blocks are regenerated in place (rrt_rows_kernel.h): the frontier must sit on a block boundary,
+          // which every state this kernel or the host's seeding writes does
+          if (((rng.pslot + rng.avail) & 15u) != 0u) status = -7;
+          live = true;
+        }
+        wave_sync();
+      }
+    }
+    if (!__any(live)) {
+      if (__any(more)) continue;  // (every row drew an episode the step skips: draw again)
+      break;
+    }
+    const size_t en = (size_t)(ep < 0 ? 0 : ep) * capn;           // node-indexed arrays of the row's episode
+    const size_t eb = (size_t)(ep < 0 ? 0 : ep) * P.n_buckets;    // bucket-indexed arrays
+    double* nodeF = B.node_f + en * 4;
+    int4* nodeI = reinterpret_cast<int4*>(B.node_i) + en;
+    int32_t* nnext = B.node_next + en;
+    int32_t* bcount = B.bucket_counts + eb;
+    int32_t* bhead = B.bucket_head + eb;
+
+    // a row takes part in this step if its episode is still running
+    bool act = live && status == 0 && !done && step < step_end;
+
+    // per-row _randbelow(n): getrandbits(bit_length(n)) until < n, one 32-bit output per try; lanes 0..7 try eight at once
+    auto randbelow = [&](bool on, uint32_t n) -> uint32_t {
+      uint32_t res = 0u;
+      bool search = on;
+      const int k = 32 - __clz((int)(n | 1u));
+      for (;;) {
+        rows_ensure(rng, search, 8u, rl);
+        uint32_t v = 0xffffffffu;
+        if (search && rl < 8) v = rows_word(rng, (uint32_t)rl) >> (32 - k);
+        const uint32_t okm = row_ballot(search && rl < 8 && v < n, rowbase);
+        const int f = okm ? (__ffs((int)okm) - 1) : 0;
+        const uint32_t got = (uint32_t)row_read((int)v, rowbase + f);
+        const bool fin = search && okm != 0u;
+        if (fin) res = got;
+        rows_advance(rng, search, fin ? (uint32_t)(f + 1) : 8u);
+        search = search && !fin;
+        if (!__any(search)) break;
+      }
+      return res;
+    };
+
+    if (__any(act)) {
+      // ---------------------------------------------------------------- bucket + node choice (:186, :214-223)
+      int b = 0;
+      if (P.step_mode) {
+        b = step_bucket;
+        if (act && b >= P.n_buckets) { status = -1; act = false; }
+      } else {
+        if (act && n_occ == 0) { status = -1; act = false; }
+        const uint32_t oi = randbelow(act, (uint32_t)n_occ);
+        if (act) b = B.occupied[en + oi];
+      }
+      int cnt_b = 0, head_b = 0;
+      if (act) { cnt_b = bcount[b]; head_b = bhead[b]; }
+      last_accepted = act ? 0 : last_accepted;
+      last_new = act ? -1 : last_new;
+      // generate_one_node on an empty bucket: (False, None) (:214-220): the step is used up, nothing else happens
+      const bool empty_b = act && cnt_b == 0;
+      if (empty_b) { step++; act = false; }
+      const uint32_t rsel = randbelow(act, (uint32_t)cnt_b);
+      // the rsel-th member of the bucket in creation order is count - 1 - rsel steps from the head of its list
+      int par = act ? head_b : 0;
+      {
+        int hops = act ? cnt_b - 1 - (int)rsel : 0;
+        while (__any(hops > 0)) {
+          if (hops > 0) { par = nnext[par]; hops--; }
+        }
+      }
+      // ---------------------------------------------------------------- steer (:251-289)
+      double cx = 0.0, cy = 0.0, cth = 0.0, ctt = 0.0;
+      if (act) {
+        const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 4);
+        const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 4 + 2);
+        cx = a.x; cy = a.y; cth = c.x; ctt = c.y;
+      }
+      const double px0 = cx, py0 = cy;
+      int n = 0;
+      {
+        rows_ensure(rng, act, 2u, rl);
+        const double u = act ? rows_random_at(rng, 0u) : 0.0;
+        rows_advance(rng, act, 2u);
+        n = act ? (int)auvp_floor(py_uniform(0.0, P.freq, u) / 1) : 0;
+      }
+      // sub-arc s draws random() numbers 2s (dist) and 2s + 1 (diff): every lane tempers its own two
+      rows_ensure(rng, act, (uint32_t)(4 * n), rl);
+      const bool active = act && rl < n;
+      double radius = 0.0, phi = 0.0;
+      bool taken = false;
+      if (active) {
+        const double dist = py_uniform(0.0, P.dist_to_end, rows_random_at(rng, (uint32_t)(2 * rl)));
+        const double diff = py_uniform(-P.diff_max, P.diff_max, rows_random_at(rng, (uint32_t)(2 * rl + 1)));
+        taken = auvp_fabs(dist) > auvp_fabs(diff);
+        if (taken) {
+          const double s1 = dist + diff, s2 = dist - diff;
+          radius = (s1 + s2) / (-s1 + s2);
+          phi = (s1 + s2) / (2 * radius);
+        }
+      }
+      rows_advance(rng, act, (uint32_t)(4 * n));
+      const uint32_t tmask = row_ballot(taken, rowbase);
+      int nmax = 0;  // longest steer among the rows (wave-uniform loop bound)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int nr = __builtin_amdgcn_readlane(n, 16 * r);
+        nmax = nr > nmax ? nr : nmax;
+      }
+      // theta = angle_wrap(theta + phi) for the taken sub-arcs only, left to right: one DPP row shift per step; lane s holds the
+      // angle after sub-arc s once s + 1 steps have run (untaken and idle lanes pass their left neighbour's angle on)
+      double th = cth;
+      for (int s = 0; s < nmax; s++) {
+        const double prev = row_prev_f64(th, cth);
+        double a = prev + phi;
+        // angle_wrap (:425-433): add -+2 pi until inside [-pi, pi] (at most once for |phi| <= pi)
+        for (int guard = 0; guard < 64; guard++) {
+          const bool hi = a > AUVP_PI, lo = a < -AUVP_PI;
+          if (!__any(taken && (hi || lo))) break;
+          a = hi ? a + (-2 * AUVP_PI) : (lo ? a + (2 * AUVP_PI) : a);
+        }
+        th = taken ? a : prev;
+      }
+      double sn, cs;
+      auvp_sincos(rl == 15 ? cth : th, &sn, &cs);  // lane 15: the entry angle
+      double dx = 0.0, dy = 0.0, dt = 0.0;
+      {
+        // sin / cos of the previous TAKEN sub-arc's angle (none: the entry angle on lane 15)
+        const uint32_t below = tmask & ((1u << rl) - 1u);
+        const int prevl = below ? (31 - __clz((int)below)) : 15;
+        const double so = row_read_f64(sn, rowbase + prevl), co = row_read_f64(cs, rowbase + prevl);
+        if (taken) {
+          dx = radius * (sn - so);
+          dy = radius * (-cs + co);
+          dt = auvp_sqrt(dx * dx + dy * dy) / 1;
+        }
+      }
+      // x += dx; y += dy; t += dt, left to right (untaken sub-arcs add an exact 0.0): the same kind of chain
+      double mx = dx, my = dy, mtt = dt;
+      for (int s = 0; s < nmax; s++) {
+        mx = row_prev_f64(mx, cx) + dx;
+        my = row_prev_f64(my, cy) + dy;
+        mtt = row_prev_f64(mtt, ctt) + dt;
+      }
+      const int napp = __popc(tmask);
+      if (act && (n_points + napp > (int)capp || napp + 2 > B.max_pts)) { status = -2; act = false; }
+      const bool wr = taken && act;
+      if (wr) {
+        const int rank = __popc(tmask & ((1u << rl) - 1u));
+        const size_t gi = (size_t)ep * capp * 4 + (size_t)(n_points + rank);  // speculative: kept only if the node is accepted
+        B.points[gi] = mx; B.points[gi + capp] = my; B.points[gi + 2 * capp] = th; B.points[gi + 3 * capp] = mtt;
+      }
+      // the row's state after the steer = the prefix values of its last sub-arc
+      {
+        const int last = rowbase + (n > 0 ? n - 1 : 0);
+        const double ex = row_read_f64(mx, last), ey = row_read_f64(my, last), et = row_read_f64(mtt, last), eth = row_read_f64(th, last);
+        if (act && n > 0) { cx = ex; cy = ey; ctt = et; cth = eth; }
+      }
+      const int cnt = napp;
+
+      // ---------------------------------------------------------------- check_collision_free (:435-458)
+      // closed rectangle (every path point and the parent's end) + obstacles behind the slot / obstacle culls
+      bool bad_pt = false;
+      {
+        const bool mine = wr || (act && rl == 15);
+        const double qx = rl == 15 ? px0 : mx, qy = rl == 15 ? py0 : my;
+        const bool wx = (qx >= P.rect[0]) && (qx <= P.rect[2]);
+        const bool wy = (qy >= P.rect[1]) && (qy <= P.rect[3]);
+        bad_pt = mine && !(wx && wy);
+      }
+      // lanes = the row's points: `pv` marks a lane that holds one
+      auto obstacle_hit = [&](bool on, bool pv, double qx, double qy) -> bool {
+        // tight box of the row's points
+        const double inf = __builtin_inf();
+        double mnx = pv ? qx : inf, mxx = pv ? qx : -inf, mny = pv ? qy : inf, mxy = pv ? qy : -inf;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          mnx = __builtin_fmin(mnx, __shfl_xor(mnx, o, 16)); mxx = __builtin_fmax(mxx, __shfl_xor(mxx, o, 16));
+          mny = __builtin_fmin(mny, __shfl_xor(mny, o, 16)); mxy = __builtin_fmax(mxy, __shfl_xor(mxy, o, 16));
+        }
+        const double ts = 0x1p-30 * (auvp_fabs(mnx) + auvp_fabs(mxx) + auvp_fabs(mny) + auvp_fabs(mxy) + 1.0);
+        const double tcx = (mnx + mxx) * 0.5, tcy = (mny + mxy) * 0.5;
+        const double thx = (mxx - mnx) * 0.5 + ts, thy = (mxy - mny) * 0.5 + ts;
+        const bool slot_hit = on && !(sbox.z < mnx - ts || sbox.x > mxx + ts || sbox.w < mny - ts || sbox.y > mxy + ts);
+        uint32_t sm = row_ballot(slot_hit, rowbase);
+        bool hit = false;
+        while (__any(sm != 0u)) {
+          const bool hs_ = sm != 0u;
+          const int j0 = hs_ ? 16 * (__ffs((int)sm) - 1) : 0;
+          sm &= sm - 1u;
+          const int oi = j0 + rl;
+          const double oxj = W.os_x[oi], oyj = W.os_y[oi], orj = (double)W.os_r[oi], otj = W.os_t[oi];
+          const bool cand = hs_ && !(auvp_fabs(oxj - tcx) > thx + orj || auvp_fabs(oyj - tcy) > thy + orj);
+          uint32_t cm = row_ballot(cand, rowbase);
+          while (__any(cm != 0u)) {
+            const bool has = cm != 0u;
+            const int cl = has ? (__ffs((int)cm) - 1) : 0;
+            cm &= cm - 1u;
+            const double ox = row_read_f64(oxj, rowbase + cl), oy = row_read_f64(oyj, rowbase + cl), ot = row_read_f64(otj, rowbase + cl);
+            const double ddx = qx - ox, ddy = qy - oy;
+            hit |= has && pv && (ddx * ddx + ddy * ddy <= ot);
+            if (row_ballot(hit, rowbase) != 0u) cm = 0u;
+          }
+          if (row_ballot(hit, rowbase) != 0u) sm = 0u;
+        }
+        return row_ballot(hit, rowbase) != 0u;
+      };
+      bool ok = false;
+      {
+        const bool pv = wr || (act && rl == 15);
+        const bool hit = obstacle_hit(act, pv, rl == 15 ? px0 : mx, rl == 15 ? py0 : my);
+        ok = act && !hit && row_ballot(bad_pt, rowbase) == 0u;
+      }
+      // ---------------------------------------------------------------- accept: add_node_to_grid (:108-159)
+      int me = -1;
+      if (ok && n_nodes >= capn) { status = -2; ok = false; act = false; }
+      if (ok) {
+        me = n_nodes;
+        int rrow = (int)(cy / P.cell), col = (int)(cx / P.cell);
+        bool idx_err = false;
+        if (rrow < 0) { rrow += P.rows; idx_err |= rrow < 0; }
+        if (col < 0) { col += P.cols; idx_err |= col < 0; }
+        int bk = -1;
+        if (!idx_err && rrow < P.rows && col < P.cols) {
+          const double raw = cth / P.delta_theta;
+          int sub = (int)auvp_floor(raw);
+          if (sub < 0) sub = (int)(P.S + sub);
+          if (sub == P.S) sub -= 1;
+          if (sub < 0) { sub += P.S; idx_err |= sub < 0; }
+          idx_err |= sub >= P.S;
+          bk = (rrow * P.cols + col) * P.S + sub;
+        }
+        if (idx_err) { status = -1; ok = false; act = false; }
+        else {
+          const int c_before = bk >= 0 ? bcount[bk] : -1;
+          const int h_before = bk >= 0 ? bhead[bk] : -1;
+          if (rl == 0) {
+            double* nf = nodeF + (size_t)me * 4;
+            *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
+            *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
+            nodeI[me] = make_int4(step, par, n_points, cnt);
+            B.node_bucket[en + me] = bk;
+            if (bk >= 0) {
+              nnext[me] = c_before > 0 ? h_before : -1;
+              bhead[bk] = me;
+              bcount[bk] = c_before + 1;
+              if (c_before == 0) B.occupied[en + n_occ] = bk;  // first node of the bucket (:157-159)
+            }
+          }
+          if (c_before == 0) n_occ++;
+          n_nodes++;
+          n_points += cnt;
+          last_accepted = 1; last_new = me;
+        }
+      }
+      // ---------------------------------------------------------------- connect_to_goal_curve_alt(mps_list[-1]) (:374-423)
+      // from the LAST list node even if this step's node was rejected (:237); a step that added no node repeats the previous
+      // step's evaluation, which was "not free" (or planning would have ended): its result is reused
+      const int lastn = n_nodes - 1;
+      double lx = cx, ly = cy, th0 = cth;
+      const bool eval = act && (ok || !have_prev_arc);
+      if (eval && !ok) {
+        const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)lastn * 4);
+        lx = a.x; ly = a.y; th0 = nodeF[(size_t)lastn * 4 + 2];
+      }
+      int n_arc = act ? prev_n_arc : -1;
+      bool free_ = false;
+      if (__any(eval)) {
+        n_arc = eval ? -1 : n_arc;
+        const double theta = auvp_atan2(gy - ly, gx - lx);
+        double diffg = theta - th0;
+        for (int guard = 0; guard < 64; guard++) {  // angle_wrap
+          const bool hi = diffg > AUVP_PI, lo = diffg < -AUVP_PI;
+          if (!__any(eval && (hi || lo))) break;
+          diffg = hi ? diffg + (-2 * AUVP_PI) : (lo ? diffg + (2 * AUVP_PI) : diffg);
+        }
+        bool go = eval && !(auvp_fabs(diffg) > AUVP_PI / 2);
+        const double r_G = auvp_hypot(gx - lx, gy - ly);
+        const double dphi = theta - th0;  // phi_G - th0 (same atan2 arguments, :387)
+        go = go && (dphi != 0);
+        double phi2 = dphi;
+        for (int guard = 0; guard < 64; guard++) {
+          const bool hi = phi2 > AUVP_PI, lo = phi2 < -AUVP_PI;
+          if (!__any(go && (hi || lo))) break;
+          phi2 = hi ? phi2 + (-2 * AUVP_PI) : (lo ? phi2 + (2 * AUVP_PI) : phi2);
+        }
+        phi2 = 2 * phi2;
+        const double sn0 = auvp_sin(dphi);
+        go = go && (sn0 != 0);
+        const double radiusg = r_G / (2 * sn0);
+        double length = radiusg * phi2;
+        if (phi2 > AUVP_PI) { phi2 -= 2 * AUVP_PI; length = -radiusg * phi2; }
+        else if (phi2 < -AUVP_PI) { phi2 += 2 * AUVP_PI; length = -radiusg * phi2; }
+        const double ang_vel = phi2 / (length / P.exp_rate);
+        double s0, c0;
+        auvp_sincos(th0, &s0, &c0);
+        const double x_C = lx - radiusg * s0;
+        const double y_C = ly + radiusg * c0;
+        const double ne = auvp_floor(length / P.exp_rate);
+        if (go) n_arc = (ne >= 0 && ne < 1e8) ? (int)ne + 1 : 0;
+        // sample the arc 16 points per row and pass; a row stops at its first pass that is not free
+        bool sampling = go;
+        free_ = go;
+        for (int i0 = 0; __any(sampling && i0 < n_arc); i0 += 16) {
+          const bool on = sampling && i0 < n_arc;
+          const int nv = on ? ((n_arc - i0) < 16 ? (n_arc - i0) : 16) : 0;
+          const int i = i0 + rl;
+          const bool pv = on && rl < nv;
+          double sa, ca;
+          auvp_sincos(ang_vel * i + th0, &sa, &ca);
+          const double ax = x_C + radiusg * sa, ay = y_C - radiusg * ca;
+          const bool wx = (ax >= P.rect[0]) && (ax <= P.rect[2]);
+          const bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
+          const bool outside = row_ballot(pv && !(wx && wy), rowbase) != 0u;
+          bool hitp = false;
+          if (__any(on && !outside)) hitp = obstacle_hit(on && !outside, pv, ax, ay);
+          if (on && (outside || hitp)) { free_ = false; sampling = false; }
+        }
+        if (free_) {
+          done = 1;
+          // len(path): the final node, the arc, every ancestor's points and the ancestors themselves
+          int L = 1 + n_arc;
+          int m = lastn;
+          bool walking = true;
+          while (__any(walking)) {
+            if (walking) {
+              const int4 r = nodeI[m];
+              if (r.y < 0) walking = false;
+              else { L += r.w + 1; m = r.y; }
+            }
+          }
+          if (rl == 0) {
+            PrrtSummary& sum = B.summary[ep];
+            sum.path_len = L; sum.last_node = lastn; sum.n_arc = n_arc;
+            sum.arc[0] = x_C; sum.arc[1] = y_C; sum.arc[2] = radiusg; sum.arc[3] = ang_vel; sum.arc[4] = th0; sum.arc[5] = length;
+          }
+        }
+      }
+      if (act) { prev_n_arc = n_arc; have_prev_arc = true; step++; }
+    }
+
+    // ---------------------------------------------------------------- rows whose episode is finished store it
+    const bool fin = live && (status != 0 || done || step >= step_end);
+    if (__any(fin)) {
+      const unsigned long long drawn = rng.drawn;
+      wave_sync();
+      if (fin) {
+        uint32_t* dst = B.mt + (size_t)ep * 624;
+        for (int i = rl; i < 624; i += 16) dst[i] = mt[i];
+        if (rl == 0) {
+          *reinterpret_cast<int4*>(B.rng_state + 4 * (size_t)ep) =
+              make_int4((int)rng.pslot, (int)rng.avail, (int)(uint32_t)(drawn & 0xffffffffull), (int)(uint32_t)(drawn >> 32));
+        }
+      }
+      wave_sync();
+      // peek the next random() without consuming it (parity probe): generated ahead in LDS only, the stored words above are
+      // what the next launch continues from
+      RowRng peek = rng;
+      rows_ensure(peek, fin, 2u, rl);
+      const double after = fin ? rows_random_at(peek, 0u) : 0.0;
+      if (fin && rl == 0) {
+        PrrtSummary& sum = B.summary[ep];
+        sum.status = status; sum.n_nodes = n_nodes; sum.n_points = n_points; sum.n_occ = n_occ; sum.steps = step;
+        sum.done = done; sum.last_accepted = last_accepted; sum.last_new_node = last_new;
+        sum.rng_after = after; sum.n_draw32 = drawn;
+        if (!done) sum.path_len = 0;
+      }
+      if (fin) { live = false; status = 0; done = 0; }
+      wave_sync();
+    }
+  }
+}
+
+}  // namespace auvp
+#endif

@@ -13,12 +13,18 @@ struct PrrtState {
   auvp::PrrtParamsDev P{};
   auvp::PrrtBuffers B{};
   DevBuf node_f, node_i, node_bucket, points, occupied, bcount, bhead, nnext, mt, rng_state, start, goal, step_bucket, summary, st_log,
-      tmp_off, tmp_out;
+      tmp_off, tmp_out, env_done, thetas;
+  DevBuf work;  // work counter of the four-episodes-per-wavefront kernel (planner_rows_kernel.h)
+  bool use_rows = false;  // decided once per batch: the two kernels keep the generator's lazy state in different block phases
+  const char* last_kernel = "";
+  unsigned long long policy_calls = 0;  // call counter of the stand-in agent (auvp_prrt_policy_random_dev)
+  bool thetas_ready = false;
 };
 
 PrrtState* prrt_of(auvp_handle* h);
 
-int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode) {
+// `sync`: wait for the launch and record its HIP-event time (the device-resident loop passes false: it only enqueues)
+int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
   S.P.step_mode = step_mode;
   const int nfreq = (int)std::floor(S.P.freq);
   const int grid = (S.E + auvp::RRT_WAVES - 1) / auvp::RRT_WAVES;
@@ -39,7 +45,25 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode) {
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipError_t le;
-  if (lat) {
+  int grid_used = grid, block_used = auvp::RRT_WAVES * 64;
+  size_t lds_used = lds;
+  S.last_kernel = "prrt_kernel";
+  if (S.use_rows) {
+    // persistent rows (four episodes per wavefront) fed from a device counter: as many workgroups as fit the chip at
+    // three per CU (one wave per SIMD each), fewer when the batch is smaller
+    S.last_kernel = "prrt_rows_kernel";
+    const int per_wg = auvp::PRW_WAVES * auvp::RW_ROWS;
+    grid_used = std::min((S.E + per_wg - 1) / per_wg, 3 * n_cu_l);
+    block_used = auvp::PRW_WAVES * 64;
+    lds_used = (size_t)per_wg * auvp::PRW_LDS_PER_EP;
+    le = S.work.reserve(sizeof(int));
+    if (le == hipSuccess) le = hipMemsetAsync(S.work.p, 0, sizeof(int), h->stream);
+    if (le == hipSuccess) le = hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::prrt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
+    if (le == hipSuccess) {
+      hipLaunchKernelGGL(auvp::prrt_rows_kernel, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, S.work.as<int>());
+      le = hipGetLastError();
+    }
+  } else if (lat) {
     if (O <= 64) le = launch(auvp::prrt_kernel<1, true>);
     else if (O <= 128) le = launch(auvp::prrt_kernel<2, true>);
     else if (O <= 256) le = launch(auvp::prrt_kernel<4, true>);
@@ -54,11 +78,12 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode) {
   }
   HIPCHK(h, le);
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  h->last_grid = grid_used; h->last_block = block_used; h->last_lds = (int)lds_used;
+  if (!sync) return AUVP_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  h->last_grid = grid; h->last_block = auvp::RRT_WAVES * 64; h->last_lds = (int)lds;
   return AUVP_OK;
 }
 
@@ -123,6 +148,18 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
     HIPCHK(h, hipMemsetAsync(S.st_log.p, 0xff, (size_t)E * p->max_step * 8 * sizeof(int32_t), h->stream));
     B.st_log = S.st_log.as<int32_t>();
   }
+  {
+    // throughput batches (more than eight episodes per CU) of the environment's planner shape run four episodes per
+    // wavefront (planner_rows_kernel.h); AUVP_PRRT_ROWS=0 / 1 forces the choice where the kernel's limits allow it
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+    if (n_cu <= 0) n_cu = 256;
+    const bool rows_ok = nfreq <= auvp::PRW_MAX_FREQ && h->W.n_obstacles <= auvp::RW_MAX_OBST && !(flags & AUVP_FLAG_ITER_LOG);
+    const char* renv = getenv("AUVP_PRRT_ROWS");
+    const char* lenv = getenv("AUVP_PRRT_LAT");
+    const bool lat = lenv ? atoi(lenv) != 0 : E <= 8 * n_cu;
+    S.use_rows = rows_ok && (renv ? atoi(renv) != 0 : !lat);
+  }
   return AUVP_OK;
 }
 
@@ -130,6 +167,10 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
 // kernel's own add_node_to_grid arithmetic (starts / goals / generator states are already on the device)
 static int prrt_plant(auvp_handle* h, PrrtState& S, int32_t E) {
   HIPCHK(h, hipMemsetAsync(S.bcount.p, 0, (size_t)E * S.P.n_buckets * sizeof(int32_t), h->stream));
+  HIPCHK(h, S.env_done.reserve((size_t)E));
+  HIPCHK(h, hipMemsetAsync(S.env_done.p, 0, (size_t)E, h->stream));
+  S.policy_calls = 0;
+  S.thetas_ready = false;
   hipLaunchKernelGGL(auvp::prrt_init_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, S.P, S.B, (int)E);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -301,6 +342,11 @@ int auvp_prrt_step_log(auvp_handle* h, int32_t ep, int32_t* log8) {
   return AUVP_OK;
 }
 
+const char* auvp_prrt_last_kernel(auvp_handle* h) {
+  if (!h) return "";
+  return prrt_of(h)->last_kernel;
+}
+
 void* auvp_prrt_summaries_dev(auvp_handle* h) {
   if (!h) return nullptr;
   PrrtState& S = *prrt_of(h);
@@ -310,14 +356,10 @@ void* auvp_prrt_summaries_dev(auvp_handle* h) {
 // RRTEnv observation arrays (gym_rrt/envs/rrt_env.py:250-295) for every episode, written to
 // caller-owned DEVICE buffers: rrt_grid [E,n_buckets,4] f64 = cell.x, cell.y, subsection.theta,
 // len(node_array); has_node [E,n_buckets] i64; num_nodes [E,n_buckets] i64.
-int auvp_prrt_observation_dev(auvp_handle* h, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev) {
-  if (!h || !rrt_grid_dev) return AUVP_ERR_ARG;
-  PrrtState& S = *prrt_of(h);
-  if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
-  HIPCHK(h, hipSetDevice(h->device));
-  // subsection thetas exactly as Grid_cell_RRT builds them (grid_cell_rrt.py:49-55)
-  std::vector<double> th(S.P.S);
-  {
+static int prrt_observation_enqueue(auvp_handle* h, PrrtState& S, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev) {
+  if (!S.thetas_ready) {
+    // subsection thetas exactly as Grid_cell_RRT builds them (grid_cell_rrt.py:49-55); once per batch
+    std::vector<double> th(S.P.S);
     const double pi = M_PI;
     double theta = 0.0;
     for (int i = 0; i < S.P.S; i++) {
@@ -325,18 +367,72 @@ int auvp_prrt_observation_dev(auvp_handle* h, void* rrt_grid_dev, void* has_node
       theta = theta + S.P.delta_theta;
       while (!(-pi <= theta && theta <= pi)) theta += theta > pi ? (-2 * pi) : (2 * pi);
     }
+    int rc;
+    if ((rc = upload(h, S.thetas, th.data(), th.size()))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `th` goes out of scope
+    S.thetas_ready = true;
   }
-  int rc;
-  if ((rc = upload(h, S.tmp_out, th.data(), th.size()))) return rc;
   const long long total = (long long)S.E * S.P.n_buckets;
   const int grid = (int)std::min<long long>((total + 255) / 256, 65535LL * 16);
-  hipLaunchKernelGGL(auvp::prrt_observation_kernel, dim3(grid), dim3(256), 0, h->stream, S.P, S.B, S.tmp_out.as<double>(), S.E,
+  hipLaunchKernelGGL(auvp::prrt_observation_kernel, dim3(grid), dim3(256), 0, h->stream, S.P, S.B, S.thetas.as<double>(), S.E,
                      reinterpret_cast<double*>(rrt_grid_dev), reinterpret_cast<long long*>(has_node_dev),
                      reinterpret_cast<long long*>(num_nodes_dev));
   HIPCHK(h, hipGetLastError());
+  return AUVP_OK;
+}
+
+int auvp_prrt_observation_dev(auvp_handle* h, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev) {
+  if (!h || !rrt_grid_dev) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc = prrt_observation_enqueue(h, S, rrt_grid_dev, has_node_dev, num_nodes_dev);
+  if (rc != AUVP_OK) return rc;
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return AUVP_OK;
 }
+
+// ---- the device-resident RRTEnv loop: every call below only ENQUEUES on the handle's stream (auvp_stream_sync waits) ----
+int auvp_prrt_env_step_dev(auvp_handle* h, const int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev,
+                           int64_t* reward_dev, uint8_t* done_dev) {
+  if (!h || !bucket_ids_dev || !reward_dev) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "auvp_prrt_create_batch not called");
+  HIPCHK(h, hipSetDevice(h->device));
+  // generate_one_node with the caller's bucket (read where it lies: the kernel takes the pointer), then the observation
+  // arrays and the step's outcome, back to back on the stream
+  const int32_t* own = S.B.step_bucket;
+  S.B.step_bucket = bucket_ids_dev;
+  int rc = prrt_launch(h, S, 1, false);
+  S.B.step_bucket = own;
+  if (rc != AUVP_OK) return rc;
+  if (rrt_grid_dev && (rc = prrt_observation_enqueue(h, S, rrt_grid_dev, has_node_dev, num_nodes_dev)) != AUVP_OK) return rc;
+  hipLaunchKernelGGL(auvp::prrt_env_outcome_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, S.B, S.E, S.env_done.as<uint8_t>(),
+                     reinterpret_cast<long long*>(reward_dev), done_dev);
+  HIPCHK(h, hipGetLastError());
+  return AUVP_OK;
+}
+
+int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uint64_t seed, int32_t* bucket_ids_dev) {
+  if (!h || !has_node_dev || !bucket_ids_dev) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(auvp::prrt_policy_random_kernel, dim3((S.E + 3) / 4), dim3(256), 0, h->stream, S.E, S.P.n_buckets,
+                     reinterpret_cast<const long long*>(has_node_dev), S.env_done.as<uint8_t>(), (unsigned long long)seed,
+                     S.policy_calls++, bucket_ids_dev);
+  HIPCHK(h, hipGetLastError());
+  return AUVP_OK;
+}
+
+int auvp_stream_sync(auvp_handle* h) {
+  if (!h) return AUVP_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+void* auvp_stream(auvp_handle* h) { return h ? (void*)h->stream : nullptr; }
 
 // the same for one episode, copied to host arrays
 int auvp_prrt_observation(auvp_handle* h, int32_t ep, double* rrt_grid, int64_t* has_node, int64_t* num_nodes) {

@@ -804,5 +804,63 @@ __global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, 
   }
 }
 
+// ---- device-resident RRTEnv loop (gym_rrt/envs/rrt_env.py:182-247): nothing of a step crosses PCIe -----------------
+// Outcome of the step just run, per environment (rrt_env.py:224-247): R_FOUND_PATH (300) when the goal arc was free,
+// R_CREATE_NODE (0) when a node was added, R_INVALID_NODE (-1) otherwise; an environment that had finished before the
+// step is skipped by it and gets reward 0.  env_done [E] is the loop's own "finished" flag.
+__global__ __launch_bounds__(256) void prrt_env_outcome_kernel(PrrtBuffers B, int n_episodes, uint8_t* __restrict__ env_done,
+                                                               long long* __restrict__ reward, uint8_t* __restrict__ done_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_episodes) return;
+  const bool was = env_done[e] != 0;
+  const PrrtSummary& s = B.summary[e];
+  const bool now = s.done != 0;
+  long long r = 0;
+  if (!was) r = now ? 300 : (s.last_accepted ? 0 : -1);
+  reward[e] = r;
+  env_done[e] = (was || now) ? 1 : 0;
+  if (done_out) done_out[e] = (was || now) ? 1 : 0;
+}
+
+// A stand-in agent for device-resident measurements and tests: every live environment picks one of the buckets its
+// observation marks occupied (has_node, rrt_env.py:250-265), uniformly, with a counter-based generator of its own
+// (splitmix64 of seed / environment / call number -- the agent's randomness, not the planner's stream); finished
+// environments get -1 (skipped by the step).  One wavefront per environment: 64 has_node entries per trip.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void prrt_policy_random_kernel(int n_episodes, int n_buckets, const long long* __restrict__ has_node,
+                                                                 const uint8_t* __restrict__ env_done, unsigned long long seed,
+                                                                 unsigned long long call, int32_t* __restrict__ bucket_out) {
+  const int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (e >= n_episodes) return;
+  const int lane = lane_id();
+  if (env_done[e]) { if (lane == 0) bucket_out[e] = -1; return; }
+  const long long* hn = has_node + (size_t)e * n_buckets;
+  int total = 0;
+  for (int b0 = 0; b0 < n_buckets; b0 += 64) {
+    const int b = b0 + lane;
+    total += __popcll(__ballot(b < n_buckets && hn[b] != 0));
+  }
+  if (total == 0) { if (lane == 0) bucket_out[e] = 0; return; }
+  const int want = (int)(splitmix64(seed ^ splitmix64(((unsigned long long)e << 32) | (call & 0xffffffffull))) % (unsigned long long)total);
+  int seen = 0;
+  for (int b0 = 0; b0 < n_buckets; b0 += 64) {
+    const int b = b0 + lane;
+    const bool is = b < n_buckets && hn[b] != 0;
+    const unsigned long long bal = __ballot(is);
+    const int c = __popcll(bal);
+    if (seen + c > want) {
+      const unsigned long long sel = __ballot(is && (int)__popcll(bal & ((1ull << lane) - 1ull)) == want - seen);
+      if (lane == 0) bucket_out[e] = b0 + (__ffsll((long long)sel) - 1);
+      return;
+    }
+    seen += c;
+  }
+}
+
 }  // namespace auvp
 #endif

@@ -50,6 +50,9 @@ class RRTEnvBatch:
         self._L = _bind()
         self._L.auvp_prrt_observation.argtypes = [C.c_void_p, C.c_int32, _lib._dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         self._L.auvp_prrt_observation_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self._L.auvp_prrt_env_step_dev.argtypes = [C.c_void_p] * 7
+        self._L.auvp_prrt_policy_random_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        self._L.auvp_stream_sync.argtypes = [C.c_void_p]
         self._pb = None
         self.state = None
 
@@ -68,6 +71,7 @@ class RRTEnvBatch:
         else:
             self._pb = PlannerBatch(self._ctx, starts, goals, self._rect, self.max_nodes, seeds=self.seeds, **kw)
         self._done = np.zeros(self.E, dtype=bool)
+        self._dev = None
         self.state = self._observe(None)
         return self.state
 
@@ -136,6 +140,47 @@ class RRTEnvBatch:
                 self.state["path"][e] = t  # id of the node added this step (tree stays on the device)
         self._done |= done_now
         return self.state, reward, self._done.copy(), {}
+
+    # ---- the device-resident loop: nothing of a step crosses PCIe (auvp_prrt_env_step_dev) ----
+    def device_buffers(self):
+        """torch device tensors the loop writes: rrt_grid [E,nb,4] f64, has_node / num_nodes [E,nb] i64, reward [E] i64,
+        done [E] u8, bucket [E] i32 (the agent's choice).  Allocated once per reset()."""
+        import torch
+        if getattr(self, "_dev", None) is None:
+            dev = torch.device("cuda", self._ctx.device)
+            nb = self.n_buckets
+            self._dev = dict(rrt_grid=torch.empty((self.E, nb, 4), dtype=torch.float64, device=dev),
+                             has_node=torch.empty((self.E, nb), dtype=torch.int64, device=dev),
+                             num_nodes=torch.empty((self.E, nb), dtype=torch.int64, device=dev),
+                             reward=torch.zeros(self.E, dtype=torch.int64, device=dev),
+                             done=torch.zeros(self.E, dtype=torch.uint8, device=dev),
+                             bucket=torch.zeros(self.E, dtype=torch.int32, device=dev))
+            d = self._dev
+            self.observation_to_device(d["rrt_grid"].data_ptr(), d["has_node"].data_ptr(), d["num_nodes"].data_ptr())
+        return self._dev
+
+    def policy_random_device(self, seed=0):
+        """stand-in agent: a random occupied bucket per live environment, chosen on the device from has_node (enqueue only)"""
+        d = self.device_buffers()
+        self._ctx._chk(self._L.auvp_prrt_policy_random_dev(self._ctx.h, C.c_void_p(d["has_node"].data_ptr()), int(seed),
+                                                           C.c_void_p(d["bucket"].data_ptr())))
+        return d["bucket"]
+
+    def step_device(self, bucket_dev=None, observe=True):
+        """RRTEnv.step for all environments with the agent's choices already in device memory (`bucket_dev`: int32 [E] torch
+        tensor on this GPU, default: the buffer policy_random_device fills).  Enqueues the step, the observation arrays and
+        the outcome on the planner's stream and returns the device tensors; call sync() before reading them from another
+        stream or the host."""
+        d = self.device_buffers()
+        b = d["bucket"] if bucket_dev is None else bucket_dev
+        self._ctx._chk(self._L.auvp_prrt_env_step_dev(
+            self._ctx.h, C.c_void_p(b.data_ptr()), C.c_void_p(d["rrt_grid"].data_ptr()) if observe else None,
+            C.c_void_p(d["has_node"].data_ptr()), C.c_void_p(d["num_nodes"].data_ptr()), C.c_void_p(d["reward"].data_ptr()),
+            C.c_void_p(d["done"].data_ptr())))
+        return d
+
+    def sync(self):
+        self._ctx._chk(self._L.auvp_stream_sync(self._ctx.h))
 
     def tree(self, e):
         s = self._pb.summaries()[e]

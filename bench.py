@@ -599,10 +599,41 @@ def bench_rrt_env(local_rank, n_env=512, n_steps=60):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     nb = env.n_buckets
-    return {"metric": "RRTEnv steps/s (batched env, host observation dict)", "value": n_env * n_steps / dt, "unit": "env-steps/s",
-            "envs": n_env, "steps": n_steps, "ms_per_batched_step": 1e3 * dt / n_steps, "buckets": nb,
-            "observation_bytes_per_step": int(n_env * nb * (32 + 8 + 8)), "nodes_created": created,
-            "note": "includes the numpy policy on the host and the download of the full observation arrays"}
+    out = {"metric": "RRTEnv steps/s (batched env, host observation dict)", "value": n_env * n_steps / dt, "unit": "env-steps/s",
+           "envs": n_env, "steps": n_steps, "ms_per_batched_step": 1e3 * dt / n_steps, "buckets": nb,
+           "observation_bytes_per_step": int(n_env * nb * (32 + 8 + 8)), "nodes_created": created,
+           "note": "includes the numpy policy on the host and the download of the full observation arrays"}
+    # the same environments with NOTHING crossing PCIe (what row f1 is for): the agent -- a stand-in kernel that picks a random
+    # occupied bucket from the has_node array in HBM -- the generate_one_node launch, the observation kernel and the
+    # reward / done kernel are enqueued back to back on the planner's stream; one wait at the end
+    env2 = RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=list(range(n_env)), max_nodes=4 * n_steps + 8, freq=10, device=local_rank)
+    env2.reset()
+    d = env2.device_buffers()
+    for _ in range(3):
+        env2.policy_random_device(seed=5)
+        env2.step_device()
+    env2.sync()
+    n2 = 3 * n_steps
+    t0 = time.perf_counter()
+    for _ in range(n2):
+        env2.policy_random_device(seed=5)
+        env2.step_device()
+    env2.sync()
+    dt2 = time.perf_counter() - t0
+    live = int((d["done"] == 0).sum().item())
+    nodes = int(d["num_nodes"].sum().item())
+    # algorithmic bytes of one batched step: observation arrays written (32 + 8 + 8 B per bucket), bucket counts read by the
+    # observation kernel (4 B) and has_node read by the agent (8 B) per environment and bucket; the planner step itself
+    # (~0.33 KB per environment) is noise next to them
+    abytes = float(n_env) * nb * (32 + 8 + 8 + 4 + 8) + n_env * 330.0
+    out["device_resident"] = {
+        "metric": "RRTEnv steps/s, device-resident loop (agent + step + observation + outcome kernels, no host transfer)",
+        "value": n_env * n2 / dt2, "unit": "env-steps/s", "envs": n_env, "steps": n2, "ms_per_batched_step": 1e3 * dt2 / n2,
+        "envs_still_running_at_end": live, "nodes_in_all_trees": nodes,
+        "roofline": roofline(abytes, 1e3 * dt2 / n2, "prrt_policy_random_kernel + prrt_kernel (step mode) + prrt_observation_kernel + prrt_env_outcome_kernel",
+                             note="wall time of the enqueue loop / steps (four launches per step on one stream, one wait at the end): "
+                                  "launch-bound, the observation write is the only HBM-sized term")}
+    return out
 
 
 def bench_planner(ctx, ranks, with_cpu, n_ep=512, max_step=2000, steps=5, warmup=1):

@@ -164,6 +164,10 @@ int auvp_prrt_grid(auvp_handle* h, int32_t episode, int32_t* occupied, int32_t* 
 /* per-step log (AUVP_FLAG_ITER_LOG): [max_step,8] bucket, picked, accepted, done, npath, arc_n, arc_free, new_node */
 int auvp_prrt_step_log(auvp_handle* h, int32_t episode, int32_t* log8);
 void* auvp_prrt_summaries_dev(auvp_handle* h);
+/* which kernel the last auvp_prrt_plan / auvp_prrt_step launch ran: "prrt_kernel" (one episode per wavefront) or
+ * "prrt_rows_kernel" (four per wavefront: throughput batches of the environment's planner shape, freq <= 15, <= 256
+ * obstacles, no step log) */
+const char* auvp_prrt_last_kernel(auvp_handle* h);
 /* RRTEnv observation arrays (gym_rrt/envs/rrt_env.py:250-295: convert_rrt_grid_to_1D,
  * generate_rrt_grid_has_node_array, convert_rrt_grid_to_1D_num_of_nodes_only) for all episodes into
  * caller-owned DEVICE buffers: rrt_grid [E,n_buckets,4] f64 = cell.x, cell.y, subsection.theta,
@@ -171,6 +175,21 @@ void* auvp_prrt_summaries_dev(auvp_handle* h);
 int auvp_prrt_observation_dev(auvp_handle* h, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev);
 /* the same for one episode, copied to host arrays */
 int auvp_prrt_observation(auvp_handle* h, int32_t episode, double* rrt_grid, int64_t* has_node, int64_t* num_nodes);
+/* RRTEnv.step (gym_rrt/envs/rrt_env.py:182-247) for every environment with NOTHING crossing PCIe: bucket_ids_dev [E]
+ * (chosen_grid_cell_idx per environment, -1 = skip; DEVICE memory, e.g. an agent's output) -> generate_one_node, then
+ * the observation arrays (as auvp_prrt_observation_dev; rrt_grid_dev may be NULL to skip them) and the step's outcome:
+ * reward_dev [E] i64 = 300 R_FOUND_PATH / 0 R_CREATE_NODE / -1 R_INVALID_NODE (0 for an environment that had already
+ * finished: it is skipped), done_dev [E] u8 (may be NULL).  Only ENQUEUES on the handle's stream: follow with
+ * auvp_stream_sync (or order other work on auvp_stream) before reading results. */
+int auvp_prrt_env_step_dev(auvp_handle* h, const int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev,
+                           void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev);
+/* stand-in agent for device-resident runs: every live environment picks, uniformly, one of the buckets has_node_dev
+ * [E,n_buckets] marks occupied (finished environments: -1); its randomness is its own (counter-based on `seed`), not
+ * the planner's stream.  Enqueues only. */
+int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uint64_t seed, int32_t* bucket_ids_dev);
+/* the handle's HIP stream (hipStream_t) and a wait for everything enqueued on it */
+void* auvp_stream(auvp_handle* h);
+int auvp_stream_sync(auvp_handle* h);
 
 /* ---------------------------------------------------------------------------------------------
  * A* variants (path_planning/astar.py, astar_real.py, astar_fixLen.py, astar_fixLenSOG.py), one

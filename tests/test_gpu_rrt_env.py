@@ -82,3 +82,59 @@ def test_env_matches_reference_rrtenv(name):
         assert np.array_equal(st["rrt_grid_num_of_nodes_only"][0], g["counts"][i]), i
     assert np.array_equal(st["rrt_grid"][0], g["final_rrt_grid"]) and np.array_equal(st["has_node"][0], g["final_has_node"])
     assert random.random() == float(g["rng_after"])
+
+
+def test_env_device_resident_loop_matches_host_loop():
+    """auvp_prrt_env_step_dev (bucket ids, observations, rewards and done flags all in HBM) against RRTEnvBatch.step fed the
+    same choices: identical rewards, done flags, observation arrays and trees; and the stand-in device agent only ever
+    picks occupied buckets (-1 for finished environments)"""
+    import torch
+    from auv_sim_amd import synth
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    from auv_sim_amd.rrt_env import RRTEnvBatch
+    w = synth.make_rect_world(seed=3, n_obstacles=64)
+    obstacles = [MPS(o[0], o[1], size=o[2]) for o in w["obstacles"].tolist()]
+    bnd = [MPS(float(w["rect"][0]), float(w["rect"][1])), MPS(float(w["rect"][2]), float(w["rect"][3]))]
+    auv, shark = MPS(float(w["start"][0]), float(w["start"][1]), z=-5.0), MPS(float(w["goal"][0]), float(w["goal"][1]), z=-5.0)
+    E, n_steps = 24, 150
+    seeds = list(range(40, 40 + E))
+    host = RRTEnvBatch(auv, shark, bnd, 5, 2, obstacles, seeds=seeds, max_nodes=n_steps + 8, freq=10)
+    devenv = RRTEnvBatch(auv, shark, bnd, 5, 2, obstacles, seeds=seeds, max_nodes=n_steps + 8, freq=10)
+    st = host.reset()
+    devenv.reset()
+    d = devenv.device_buffers()
+    assert np.array_equal(d["rrt_grid"].cpu().numpy(), st["rrt_grid"])
+    rng = np.random.default_rng(1)
+    dev = d["bucket"].device
+    for i in range(n_steps):
+        has = st["has_node"] != 0
+        choice = np.array([rng.choice(np.flatnonzero(h)) if (h.any() and rng.random() < 0.9) else int(rng.integers(0, has.shape[1]))
+                           for h in has], dtype=np.int32)
+        st, reward, done, _ = host.step(choice)
+        dd = devenv.step_device(torch.from_numpy(choice).to(dev))
+        devenv.sync()
+        assert np.array_equal(dd["reward"].cpu().numpy(), reward), i
+        assert np.array_equal(dd["done"].cpu().numpy().astype(bool), done), i
+        assert np.array_equal(dd["rrt_grid"].cpu().numpy(), st["rrt_grid"])
+        assert np.array_equal(dd["has_node"].cpu().numpy(), st["has_node"])
+        assert np.array_equal(dd["num_nodes"].cpu().numpy(), st["rrt_grid_num_of_nodes_only"])
+        if done.all():
+            break
+    assert done.any() and (reward == 300).any() or i == n_steps - 1
+    for e in (0, E - 1):
+        a, b = host.tree(e), devenv.tree(e)
+        assert np.array_equal(a["nodes"], b["nodes"]) and np.array_equal(a["parent"], b["parent"])
+    # the stand-in agent: an occupied bucket for every live environment, -1 for the finished ones; several calls differ
+    picks = []
+    for k in range(4):
+        b = devenv.policy_random_device(seed=7)
+        devenv.sync()
+        b = b.cpu().numpy()
+        hn = d["has_node"].cpu().numpy()
+        dn = d["done"].cpu().numpy().astype(bool)
+        assert (b[dn] == -1).all()
+        live = np.flatnonzero(~dn)
+        assert all(hn[e, b[e]] == 1 for e in live)
+        picks.append(b.copy())
+    if (~dn).any() and (hn[~dn].sum(axis=1) > 3).any():
+        assert any(not np.array_equal(picks[0], p) for p in picks[1:])
