@@ -27,7 +27,10 @@ int auvp_prrt_replan_particles(auvp_handle* h, const double* start4, const auvp_
   M.xform = h->d_tmp4.as<double>();
   M.seed_base = seed_base; M.n_filters = F.F; M.n_particles = F.N;
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(auvp::prrt_from_particles_kernel, dim3((E + 63) / 64), dim3(64), 0, h->stream, S.B, M, F.st.as<double>(), (int)E);
+  HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::prrt_from_particles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                auvp::PRRT_SEED_LDS));
+  hipLaunchKernelGGL(auvp::prrt_from_particles_kernel, dim3((E + 63) / 64), dim3(64), auvp::PRRT_SEED_LDS, h->stream, S.B, M,
+                     F.st.as<double>(), (int)E);
   HIPCHK(h, hipGetLastError());
   rc = prrt_plant(h, S, E);
   if (rc != AUVP_OK) return rc;

@@ -46,7 +46,6 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
   uint32_t* mt = reinterpret_cast<uint32_t*>(smem + (size_t)(wave * RW_ROWS + row) * PRW_LDS_PER_EP);
   const int capn = B.cap_nodes;
   const size_t capp = (size_t)B.cap_points;
-  const double4 sbox = reinterpret_cast<const double4*>(W.os_box)[rl];  // lane rl: bounding box of obstacle slot rl
   const int nfreq = (int)P.freq;
 
   RowRng rng;
@@ -57,7 +56,6 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
   int n_nodes = 0, n_points = 0, n_occ = 0, step = 0, done = 0, status = 0, last_accepted = 0, last_new = -1;
   int prev_n_arc = -1, step_end = 0, step_bucket = 0;
   bool have_prev_arc = false;
-  double gx = 0.0, gy = 0.0;
 
   for (;;) {
     // ---------------------------------------------------------------- rows without an episode take the next one
@@ -89,7 +87,6 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           n_nodes = sm.n_nodes; n_points = sm.n_points; n_occ = sm.n_occ; step = sm.steps; done = sm.done; status = sm.status;
           last_accepted = 0; last_new = -1; prev_n_arc = -1; have_prev_arc = false;
           step_end = P.step_mode ? step + 1 : P.max_step;
-          gx = B.goal[2 * (size_t)ep]; gy = B.goal[2 * (size_t)ep + 1];
           // whole 16-word blocks are regenerated in place (rrt_rows_kernel.h): the frontier must sit on a block boundary,
           // which every state this kernel or the host's seeding writes does
           if (((rng.pslot + rng.avail) & 15u) != 0u) status = -7;
@@ -243,9 +240,14 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         B.points[gi] = mx; B.points[gi + capp] = my; B.points[gi + 2 * capp] = th; B.points[gi + 3 * capp] = mtt;
       }
       // the row's state after the steer = the prefix values of its last sub-arc
+      // (sin, cos of the row's final angle -- lane n - 1's, or the entry angle's on lane 15 for a steer without sub-arcs --
+      // are what the goal arc needs of an accepted node: auvp_sincos of the same argument)
+      double fin_sn, fin_cs;
       {
         const int last = rowbase + (n > 0 ? n - 1 : 0);
         const double ex = row_read_f64(mx, last), ey = row_read_f64(my, last), et = row_read_f64(mtt, last), eth = row_read_f64(th, last);
+        const int lsc = rowbase + (n > 0 ? n - 1 : 15);
+        fin_sn = row_read_f64(sn, lsc); fin_cs = row_read_f64(cs, lsc);
         if (act && n > 0) { cx = ex; cy = ey; ctt = et; cth = eth; }
       }
       const int cnt = napp;
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         const double ts = 0x1p-30 * (auvp_fabs(mnx) + auvp_fabs(mxx) + auvp_fabs(mny) + auvp_fabs(mxy) + 1.0);
         const double tcx = (mnx + mxx) * 0.5, tcy = (mny + mxy) * 0.5;
         const double thx = (mxx - mnx) * 0.5 + ts, thy = (mxy - mny) * 0.5 + ts;
+        const double4 sbox = reinterpret_cast<const double4*>(W.os_box)[rl];  // lane rl: bounding box of obstacle slot rl
         const bool slot_hit = on && !(sbox.z < mnx - ts || sbox.x > mxx + ts || sbox.w < mny - ts || sbox.y > mxy + ts);
         uint32_t sm = row_ballot(slot_hit, rowbase);
         bool hit = false;
@@ -359,6 +362,8 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       bool free_ = false;
       if (__any(eval)) {
         n_arc = eval ? -1 : n_arc;
+        const double2 goal = *reinterpret_cast<const double2*>(B.goal + 2 * (size_t)(ep < 0 ? 0 : ep));
+        const double gx = goal.x, gy = goal.y;
         const double theta = auvp_atan2(gy - ly, gx - lx);
         double diffg = theta - th0;
         for (int guard = 0; guard < 64; guard++) {  // angle_wrap
@@ -384,8 +389,14 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         if (phi2 > AUVP_PI) { phi2 -= 2 * AUVP_PI; length = -radiusg * phi2; }
         else if (phi2 < -AUVP_PI) { phi2 += 2 * AUVP_PI; length = -radiusg * phi2; }
         const double ang_vel = phi2 / (length / P.exp_rate);
-        double s0, c0;
-        auvp_sincos(th0, &s0, &c0);
+        // sin / cos of th0: an accepted node's angle went through the steer's sincos already; only an arc from an older
+        // node (this step's was rejected and no arc has been evaluated yet) needs its own
+        double s0 = fin_sn, c0 = fin_cs;
+        if (__any(eval && !ok)) {
+          double s1, c1;
+          auvp_sincos(th0, &s1, &c1);
+          if (!ok) { s0 = s1; c0 = c1; }
+        }
         const double x_C = lx - radiusg * s0;
         const double y_C = ly + radiusg * c0;
         const double ne = auvp_floor(length / P.exp_rate);

@@ -762,24 +762,66 @@ __device__ inline void mt_seed_by_array(unsigned long long seed, uint32_t* mt) {
   mt[0] = 0x80000000u;
 }
 
+// One wavefront seeds 64 generators at once.  init_by_array is a serial recurrence per generator (1 871 dependent steps), so
+// the work is one thread per episode -- but with the state column in LDS (a read-modify-write of global memory per step
+// made the round-2 kernel 0.3 ms for 12 500 episodes).  Layout mtl[word * 65 + thread]: conflict-free both for the
+// per-thread recurrence (bank = word + thread) and for the coalesced write-out (one episode's 624 words by 64 lanes).
+constexpr int PRRT_SEED_LDS = 624 * 65 * 4;
 __global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, PrrtGoalMap M, const double* __restrict__ pf_state,
                                                                  int n_episodes) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_episodes) return;
-  const int f = e / M.n_particles, p = e - f * M.n_particles;
-  const double* st = pf_state + (size_t)f * 5 * M.n_particles;  // SoA [F][5][N]: x, y, ...
-  const double* xf = M.xform + 4 * (size_t)f;
-  double gx = st[p] * xf[0] + xf[1];
-  double gy = st[(size_t)M.n_particles + p] * xf[2] + xf[3];
-  gx = gx < M.clamp[0] ? M.clamp[0] : (gx > M.clamp[2] ? M.clamp[2] : gx);
-  gy = gy < M.clamp[1] ? M.clamp[1] : (gy > M.clamp[3] ? M.clamp[3] : gy);
-  double* g = const_cast<double*>(B.goal) + 2 * (size_t)e;
-  g[0] = gx; g[1] = gy;
-  double* s = const_cast<double*>(B.start) + 4 * (size_t)e;
-  s[0] = M.start[0]; s[1] = M.start[1]; s[2] = M.start[2]; s[3] = M.start[3];
-  mt_seed_by_array(M.seed_base + (unsigned long long)e, B.mt + (size_t)e * 624);
-  int32_t* rs = B.rng_state + 4 * (size_t)e;
-  rs[0] = 0; rs[1] = 0; rs[2] = 0; rs[3] = 0;  // a freshly seeded generator: nothing generated yet
+  extern __shared__ __align__(16) unsigned char seed_smem[];
+  uint32_t* mtl = reinterpret_cast<uint32_t*>(seed_smem);
+  const int t = (int)threadIdx.x;
+  const int e0 = (int)blockIdx.x * 64;
+  const int e = e0 + t;
+  const bool valid = e < n_episodes;
+  if (valid) {
+    const int f = e / M.n_particles, p = e - f * M.n_particles;
+    const double* st = pf_state + (size_t)f * 5 * M.n_particles;  // SoA [F][5][N]: x, y, ...
+    const double* xf = M.xform + 4 * (size_t)f;
+    double gx = st[p] * xf[0] + xf[1];
+    double gy = st[(size_t)M.n_particles + p] * xf[2] + xf[3];
+    gx = gx < M.clamp[0] ? M.clamp[0] : (gx > M.clamp[2] ? M.clamp[2] : gx);
+    gy = gy < M.clamp[1] ? M.clamp[1] : (gy > M.clamp[3] ? M.clamp[3] : gy);
+    double* g = const_cast<double*>(B.goal) + 2 * (size_t)e;
+    g[0] = gx; g[1] = gy;
+    double* s = const_cast<double*>(B.start) + 4 * (size_t)e;
+    s[0] = M.start[0]; s[1] = M.start[1]; s[2] = M.start[2]; s[3] = M.start[3];
+    int32_t* rs = B.rng_state + 4 * (size_t)e;
+    rs[0] = 0; rs[1] = 0; rs[2] = 0; rs[3] = 0;  // a freshly seeded generator: nothing generated yet
+  }
+  // random.seed(seed_base + e) = init_by_array over the 32-bit limbs of the seed (the arithmetic of seed_mt() on the host)
+  {
+    const unsigned long long seed = M.seed_base + (unsigned long long)(valid ? e : 0);
+    const uint32_t key[2] = {(uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)};
+    const int klen = key[1] ? 2 : 1;
+    uint32_t* m = mtl + t;
+    uint32_t prev = 19650218u;
+    m[0] = prev;
+    for (int i = 1; i < 624; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; m[i * 65] = prev; }
+    int i = 1, j = 0;
+    prev = m[0];
+    for (int k = 624; k; k--) {
+      prev = (m[i * 65] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+      m[i * 65] = prev;
+      i++; j++;
+      if (i >= 624) { m[0] = prev; i = 1; }
+      if (j >= klen) j = 0;
+    }
+    for (int k = 623; k; k--) {
+      prev = (m[i * 65] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+      m[i * 65] = prev;
+      i++;
+      if (i >= 624) { m[0] = prev; i = 1; }
+    }
+    m[0] = 0x80000000u;
+  }
+  __syncthreads();
+  const int n_here = (n_episodes - e0) < 64 ? (n_episodes - e0) : 64;
+  for (int q = 0; q < n_here; q++) {
+    uint32_t* dst = B.mt + (size_t)(e0 + q) * 624;
+    for (int w = t; w < 624; w += 64) dst[w] = mtl[w * 65 + q];
+  }
 }
 
 // RRTEnv's per-step observation arrays (gym_rrt/envs/rrt_env.py:250-295), elementwise over

@@ -102,21 +102,22 @@ def test_astar_fixlen_sog_on_the_reference_shark_csv(tmp_path, stem, orc):
     class Cell:
         def __init__(self, b):
             self.bounds = b
-    # 987 = 47 x 21 cells of 10 m over the window the hard-coded visited bitmap covers (astar_fixLenSOG.py:281-282)
-    cells = [Cell((-300.0 + 10.0 * c, -100.0 + 10.0 * r, -290.0 + 10.0 * c, -90.0 + 10.0 * r)) for r in range(21) for c in range(47)]
+    # 987 = 47 x 21 cells of 8 m inside the window the hard-coded visited bitmap covers (x + 500, y + 200 index a 600 x 600
+    # array, astar_fixLenSOG.py:655-657)
+    cells = [Cell((-300.0 + 8.0 * c, -100.0 + 8.0 * r, -292.0 + 8.0 * c, -92.0 + 8.0 * r)) for r in range(21) for c in range(47)]
     shark = createSharkGrid(str(p), cells)
     pre = stem + "_sog_"
     n = int(g[pre + "lens"][0])
     assert all(len(v) == n for v in shark.values()) and n in (986, 985)
     rng = np.random.default_rng(8)
-    obstacles = np.column_stack([rng.uniform(-280, 150, 24), rng.uniform(-80, 90, 24), rng.uniform(2, 6, 24)])
-    habitats = np.column_stack([rng.uniform(-280, 150, 8), rng.uniform(-80, 90, 8), rng.uniform(10, 25, 8)])
-    poly = [(-300.0, -100.0), (170.0, -100.0), (170.0, 110.0), (-300.0, 110.0)]
+    obstacles = np.column_stack([rng.uniform(-280, 60, 24), rng.uniform(-80, 50, 24), rng.uniform(2, 6, 24)])
+    habitats = np.column_stack([rng.uniform(-280, 60, 8), rng.uniform(-80, 50, 8), rng.uniform(10, 25, 8)])
+    poly = [(-300.0, -100.0), (76.0, -100.0), (76.0, 68.0), (-300.0, 68.0)]
     bins = g[pre + "keys"].astype(np.float64)
     cell_arr = np.array([c.bounds for c in cells[:n]])
     prob = g[pre + "vals"].reshape(len(bins), n)
     obs, hab, bnd = _mps(obstacles.tolist()), _mps(habitats.tolist()), [MPS(x, y) for x, y in poly]
-    for start, limit in (((-250.0, -50.0), 200.0), ((100.0, 60.0), 300.0), ((-100.0, 0.0), 100.0)):
+    for start, limit in (((-250.0, -50.0), 200.0), ((20.0, 30.0), 300.0), ((-100.0, 0.0), 100.0)):
         res = astar(start, obs, bnd, hab, shark, {}, 1.0).astar(limit, [0, 10, 10, 100], {})
         o = oa.run("astar_fixLenSOG", np.array(start), obstacles=obstacles, habitats=habitats, polygon=np.array(poly), bins=bins,
                    cells=cell_arr, prob=prob, limit=limit, weights=(0, 10, 10, 100), velocity=1.0, cap_nodes=200000, kind="portable")
