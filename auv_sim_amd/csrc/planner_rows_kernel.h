@@ -37,13 +37,22 @@ __device__ __forceinline__ uint32_t rows_word(const RowRng& r, uint32_t j) {
   return mt_temper(r.s[k]);
 }
 
+// LDS per episode: the generator state and, when it fits 16 bits per entry, a copy of the episode's list of occupied buckets
+// (random.choice(occupied) starts every step: with the list in LDS the step's chain of dependent global reads is one shorter)
+__host__ __device__ inline int prrt_rows_occ_bytes(int n_buckets, int max_step) {
+  const int b = ((max_step + 1) * 2 + 15) & ~15;
+  return (n_buckets <= 65535 && b <= 832) ? b : 0;
+}
+
 __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes,
-                                                                      int* __restrict__ work_counter) {
+                                                                      int* __restrict__ work_counter, int occ_bytes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = (int)(threadIdx.x >> 6);
   const int lane = lane_id();
   const int row = lane >> 4, rl = lane & 15, rowbase = lane & 48;
-  uint32_t* mt = reinterpret_cast<uint32_t*>(smem + (size_t)(wave * RW_ROWS + row) * PRW_LDS_PER_EP);
+  unsigned char* ebase = smem + (size_t)(wave * RW_ROWS + row) * (PRW_LDS_PER_EP + occ_bytes);
+  uint32_t* mt = reinterpret_cast<uint32_t*>(ebase);
+  uint16_t* occl = reinterpret_cast<uint16_t*>(ebase + PRW_LDS_PER_EP);  // [max_step + 1] when occ_bytes != 0
   const int capn = B.cap_nodes;
   const size_t capp = (size_t)B.cap_points;
   const int nfreq = (int)P.freq;
@@ -85,6 +94,10 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           rng.drawn = ((unsigned long long)(uint32_t)rs.z) | ((unsigned long long)(uint32_t)rs.w << 32);
           const PrrtSummary& sm = B.summary[ep];
           n_nodes = sm.n_nodes; n_points = sm.n_points; n_occ = sm.n_occ; step = sm.steps; done = sm.done; status = sm.status;
+          if (occ_bytes) {
+            const int32_t* og = B.occupied + (size_t)ep * capn;
+            for (int i = rl; i < n_occ; i += 16) occl[i] = (uint16_t)og[i];
+          }
           last_accepted = 0; last_new = -1; prev_n_arc = -1; have_prev_arc = false;
           step_end = P.step_mode ? step + 1 : P.max_step;
           // whole 16-word blocks are regenerated in place (rrt_rows_kernel.h): the frontier must sit on a block boundary,
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       } else {
         if (act && n_occ == 0) { status = -1; act = false; }
         const uint32_t oi = randbelow(act, (uint32_t)n_occ);
-        if (act) b = B.occupied[en + oi];
+        if (act) b = occ_bytes ? (int)occl[oi] : B.occupied[en + oi];
       }
       int cnt_b = 0, head_b = 0;
       if (act) { cnt_b = bcount[b]; head_b = bhead[b]; }
@@ -252,6 +265,28 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       }
       const int cnt = napp;
 
+      // where the new node would go (add_node_to_grid :108-159: int(y / cs), int(x / cs) with Python's negative-index wrap,
+      // floor(theta / delta_theta)) and that bucket's size and head: requested now, used by the accept below, so the reads
+      // travel while the collision test runs
+      bool pre_err = false;
+      int pre_bk = -1, pre_c = -1, pre_h = -1;
+      if (act) {
+        int rrow = (int)(cy / P.cell), col = (int)(cx / P.cell);
+        if (rrow < 0) { rrow += P.rows; pre_err |= rrow < 0; }
+        if (col < 0) { col += P.cols; pre_err |= col < 0; }
+        if (!pre_err && rrow < P.rows && col < P.cols) {
+          const double raw = cth / P.delta_theta;
+          int sub = (int)auvp_floor(raw);
+          if (sub < 0) sub = (int)(P.S + sub);
+          if (sub == P.S) sub -= 1;
+          if (sub < 0) { sub += P.S; pre_err |= sub < 0; }
+          pre_err |= sub >= P.S;
+          pre_bk = (rrow * P.cols + col) * P.S + sub;
+        }
+        if (pre_err) pre_bk = -1;
+        if (pre_bk >= 0) { pre_c = bcount[pre_bk]; pre_h = bhead[pre_bk]; }
+      }
+
       // ---------------------------------------------------------------- check_collision_free (:435-458)
       // closed rectangle (every path point and the parent's end) + obstacles behind the slot / obstacle culls
       bool bad_pt = false;
@@ -311,24 +346,9 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       if (ok && n_nodes >= capn) { status = -2; ok = false; act = false; }
       if (ok) {
         me = n_nodes;
-        int rrow = (int)(cy / P.cell), col = (int)(cx / P.cell);
-        bool idx_err = false;
-        if (rrow < 0) { rrow += P.rows; idx_err |= rrow < 0; }
-        if (col < 0) { col += P.cols; idx_err |= col < 0; }
-        int bk = -1;
-        if (!idx_err && rrow < P.rows && col < P.cols) {
-          const double raw = cth / P.delta_theta;
-          int sub = (int)auvp_floor(raw);
-          if (sub < 0) sub = (int)(P.S + sub);
-          if (sub == P.S) sub -= 1;
-          if (sub < 0) { sub += P.S; idx_err |= sub < 0; }
-          idx_err |= sub >= P.S;
-          bk = (rrow * P.cols + col) * P.S + sub;
-        }
-        if (idx_err) { status = -1; ok = false; act = false; }
+        if (pre_err) { status = -1; ok = false; act = false; }
         else {
-          const int c_before = bk >= 0 ? bcount[bk] : -1;
-          const int h_before = bk >= 0 ? bhead[bk] : -1;
+          const int bk = pre_bk, c_before = pre_c, h_before = pre_h;
           if (rl == 0) {
             double* nf = nodeF + (size_t)me * 4;
             *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
@@ -339,7 +359,10 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
               nnext[me] = c_before > 0 ? h_before : -1;
               bhead[bk] = me;
               bcount[bk] = c_before + 1;
-              if (c_before == 0) B.occupied[en + n_occ] = bk;  // first node of the bucket (:157-159)
+              if (c_before == 0) {  // first node of the bucket (:157-159)
+                B.occupied[en + n_occ] = bk;
+                if (occ_bytes) occl[n_occ] = (uint16_t)bk;
+              }
             }
           }
           if (c_before == 0) n_occ++;

@@ -55,12 +55,13 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     const int per_wg = auvp::PRW_WAVES * auvp::RW_ROWS;
     grid_used = std::min((S.E + per_wg - 1) / per_wg, 3 * n_cu_l);
     block_used = auvp::PRW_WAVES * 64;
-    lds_used = (size_t)per_wg * auvp::PRW_LDS_PER_EP;
+    const int occ_bytes = auvp::prrt_rows_occ_bytes(S.P.n_buckets, S.P.max_step);
+    lds_used = (size_t)per_wg * (auvp::PRW_LDS_PER_EP + occ_bytes);
     le = S.work.reserve(sizeof(int));
     if (le == hipSuccess) le = hipMemsetAsync(S.work.p, 0, sizeof(int), h->stream);
     if (le == hipSuccess) le = hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::prrt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
     if (le == hipSuccess) {
-      hipLaunchKernelGGL(auvp::prrt_rows_kernel, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, S.work.as<int>());
+      hipLaunchKernelGGL(auvp::prrt_rows_kernel, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, S.work.as<int>(), occ_bytes);
       le = hipGetLastError();
     }
   } else if (lat) {
