@@ -311,6 +311,12 @@ class Context:
         self._chk(self.L.auvp_rrt_phase_clocks(self.h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
         return out
 
+    def prrt_last_kernel(self):
+        """name of the kernel the last Planner_RRT launch ran (prrt_kernel: one episode per wavefront; prrt_rows_kernel: four)"""
+        self.L.auvp_prrt_last_kernel.restype = C.c_char_p
+        self.L.auvp_prrt_last_kernel.argtypes = [C.c_void_p]
+        return (self.L.auvp_prrt_last_kernel(self.h) or b"").decode()
+
     def last_kernel_ms(self):
         return float(self.L.auvp_last_kernel_ms(self.h))
 

@@ -671,7 +671,7 @@ def bench_planner(ctx, ranks, with_cpu, n_ep=512, max_step=2000, steps=5, warmup
     tot_steps = ranks.sum(summ["steps"].sum())
     k_ms = float(np.mean(kms[-steps:]))
     abytes = planner_bytes(summ)
-    traffic = pmc_traffic("planner_rrt", ["prrt_kernel"], float(summ["steps"].sum()))
+    traffic = pmc_traffic("planner_rrt", [ctx.prrt_last_kernel()], float(summ["steps"].sum()))
     out = {"metric": "Planner_RRT steps/s (generate_one_node calls)", "value": tot_steps * steps / dt, "unit": "steps/s",
            "ms_per_step": 1e3 * dt / steps, "steps": steps, "episodes": n_ep, "episodes_this_rank": n,
            "planner_steps_per_step": tot_steps, "episodes_done": int(ranks.sum(summ["done"].sum())),
@@ -679,7 +679,7 @@ def bench_planner(ctx, ranks, with_cpu, n_ep=512, max_step=2000, steps=5, warmup
            "gather_ms_per_rank": ranks.all(float(np.mean([g for g in gms[-steps:] if g is not None])) if gms and gms[-1] is not None else None),
            "steps_per_s_plan_launch_only": float(summ["steps"].sum()) / (k_ms * 1e-3),
            "config": "%d x Planner_RRT.planning(2000), 200 m env, 256 obstacles, cell 5 m, freq 10" % n_ep,
-           "roofline": roofline(abytes, k_ms, "prrt_kernel", traffic,
+           "roofline": roofline(abytes, k_ms, ctx.prrt_last_kernel(), traffic,
                                 bytes_per_step=abytes / max(float(summ["steps"].sum()), 1.0),
                                 note="512 waves on 1 024 SIMDs: a latency measurement")}
     if with_cpu:
@@ -738,8 +738,16 @@ def bench_config5(ctx, ranks, n_filters=25, n_particles=500, max_step=200, track
     if (st != 0).any():
         return {"error": "filter status %s" % np.unique(st)}
     total = ranks.sum(steps_done)
+    abytes = planner_bytes(summ)  # of the last tracking step's plan launch
+    steps_last = float(summ["steps"].sum())
+    kname = ctx.prrt_last_kernel()
     return {"metric": "config 5: Planner_RRT steps/s, one replan per particle hypothesis per tracking step",
             "value": total / dt, "unit": "steps/s", "ms_per_tracking_step": 1e3 * dt / track_steps,
+            "planner_steps_per_tracking_step": steps_last, "steps_per_s_plan_launch_only": steps_last / (plan_ms[-1] * 1e-3),
+            "roofline": roofline(abytes, plan_ms[-1], kname, pmc_traffic("config5", [kname], steps_last),
+                                 bytes_per_step=abytes / max(steps_last, 1.0),
+                                 note="the last tracking step's plan launch; ~3 waves per SIMD, each step a chain of dependent "
+                                      "fp64 sequences (atan2 / sincos / divisions) and tree reads: issue and latency bound, not HBM"),
             "episodes_per_gpu": E, "filters_per_gpu": n_filters, "particles_per_filter": n_particles, "max_step": max_step,
             "tracking_steps": track_steps, "episodes_done_last_step": done,
             "episode_replans_per_s": ranks.world * E * track_steps / dt,
