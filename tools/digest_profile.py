@@ -47,11 +47,11 @@ MEAS = {
 
 
 def short(name):
-    for n in ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel", "astar_kernel", "astar_path_kernel", "prrt_rows_kernel",
-              "prrt_kernel", "prrt_from_particles_kernel", "pf_step_kernel", "pf_create_kernel"):
-        if n in name:
-            return n
-    return name.split("(")[0][:60]
+    """auvp::rrt_explore_kernel<4, 2, false>(...) -> rrt_explore_kernel (the exact function name: prrt_rows_kernel is not
+    rrt_rows_kernel)"""
+    import re
+    m = re.search(r"auvp::([A-Za-z0-9_]+)", name)
+    return m.group(1) if m else name.split("(")[0][:60]
 
 
 out = {"tag": tag, "measurements": {}}
@@ -63,7 +63,7 @@ for key, (needles, units_field) in MEAS.items():
             continue
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if any(n in r["Kernel_Name"] for n in needles):
+                if short(r["Kernel_Name"]) in needles:
                     per_kernel[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     if not per_kernel:
         continue
