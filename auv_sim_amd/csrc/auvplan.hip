@@ -699,20 +699,31 @@ int auvp_rrt_run(auvp_handle* h) {
     if (const char* ne = getenv("AUVP_NN_EXACT")) if (atoi(ne) != 0) PR.flags |= AUVP_KFLAG_NN_EXACT;
   }
   const int jslots = (O_ <= 64 ? 1 : (O_ <= 128 ? 2 : (O_ <= 256 ? 4 : (O_ <= 512 ? 8 : 16)))) * 64;
+  int n_cu_ = 256;
+  (void)hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, h->device);
+  if (n_cu_ <= 0) n_cu_ = 256;
+  const bool diag = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_LEAF_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
+  // Small batches (at most eight episodes per CU: config 2's 1 024 replicas) get workgroups of fewer waves, so that every CU
+  // holds one (1 024 episodes: 256 workgroups of four waves = one wave per SIMD, instead of 128 CUs with two per SIMD:
+  // 208 -> 229 M expansions/s).  A latency instantiation on top of that -- 124 VGPRs without the 80-register cap, the steer's
+  // running sums as 32 unrolled steps with all reads up front -- was bit-identical and SLOWER (4.2 -> 5.7 us per expansion:
+  // the loops only run n / 2 ~ 7 trips) and is not kept.
+  const bool small_batch = E <= 8 * n_cu_;
+  int xw = RRT_X_WAVES;
+  if (small_batch) { xw = (E + n_cu_ - 1) / n_cu_; xw = xw < 1 ? 1 : (xw > RRT_X_WAVES ? RRT_X_WAVES : xw); }
   const size_t lds = (size_t)rrt_lds_plan(P.K, h->max_pts, nfreq, jslots,
-                                          rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins)).total;
+                                          rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), xw).total;
   if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB (K=%d, freq=%d)", lds, P.K, nfreq);
-  const int grid = (E + RRT_X_WAVES - 1) / RRT_X_WAVES;
+  const int grid = (E + xw - 1) / xw;
   const int O = h->W.n_obstacles;
   auto launch = [&](auto kern) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(RRT_X_WAVES * 64), lds, h->stream, h->W, PR, B, (int)E, h->max_pts);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(xw * 64), lds, h->stream, h->W, PR, B, (int)E, h->max_pts);
     return hipGetLastError();
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipError_t le = hipSuccess;
-  const bool diag = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_LEAF_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
   // four episodes per wavefront (rrt_rows_kernel.h) where its limits allow; one episode per wavefront otherwise
   const RowsLdsPlan rp = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins));
   const bool iter_log = (P.flags & (AUVP_FLAG_ITER_LOG | AUVP_FLAG_PHASE_CLOCKS)) != 0;
@@ -720,14 +731,11 @@ int auvp_rrt_run(auvp_handle* h) {
   // CU) runs faster there -- the rows kernel would leave the SIMDs with one or two waves.  Measured on MI355X, M
   // expansions/s one-episode vs rows: 4 096 episodes 616 vs 507, 6 144 episodes 704 vs 645, 8 192 episodes 699 vs 849,
   // 10 240 episodes 737 vs 877.  AUVP_ROWS=1 / 0 force it on (limits permitting) / off.
-  int n_cu_ = 256;
-  (void)hipDeviceGetAttribute(&n_cu_, hipDeviceAttributeMultiprocessorCount, h->device);
-  if (n_cu_ <= 0) n_cu_ = 256;
   const char* rows_env = getenv("AUVP_ROWS");
   const bool rows_ok = P.mode == 0 && !iter_log && nfreq <= RW_MAX_FREQ && O_ <= RW_MAX_OBST && P.max_iter < 65534 &&
                        rp.total <= 160 * 1024;
   const bool use_rows = rows_ok && (rows_env ? atoi(rows_env) != 0 : E > 24 * n_cu_);
-  int grid_used = grid, block_used = RRT_X_WAVES * 64, lds_used = (int)lds;
+  int grid_used = grid, block_used = xw * 64, lds_used = (int)lds;
   if (use_rows) {
     // a workgroup of up to 12 waves (48 episodes) fills one CU; a batch that cannot give every CU such a workgroup is
     // spread over all CUs with fewer waves per workgroup instead of leaving CUs idle

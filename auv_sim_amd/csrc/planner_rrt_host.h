@@ -27,25 +27,28 @@ PrrtState* prrt_of(auvp_handle* h);
 int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
   S.P.step_mode = step_mode;
   const int nfreq = (int)std::floor(S.P.freq);
-  const int grid = (S.E + auvp::RRT_WAVES - 1) / auvp::RRT_WAVES;
   // latency run (at most two waves per SIMD on this GPU) or throughput run: register budget and steer differ (planner_rrt_kernel.h)
   int n_cu_l = 256;
   (void)hipDeviceGetAttribute(&n_cu_l, hipDeviceAttributeMultiprocessorCount, h->device);
   if (n_cu_l <= 0) n_cu_l = 256;
   const char* lenv = getenv("AUVP_PRRT_LAT");
   const bool lat = lenv ? atoi(lenv) != 0 : S.E <= 8 * n_cu_l;
-  const size_t lds = (size_t)auvp::RRT_WAVES * auvp::prrt_lds_per_wave(S.B.max_pts, nfreq, lat);
+  // latency runs: workgroups small enough that every CU gets one (512 episodes: 256 workgroups of two waves)
+  int wg_waves = auvp::RRT_WAVES;
+  if (lat) { wg_waves = (S.E + n_cu_l - 1) / n_cu_l; wg_waves = wg_waves < 1 ? 1 : (wg_waves > auvp::RRT_WAVES ? auvp::RRT_WAVES : wg_waves); }
+  const int grid = (S.E + wg_waves - 1) / wg_waves;
+  const size_t lds = (size_t)wg_waves * auvp::prrt_lds_per_wave(S.B.max_pts, nfreq, lat);
   if (lds > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %zu B > 160 KiB", lds);
   const int O = h->W.n_obstacles;
   auto launch = [&](auto kern) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(auvp::RRT_WAVES * 64), lds, h->stream, h->W, S.P, S.B, S.E);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(wg_waves * 64), lds, h->stream, h->W, S.P, S.B, S.E);
     return hipGetLastError();
   };
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipError_t le;
-  int grid_used = grid, block_used = auvp::RRT_WAVES * 64;
+  int grid_used = grid, block_used = wg_waves * 64;
   size_t lds_used = lds;
   S.last_kernel = "prrt_kernel";
   if (S.use_rows) {

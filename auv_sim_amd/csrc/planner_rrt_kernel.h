@@ -138,7 +138,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
-  const int ep = (int)blockIdx.x * RRT_WAVES + wave;
+  const int ep = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;  // (RRT_WAVES episodes per workgroup; fewer for small batches)
   if (ep >= n_episodes) return;
   const int nfreq = (int)P.freq;
   const int C = nfreq < 1 ? 1 : (nfreq > 63 ? 63 : nfreq);

@@ -90,12 +90,14 @@ struct RrtLdsPlan {
   int tables, scratch, mt, pts, bins, per_wave, total;
 };
 
-__host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq, int obst_slots, int tables_bytes) {
+__host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq, int obst_slots, int tables_bytes,
+                                                   int waves = RRT_X_WAVES) {
   RrtLdsPlan p;
   p.chunk = nfreq < 1 ? 1 : (nfreq > RRT_MAX_CHUNK ? RRT_MAX_CHUNK : nfreq);
   const int C = p.chunk;
   int steer_u = (64 + 3 * C + 3) * 8;  // 64 leading random() values + the steer window
-  int steer_s = (4 * ((C + 2) & ~1) + (C + 1) * 3 + 4) * 8;  // inc rows (16-byte aligned), sc, phi + path bounding box
+  // inc rows, sc and phi all padded to the even row length CS = C + 1 rounded up
+  int steer_s = (7 * ((C + 2) & ~1) + 4) * 8;
   int s = steer_u > steer_s ? steer_u : steer_s;
   p.scratch = (s + 15) & ~15;
   p.mt = 624 * 4;
@@ -103,7 +105,7 @@ __host__ __device__ inline RrtLdsPlan rrt_lds_plan(int K, int max_pts, int nfreq
   p.bins = (((K + 2) * 4) + 15) & ~15;
   p.per_wave = p.scratch + p.mt + p.pts + p.bins;
   p.tables = (tables_bytes + 15) & ~15;
-  p.total = p.tables + RRT_X_WAVES * p.per_wave + obst_slots * (3 * 8 + 4);  // + obstacle tile x,y,T (f64), r (f32)
+  p.total = p.tables + waves * p.per_wave + obst_slots * (3 * 8 + 4);  // + obstacle tile x,y,T (f64), r (f32)
   return p;
 }
 
@@ -441,14 +443,15 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 4 : 2) : (
   const int wave = uni((int)(threadIdx.x >> 6));  // wave-uniform: keeps every per-episode address scalar
   const int lane = lane_id();
   const int nfreq = (int)P.freq;
-  const RrtLdsPlan plan = rrt_lds_plan(P.K, max_pts, nfreq, J * 64, rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins));
+  const int xw = (int)(blockDim.x >> 6);  // episodes per workgroup (RRT_X_WAVES; fewer for batches that would leave CUs idle)
+  const RrtLdsPlan plan = rrt_lds_plan(P.K, max_pts, nfreq, J * 64, rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins), xw);
   const int C = plan.chunk;
   unsigned char* wbase = smem + plan.tables + (size_t)wave * plan.per_wave;
   double* scratch = reinterpret_cast<double*>(wbase);
   double* u_win = scratch;                         // [3C+3]      (steer, phase 1)
   double* inc = scratch;                           // [(C+1)*4]   (steer, phase 2: aliases u_win)
   double* sc = scratch + (size_t)4 * ((C + 2) & ~1);  // [(C+1)*2]
-  double* phi_l = sc + (size_t)(C + 1) * 2;           // [C+1]
+  double* phi_l = sc + (size_t)2 * ((C + 2) & ~1);    // [CS]
   uint32_t* mt = reinterpret_cast<uint32_t*>(wbase + plan.scratch);
   double(*pts)[2] = reinterpret_cast<double(*)[2]>(wbase + plan.scratch + plan.mt);
   int32_t* bin_count = reinterpret_cast<int32_t*>(wbase + plan.scratch + plan.mt + plan.pts);
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 4 : 2) : (
   const RrtParamsDev& Q = *S.params;
   // obstacles: SoA tile shared by the episodes of the workgroup, padded to J*64 (slot j, lane l =
   // obstacle j*64 + l); with the bounding-box cull most slots are only touched by 3 reads per expansion
-  double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)RRT_X_WAVES * plan.per_wave);
+  double* olx = reinterpret_cast<double*>(smem + plan.tables + (size_t)xw * plan.per_wave);
   double* oly = olx + J * 64;
   double* olt = oly + J * 64;
   // cull radius: >= sqrt(T) with margin, rounded up to a float (it only has to be conservative; 1 KB less LDS
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 4 : 2) : (
   }
   __syncthreads();
 
-  const int ep = (int)blockIdx.x * RRT_X_WAVES + wave;
+  const int ep = (int)blockIdx.x * xw + wave;
   if (ep >= n_episodes) return;  // no workgroup barrier after this point
 
   // ---- per-episode views (scalar bases) ----
@@ -695,7 +698,8 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 4 : 2) : (
       }
       wave_sync();  // the window is dead: its LDS becomes the steer scratch
       if (c0 == 0) fetch_parent();
-      if (lane <= C) phi_l[lane] = phi;  // untaken / idle lanes add an exact 0.0
+      const int CS = (C + 2) & ~1;  // chain-major: chain c owns inc[c*CS .. c*CS+C], 16-byte aligned rows
+      if (lane < CS) phi_l[lane] = phi;  // untaken / idle lanes add an exact 0.0
       wave_sync();
       // theta += phi, left to right, by one lane; prefix angles written back in place
       if (lane == 0) {
@@ -724,9 +728,8 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 4 : 2) : (
         mv = auvp_sqrt(dx * dx + dy * dy);
         dt = mv / vt;
       }
-      const int CS = (C + 2) & ~1;  // chain-major: chain c owns inc[c*CS .. c*CS+C], 16-byte aligned rows
       if (active) { inc[lane] = dx; inc[CS + lane] = dy; inc[2 * CS + lane] = dt; inc[3 * CS + lane] = mv; }
-      else if (lane <= C) { inc[lane] = 0.0; inc[CS + lane] = 0.0; inc[2 * CS + lane] = 0.0; inc[3 * CS + lane] = 0.0; }
+      else if (lane < CS) { inc[lane] = 0.0; inc[CS + lane] = 0.0; inc[2 * CS + lane] = 0.0; inc[3 * CS + lane] = 0.0; }
       wave_sync();
       // x += dx; y += dy; t += dt; length += movement: four serial chains, one lane each
       if (lane < 4) {
