@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised GPU-vs-checker soak (run by hand on a GPU box: python tests/experiments/soak_gpu.py [n_cases] [seed] [big]).
 Every case draws a world and planner parameters at random and compares, bit for bit, the four-episode-per-wavefront
-kernel, the one-episode kernel and the CPU checker (RRT.exploring), the astar_fixLenSOG / astar_fixLen searches and
-Planner_RRT.planning with the checker.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
+kernel, the one-episode kernel and the CPU checker (RRT.exploring, time-bin sampling; nearest-neighbour -- scan and fallback --
+and plan-time sampling), the astar_fixLenSOG / astar_fixLen searches and Planner_RRT.planning (latency, throughput and
+four-episodes-per-wavefront kernels) with the checker.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
 import os
 import random
 import sys
@@ -62,6 +63,41 @@ def rrt_case(i):
                 print("RRT MISMATCH case", i, "episode", e, "variant rows/tight", key, kw, "obst", nob)
 
 
+def rrt_modes_case(i):
+    """the other parent-sampling modes of RRT.exploring: nearest neighbour (streaming scan and its sqrt-per-node fallback) and
+    plan-time bisect, against the checker"""
+    global fails
+    size = rng.choice([120.0, 300.0, 900.0])
+    nob = rng.choice([0, 40, 256])
+    w = synth.make_world(seed=rng.randrange(10 ** 6), n_obstacles=nob, box=(-300.0, -100.0, -300.0 + size, -100.0 + size),
+                         cell=rng.choice([10.0, 25.0]), n_habitats=rng.choice([0, 10]), obst_radius=(1.0, rng.choice([3.0, 9.0])))
+    kw = dict(freq=rng.choice([1, 7, 30, 45]), dist_to_end=rng.choice([0.5, 2.0, 5.0]), diff_max=rng.choice([0.1, 0.5]),
+              min_dist=rng.choice([0.0, 0.5]), v=rng.choice([0.7, 2.0]), max_traj_time=rng.choice([40.0, 500.0, 5000.0]),
+              weights=(rng.choice([-3.0, 2.5]), rng.choice([-3.0, 4.0]), rng.choice([-4.0, 1.7])))
+    E, n_iter = rng.choice([1, 6]), rng.choice([300, 1200, 2500])
+    ctx.set_world(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
+    init = np.zeros((E, 6)); init[:, 0], init[:, 1] = w["start"]; init[:, 2] = np.linspace(-3, 3, E)
+    seeds = np.array([rng.randrange(2 ** 40) for _ in range(E)], dtype=np.uint64)
+    wo = orc.WorldArrays(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
+    for mode, env in (("nn", {}), ("nn", {"AUVP_NN_EXACT": "1"}), ("plantime", {})):
+        os.environ.update(env)
+        s = ctx.rrt_explore_batch(init, seeds, n_iter, mode=mode, **kw).copy()
+        trees = [ctx.tree(e, s[e]) for e in range(E)]
+        for k in env:
+            os.environ.pop(k)
+        for e in range(E):
+            r = orc.rrt_explore(wo, int(seeds[e]), n_iter, mode=mode, init=init[e], kind="portable", **kw)
+            ok = (s[e]["status"], s[e]["n_nodes"], s[e]["n_points"], s[e]["n_leaves"], s[e]["best_leaf"]) == \
+                 (r["status"], r["n_nodes"], r["n_points"], r["n_leaves"], r["best_leaf"])
+            ok = ok and np.array_equal(trees[e]["parent"], r["parent"]) and np.array_equal(trees[e]["nodes"], r["nodes"]) and \
+                s[e]["rng_after"] == r["rng_after"]
+            if ok and r["status"] == 0:
+                ok = np.array_equal(np.array(s[e]["best_cost"]), r["best_cost"])
+            if not ok:
+                fails += 1
+                print("RRT MODE MISMATCH case", i, "episode", e, mode, env, kw, "obst", nob)
+
+
 def astar_case(i):
     global fails
     cell = rng.choice([5.0, 10.0, 14.0, 20.0])
@@ -102,18 +138,33 @@ def planner_case(i):
     starts = np.tile(np.array([w["start"][0], w["start"][1], rng.uniform(-3, 3), 0.0]), (n_ep, 1))
     goals = np.tile(w["goal"], (n_ep, 1))
     seeds = np.array([rng.randrange(2 ** 40) for _ in range(n_ep)], dtype=np.uint64)
-    s = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, freq=freq, cell=cell, subs=subs).plan()
-    for e in range(n_ep):
-        r = op.planning(w["obstacles"], w["rect"], starts[e], goals[e], int(seeds[e]), max_step, freq=freq, cell=cell, subs=subs, kind="portable")
-        ok = (int(s["status"][e]), int(s["n_nodes"][e]), int(s["steps"][e]), bool(s["done"][e])) == \
-             (r["status"], r["n_nodes"], r["steps"], r["done"]) and float(s["rng_after"][e]) == r["rng_after"]
-        if not ok:
-            fails += 1
-            print("PLANNER MISMATCH case", i, "episode", e, freq, cell, subs, max_step)
+    goals[1] = [w["start"][0] + rng.uniform(3, 12), w["start"][1] + rng.uniform(-3, 3)]  # a goal that is reached early
+    # the one-episode kernel (latency and throughput instantiations) and, where its limits allow, four episodes per wavefront
+    variants = [("lat", {"AUVP_PRRT_ROWS": "0", "AUVP_PRRT_LAT": "1"}), ("thr", {"AUVP_PRRT_ROWS": "0", "AUVP_PRRT_LAT": "0"})]
+    if freq <= 15 and len(w["obstacles"]) <= 256:
+        variants.append(("rows", {"AUVP_PRRT_ROWS": "1", "AUVP_PRRT_LAT": "0"}))
+    ref = [op.planning(w["obstacles"], w["rect"], starts[e], goals[e], int(seeds[e]), max_step, freq=freq, cell=cell, subs=subs,
+                       kind="portable") for e in range(n_ep)]
+    for name, env in variants:
+        os.environ.update(env)
+        pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, freq=freq, cell=cell, subs=subs)
+        s = pb.plan()
+        trees = [pb.tree(e, s[e]) for e in range(n_ep)]
+        for k in env:
+            os.environ.pop(k)
+        for e in range(n_ep):
+            r = ref[e]
+            ok = (int(s["status"][e]), int(s["n_nodes"][e]), int(s["steps"][e]), bool(s["done"][e])) == \
+                 (r["status"], r["n_nodes"], r["steps"], r["done"]) and float(s["rng_after"][e]) == r["rng_after"]
+            ok = ok and np.array_equal(trees[e]["nodes"], r["nodes"][:, :4]) and np.array_equal(trees[e]["parent"], r["parent"])
+            if not ok:
+                fails += 1
+                print("PLANNER MISMATCH case", i, "episode", e, name, freq, cell, subs, max_step)
 
 
 for i in range(n_cases):
     rrt_case(i)
+    rrt_modes_case(i)
     astar_case(i)
     try:
         planner_case(i)
