@@ -170,7 +170,8 @@ class RRTEnvBatch:
         """RRTEnv.step for all environments with the agent's choices already in device memory (`bucket_dev`: int32 [E] torch
         tensor on this GPU, default: the buffer policy_random_device fills).  Enqueues the step, the observation arrays and
         the outcome on the planner's stream and returns the device tensors; call sync() before reading them from another
-        stream or the host."""
+        stream or the host.  The planner's stream is not torch's: an agent that wrote `bucket_dev` on torch's current stream
+        synchronises that stream (torch.cuda.current_stream().synchronize()) before this call."""
         d = self.device_buffers()
         b = d["bucket"] if bucket_dev is None else bucket_dev
         self._ctx._chk(self._L.auvp_prrt_env_step_dev(
