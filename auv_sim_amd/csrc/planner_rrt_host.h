@@ -17,7 +17,9 @@ struct PrrtState {
   DevBuf work;  // work counter of the four-episodes-per-wavefront kernel (planner_rows_kernel.h)
   bool use_rows = false;  // decided once per batch: the two kernels keep the generator's lazy state in different block phases
   const char* last_kernel = "";
-  unsigned long long policy_calls = 0;  // call counter of the stand-in agent (auvp_prrt_policy_random_dev)
+  DevBuf loop_step;  // device word: steps of the device-resident env loop so far (mixed into the stand-in agent's draws)
+  std::vector<hipGraphExec_t> graphs;  // captured step graphs of the device-resident loop (auvp_graph_*)
+  ~PrrtState() { for (auto g : graphs) if (g) (void)hipGraphExecDestroy(g); }
   bool thetas_ready = false;
 };
 
@@ -46,7 +48,7 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(wg_waves * 64), lds, h->stream, h->W, S.P, S.B, S.E);
     return hipGetLastError();
   };
-  HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+  if (sync) HIPCHK(h, hipEventRecord(h->ev0, h->stream));  // (enqueue-only calls may be under stream capture: no events)
   hipError_t le;
   int grid_used = grid, block_used = wg_waves * 64;
   size_t lds_used = lds;
@@ -81,7 +83,7 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     else le = launch(auvp::prrt_kernel<16, false>);
   }
   HIPCHK(h, le);
-  HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  if (sync) HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   h->last_grid = grid_used; h->last_block = block_used; h->last_lds = (int)lds_used;
   if (!sync) return AUVP_OK;
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -173,7 +175,8 @@ static int prrt_plant(auvp_handle* h, PrrtState& S, int32_t E) {
   HIPCHK(h, hipMemsetAsync(S.bcount.p, 0, (size_t)E * S.P.n_buckets * sizeof(int32_t), h->stream));
   HIPCHK(h, S.env_done.reserve((size_t)E));
   HIPCHK(h, hipMemsetAsync(S.env_done.p, 0, (size_t)E, h->stream));
-  S.policy_calls = 0;
+  HIPCHK(h, S.loop_step.reserve(sizeof(unsigned long long)));
+  HIPCHK(h, hipMemsetAsync(S.loop_step.p, 0, sizeof(unsigned long long), h->stream));
   S.thetas_ready = false;
   hipLaunchKernelGGL(auvp::prrt_init_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, S.P, S.B, (int)E);
   HIPCHK(h, hipGetLastError());
@@ -412,7 +415,7 @@ int auvp_prrt_env_step_dev(auvp_handle* h, const int32_t* bucket_ids_dev, void* 
   if (rc != AUVP_OK) return rc;
   if (rrt_grid_dev && (rc = prrt_observation_enqueue(h, S, rrt_grid_dev, has_node_dev, num_nodes_dev)) != AUVP_OK) return rc;
   hipLaunchKernelGGL(auvp::prrt_env_outcome_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, S.B, S.E, S.env_done.as<uint8_t>(),
-                     reinterpret_cast<long long*>(reward_dev), done_dev);
+                     reinterpret_cast<long long*>(reward_dev), done_dev, S.loop_step.as<unsigned long long>());
   HIPCHK(h, hipGetLastError());
   return AUVP_OK;
 }
@@ -424,7 +427,7 @@ int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uin
   HIPCHK(h, hipSetDevice(h->device));
   hipLaunchKernelGGL(auvp::prrt_policy_random_kernel, dim3((S.E + 3) / 4), dim3(256), 0, h->stream, S.E, S.P.n_buckets,
                      reinterpret_cast<const long long*>(has_node_dev), S.env_done.as<uint8_t>(), (unsigned long long)seed,
-                     S.policy_calls++, bucket_ids_dev);
+                     S.loop_step.as<unsigned long long>(), bucket_ids_dev);
   HIPCHK(h, hipGetLastError());
   return AUVP_OK;
 }
@@ -437,6 +440,40 @@ int auvp_stream_sync(auvp_handle* h) {
 }
 
 void* auvp_stream(auvp_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+// ---- hipGraph capture of a launch-bound inner loop on the handle's stream ------------------------------------------------
+// Between auvp_graph_begin and auvp_graph_end every enqueue-only entry point (auvp_prrt_policy_random_dev,
+// auvp_prrt_env_step_dev, a caller's own kernels on auvp_stream) is recorded instead of run; auvp_graph_launch replays the
+// recorded step n times back to back.  Call the entry points once un-captured first (they allocate and upload on first use).
+int auvp_graph_begin(auvp_handle* h) {
+  if (!h) return AUVP_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  return AUVP_OK;
+}
+
+int auvp_graph_end(auvp_handle* h, int32_t* graph_id) {
+  if (!h || !graph_id) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  hipGraph_t g = nullptr;
+  HIPCHK(h, hipStreamEndCapture(h->stream, &g));
+  hipGraphExec_t ge = nullptr;
+  hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess) return fail(h, AUVP_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  S.graphs.push_back(ge);
+  *graph_id = (int32_t)S.graphs.size() - 1;
+  return AUVP_OK;
+}
+
+int auvp_graph_launch(auvp_handle* h, int32_t graph_id, int32_t n_times) {
+  if (!h || n_times < 0) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (graph_id < 0 || graph_id >= (int32_t)S.graphs.size() || !S.graphs[graph_id]) return fail(h, AUVP_ERR_ARG, "no such graph");
+  HIPCHK(h, hipSetDevice(h->device));
+  for (int i = 0; i < n_times; i++) HIPCHK(h, hipGraphLaunch(S.graphs[graph_id], h->stream));
+  return AUVP_OK;
+}
 
 // the same for one episode, copied to host arrays
 int auvp_prrt_observation(auvp_handle* h, int32_t ep, double* rrt_grid, int64_t* has_node, int64_t* num_nodes) {

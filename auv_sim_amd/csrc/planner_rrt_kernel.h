@@ -851,8 +851,12 @@ __global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, 
 // R_CREATE_NODE (0) when a node was added, R_INVALID_NODE (-1) otherwise; an environment that had finished before the
 // step is skipped by it and gets reward 0.  env_done [E] is the loop's own "finished" flag.
 __global__ __launch_bounds__(256) void prrt_env_outcome_kernel(PrrtBuffers B, int n_episodes, uint8_t* __restrict__ env_done,
-                                                               long long* __restrict__ reward, uint8_t* __restrict__ done_out) {
+                                                               long long* __restrict__ reward, uint8_t* __restrict__ done_out,
+                                                               unsigned long long* __restrict__ loop_step) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  // the loop's step counter lives in HBM (the stand-in agent mixes it into its draws): a captured graph of one step can be
+  // replayed, every replay sees the next value
+  if (e == 0) *loop_step = *loop_step + 1ull;
   if (e >= n_episodes) return;
   const bool was = env_done[e] != 0;
   const PrrtSummary& s = B.summary[e];
@@ -876,9 +880,11 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 }
 __global__ __launch_bounds__(256) void prrt_policy_random_kernel(int n_episodes, int n_buckets, const long long* __restrict__ has_node,
                                                                  const uint8_t* __restrict__ env_done, unsigned long long seed,
-                                                                 unsigned long long call, int32_t* __restrict__ bucket_out) {
+                                                                 const unsigned long long* __restrict__ loop_step,
+                                                                 int32_t* __restrict__ bucket_out) {
   const int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
   if (e >= n_episodes) return;
+  const unsigned long long call = *loop_step;
   const int lane = lane_id();
   if (env_done[e]) { if (lane == 0) bucket_out[e] = -1; return; }
   const long long* hn = has_node + (size_t)e * n_buckets;

@@ -53,6 +53,9 @@ class RRTEnvBatch:
         self._L.auvp_prrt_env_step_dev.argtypes = [C.c_void_p] * 7
         self._L.auvp_prrt_policy_random_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         self._L.auvp_stream_sync.argtypes = [C.c_void_p]
+        self._L.auvp_graph_begin.argtypes = [C.c_void_p]
+        self._L.auvp_graph_end.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self._L.auvp_graph_launch.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
         self._pb = None
         self.state = None
 
@@ -182,6 +185,21 @@ class RRTEnvBatch:
 
     def sync(self):
         self._ctx._chk(self._L.auvp_stream_sync(self._ctx.h))
+
+    def capture_step(self, enqueue):
+        """record what `enqueue()` puts on the planner's stream (policy_random_device, step_device, ...) as a hipGraph of one
+        step; returns its id for replay(id, n).  One un-captured step must have run before (first-use allocations)."""
+        gid = C.c_int32(-1)
+        self._ctx._chk(self._L.auvp_graph_begin(self._ctx.h))
+        try:
+            enqueue()
+        finally:
+            self._ctx._chk(self._L.auvp_graph_end(self._ctx.h, C.byref(gid)))
+        return int(gid.value)
+
+    def replay(self, graph_id, n_times=1):
+        """n_times replays of a captured step, back to back on the planner's stream (enqueue only)"""
+        self._ctx._chk(self._L.auvp_graph_launch(self._ctx.h, int(graph_id), int(n_times)))
 
     def tree(self, e):
         s = self._pb.summaries()[e]

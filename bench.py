@@ -606,7 +606,7 @@ def bench_rrt_env(local_rank, n_env=512, n_steps=60):
     # the same environments with NOTHING crossing PCIe (what row f1 is for): the agent -- a stand-in kernel that picks a random
     # occupied bucket from the has_node array in HBM -- the generate_one_node launch, the observation kernel and the
     # reward / done kernel are enqueued back to back on the planner's stream; one wait at the end
-    env2 = RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=list(range(n_env)), max_nodes=4 * n_steps + 8, freq=10, device=local_rank)
+    env2 = RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=list(range(n_env)), max_nodes=8 * n_steps + 16, freq=10, device=local_rank)
     env2.reset()
     d = env2.device_buffers()
     for _ in range(3):
@@ -620,6 +620,18 @@ def bench_rrt_env(local_rank, n_env=512, n_steps=60):
         env2.step_device()
     env2.sync()
     dt2 = time.perf_counter() - t0
+    # ... and the same step captured once as a hipGraph and replayed (launch-bound inner loop: one graph launch per step instead
+    # of four kernel launches)
+    def one_step():
+        env2.policy_random_device(seed=5)
+        env2.step_device()
+    gid = env2.capture_step(one_step)
+    env2.replay(gid, 3)
+    env2.sync()
+    t0 = time.perf_counter()
+    env2.replay(gid, n2)
+    env2.sync()
+    dt3 = time.perf_counter() - t0
     live = int((d["done"] == 0).sum().item())
     nodes = int(d["num_nodes"].sum().item())
     # algorithmic bytes of one batched step: observation arrays written (32 + 8 + 8 B per bucket), bucket counts read by the
@@ -630,6 +642,8 @@ def bench_rrt_env(local_rank, n_env=512, n_steps=60):
         "metric": "RRTEnv steps/s, device-resident loop (agent + step + observation + outcome kernels, no host transfer)",
         "value": n_env * n2 / dt2, "unit": "env-steps/s", "envs": n_env, "steps": n2, "ms_per_batched_step": 1e3 * dt2 / n2,
         "envs_still_running_at_end": live, "nodes_in_all_trees": nodes,
+        "hipgraph_replay": {"value": n_env * n2 / dt3, "unit": "env-steps/s", "ms_per_batched_step": 1e3 * dt3 / n2,
+                            "note": "the same four-kernel step captured once on the planner's stream and replayed"},
         "roofline": roofline(abytes, 1e3 * dt2 / n2, "prrt_policy_random_kernel + prrt_kernel (step mode) + prrt_observation_kernel + prrt_env_outcome_kernel",
                              note="wall time of the enqueue loop / steps (four launches per step on one stream, one wait at the end): "
                                   "launch-bound, the observation write is the only HBM-sized term")}

@@ -190,6 +190,13 @@ int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uin
 /* the handle's HIP stream (hipStream_t) and a wait for everything enqueued on it */
 void* auvp_stream(auvp_handle* h);
 int auvp_stream_sync(auvp_handle* h);
+/* hipGraph capture of a launch-bound step loop: everything the enqueue-only entry points (auvp_prrt_policy_random_dev,
+ * auvp_prrt_env_step_dev, the caller's own kernels on auvp_stream) put on the stream between begin and end is recorded
+ * instead of run; auvp_graph_launch replays it n_times back to back (enqueue only).  The loop's step counter lives in
+ * HBM, so every replay of the stand-in agent draws anew.  Run one un-captured step first. */
+int auvp_graph_begin(auvp_handle* h);
+int auvp_graph_end(auvp_handle* h, int32_t* graph_id);
+int auvp_graph_launch(auvp_handle* h, int32_t graph_id, int32_t n_times);
 
 /* ---------------------------------------------------------------------------------------------
  * A* variants (path_planning/astar.py, astar_real.py, astar_fixLen.py, astar_fixLenSOG.py), one

@@ -138,3 +138,40 @@ def test_env_device_resident_loop_matches_host_loop():
         picks.append(b.copy())
     if (~dn).any() and (hn[~dn].sum(axis=1) > 3).any():
         assert any(not np.array_equal(picks[0], p) for p in picks[1:])
+
+
+def test_env_device_loop_as_a_graph_equals_eager():
+    """one step of the device-resident loop (stand-in agent + generate_one_node + observation + outcome) captured as a
+    hipGraph and replayed n times == the same n steps enqueued one by one: the loop's step counter lives in HBM, so every
+    replay draws anew"""
+    from auv_sim_amd import synth
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    from auv_sim_amd.rrt_env import RRTEnvBatch
+    w = synth.make_rect_world(seed=3, n_obstacles=64)
+    obstacles = [MPS(o[0], o[1], size=o[2]) for o in w["obstacles"].tolist()]
+    bnd = [MPS(float(w["rect"][0]), float(w["rect"][1])), MPS(float(w["rect"][2]), float(w["rect"][3]))]
+    auv, shark = MPS(float(w["start"][0]), float(w["start"][1]), z=-5.0), MPS(float(w["goal"][0]), float(w["goal"][1]), z=-5.0)
+    E, n_steps = 40, 90
+    out = []
+    for graph in (False, True):
+        env = RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=list(range(E)), max_nodes=n_steps + 8, freq=10)
+        env.reset()
+        d = env.device_buffers()
+
+        def one_step():
+            env.policy_random_device(seed=3)
+            env.step_device()
+        one_step()  # first-use allocations; also step 0 of both runs
+        if graph:
+            gid = env.capture_step(one_step)
+            env.replay(gid, n_steps - 1)
+        else:
+            for _ in range(n_steps - 1):
+                one_step()
+        env.sync()
+        out.append((d["num_nodes"].cpu().numpy().copy(), d["reward"].cpu().numpy().copy(), d["done"].cpu().numpy().copy(),
+                    [env.tree(e)["nodes"] for e in (0, E - 1)]))
+    a, b = out
+    assert a[0].sum() > E * 5  # trees grew
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert all(np.array_equal(x, y) for x, y in zip(a[3], b[3]))
