@@ -119,18 +119,18 @@ AUVP_HD double auvp_atan(double x) {
     double r = hi3 + lo3;
     return neg ? -r : r;
   }
+  // one division for whichever reduction applies: the lanes of a wavefront usually need different ones, and four divergent
+  // branches with a division each would run one after the other (same operations per lane either way)
   int id;
-  double hi = 0.0, lo = 0.0;
+  double hi = 0.0, lo = 0.0, num = 0.0, den = 1.0;
   if (ax < 0.4375) {
     if (ax < 0x1p-27) return x;
     id = -1;
-  } else if (ax < 1.1875) {
-    if (ax < 0.6875) { id = 0; ax = (2.0 * ax - 1.0) / (2.0 + ax); hi = hi0; lo = lo0; }
-    else { id = 1; ax = (ax - 1.0) / (ax + 1.0); hi = hi1; lo = lo1; }
-  } else {
-    if (ax < 2.4375) { id = 2; ax = (ax - 1.5) / (1.0 + 1.5 * ax); hi = hi2; lo = lo2; }
-    else { id = 3; ax = -1.0 / ax; hi = hi3; lo = lo3; }
-  }
+  } else if (ax < 0.6875) { id = 0; num = 2.0 * ax - 1.0; den = 2.0 + ax; hi = hi0; lo = lo0; }
+  else if (ax < 1.1875) { id = 1; num = ax - 1.0; den = ax + 1.0; hi = hi1; lo = lo1; }
+  else if (ax < 2.4375) { id = 2; num = ax - 1.5; den = 1.0 + 1.5 * ax; hi = hi2; lo = lo2; }
+  else { id = 3; num = -1.0; den = ax; hi = hi3; lo = lo3; }
+  if (id >= 0) ax = num / den;
   double z = ax * ax;
   double w = z * z;
   double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
