@@ -43,3 +43,80 @@ def test_rccl_gather_single_rank_round_trip():
     ctx._chk(g.L.auvp_gather(ctx.h, C.c_void_p(view.data_ptr()), view.numel(), C.c_void_p(recv.data_ptr())))
     assert torch.equal(recv, view)
     g.close()
+
+
+def _two_rank_worker(rank, world, id_path, E_total, q):
+    """one process per GPU: the C-ABI gather with a real two-rank RCCL communicator (no torch.distributed involved)"""
+    import os
+    import sys
+    import time
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from auv_sim_amd import _lib, distributed as D
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    ctx = _lib.Context(rank)
+
+    def exchange(mine):  # rank 0 writes the 128-byte id to a file, the others wait for it
+        if rank == 0:
+            with open(id_path + ".tmp", "wb") as f:
+                f.write(mine)
+            os.replace(id_path + ".tmp", id_path)
+            return mine
+        for _ in range(600):
+            if os.path.exists(id_path):
+                return open(id_path, "rb").read()
+            time.sleep(0.1)
+        return b""
+    g = D.RcclGather(ctx, rank, world, exchange)
+    ok = g.info() == (world, rank, world)
+    lo, hi = D.shard_range(E_total, rank, world)
+    n = hi - lo
+    rec = torch.zeros((n, 112), dtype=torch.uint8, device=dev)
+    for i in range(n):
+        rec[i] = (lo + i) % 251
+    out = g.gather_records(rec)
+    lens = torch.tensor([2 + ((lo + i) % 4) for i in range(n)], dtype=torch.int64, device=dev)
+    paths = torch.zeros((int(lens.sum().item()), 7), dtype=torch.float64, device=dev)
+    pos = 0
+    for i in range(n):
+        L = int(lens[i])
+        paths[pos:pos + L, 0] = lo + i
+        pos += L
+    all_len, blocks = g.gather_paths(paths, lens)
+    for r in range(world):
+        rlo, rhi = D.shard_range(E_total, r, world)
+        ok &= out[r].shape == (rhi - rlo, 112) and len(all_len[r]) == rhi - rlo
+        pos = 0
+        for i in range(rhi - rlo):
+            e = rlo + i
+            ok &= bool((out[r][i] == e % 251).all())
+            L = int(all_len[r][i])
+            ok &= L == 2 + (e % 4) and bool((blocks[r][pos:pos + L, 0] == e).all())
+            pos += L
+    # the equal-block entry point too
+    send = torch.full((16,), rank + 1, dtype=torch.uint8, device=dev)
+    recv = torch.zeros(16 * world, dtype=torch.uint8, device=dev)
+    ctx._chk(g.L.auvp_gather(ctx.h, C.c_void_p(send.data_ptr()), 16, C.c_void_p(recv.data_ptr())))
+    ok &= all(bool((recv[16 * r:16 * r + 16] == r + 1).all()) for r in range(world))
+    g.close()
+    q.put((rank, bool(ok)))
+
+
+@pytest.mark.parametrize("E_total", [9, 1])  # uneven shards; one rank with nothing to send
+def test_rccl_gather_two_ranks(tmp_path, E_total):
+    """needs two GPUs (skipped on the one-GPU boxes of this pool): two processes, one GPU each, a real two-rank communicator
+    through auvp_comm_init, the count exchange + grouped broadcasts of the variable-length gather with different roots"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, str(tmp_path / "rccl_id"), E_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
