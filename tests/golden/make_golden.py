@@ -375,6 +375,15 @@ def g3():
         ("g3_tb_c40000", 7, dict(seed=2, n_obstacles=256, box=(-1000.0, -1000.0, 1000.0, 1000.0), cell=10.0, n_bins=10,
                                  bin_len=50, n_habitats=10), 1500, "timebin",
          {"max_traj_time": 120.0, "shark_interval": 30, "keep_points": False, "store_world": False}),
+        # round 3: nearest-neighbour parent sampling on the bench world -- the headline's horizon (the time-stamp rule of
+        # :138-139 rejects most samples, ~100 qualifying leaves) and a horizon long enough for the tree to keep growing
+        # (every iteration scans a longer list; duplicated positions and near-equidistant nodes decide get_closest_mps)
+        ("g3_nn_c40000_i3000", 7, dict(seed=2, n_obstacles=256, box=(-1000.0, -1000.0, 1000.0, 1000.0), cell=10.0, n_bins=10,
+                                       bin_len=50, n_habitats=10), 3000, "nn",
+         {"max_traj_time": 500.0, "keep_points": False, "store_world": False}),
+        ("g3_nn_long_c40000_i4000", 7, dict(seed=2, n_obstacles=256, box=(-1000.0, -1000.0, 1000.0, 1000.0), cell=10.0, n_bins=10,
+                                            bin_len=50, n_habitats=10), 4000, "nn",
+         {"max_traj_time": 20000.0, "keep_points": False, "store_world": False}),
     ]
     only = os.environ.get("AUVP_G3_ONLY")
     for name, seed, wk, n_iter, mode, extra in specs:
