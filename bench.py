@@ -1084,6 +1084,14 @@ def main():
                     r = {"error": "%s: %s" % (type(e).__name__, e)}
                 if rank == 0:
                     out[name] = r
+        if rank == 0 and isinstance(out.get("rrt_nn_long_horizon"), dict) and "roofline" in out["rrt_nn_long_horizon"]:
+            # the headline's parent sampling (time bins) reads one node per iteration; the SAME path with nearest-neighbour
+            # parent sampling streams the whole tree every iteration -- that side measurement is where the HBM roofline
+            # fraction of the path is visible
+            nl = out["rrt_nn_long_horizon"]["roofline"]
+            out["roofline"]["streaming_side_measurement"] = {
+                "name": "rrt_nn_long_horizon", "frac": nl["frac"], "achieved": nl["achieved"], "unit": nl["unit"],
+                "traffic": nl.get("traffic"), "kernel_ms": nl["kernel_ms"]}
     if rank == 0:
         print(json.dumps(out))
     if world_size > 1:
