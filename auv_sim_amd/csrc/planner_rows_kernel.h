@@ -112,13 +112,16 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       if (__any(more)) continue;  // (every row drew an episode the step skips: draw again)
       break;
     }
-    const size_t en = (size_t)(ep < 0 ? 0 : ep) * capn;           // node-indexed arrays of the row's episode
-    const size_t eb = (size_t)(ep < 0 ? 0 : ep) * P.n_buckets;    // bucket-indexed arrays
-    double* nodeF = B.node_f + en * 4;
-    int4* nodeI = reinterpret_cast<int4*>(B.node_i) + en;
-    int32_t* nnext = B.node_next + en;
-    int32_t* bcount = B.bucket_counts + eb;
-    int32_t* bhead = B.bucket_head + eb;
+    // per-episode array bases are formed where they are used, from the episode id alone (an opaque copy keeps the compiler
+    // from hoisting seven 64-bit pointers into registers for the whole step)
+    auto epq = [&]() { int v = ep < 0 ? 0 : ep; asm volatile("" : "+v"(v)); return (size_t)v; };
+#define en (epq() * (size_t)capn)
+#define eb (epq() * (size_t)P.n_buckets)
+#define nodeF (B.node_f + en * 4)
+#define nodeI (reinterpret_cast<int4*>(B.node_i) + en)
+#define nnext (B.node_next + en)
+#define bcount (B.bucket_counts + eb)
+#define bhead (B.bucket_head + eb)
 
     // a row takes part in this step if its episode is still running
     bool act = live && status == 0 && !done && step < step_end;
@@ -497,5 +500,12 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
   }
 }
 
+#undef en
+#undef eb
+#undef nodeF
+#undef nodeI
+#undef nnext
+#undef bcount
+#undef bhead
 }  // namespace auvp
 #endif
