@@ -1,9 +1,11 @@
 """Drop-in for path_planning/astar_fixLenSOG.py: `astar(start, obstacleList, boundaryList, habitatList,
 sharkGrid, shark_dict, AUV_velocity).astar(pathLenLimit, weights, shark_traj)` -> dict with
 "path length", "path" (smoothed), "cost", "cost list", "node" -- or None when the open list runs empty
-(astar_fixLenSOG.py:111,551,618).  `sharkGrid` must be given ({(t0,t1): {cell.bounds: prob}}); the
-reference's fallback for `{}` (splitCell + a CSV path relative to its repo root, :127-132) needs shapely
-and is not reproduced.  `self.visited_nodes` persists across calls, as in the reference."""
+(astar_fixLenSOG.py:111,551,618).  `sharkGrid` is {(t0,t1): {cell.bounds: prob}}.  The reference's fallback for `{}`
+(:127-132: `cell_list = splitCell(boundary_poly, 10)`, then createSharkGrid on a CSV path relative to its repo root) needs
+shapely for the split; here the caller passes that cell list and the CSV path (`cell_list=`, `shark_csv=`, additive) and the
+module's own createSharkGrid loads it the way the reference's does.  `self.visited_nodes` persists across calls, as in the
+reference."""
 import numpy as np
 
 from . import _astar_common as ac
@@ -30,9 +32,13 @@ def createSharkGrid(filepath, cell_list):
 
 class astar:
     def __init__(self, start, obstacleList, boundaryList, habitatList, sharkGrid, shark_dict, AUV_velocity,
-                 cap_nodes=200000, device=0):
+                 cap_nodes=200000, device=0, cell_list=None, shark_csv=None):
         if not sharkGrid:
-            raise ValueError("sharkGrid is required (the reference's CSV/splitCell fallback is not reproduced)")
+            if cell_list is None or shark_csv is None:
+                raise ValueError("sharkGrid is empty: pass cell_list= (the reference's splitCell(boundary_poly, 10)) and shark_csv= "
+                                 "(its 'path_planning/shark_data/AUVGrid_prob_500_straight.csv') for the fallback of :127-132")
+            self.cell_list = cell_list
+            sharkGrid = createSharkGrid(shark_csv, cell_list)
         self.start = start
         self.velocity = AUV_velocity
         self.obstacle_list = obstacleList

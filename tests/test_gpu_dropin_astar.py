@@ -117,6 +117,11 @@ def test_astar_fixlen_sog_on_the_reference_shark_csv(tmp_path, stem, orc):
     cell_arr = np.array([c.bounds for c in cells[:n]])
     prob = g[pre + "vals"].reshape(len(bins), n)
     obs, hab, bnd = _mps(obstacles.tolist()), _mps(habitats.tolist()), [MPS(x, y) for x, y in poly]
+    # the reference's `sharkGrid == {}` fallback (:127-132) with the cell list and the CSV handed in
+    fb = astar((-250.0, -50.0), obs, bnd, hab, {}, {}, 1.0, cell_list=cells, shark_csv=str(p))
+    assert list(fb.sharkGrid.keys()) == list(shark.keys()) and fb.sharkGrid[list(shark.keys())[0]] == shark[list(shark.keys())[0]]
+    with pytest.raises(ValueError):
+        astar((-250.0, -50.0), obs, bnd, hab, {}, {}, 1.0)
     for start, limit in (((-250.0, -50.0), 200.0), ((20.0, 30.0), 300.0), ((-100.0, 0.0), 100.0)):
         res = astar(start, obs, bnd, hab, shark, {}, 1.0).astar(limit, [0, 10, 10, 100], {})
         o = oa.run("astar_fixLenSOG", np.array(start), obstacles=obstacles, habitats=habitats, polygon=np.array(poly), bins=bins,
