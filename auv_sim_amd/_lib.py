@@ -115,6 +115,8 @@ def load():
     L.auvp_last_kernel_ms.restype = C.c_double
     L.auvp_last_launch.argtypes = [vp, _ip, _ip, _ip]
     L.auvp_rrt_last_launch_parts.argtypes = [vp, _dp, _dp, _ip]
+    L.auvp_rrt_last_leaf_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.auvp_hbm_probe.argtypes = [vp, C.c_uint64, C.c_int32, _dp, _dp]
     _lib = L
     return L
 
@@ -325,6 +327,19 @@ class Context:
         a, b, k = C.c_double(), C.c_double(), C.c_int32()
         self._chk(self.L.auvp_rrt_last_launch_parts(self.h, C.byref(a), C.byref(b), C.byref(k)))
         return a.value, b.value, k.value
+
+    def last_leaf_stats(self):
+        """of the last rrt_run's leaf pass, summed over the batch: nodes visited, their path points, path elements re-summed
+        in the reference's order, leaves re-summed"""
+        out = (C.c_int64 * 4)()
+        self._chk(self.L.auvp_rrt_last_leaf_stats(self.h, out))
+        return dict(zip(("nodes_visited", "points_visited", "elements_resummed", "leaves_resummed"), (int(v) for v in out)))
+
+    def hbm_probe(self, n_bytes=4 << 30, reps=3):
+        """measured HBM streaming rates of this GPU in GB/s: (read, copy [read + written bytes])"""
+        r, c = C.c_double(), C.c_double()
+        self._chk(self.L.auvp_hbm_probe(self.h, int(n_bytes), int(reps), C.byref(r), C.byref(c)))
+        return r.value, c.value
 
     def last_launch(self):
         g, b, l = C.c_int32(), C.c_int32(), C.c_int32()

@@ -153,6 +153,10 @@ struct RrtBuffers {
   double* leaf_cost;  // optional [E][cap_leaves][6]
   int32_t* leaf_iter;
   unsigned long long* phase_clocks;  // optional [E][5] shader clocks per phase
+  // optional [4], summed over the episodes of a launch by rrt_leaf_kernel: nodes visited by its sweep (qualifying leaves and
+  // their ancestors), path points of those nodes, path elements re-summed in the reference's order, leaves re-summed --
+  // the units of the leaf pass's compulsory-traffic figure (bench.py)
+  unsigned long long* leaf_stats;
 };
 
 }  // namespace auvp

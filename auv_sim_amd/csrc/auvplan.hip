@@ -60,7 +60,7 @@ struct auvp_handle {
   RrtBuffers B{};
   int max_pts = 0;
   DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_phase, d_node_c, d_node_q, d_node_xy, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+      d_leaf_c, d_leaf_i, d_phase, d_leaf_stats, d_node_c, d_node_q, d_node_xy, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
@@ -650,6 +650,8 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
     B.leaf_iter = h->d_leaf_i.as<int32_t>();
   }
   B.phase_clocks = nullptr;
+  HIPCHK(h, h->d_leaf_stats.reserve(4 * sizeof(unsigned long long)));
+  B.leaf_stats = h->d_leaf_stats.as<unsigned long long>();
   if (flags & AUVP_FLAG_PHASE_CLOCKS) {
     HIPCHK(h, h->d_phase.reserve((size_t)E * 5 * sizeof(unsigned long long)));
     HIPCHK(h, hipMemsetAsync(h->d_phase.p, 0, (size_t)E * 5 * sizeof(unsigned long long), h->stream));
@@ -722,6 +724,7 @@ int auvp_rrt_run(auvp_handle* h) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(xw * 64), lds, h->stream, h->W, PR, B, (int)E, h->max_pts);
     return hipGetLastError();
   };
+  if (B.leaf_stats) HIPCHK(h, hipMemsetAsync(B.leaf_stats, 0, 4 * sizeof(unsigned long long), h->stream));  // (before the timed region)
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipError_t le = hipSuccess;
   // four episodes per wavefront (rrt_rows_kernel.h) where its limits allow; one episode per wavefront otherwise
@@ -931,6 +934,14 @@ int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_m
   if (expand_ms) *expand_ms = h->last_expand_ms;
   if (leaf_ms) *leaf_ms = h->last_leaf_ms;
   if (episodes_per_wave) *episodes_per_wave = h->last_rows ? 4 : 1;
+  return AUVP_OK;
+}
+
+int auvp_rrt_last_leaf_stats(auvp_handle* h, int64_t* out4) {
+  if (!h || !out4) return AUVP_ERR_ARG;
+  if (!h->have_batch || !h->B.leaf_stats) return fail(h, AUVP_ERR_STATE, "no batch has run");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(out4, h->B.leaf_stats, 4 * sizeof(int64_t), hipMemcpyDeviceToHost));
   return AUVP_OK;
 }
 

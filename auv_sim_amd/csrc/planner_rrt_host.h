@@ -18,8 +18,13 @@ struct PrrtState {
   bool use_rows = false;  // decided once per batch: the two kernels keep the generator's lazy state in different block phases
   const char* last_kernel = "";
   DevBuf loop_step;  // device word: steps of the device-resident env loop so far (mixed into the stand-in agent's draws)
-  std::vector<hipGraphExec_t> graphs;  // captured step graphs of the device-resident loop (auvp_graph_*)
-  ~PrrtState() { for (auto g : graphs) if (g) (void)hipGraphExecDestroy(g); }
+  DevBuf env_err;    // device int32[2]: {status, environment} of the first episode that failed inside the device-resident loop
+  // captured step graphs of the device-resident loop (auvp_graph_*).  A graph holds raw device pointers (this batch's
+  // buffers and the caller's observation / reward arrays): it dies with the batch it was captured for -- prrt_configure
+  // destroys them, and the ids stay taken so that a stale id can never reach another batch's graph.
+  std::vector<hipGraphExec_t> graphs;
+  void drop_graphs() { for (auto& g : graphs) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; } }
+  ~PrrtState() { drop_graphs(); }
   bool thetas_ready = false;
 };
 
@@ -106,6 +111,7 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
   const int ics = (int)p->cell_side_length;
   if (ics <= 0 || p->subsections <= 0 || p->max_step <= 0 || !(p->freq >= 0)) return fail(h, AUVP_ERR_ARG, "bad params");
   S.ready = false;
+  S.drop_graphs();  // they replay launches on the previous batch's buffers
   auvp::PrrtParamsDev& P = S.P;
   for (int i = 0; i < 4; i++) P.rect[i] = p->rect[i];
   P.exp_rate = p->exp_rate; P.dist_to_end = p->dist_to_end; P.diff_max = p->diff_max; P.freq = p->freq;
@@ -149,6 +155,8 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
   B.step_bucket = S.step_bucket.as<int32_t>();
   B.start = S.start.as<double>(); B.goal = S.goal.as<double>();
   B.st_log = nullptr;
+  B.env_flags = 0; B._pad_env = 0; B.env_done = nullptr; B.env_reward = nullptr; B.env_done_out = nullptr;
+  B.env_bucket_out = nullptr; B.env_loop_step = nullptr; B.env_agent_seed = 0ull; B.env_err = nullptr;
   if (flags & AUVP_FLAG_ITER_LOG) {
     HIPCHK(h, S.st_log.reserve((size_t)E * p->max_step * 8 * sizeof(int32_t)));
     HIPCHK(h, hipMemsetAsync(S.st_log.p, 0xff, (size_t)E * p->max_step * 8 * sizeof(int32_t), h->stream));
@@ -177,6 +185,8 @@ static int prrt_plant(auvp_handle* h, PrrtState& S, int32_t E) {
   HIPCHK(h, hipMemsetAsync(S.env_done.p, 0, (size_t)E, h->stream));
   HIPCHK(h, S.loop_step.reserve(sizeof(unsigned long long)));
   HIPCHK(h, hipMemsetAsync(S.loop_step.p, 0, sizeof(unsigned long long), h->stream));
+  HIPCHK(h, S.env_err.reserve(2 * sizeof(int32_t)));
+  HIPCHK(h, hipMemsetAsync(S.env_err.p, 0, 2 * sizeof(int32_t), h->stream));
   S.thetas_ready = false;
   hipLaunchKernelGGL(auvp::prrt_init_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, S.P, S.B, (int)E);
   HIPCHK(h, hipGetLastError());
@@ -363,7 +373,8 @@ void* auvp_prrt_summaries_dev(auvp_handle* h) {
 // RRTEnv observation arrays (gym_rrt/envs/rrt_env.py:250-295) for every episode, written to
 // caller-owned DEVICE buffers: rrt_grid [E,n_buckets,4] f64 = cell.x, cell.y, subsection.theta,
 // len(node_array); has_node [E,n_buckets] i64; num_nodes [E,n_buckets] i64.
-static int prrt_observation_enqueue(auvp_handle* h, PrrtState& S, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev) {
+static int prrt_observation_enqueue(auvp_handle* h, PrrtState& S, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev,
+                                    unsigned long long* tick = nullptr) {
   if (!S.thetas_ready) {
     // subsection thetas exactly as Grid_cell_RRT builds them (grid_cell_rrt.py:49-55); once per batch
     std::vector<double> th(S.P.S);
@@ -383,7 +394,7 @@ static int prrt_observation_enqueue(auvp_handle* h, PrrtState& S, void* rrt_grid
   const int grid = (int)std::min<long long>((total + 255) / 256, 65535LL * 16);
   hipLaunchKernelGGL(auvp::prrt_observation_kernel, dim3(grid), dim3(256), 0, h->stream, S.P, S.B, S.thetas.as<double>(), S.E,
                      reinterpret_cast<double*>(rrt_grid_dev), reinterpret_cast<long long*>(has_node_dev),
-                     reinterpret_cast<long long*>(num_nodes_dev));
+                     reinterpret_cast<long long*>(num_nodes_dev), tick);
   HIPCHK(h, hipGetLastError());
   return AUVP_OK;
 }
@@ -400,35 +411,91 @@ int auvp_prrt_observation_dev(auvp_handle* h, void* rrt_grid_dev, void* has_node
 }
 
 // ---- the device-resident RRTEnv loop: every call below only ENQUEUES on the handle's stream (auvp_stream_sync waits) ----
+// One environment step = TWO launches: generate_one_node for every live environment with the step's outcome (reward, done
+// flag) written by the same launch -- and, for auvp_prrt_env_step_agent_dev, the stand-in agent's pick made inside it --
+// then the observation arrays, whose launch also advances the loop's step counter.  (Batches the four-episodes-per-wavefront
+// kernel serves keep the agent and the outcome as small launches of their own.)
+static int prrt_env_step_enqueue(auvp_handle* h, PrrtState& S, const int32_t* bucket_ids_dev, bool agent, uint64_t agent_seed,
+                                 int32_t* bucket_out_dev, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev,
+                                 int64_t* reward_dev, uint8_t* done_dev) {
+  auvp::PrrtBuffers& B = S.B;
+  B.env_done = S.env_done.as<uint8_t>(); B.env_reward = reinterpret_cast<long long*>(reward_dev); B.env_done_out = done_dev;
+  B.env_bucket_out = bucket_out_dev; B.env_loop_step = S.loop_step.as<unsigned long long>(); B.env_agent_seed = agent_seed;
+  B.env_err = S.env_err.as<int32_t>();
+  const int32_t* own = B.step_bucket;
+  int rc;
+  if (!S.use_rows) {
+    B.env_flags = PRRT_ENV_OUTCOME | (agent ? PRRT_ENV_AGENT : 0);
+    if (!agent) B.step_bucket = bucket_ids_dev;
+    rc = prrt_launch(h, S, 1, false);
+  } else {
+    B.env_flags = 0;
+    if (agent) {
+      hipLaunchKernelGGL(auvp::prrt_policy_random_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, B, S.E,
+                         (unsigned long long)agent_seed, S.loop_step.as<unsigned long long>(), bucket_out_dev);
+      HIPCHK(h, hipGetLastError());
+    }
+    const int32_t* ids = agent ? bucket_out_dev : bucket_ids_dev;
+    B.step_bucket = ids;
+    rc = prrt_launch(h, S, 1, false);
+    if (rc == AUVP_OK) {
+      hipLaunchKernelGGL(auvp::prrt_env_outcome_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, B, S.E, ids);
+      rc = hipGetLastError() == hipSuccess ? AUVP_OK : fail(h, AUVP_ERR_HIP, "prrt_env_outcome_kernel launch");
+    }
+  }
+  B.step_bucket = own;
+  B.env_flags = 0;
+  if (rc != AUVP_OK) return rc;
+  if (rrt_grid_dev) return prrt_observation_enqueue(h, S, rrt_grid_dev, has_node_dev, num_nodes_dev, S.loop_step.as<unsigned long long>());
+  hipLaunchKernelGGL(auvp::prrt_env_tick_kernel, dim3(1), dim3(1), 0, h->stream, S.loop_step.as<unsigned long long>());
+  HIPCHK(h, hipGetLastError());
+  return AUVP_OK;
+}
+
 int auvp_prrt_env_step_dev(auvp_handle* h, const int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev,
                            int64_t* reward_dev, uint8_t* done_dev) {
   if (!h || !bucket_ids_dev || !reward_dev) return AUVP_ERR_ARG;
   PrrtState& S = *prrt_of(h);
   if (!S.ready) return fail(h, AUVP_ERR_STATE, "auvp_prrt_create_batch not called");
   HIPCHK(h, hipSetDevice(h->device));
-  // generate_one_node with the caller's bucket (read where it lies: the kernel takes the pointer), then the observation
-  // arrays and the step's outcome, back to back on the stream
-  const int32_t* own = S.B.step_bucket;
-  S.B.step_bucket = bucket_ids_dev;
-  int rc = prrt_launch(h, S, 1, false);
-  S.B.step_bucket = own;
-  if (rc != AUVP_OK) return rc;
-  if (rrt_grid_dev && (rc = prrt_observation_enqueue(h, S, rrt_grid_dev, has_node_dev, num_nodes_dev)) != AUVP_OK) return rc;
-  hipLaunchKernelGGL(auvp::prrt_env_outcome_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, S.B, S.E, S.env_done.as<uint8_t>(),
-                     reinterpret_cast<long long*>(reward_dev), done_dev, S.loop_step.as<unsigned long long>());
+  return prrt_env_step_enqueue(h, S, bucket_ids_dev, false, 0, nullptr, rrt_grid_dev, has_node_dev, num_nodes_dev, reward_dev, done_dev);
+}
+
+int auvp_prrt_env_step_agent_dev(auvp_handle* h, uint64_t seed, int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev,
+                                 void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev) {
+  if (!h || !bucket_ids_dev || !reward_dev) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "auvp_prrt_create_batch not called");
+  HIPCHK(h, hipSetDevice(h->device));
+  return prrt_env_step_enqueue(h, S, nullptr, true, seed, bucket_ids_dev, rrt_grid_dev, has_node_dev, num_nodes_dev, reward_dev, done_dev);
+}
+
+int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uint64_t seed, int32_t* bucket_ids_dev) {
+  (void)has_node_dev;  // the agent reads the planner's own list of occupied buckets: the set has_node marks, without the scan
+  if (!h || !bucket_ids_dev) return AUVP_ERR_ARG;
+  PrrtState& S = *prrt_of(h);
+  if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
+  HIPCHK(h, hipSetDevice(h->device));
+  auvp::PrrtBuffers B = S.B;
+  B.env_done = S.env_done.as<uint8_t>();
+  hipLaunchKernelGGL(auvp::prrt_policy_random_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, B, S.E, (unsigned long long)seed,
+                     S.loop_step.as<unsigned long long>(), bucket_ids_dev);
   HIPCHK(h, hipGetLastError());
   return AUVP_OK;
 }
 
-int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uint64_t seed, int32_t* bucket_ids_dev) {
-  if (!h || !has_node_dev || !bucket_ids_dev) return AUVP_ERR_ARG;
+// {status, environment} of the first episode that failed on the device inside the device-resident loop (0: none).  Waits
+// for the stream.  The host loop (auvp_prrt_step + summaries) surfaces the same failures as summary.status < 0.
+int auvp_prrt_env_check(auvp_handle* h, int32_t* status, int32_t* env) {
+  if (!h || !status) return AUVP_ERR_ARG;
   PrrtState& S = *prrt_of(h);
   if (!S.ready) return fail(h, AUVP_ERR_STATE, "no planner batch");
   HIPCHK(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(auvp::prrt_policy_random_kernel, dim3((S.E + 3) / 4), dim3(256), 0, h->stream, S.E, S.P.n_buckets,
-                     reinterpret_cast<const long long*>(has_node_dev), S.env_done.as<uint8_t>(), (unsigned long long)seed,
-                     S.loop_step.as<unsigned long long>(), bucket_ids_dev);
-  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int32_t e2[2] = {0, 0};
+  HIPCHK(h, hipMemcpy(e2, S.env_err.p, sizeof e2, hipMemcpyDeviceToHost));
+  *status = e2[0];
+  if (env) *env = e2[1];
   return AUVP_OK;
 }
 
@@ -440,6 +507,25 @@ int auvp_stream_sync(auvp_handle* h) {
 }
 
 void* auvp_stream(auvp_handle* h) { return h ? (void*)h->stream : nullptr; }
+
+// HIP-event time of a region of the handle's stream the CALLER brackets (enqueue-only loops: auvp_prrt_env_step_dev,
+// auvp_graph_launch): auvp_stream_mark(h, 0) before, auvp_stream_mark(h, 1) after, auvp_stream_elapsed_ms waits and reads.
+int auvp_stream_mark(auvp_handle* h, int32_t which) {
+  if (!h || (which != 0 && which != 1)) return AUVP_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventRecord(which ? h->ev1 : h->ev0, h->stream));
+  return AUVP_OK;
+}
+
+int auvp_stream_elapsed_ms(auvp_handle* h, double* ms) {
+  if (!h || !ms) return AUVP_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventSynchronize(h->ev1));
+  float f = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&f, h->ev0, h->ev1));
+  *ms = f;
+  return AUVP_OK;
+}
 
 // ---- hipGraph capture of a launch-bound inner loop on the handle's stream ------------------------------------------------
 // Between auvp_graph_begin and auvp_graph_end every enqueue-only entry point (auvp_prrt_policy_random_dev,
@@ -469,7 +555,8 @@ int auvp_graph_end(auvp_handle* h, int32_t* graph_id) {
 int auvp_graph_launch(auvp_handle* h, int32_t graph_id, int32_t n_times) {
   if (!h || n_times < 0) return AUVP_ERR_ARG;
   PrrtState& S = *prrt_of(h);
-  if (graph_id < 0 || graph_id >= (int32_t)S.graphs.size() || !S.graphs[graph_id]) return fail(h, AUVP_ERR_ARG, "no such graph");
+  if (graph_id < 0 || graph_id >= (int32_t)S.graphs.size()) return fail(h, AUVP_ERR_ARG, "no such graph");
+  if (!S.graphs[graph_id]) return fail(h, AUVP_ERR_STATE, "graph %d was captured for an earlier batch (a new batch invalidates its graphs)", graph_id);
   HIPCHK(h, hipSetDevice(h->device));
   for (int i = 0; i < n_times; i++) HIPCHK(h, hipGraphLaunch(S.graphs[graph_id], h->stream));
   return AUVP_OK;

@@ -56,7 +56,55 @@ struct PrrtBuffers {
   const int32_t* step_bucket;  // step mode: [E] bucket id chosen by the caller (<0: skip episode)
   PrrtSummary* summary;  // [E]
   int32_t* st_log;       // optional [E][max_step][8]: bucket, picked, accepted, done, npath, arc_n, arc_free, -
+  // ---- device-resident RRTEnv loop (gym_rrt/envs/rrt_env.py:182-247), step mode of prrt_kernel only.  env_flags == 0: a
+  // plain planner step.  PRRT_ENV_OUTCOME: the launch also writes the step's reward / done flag (what RRTEnv.step returns);
+  // PRRT_ENV_AGENT: a stand-in agent inside the launch picks the bucket (a uniformly random occupied one) instead of
+  // step_bucket -- two launches per environment step (this one + the observation arrays) instead of four.
+  int32_t env_flags, _pad_env;
+  uint8_t* env_done;          // [E] the loop's own "finished" flag (also set when an episode fails on the device)
+  long long* env_reward;      // [E]
+  uint8_t* env_done_out;      // [E] optional copy of env_done for the caller
+  int32_t* env_bucket_out;    // [E] PRRT_ENV_AGENT: the bucket the agent picked (-1: finished environment)
+  const unsigned long long* env_loop_step;  // device word: steps of the loop so far (mixed into the agent's draws)
+  unsigned long long env_agent_seed;
+  int32_t* env_err;           // [2] {status, environment} of the first episode that failed on the device (0: none)
 };
+#define PRRT_ENV_OUTCOME 1
+#define PRRT_ENV_AGENT 2
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+// The stand-in agent of the device-resident loop (tests and measurements; a real agent writes step_bucket itself): every
+// live environment picks one of its occupied buckets uniformly -- entry `want` of the planner's own list of occupied
+// buckets, the same set the observation's has_node array marks (rrt_env.py:250-265) -- with a counter-based generator of its
+// own (splitmix64 of seed / environment / call number: the agent's randomness, not the planner's stream).  -1 for a
+// finished environment (the step skips it), 0 when nothing is occupied.
+__device__ __forceinline__ int prrt_agent_pick(const PrrtBuffers& B, int e, bool finished, unsigned long long seed, unsigned long long call) {
+  if (finished) return -1;
+  const int n_occ = B.summary[e].n_occ;
+  if (n_occ <= 0) return 0;
+  const int want = (int)(splitmix64(seed ^ splitmix64(((unsigned long long)e << 32) | (call & 0xffffffffull))) % (unsigned long long)n_occ);
+  return B.occupied[(size_t)e * B.cap_nodes + want];
+}
+// RRTEnv.step's outcome of one environment (rrt_env.py:224-247): R_FOUND_PATH (300) when the goal arc was free,
+// R_CREATE_NODE (0) when a node was added, R_INVALID_NODE (-1) otherwise; an environment that had finished before the step,
+// or that the agent skipped (bucket < 0), gets reward 0 and keeps its flag; an episode that failed on the device (status < 0:
+// capacity, bad bucket, generator phase) is flagged finished, rewarded 0 and reported through env_err.
+__device__ __forceinline__ void prrt_env_outcome(const PrrtBuffers& B, int e, bool was, bool skipped, int status, int done, int last_accepted) {
+  const bool err = status < 0;
+  const bool now = done != 0;
+  long long r = 0;
+  if (!was && !skipped && !err) r = now ? 300 : (last_accepted ? 0 : -1);
+  const uint8_t flag = (was || (!skipped && now) || err) ? 1 : 0;
+  B.env_reward[e] = r;
+  B.env_done[e] = flag;
+  if (B.env_done_out) B.env_done_out[e] = flag;
+  if (err && B.env_err && atomicCAS(&B.env_err[0], 0, status) == 0) B.env_err[1] = e;
+}
 
 // LDS per wave: the generator state and the path points; the throughput instantiation adds its steer scratch
 __host__ __device__ inline int prrt_lds_per_wave(int max_pts, int nfreq, bool lat) {
@@ -155,8 +203,22 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
   double* bbox_l = scratch + (size_t)(C + 1) * 6;  // [4] xmin, ymin, xmax, ymax of the steer
   (void)u_win; (void)inc; (void)sc; (void)phi_l; (void)bbox_l;
 
-  const int step_bucket = P.step_mode ? uni(B.step_bucket[ep]) : 0;
-  if (P.step_mode && step_bucket < 0) return;
+  int step_bucket = 0;
+  const bool env = P.step_mode && B.env_flags != 0;
+  bool env_was = false;
+  if (P.step_mode) {
+    if (env) env_was = uni((int)B.env_done[ep]) != 0;
+    if (env && (B.env_flags & PRRT_ENV_AGENT)) {
+      step_bucket = uni(prrt_agent_pick(B, ep, env_was, B.env_agent_seed, *B.env_loop_step));
+      if (lane == 0) B.env_bucket_out[ep] = step_bucket;
+    } else {
+      step_bucket = uni(B.step_bucket[ep]);
+    }
+    if (step_bucket < 0 || env_was) {  // skipped by the caller / finished: the episode is not touched at all
+      if (env && lane == 0) prrt_env_outcome(B, ep, env_was, true, uni(B.summary[ep].status), 0, 0);
+      return;
+    }
+  }
 
   double ox[J], oy[J], ot[J], orr[J];
 #pragma unroll
@@ -633,6 +695,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
     sum.done = done; sum.last_accepted = last_accepted; sum.last_new_node = last_new;
     sum.rng_after = after; sum.n_draw32 = drawn;
     if (!done) { sum.path_len = 0; }
+    if (env) prrt_env_outcome(B, ep, false, false, status, done, last_accepted);
   }
 }
 
@@ -829,7 +892,10 @@ __global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, 
 // The reference rebuilds these three O(#buckets) Python lists after every node.
 __global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, PrrtBuffers B, const double* __restrict__ thetas,
                                                                int n_episodes, double* __restrict__ rrt_grid,
-                                                               long long* __restrict__ has_node, long long* __restrict__ num_nodes) {
+                                                               long long* __restrict__ has_node, long long* __restrict__ num_nodes,
+                                                               unsigned long long* __restrict__ loop_step_tick) {
+  // (device-resident loop: this launch closes the step -- everything that reads the loop's step counter ran before it)
+  if (loop_step_tick && blockIdx.x == 0 && threadIdx.x == 0) *loop_step_tick = *loop_step_tick + 1ull;
   const long long total = (long long)n_episodes * P.n_buckets;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(i % P.n_buckets);
@@ -847,67 +913,28 @@ __global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, 
 }
 
 // ---- device-resident RRTEnv loop (gym_rrt/envs/rrt_env.py:182-247): nothing of a step crosses PCIe -----------------
-// Outcome of the step just run, per environment (rrt_env.py:224-247): R_FOUND_PATH (300) when the goal arc was free,
-// R_CREATE_NODE (0) when a node was added, R_INVALID_NODE (-1) otherwise; an environment that had finished before the
-// step is skipped by it and gets reward 0.  env_done [E] is the loop's own "finished" flag.
-__global__ __launch_bounds__(256) void prrt_env_outcome_kernel(PrrtBuffers B, int n_episodes, uint8_t* __restrict__ env_done,
-                                                               long long* __restrict__ reward, uint8_t* __restrict__ done_out,
-                                                               unsigned long long* __restrict__ loop_step) {
+// The step's outcome and the stand-in agent live inside prrt_kernel's step mode (PrrtBuffers::env_*).  The kernels below
+// serve the launches that cannot carry them: the four-episodes-per-wavefront kernel (batches of more than eight
+// environments per CU) and callers that want the agent as a launch of its own.
+__global__ __launch_bounds__(256) void prrt_env_outcome_kernel(PrrtBuffers B, int n_episodes, const int32_t* __restrict__ bucket_ids) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  // the loop's step counter lives in HBM (the stand-in agent mixes it into its draws): a captured graph of one step can be
-  // replayed, every replay sees the next value
-  if (e == 0) *loop_step = *loop_step + 1ull;
   if (e >= n_episodes) return;
-  const bool was = env_done[e] != 0;
+  const bool was = B.env_done[e] != 0;
   const PrrtSummary& s = B.summary[e];
-  const bool now = s.done != 0;
-  long long r = 0;
-  if (!was) r = now ? 300 : (s.last_accepted ? 0 : -1);
-  reward[e] = r;
-  env_done[e] = (was || now) ? 1 : 0;
-  if (done_out) done_out[e] = (was || now) ? 1 : 0;
+  const bool skipped = was || (bucket_ids && bucket_ids[e] < 0);
+  prrt_env_outcome(B, e, was, skipped, s.status, s.done, s.last_accepted);
 }
 
-// A stand-in agent for device-resident measurements and tests: every live environment picks one of the buckets its
-// observation marks occupied (has_node, rrt_env.py:250-265), uniformly, with a counter-based generator of its own
-// (splitmix64 of seed / environment / call number -- the agent's randomness, not the planner's stream); finished
-// environments get -1 (skipped by the step).  One wavefront per environment: 64 has_node entries per trip.
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-  x += 0x9e3779b97f4a7c15ull;
-  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
-  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
-  return x ^ (x >> 31);
-}
-__global__ __launch_bounds__(256) void prrt_policy_random_kernel(int n_episodes, int n_buckets, const long long* __restrict__ has_node,
-                                                                 const uint8_t* __restrict__ env_done, unsigned long long seed,
+// the loop's step counter lives in HBM (the stand-in agent mixes it into its draws): a captured graph of one step can be
+// replayed, every replay sees the next value.  One thread, after everything of the step that reads the counter.
+__global__ void prrt_env_tick_kernel(unsigned long long* __restrict__ loop_step) { *loop_step = *loop_step + 1ull; }
+
+__global__ __launch_bounds__(256) void prrt_policy_random_kernel(PrrtBuffers B, int n_episodes, unsigned long long seed,
                                                                  const unsigned long long* __restrict__ loop_step,
                                                                  int32_t* __restrict__ bucket_out) {
-  const int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_episodes) return;
-  const unsigned long long call = *loop_step;
-  const int lane = lane_id();
-  if (env_done[e]) { if (lane == 0) bucket_out[e] = -1; return; }
-  const long long* hn = has_node + (size_t)e * n_buckets;
-  int total = 0;
-  for (int b0 = 0; b0 < n_buckets; b0 += 64) {
-    const int b = b0 + lane;
-    total += __popcll(__ballot(b < n_buckets && hn[b] != 0));
-  }
-  if (total == 0) { if (lane == 0) bucket_out[e] = 0; return; }
-  const int want = (int)(splitmix64(seed ^ splitmix64(((unsigned long long)e << 32) | (call & 0xffffffffull))) % (unsigned long long)total);
-  int seen = 0;
-  for (int b0 = 0; b0 < n_buckets; b0 += 64) {
-    const int b = b0 + lane;
-    const bool is = b < n_buckets && hn[b] != 0;
-    const unsigned long long bal = __ballot(is);
-    const int c = __popcll(bal);
-    if (seen + c > want) {
-      const unsigned long long sel = __ballot(is && (int)__popcll(bal & ((1ull << lane) - 1ull)) == want - seen);
-      if (lane == 0) bucket_out[e] = b0 + (__ffsll((long long)sel) - 1);
-      return;
-    }
-    seen += c;
-  }
+  bucket_out[e] = prrt_agent_pick(B, e, B.env_done[e] != 0, seed, *loop_step);
 }
 
 }  // namespace auvp

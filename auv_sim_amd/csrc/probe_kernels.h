@@ -77,6 +77,34 @@ __global__ __launch_bounds__(64) void nn_probe_kernel(const double2* __restrict_
   if (lane_id() == 0) { out[i] = r; slow[i] = sl; }
 }
 
+// ---- HBM streaming probes: the MEASURED roof the bench's bandwidth fractions are quoted against -------------------------
+// Read probe: every lane keeps eight 16-byte loads in flight (the access shape of the nearest-neighbour scan: 1 KB per
+// wave-instruction, 8 KB per wave and trip), grid-stride over 32-KB chunks per workgroup; the values are folded into one
+// word per lane that is stored only if it equals a value the memset pattern cannot produce (keeps the loads alive).
+__global__ __launch_bounds__(256) void hbm_read_probe_kernel(const uint4* __restrict__ src, unsigned long long n16, uint32_t* __restrict__ sink) {
+  const unsigned long long chunk = 256ull * 8ull;  // uint4 elements per workgroup and trip
+  uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+  for (unsigned long long c0 = (unsigned long long)blockIdx.x * chunk; c0 + chunk <= n16; c0 += (unsigned long long)gridDim.x * chunk) {
+    uint4 q[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) q[u] = src[c0 + (unsigned long long)u * 256ull + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { acc.x ^= q[u].x; acc.y += q[u].y; acc.z ^= q[u].z; acc.w += q[u].w; }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[blockIdx.x] = acc.x;
+}
+// Copy probe: 16-byte loads and stores, four in flight per lane; bytes moved = 2 x the buffer half
+__global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned long long n16) {
+  const unsigned long long chunk = 256ull * 4ull;
+  for (unsigned long long c0 = (unsigned long long)blockIdx.x * chunk; c0 + chunk <= n16; c0 += (unsigned long long)gridDim.x * chunk) {
+    uint4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) q[u] = src[c0 + (unsigned long long)u * 256ull + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < 4; u++) dst[c0 + (unsigned long long)u * 256ull + threadIdx.x] = q[u];
+  }
+}
+
 __global__ void sincos_probe_kernel(int n, const double* __restrict__ x, double* __restrict__ s, double* __restrict__ c) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) auvp_sincos(x[i], &s[i], &c[i]);
@@ -171,6 +199,49 @@ int auvp_nn_closest_batch(auvp_handle* h, int32_t n_nodes, const double* xy, int
   HIPCHK(h, hipMemcpyAsync(out_index, h->d_tmp2.p, (size_t)n_queries * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   if (out_slow) HIPCHK(h, hipMemcpyAsync(out_slow, h->d_tmp3.p, (size_t)n_queries * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_hbm_probe(auvp_handle* h, uint64_t bytes, int32_t reps, double* read_GBps, double* copy_GBps) {
+  if (!h || reps <= 0 || !read_GBps) return AUVP_ERR_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  // whole 32-KB chunks; at least 64 MB so that the launch is long against its own start-up
+  const unsigned long long chunk_b = 256ull * 8ull * 16ull;
+  unsigned long long nb = (bytes < (64ull << 20) ? (64ull << 20) : bytes) / chunk_b * chunk_b;
+  DevBuf buf, sink;
+  HIPCHK(h, buf.reserve((size_t)nb));
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+  if (n_cu <= 0) n_cu = 256;
+  const int grid = n_cu * 8;
+  HIPCHK(h, sink.reserve((size_t)grid * sizeof(uint32_t)));
+  HIPCHK(h, hipMemsetAsync(buf.p, 0x5a, (size_t)nb, h->stream));
+  const unsigned long long n16 = nb / 16ull;
+  auto timed = [&](auto enqueue, double moved, double* out) -> int {
+    enqueue();  // warm-up (page tables, clocks)
+    double best = 0.0;
+    for (int r = 0; r < reps; r++) {
+      HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+      enqueue();
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      if (ms > 0.f) best = std::max(best, moved / (ms * 1e-3) / 1e9);
+    }
+    *out = best;
+    return AUVP_OK;
+  };
+  int rc = timed([&] { hipLaunchKernelGGL(hbm_read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, buf.as<uint4>(), n16, sink.as<uint32_t>()); },
+                 (double)nb, read_GBps);
+  if (rc != AUVP_OK) return rc;
+  if (copy_GBps) {
+    const unsigned long long half16 = (n16 / 2ull) / 1024ull * 1024ull;
+    rc = timed([&] { hipLaunchKernelGGL(hbm_copy_probe_kernel, dim3(grid), dim3(256), 0, h->stream, buf.as<uint4>(), buf.as<uint4>() + half16, half16); },
+               2.0 * 16.0 * (double)half16, copy_GBps);
+    if (rc != AUVP_OK) return rc;
+  }
   return AUVP_OK;
 }
 

@@ -371,11 +371,15 @@ __device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtTables& S,
 // flight per lane, 1 KB per wave-instruction) and ranks by the SQUARED distance -- sqrt is monotone, so the minimum of
 // RN(sqrt(d2)) is taken where d2 is smallest -- with two running minima per lane:
 //   bd / bt  smallest d2 of the lane's nodes and the block it first appeared in (strict <: the first of equal values)
-//   sd       second smallest d2 of the lane's nodes (counting multiplicity)
+//   sd       second smallest DISTINCT d2 of the lane's nodes (a value equal to the running minimum is skipped: duplicated
+//            positions are common -- a steer with zero sub-arcs copies its parent -- and a lane that holds the minimum
+//            twice must still see a third, slightly larger value)
 // Afterwards gmin = wave minimum of bd.  Two different d2 can still round to the same sqrt; such a value lies within a few
-// ulps above gmin.  If no lane's bd or sd falls in (gmin, gmin (1 + 2^-49)] -- a lane's third smallest value cannot be
-// there unless its second is -- every node with RN(sqrt(d2)) == RN(sqrt(gmin)) has d2 == gmin exactly, and the answer is
-// the smallest index among them (duplicated positions are common: a steer with zero sub-arcs copies its parent).
+// ulps above gmin.  A lane's values other than its smallest are all >= its sd (sd is the smallest value that differs from
+// the final bd: a value skipped as "equal to the running minimum" either equals the final bd or was that minimum when a
+// smaller one replaced it, which put it into sd), so if no lane's bd or sd falls in (gmin, gmin (1 + 2^-49)] no node at all
+// has its d2 there: every node with RN(sqrt(d2)) == RN(sqrt(gmin)) has d2 == gmin exactly, and the answer is the smallest
+// index among them.
 // Otherwise (never observed: it needs two nodes equidistant from the sample to 1e-15) the scan is repeated the reference's
 // way, sqrt per node.  Entries past the tree's end hold +inf: a block is always read whole.
 constexpr int RRT_NN_UNROLL = 8;
@@ -400,7 +404,8 @@ __device__ __forceinline__ int nn_closest(const double2* __restrict__ xy, int n_
       const double ddx = rx - q[u].x, ddy = ry - q[u].y;
       const double d2 = ddx * ddx + ddy * ddy;
       const bool lt = d2 < bd;
-      sd = __builtin_fmin(sd, __builtin_fmax(bd, d2));  // the larger of {old minimum, newcomer} competes for second place
+      // the larger of {old minimum, newcomer} competes for second place -- unless they are equal (second DISTINCT value)
+      sd = (d2 != bd) ? __builtin_fmin(sd, __builtin_fmax(bd, d2)) : sd;
       bd = lt ? d2 : bd;
       bt = lt ? base + u * 64 : bt;
     }
@@ -436,7 +441,7 @@ __device__ __forceinline__ int nn_closest(const double2* __restrict__ xy, int n_
 }
 
 template <int J, int MODE, bool DIAG>
-__global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 4 : 2) : (J <= 4 ? 6 : 2))) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
+__global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (J <= 4 ? 6 : 2))) void rrt_explore_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B,
                                                                      int n_episodes, int max_pts) {
   extern __shared__ __align__(16) unsigned char smem[];
   const RrtTables S = rrt_tables_view(smem, W.n_habitats, W.n_poly);
@@ -1006,6 +1011,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
 
   int n_leaves = 0, best_leaf = -1, best_L = 0;
   long long leaf_elems = 0;
+  int st_nodes = 0, st_points = 0, st_resummed = 0, st_releaves = 0;  // RrtBuffers::leaf_stats (wave-uniform: scalar registers)
   double best_tot = __builtin_inf(), best_c0 = 0.0, best_c1 = 0.0, best_c2 = 0.0, best_len = 0.0;
   double min_hi = __builtin_inf();  // smallest upper bound among the qualifying leaves seen so far
   // ---------------------------------------------------------------- 0. which nodes matter
@@ -1065,6 +1071,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     }
     const int cpos = incl - (live ? r.w : 0);
     const int n_slots = __builtin_amdgcn_readlane(incl, 63);
+    st_nodes = uni(st_nodes + nlive); st_points = uni(st_points + n_slots);
     c_cpos[lane] = live ? cpos : 0x7fffffff;
     c_off[lane] = r.z;
     c_S[lane] = 0.0; c_hits[lane] = 0; c_vis[lane] = 0ull;
@@ -1259,6 +1266,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
         mm = rr.y; rr = rr_up; tvn = tvn_up;
       }
       const int lhits = __builtin_amdgcn_readlane(hits, l), lelems = __builtin_amdgcn_readlane(elems, l);
+      st_resummed = uni(st_resummed + lelems); st_releaves = uni(st_releaves + 1);
       const unsigned long long lvis = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(vis >> 32), l) << 32) |
                                       (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(vis & 0xffffffffull), l);
       const double lctt = readlane_f64(ctt, l), llen = readlane_f64(nlen, l);
@@ -1295,6 +1303,10 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     wave_sync();
   }
   if (lane == 0) {
+    if (B.leaf_stats) {
+      atomicAdd(&B.leaf_stats[0], (unsigned long long)st_nodes); atomicAdd(&B.leaf_stats[1], (unsigned long long)st_points);
+      atomicAdd(&B.leaf_stats[2], (unsigned long long)st_resummed); atomicAdd(&B.leaf_stats[3], (unsigned long long)st_releaves);
+    }
     sum.n_leaves = n_leaves;
     sum.leaf_elems = leaf_elems;
     sum.best_leaf = best_leaf;

@@ -51,6 +51,8 @@ class RRTEnvBatch:
         self._L.auvp_prrt_observation.argtypes = [C.c_void_p, C.c_int32, _lib._dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         self._L.auvp_prrt_observation_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         self._L.auvp_prrt_env_step_dev.argtypes = [C.c_void_p] * 7
+        self._L.auvp_prrt_env_step_agent_dev.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
+        self._L.auvp_prrt_env_check.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self._L.auvp_prrt_policy_random_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         self._L.auvp_stream_sync.argtypes = [C.c_void_p]
         self._L.auvp_graph_begin.argtypes = [C.c_void_p]
@@ -75,6 +77,8 @@ class RRTEnvBatch:
             self._pb = PlannerBatch(self._ctx, starts, goals, self._rect, self.max_nodes, seeds=self.seeds, **kw)
         self._done = np.zeros(self.E, dtype=bool)
         self._dev = None
+        self._graphs = set()   # the new batch invalidated the handle's captured graphs (they replay on the old buffers)
+        self._mode = None      # "host" (step) or "device" (step_device / replay): one per reset(), see _enter
         self.state = self._observe(None)
         return self.state
 
@@ -111,9 +115,21 @@ class RRTEnvBatch:
                                                          C.c_void_p(has_node_ptr) if has_node_ptr else None,
                                                          C.c_void_p(num_nodes_ptr) if num_nodes_ptr else None))
 
+    def _enter(self, mode):
+        """The host loop keeps its finished flags and observation arrays on the host, the device-resident loop keeps its own
+        in HBM; neither updates the other, so one episode (one reset()) runs in ONE of the two modes."""
+        if self._pb is None:
+            raise RuntimeError("reset() first")
+        if self._mode is None:
+            self._mode = mode
+        elif self._mode != mode:
+            raise RuntimeError("RRTEnvBatch: %s stepping after %s stepping in the same episode; call reset() to switch"
+                               % (mode, self._mode))
+
     def step(self, chosen_grid_cell_idx, step_num=None):
         """chosen_grid_cell_idx [E] (RRTEnv.step's flat index over cells x subsections).
         Returns (state, reward [E], done [E], {})"""
+        self._enter("host")
         idx = np.asarray(chosen_grid_cell_idx, dtype=np.int64).reshape(self.E)
         # flat index -> bucket id: (row*cols + col)*S + k is the same flattening RRTEnv uses (:203-213)
         buckets = np.where(self._done, -1, idx).astype(np.int32)
@@ -163,42 +179,74 @@ class RRTEnvBatch:
         return self._dev
 
     def policy_random_device(self, seed=0):
-        """stand-in agent: a random occupied bucket per live environment, chosen on the device from has_node (enqueue only)"""
+        """stand-in agent as a launch of its own: a random occupied bucket per live environment (-1 for finished ones),
+        chosen on the device from the planner's list of occupied buckets (enqueue only)"""
+        self._enter("device")
         d = self.device_buffers()
         self._ctx._chk(self._L.auvp_prrt_policy_random_dev(self._ctx.h, C.c_void_p(d["has_node"].data_ptr()), int(seed),
                                                            C.c_void_p(d["bucket"].data_ptr())))
         return d["bucket"]
 
-    def step_device(self, bucket_dev=None, observe=True):
+    def step_device(self, bucket_dev=None, observe=True, agent_seed=None):
         """RRTEnv.step for all environments with the agent's choices already in device memory (`bucket_dev`: int32 [E] torch
-        tensor on this GPU, default: the buffer policy_random_device fills).  Enqueues the step, the observation arrays and
-        the outcome on the planner's stream and returns the device tensors; call sync() before reading them from another
-        stream or the host.  The planner's stream is not torch's: an agent that wrote `bucket_dev` on torch's current stream
-        synchronises that stream (torch.cuda.current_stream().synchronize()) before this call."""
+        tensor on this GPU, default: the buffer policy_random_device fills; -1 skips an environment: reward 0, done flag
+        unchanged).  `agent_seed` (int): the stand-in agent picks inside the planner launch instead and `bucket` receives its
+        choices.  Enqueues the step (two launches: planner step + outcome, observation arrays) on the planner's stream and
+        returns the device tensors; call sync() before reading them from another stream or the host.  The planner's stream is
+        not torch's: an agent that wrote `bucket_dev` on torch's current stream synchronises that stream
+        (torch.cuda.current_stream().synchronize()) before this call."""
+        self._enter("device")
         d = self.device_buffers()
-        b = d["bucket"] if bucket_dev is None else bucket_dev
-        self._ctx._chk(self._L.auvp_prrt_env_step_dev(
-            self._ctx.h, C.c_void_p(b.data_ptr()), C.c_void_p(d["rrt_grid"].data_ptr()) if observe else None,
-            C.c_void_p(d["has_node"].data_ptr()), C.c_void_p(d["num_nodes"].data_ptr()), C.c_void_p(d["reward"].data_ptr()),
-            C.c_void_p(d["done"].data_ptr())))
+        obs = (C.c_void_p(d["rrt_grid"].data_ptr()) if observe else None, C.c_void_p(d["has_node"].data_ptr()),
+               C.c_void_p(d["num_nodes"].data_ptr()), C.c_void_p(d["reward"].data_ptr()), C.c_void_p(d["done"].data_ptr()))
+        if agent_seed is not None:
+            self._ctx._chk(self._L.auvp_prrt_env_step_agent_dev(self._ctx.h, int(agent_seed), C.c_void_p(d["bucket"].data_ptr()), *obs))
+        else:
+            b = d["bucket"] if bucket_dev is None else bucket_dev
+            self._ctx._chk(self._L.auvp_prrt_env_step_dev(self._ctx.h, C.c_void_p(b.data_ptr()), *obs))
         return d
 
     def sync(self):
+        """wait for the planner's stream; raises if an episode failed on the device since reset() (the host loop raises the
+        same failures from step())"""
         self._ctx._chk(self._L.auvp_stream_sync(self._ctx.h))
+        if self._mode == "device":
+            st, env = C.c_int32(0), C.c_int32(0)
+            self._ctx._chk(self._L.auvp_prrt_env_check(self._ctx.h, C.byref(st), C.byref(env)))
+            if st.value < 0:
+                raise _lib.AuvpError(int(st.value), "planner episode %d failed on the device" % env.value)
+
+    def timed(self, enqueue):
+        """device time in ms (HIP events on the planner's stream) of what `enqueue()` puts on it; waits for it"""
+        L = self._L
+        L.auvp_stream_mark.argtypes = [C.c_void_p, C.c_int32]
+        L.auvp_stream_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._ctx._chk(L.auvp_stream_mark(self._ctx.h, 0))
+        enqueue()
+        self._ctx._chk(L.auvp_stream_mark(self._ctx.h, 1))
+        ms = C.c_double(0.0)
+        self._ctx._chk(L.auvp_stream_elapsed_ms(self._ctx.h, C.byref(ms)))
+        return ms.value
 
     def capture_step(self, enqueue):
         """record what `enqueue()` puts on the planner's stream (policy_random_device, step_device, ...) as a hipGraph of one
-        step; returns its id for replay(id, n).  One un-captured step must have run before (first-use allocations)."""
+        step; returns its id for replay(id, n).  One un-captured step must have run before (first-use allocations).  The
+        graph belongs to this episode's batch and device buffers: reset() drops it."""
+        self._enter("device")
         gid = C.c_int32(-1)
         self._ctx._chk(self._L.auvp_graph_begin(self._ctx.h))
         try:
             enqueue()
         finally:
             self._ctx._chk(self._L.auvp_graph_end(self._ctx.h, C.byref(gid)))
+        self._graphs.add(int(gid.value))
         return int(gid.value)
 
     def replay(self, graph_id, n_times=1):
         """n_times replays of a captured step, back to back on the planner's stream (enqueue only)"""
+        self._enter("device")
+        if int(graph_id) not in self._graphs:
+            raise _lib.AuvpError(-4, "graph %d was not captured since the last reset()" % int(graph_id))
         self._ctx._chk(self._L.auvp_graph_launch(self._ctx.h, int(graph_id), int(n_times)))
 
     def tree(self, e):

@@ -50,6 +50,28 @@ def rrt_bytes(summ):
     return iters * (48 + 4) + nodes * (52 + 8) + pts * 56 + walked * (24 + 8) + scanned * 16
 
 
+def rrt_expand_bytes(summ):
+    """the expansion kernel's share of B_exp: 48 parent read + 4 bin-index read per iteration; 52 node write +
+    8 bin append per accepted node; 56 per stored path point; nearest-neighbour sampling: 16 per node scanned"""
+    iters = float(summ["iters_run"].sum())
+    nodes = float((summ["n_nodes"] - 1).sum())
+    return iters * 52 + nodes * 60 + float(summ["n_points"].sum()) * 56 + float(summ["nn_scanned"].sum()) * 16
+
+
+def rrt_leaf_bytes(summ, st):
+    """COMPULSORY bytes of the leaf pass (rrt_leaf_kernel), every tree element at most once -- SURVEY 8(d) bills q L 32 bytes
+    per expansion for the leaf->root walks of the qualifying leaves, but a path element's cost term does not depend on the
+    leaf, so the pass evaluates each element of the visited part of the tree ONCE:
+      every node: parent link + qualifying flag (the backward marking sweep)                     16 + 1
+      every visited node (a qualifying leaf or an ancestor of one): link record, x y t length, the parent's running
+        sums read, its own term and sums written                                              16 + 32 + 32 + 16 + 32
+      every path point of a visited node: x, y, t                                                     24
+      every element re-summed in the reference's order (the record setters): x, y, t + its node's share    24
+    `st` = ctx.last_leaf_stats() of the same launch."""
+    return (float(summ["n_nodes"].sum()) * 17 + st["nodes_visited"] * 128.0 + st["points_visited"] * 24.0 +
+            st["elements_resummed"] * 24.0)
+
+
 def planner_bytes(summ):
     """Planner_RRT step: 48 parent read + 4 bucket-index read per step; 52 node write + 8 bucket append per accepted
     node; 56 per stored path point (goal-arc points are transient)."""
@@ -68,11 +90,73 @@ def astar_bytes(summ, variant):
     return cells * per_cell + scanned * 8.0
 
 
-def roofline(abytes, k_ms, kernel, traffic=None, **extra):
-    """`traffic`: the dict pmc_traffic() returns (or None)"""
+N_SIMD = 1024  # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+HBM_MEASURED = {"read_GBps": None, "copy_GBps": None}  # filled once per run by measure_hbm() (auvp_hbm_probe)
+
+
+def measure_hbm(ctx, n_bytes=4 << 30, reps=3):
+    """the MEASURED HBM roof of this GPU (north star: "fraction of the measured HBM roofline"): a timed streaming read of
+    4 GiB with eight 16-byte loads in flight per lane (the nearest-neighbour scan's access shape) and a 16-byte copy, HIP
+    events on the planner's stream (libauvplan.so: auvp_hbm_probe)"""
+    try:
+        r, c = ctx.hbm_probe(n_bytes, reps)
+        HBM_MEASURED.update(read_GBps=r, copy_GBps=c, bytes=int(n_bytes), reps=int(reps))
+    except Exception as e:  # the probe must not cost the headline line
+        HBM_MEASURED.update(error="%s: %s" % (type(e).__name__, e))
+    return HBM_MEASURED
+
+
+def _pmc():
+    try:
+        return json.load(open(PMC_FILE))
+    except Exception:
+        return None
+
+
+def pmc_valu_issue(meas, kernel=None):
+    """fraction of the chip's vector-issue slots the profiled launch used: SQ_INSTS_VALU x 4 cycles / (1 024 SIMDs x
+    GRBM_GUI_ACTIVE / 8 XCDs) -- a wave64 instruction occupies its SIMD-32 for >= 4 cycles when one wave issues back to back
+    (fp64 and transcendental instructions take longer, so this is a LOWER bound of the pipe's occupancy).  From the committed
+    PMC passes (profiles/pmc_latest.json); `kernel`: one kernel of the measurement, None: all of them."""
+    pj = _pmc()
+    try:
+        m = pj["measurements"][meas]
+        c = m["kernels"][kernel]["per_launch"] if kernel else m["per_launch"]
+        return 4.0 * float(c["SQ_INSTS_VALU"]) / (N_SIMD * float(c["GRBM_GUI_ACTIVE"]) / 8.0)
+    except Exception:
+        return None
+
+
+def pmc_kernel_traffic(meas, kernel, units_now):
+    """(2 x FETCH_SIZE + WRITE_SIZE, FETCH_SIZE + WRITE_SIZE) of ONE kernel of a profiled measurement, bytes per launch"""
+    pj = _pmc()
+    try:
+        m = pj["measurements"][meas]
+        c = m["kernels"][kernel]["per_launch"]
+        f, w = 1024.0 * float(c["FETCH_SIZE"]), 1024.0 * float(c["WRITE_SIZE"])
+        u0 = float(m.get("units") or 0.0)
+        sc = units_now / u0 if (u0 > 0 and units_now) else 1.0
+        return (2.0 * f + w) * sc, (f + w) * sc
+    except Exception:
+        return None, None
+
+
+def roofline(abytes, k_ms, kernel, traffic=None, valu_issue_frac=None, **extra):
+    """`traffic`: the dict pmc_traffic() returns (or None).  `bound` names the roof that binds: "hbm" unless the kernel's
+    vector-issue fraction (pmc_valu_issue) exceeds its HBM fraction -- then "valu_issue" (fp64 VALU issue; no MFMA work on
+    this path).  achieved / peak / frac are always the HBM figures (GB/s against the 8 TB/s datasheet peak);
+    frac_of_measured is against this GPU's measured streaming read rate."""
     ach = abytes / (k_ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+    frac = ach / HBM_PEAK_GBS
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
          "traffic": None, "kernel": kernel, "kernel_ms": k_ms, "algorithmic_bytes_per_launch": abytes}
+    if HBM_MEASURED.get("read_GBps"):
+        r["hbm_measured_GBps"] = HBM_MEASURED["read_GBps"]
+        r["frac_of_measured"] = ach / HBM_MEASURED["read_GBps"]
+    if valu_issue_frac is not None:
+        r["valu_issue_frac"] = valu_issue_frac
+        if valu_issue_frac > frac:
+            r["bound"] = "valu_issue"
     r.update(traffic or {})
     r.update(extra)
     return r
@@ -343,6 +427,41 @@ def timed_steps(ranks, step, steps, warmup):
 RRT_KW = dict(freq=30, bin_interval=5, v=2, max_traj_time=500.0, weights=(-3, -3, -4))
 
 
+def rrt_pass_rooflines(ctx, summ, meas, exp_ms, leaf_ms, kname, **extra):
+    """One pass of RRT.exploring = two launches.  Returns the roofline of the DOMINANT kernel (the tree expansion: its own
+    algorithmic bytes over its own HIP-event time) with the leaf pass and the whole-pass SURVEY 8(d) figure beside it as
+    flat scalars (the driver's record keeps scalars of this object, not nested dicts):
+      leaf_*      rrt_leaf_kernel against its COMPULSORY bytes (rrt_leaf_bytes: every tree element once)
+      pass_8d_*   B_exp of SURVEY 8(d) x expansions over both launches -- the figure of rounds 1-3; it bills the leaf pass
+                  32 bytes per element of EVERY qualifying leaf's path, which the pass never moves (it evaluates an element
+                  once), so it overstates the bandwidth of that launch; kept for continuity, labelled"""
+    iters = float(summ["iters_run"].sum())
+    st = ctx.last_leaf_stats()
+    a_exp, a_leaf, a_8d = rrt_expand_bytes(summ), rrt_leaf_bytes(summ, st), rrt_bytes(summ)
+    whole = pmc_traffic(meas, [kname, "rrt_leaf_kernel"], iters)
+    comparable = whole["traffic"] is not None
+    tx2, traw = pmc_kernel_traffic(meas, kname, iters) if comparable else (None, None)
+    lx2, lraw = pmc_kernel_traffic(meas, "rrt_leaf_kernel", iters) if comparable else (None, None)
+    vi = pmc_valu_issue(meas, kname) if comparable else None
+    lvi = pmc_valu_issue(meas, "rrt_leaf_kernel") if comparable else None
+    leaf_ach = a_leaf / (leaf_ms * 1e-3) / 1e9 if leaf_ms > 0 else 0.0
+    pass_ach = a_8d / ((exp_ms + leaf_ms) * 1e-3) / 1e9
+    r = roofline(a_exp, exp_ms, kname, {"traffic": tx2, "traffic_raw": traw, "traffic_source": whole["traffic_source"]},
+                 valu_issue_frac=vi, bytes_per_expansion=a_exp / iters,
+                 leaf_kernel="rrt_leaf_kernel", leaf_kernel_ms=leaf_ms, leaf_compulsory_bytes=a_leaf, leaf_achieved=leaf_ach,
+                 leaf_frac=leaf_ach / HBM_PEAK_GBS, leaf_valu_issue_frac=lvi, leaf_traffic=lx2, leaf_traffic_raw=lraw,
+                 leaf_nodes_visited=st["nodes_visited"], leaf_points_visited=st["points_visited"],
+                 leaf_elements_resummed=st["elements_resummed"], leaf_bound="latency (scattered 264-B runs; DESIGN.md)",
+                 pass_kernel_ms=exp_ms + leaf_ms, pass_8d_bytes=a_8d, pass_8d_bytes_per_expansion=a_8d / iters,
+                 pass_8d_achieved=pass_ach, pass_8d_frac=pass_ach / HBM_PEAK_GBS,
+                 pass_traffic=whole["traffic"], pass_traffic_raw=whole["traffic_raw"],
+                 pass_8d_note="SURVEY 8(d) B_exp x expansions / both launches: bills q L 32 B of leaf->root walks the leaf pass does not move",
+                 **extra)
+    if HBM_MEASURED.get("read_GBps"):
+        r["leaf_frac_of_measured"] = leaf_ach / HBM_MEASURED["read_GBps"]
+    return r
+
+
 def bench_single_episode(ctx, world, args, reps=3):
     """SURVEY 8(d) config 2 latency test: ONE episode on one GPU (a serial chain: one wavefront busy)."""
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
@@ -358,18 +477,21 @@ def bench_single_episode(ctx, world, args, reps=3):
             "expansions_per_s": float(summ[0]["iters_run"]) / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / float(summ[0]["iters_run"])}
 
 
-def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0, mode=None, kw=None):
+def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0, mode=None, kw=None, meas="-"):
+    """`meas`: key of this measurement's committed counter passes in profiles/pmc_latest.json ("-": none)"""
     mode = mode or args.mode
     kw = kw or RRT_KW
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     init = np.zeros((n_ep, 6))
     init[:, 0], init[:, 1] = world["start"]
     ctx.rrt_prepare(init, np.arange(n_ep, dtype=np.uint64), args.iters, mode=mode, **kw)
-    ms = []
+    ms, ems, lms = [], [], []
     for i in range(reps + 1):
         ctx.rrt_run()
         if i:
             ms.append(ctx.last_kernel_ms())
+            ems.append(ctx.last_launch_parts()[0])
+            lms.append(ctx.last_launch_parts()[1])
     summ = ctx.summaries()
     if (summ["status"] < 0).any():
         return {"error": "episode status %s" % np.unique(summ["status"])}
@@ -379,10 +501,8 @@ def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0, mode=None, kw=No
            "accept_rate": float((summ["n_nodes"] - 1).sum()) / iters,
            "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters,
            "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
-           "roofline": roofline(rrt_bytes(summ), k_ms,
-                                ("rrt_rows_kernel" if ctx.last_launch_parts()[2] == 4 else "rrt_explore_kernel") + " + rrt_leaf_kernel",
-                                bytes_per_expansion=rrt_bytes(summ) / iters,
-                                kernels_ms=dict(zip(("expansion", "leaf"), ctx.last_launch_parts()[:2])))}
+           "roofline": rrt_pass_rooflines(ctx, summ, meas, float(np.mean(ems)), float(np.mean(lms)),
+                                          "rrt_rows_kernel" if ctx.last_launch_parts()[2] == 4 else "rrt_explore_kernel")}
     if cpu_seconds > 0:
         from oracle import orc
         w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
@@ -416,7 +536,7 @@ def bench_rrt_replicas(ctx, args, n_ep=1024):
     return out
 
 
-def bench_rrt_nn(ctx, args, with_cpu, n_ep=4096, long_horizon=False):
+def bench_rrt_nn(ctx, args, with_cpu, n_ep=None, long_horizon=False):
     """The nearest-neighbour parent selection of RRT.exploring (plan_time=False: get_random_mps + get_closest_mps,
     rrt_dubins.py:333-343,505-513) at the full 10 000-iteration budget on the headline world: every iteration reads x, y of
     every node of the episode's tree (16 B each) -- the part of the path that streams memory.
@@ -424,10 +544,14 @@ def bench_rrt_nn(ctx, args, with_cpu, n_ep=4096, long_horizon=False):
                            ~94 % of the samples, the trees stop at ~550 nodes, so the x,y mirrors of all episodes (36 MB)
                            are served by L2 / Infinity Cache
       rrt_nn_long_horizon  max_traj_time = 20 000 s: the 10k-node budget is what ends the tree (~9 600 nodes, ~77 KB per
-                           scan on average); n_ep x 160 KB of x,y mirror = 0.66 GB >> the 256 MB Infinity Cache: HBM"""
+                           scan on average); run on the headline's batch (12 288 episodes x 158 KB of x,y mirror = 1.9 GB,
+                           7.5 x the 256 MB Infinity Cache, so the cache cannot serve the scans): HBM"""
     world = bench_world(args.obstacles, args.grid)
     kw = dict(RRT_KW, max_traj_time=20000.0) if long_horizon else RRT_KW
-    out = _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=6.0 if with_cpu else 0.0, mode="nn", kw=kw)
+    if n_ep is None:
+        n_ep = args.episodes_fit if long_horizon else min(4096, args.episodes_fit)
+    out = _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=6.0 if with_cpu else 0.0, mode="nn", kw=kw,
+                     meas="rrt_nn_long_horizon" if long_horizon else "rrt_nn")
     if "error" in out:
         return out
     out["metric"] = "RRT.exploring expansions/s, nearest-neighbour sampling, %d obstacles, %dx%d cells, max_traj_time %g s" % (
@@ -440,8 +564,6 @@ def bench_rrt_nn(ctx, args, with_cpu, n_ep=4096, long_horizon=False):
     out["xy_mirror_working_set_bytes"] = 16.0 * float(summ["n_nodes"].sum())
     out["scan_GBps"] = 16.0 * scanned / (ctx.last_launch_parts()[0] * 1e-3) / 1e9
     out["iters_per_launch"] = float(summ["iters_run"].sum())
-    out["roofline"].update(pmc_traffic("rrt_nn_long_horizon" if long_horizon else "rrt_nn", ["rrt_explore_kernel", "rrt_leaf_kernel"],
-                                       out["iters_per_launch"]))
     ref = recorded_reference(("rrt_exploring_nn_long_o%d" if long_horizon else "rrt_exploring_nn_o%d") % args.obstacles)
     if ref:
         out["reference_recorded"] = {"value": ref["ref_expansions_per_s_1proc"], "unit": "expansions/s", "cores": 1,
@@ -514,7 +636,7 @@ def bench_astar(ctx, ranks, with_cpu, n_inst=1024, steps=5, warmup=1, variants=T
            "gather_ms_per_rank": ranks.all(float(np.mean([g for g in gms[-steps:] if g is not None])) if gms and gms[-1] is not None else None),
            "cells_per_s_search_launch_only": float(summ["n_children"].sum()) / (k_ms * 1e-3),
            "config": "%d x astar_fixLenSOG, 64 obstacles, 10 habitats, 400-cell grid x 10 bins, limits 100/200/300" % n_inst,
-           "roofline": roofline(abytes, k_ms, "astar_kernel", traffic,
+           "roofline": roofline(abytes, k_ms, "astar_kernel", traffic, valu_issue_frac=pmc_valu_issue("astar") if traffic["traffic"] is not None else None,
                                 bytes_per_cell=abytes / max(float(summ["n_children"].sum()), 1.0),
                                 note="one wave per instance at 1 wave/SIMD: a latency measurement, not a bandwidth one")}
     if ranks.world == 1 and variants:
@@ -603,50 +725,46 @@ def bench_rrt_env(local_rank, n_env=512, n_steps=60):
            "envs": n_env, "steps": n_steps, "ms_per_batched_step": 1e3 * dt / n_steps, "buckets": nb,
            "observation_bytes_per_step": int(n_env * nb * (32 + 8 + 8)), "nodes_created": created,
            "note": "includes the numpy policy on the host and the download of the full observation arrays"}
-    # the same environments with NOTHING crossing PCIe (what row f1 is for): the agent -- a stand-in kernel that picks a random
-    # occupied bucket from the has_node array in HBM -- the generate_one_node launch, the observation kernel and the
-    # reward / done kernel are enqueued back to back on the planner's stream; one wait at the end
+    # the same environments with NOTHING crossing PCIe (what row f1 is for): two launches per step -- generate_one_node for
+    # every live environment with the stand-in agent's pick made inside the launch and the outcome (reward, done flag) written
+    # by it, then the observation arrays -- enqueued back to back on the planner's stream; one wait at the end
     env2 = RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=list(range(n_env)), max_nodes=8 * n_steps + 16, freq=10, device=local_rank)
     env2.reset()
     d = env2.device_buffers()
+
+    def one_step():
+        env2.step_device(agent_seed=5)
     for _ in range(3):
-        env2.policy_random_device(seed=5)
-        env2.step_device()
+        one_step()
     env2.sync()
     n2 = 3 * n_steps
     t0 = time.perf_counter()
-    for _ in range(n2):
-        env2.policy_random_device(seed=5)
-        env2.step_device()
-    env2.sync()
+    dev_ms = env2.timed(lambda: [one_step() for _ in range(n2)])
     dt2 = time.perf_counter() - t0
-    # ... and the same step captured once as a hipGraph and replayed (launch-bound inner loop: one graph launch per step instead
-    # of four kernel launches)
-    def one_step():
-        env2.policy_random_device(seed=5)
-        env2.step_device()
+    # ... and the same step captured once as a hipGraph and replayed
     gid = env2.capture_step(one_step)
     env2.replay(gid, 3)
     env2.sync()
     t0 = time.perf_counter()
-    env2.replay(gid, n2)
-    env2.sync()
+    dev_ms3 = env2.timed(lambda: env2.replay(gid, n2))
     dt3 = time.perf_counter() - t0
     live = int((d["done"] == 0).sum().item())
     nodes = int(d["num_nodes"].sum().item())
-    # algorithmic bytes of one batched step: observation arrays written (32 + 8 + 8 B per bucket), bucket counts read by the
-    # observation kernel (4 B) and has_node read by the agent (8 B) per environment and bucket; the planner step itself
-    # (~0.33 KB per environment) is noise next to them
-    abytes = float(n_env) * nb * (32 + 8 + 8 + 4 + 8) + n_env * 330.0
+    # algorithmic bytes of one batched step: observation arrays written (32 + 8 + 8 B per bucket) and the bucket counts the
+    # observation kernel reads (4 B) per environment and bucket; the planner step itself (~0.33 KB per
+    # environment) is noise next to them
+    abytes = float(n_env) * nb * (32 + 8 + 8 + 4) + n_env * 330.0
     out["device_resident"] = {
-        "metric": "RRTEnv steps/s, device-resident loop (agent + step + observation + outcome kernels, no host transfer)",
+        "metric": "RRTEnv steps/s, device-resident loop (planner step with agent + outcome inside, observation kernel; no host transfer)",
         "value": n_env * n2 / dt2, "unit": "env-steps/s", "envs": n_env, "steps": n2, "ms_per_batched_step": 1e3 * dt2 / n2,
+        "device_ms_per_batched_step": dev_ms / n2, "launches_per_step": 2,
         "envs_still_running_at_end": live, "nodes_in_all_trees": nodes,
         "hipgraph_replay": {"value": n_env * n2 / dt3, "unit": "env-steps/s", "ms_per_batched_step": 1e3 * dt3 / n2,
-                            "note": "the same four-kernel step captured once on the planner's stream and replayed"},
-        "roofline": roofline(abytes, 1e3 * dt2 / n2, "prrt_policy_random_kernel + prrt_kernel (step mode) + prrt_observation_kernel + prrt_env_outcome_kernel",
-                             note="wall time of the enqueue loop / steps (four launches per step on one stream, one wait at the end): "
-                                  "launch-bound, the observation write is the only HBM-sized term")}
+                            "device_ms_per_batched_step": dev_ms3 / n2,
+                            "note": "the same two-kernel step captured once on the planner's stream and replayed"},
+        "roofline": roofline(abytes, dev_ms / n2, "prrt_kernel (step mode: agent + generate_one_node + outcome) + prrt_observation_kernel",
+                             note="kernel_ms = HIP-event time of the enqueued loop / steps (device time incl. the boundary between "
+                                  "the two dependent launches, not host wall time); the observation write is the only HBM-sized term")}
     return out
 
 
@@ -694,6 +812,7 @@ def bench_planner(ctx, ranks, with_cpu, n_ep=512, max_step=2000, steps=5, warmup
            "steps_per_s_plan_launch_only": float(summ["steps"].sum()) / (k_ms * 1e-3),
            "config": "%d x Planner_RRT.planning(2000), 200 m env, 256 obstacles, cell 5 m, freq 10" % n_ep,
            "roofline": roofline(abytes, k_ms, ctx.prrt_last_kernel(), traffic,
+                                valu_issue_frac=pmc_valu_issue("planner_rrt") if traffic["traffic"] is not None else None,
                                 bytes_per_step=abytes / max(float(summ["steps"].sum()), 1.0),
                                 note="512 waves on 1 024 SIMDs: a latency measurement")}
     if with_cpu:
@@ -755,10 +874,12 @@ def bench_config5(ctx, ranks, n_filters=25, n_particles=500, max_step=200, track
     abytes = planner_bytes(summ)  # of the last tracking step's plan launch
     steps_last = float(summ["steps"].sum())
     kname = ctx.prrt_last_kernel()
+    c5_traffic = pmc_traffic("config5", [kname], steps_last)
     return {"metric": "config 5: Planner_RRT steps/s, one replan per particle hypothesis per tracking step",
             "value": total / dt, "unit": "steps/s", "ms_per_tracking_step": 1e3 * dt / track_steps,
             "planner_steps_per_tracking_step": steps_last, "steps_per_s_plan_launch_only": steps_last / (plan_ms[-1] * 1e-3),
-            "roofline": roofline(abytes, plan_ms[-1], kname, pmc_traffic("config5", [kname], steps_last),
+            "roofline": roofline(abytes, plan_ms[-1], kname, c5_traffic,
+                                 valu_issue_frac=pmc_valu_issue("config5") if c5_traffic["traffic"] is not None else None,
                                  bytes_per_step=abytes / max(steps_last, 1.0),
                                  note="the last tracking step's plan launch; ~3 waves per SIMD, each step a chain of dependent "
                                       "fp64 sequences (atan2 / sincos / divisions) and tree reads: issue and latency bound, not HBM"),
@@ -946,6 +1067,8 @@ def main():
 
     ctx = _lib.Context(local_rank)
     ranks = Ranks(ctx, rank, world_size, dev, use_rccl=not one_gpu)
+    if rank == 0:
+        measure_hbm(ctx)  # 4 GiB streaming read + copy, a few ms: the measured roof every roofline object quotes
     sides = {
         "single_episode": lambda: bench_single_episode(ctx, world, args),
         "rrt_64_obstacles": lambda: bench_rrt_o64(ctx, args),
@@ -1024,6 +1147,7 @@ def main():
         sys.exit("device error status in %d episodes: %s" % (int(bad.sum()), np.unique(summ["status"][bad])))
     iters_local = float(summ["iters_run"].sum())
     iters_per_step = ranks.sum(iters_local)
+    acc_per_step = ranks.sum(float((summ["n_nodes"] - 1).sum()))
     value = iters_per_step * args.steps / dt
     k_ms = float(np.mean(kms[-args.steps:]))
     k_all = ranks.all(k_ms)
@@ -1031,20 +1155,19 @@ def main():
     rccl_info_all = ranks.all(ranks.rccl_info) if world_size > 1 else None
     out = None
     if rank == 0:
-        abytes = rrt_bytes(summ)
         grid, block, lds = ctx.last_launch()
         exp_ms = float(np.mean([p[0] for p in parts[-args.steps:]]))
         leaf_ms = float(np.mean([p[1] for p in parts[-args.steps:]]))
         per_wave = parts[-1][2]
         kname = "rrt_rows_kernel" if per_wave == 4 else "rrt_explore_kernel"
-        traffic = pmc_traffic("headline", [kname, "rrt_leaf_kernel"], iters_local)
+        wl = "RRT.exploring %d obst %dx%d cells %d iters x %d episodes/GPU, %s parent sampling" % (
+            args.obstacles, args.grid, args.grid, args.iters, E, args.mode)
         out = {
             "metric": "RRT-Dubins node expansions/s (RRT.exploring)", "value": value, "unit": "expansions/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "rrt_dubins.py RRT.exploring, %d obstacles, %dx%d-cell Catalina-like grid, "
-                                   "%d-iteration budget per episode, %d episodes per GPU per step, %s parent sampling"
-                                   % (args.obstacles, args.grid, args.grid, args.iters, E, args.mode),
+            "config": {"workload": wl[:120],
+                       "reference": "path_planning/rrt_dubins.py:92 RRT.exploring, Catalina-like synthetic grid (SURVEY 8(d) config 2, O=256)",
                        "episodes_per_gpu": E, "iters": args.iters, "obstacles": args.obstacles,
                        "cells": int(len(world["cells"])), "parallelism": "episodes sharded x%d" % world_size,
                        "gather": ranks.gather.name if ranks.gather is not None else None, "gather_note": ranks.gather_note,
@@ -1052,20 +1175,24 @@ def main():
                        # of every rank, and the RCCL image the C-ABI bound
                        "rccl_comm_info_per_rank": rccl_info_all, "rccl_ranks_seen": (rccl_info_all[0][2] if rccl_info_all and rccl_info_all[0] else None),
                        "rccl_library": ranks.rccl_library},
-            # one pass of the path = two launches on the handle's stream: the tree expansion and the leaf pass (cost terms,
-            # ranking); kernel_ms is the HIP-event time around both, the algorithmic bytes are those of the whole pass
-            "roofline": roofline(abytes, k_ms, kname + " + rrt_leaf_kernel", traffic,
-                                 bytes_per_expansion=abytes / iters_local,
-                                 kernels_ms={kname: exp_ms, "rrt_leaf_kernel": leaf_ms}, episodes_per_wavefront=per_wave,
-                                 launch={"grid": grid, "block": block, "lds_bytes": lds},
-                                 note="the expansion (94 % of the pass) is fp64-VALU issue bound, the leaf pass latency bound (DESIGN.md)"),
+            # one pass of the path = two launches on the handle's stream: the tree expansion (the dominant kernel: this
+            # object's achieved / frac are ITS algorithmic bytes over ITS HIP-event time) and the leaf pass (leaf_*: compulsory
+            # bytes); pass_8d_* = the whole-pass SURVEY 8(d) figure of earlier rounds, labelled
+            "roofline": rrt_pass_rooflines(ctx, summ, "headline", exp_ms, leaf_ms, kname, episodes_per_wavefront=per_wave,
+                                           launch_grid=grid, launch_block=block, launch_lds_bytes=lds,
+                                           hbm_measured_copy_GBps=HBM_MEASURED.get("copy_GBps"),
+                                           note="expansion kernel: fp64 VALU issue binds (valu_issue_frac), HBM does not; "
+                                                "leaf pass: latency bound (DESIGN.md 4)"),
             "expansions_per_s_kernel_only": iters_local / (k_ms * 1e-3),
             "expansions_per_s_expansion_kernel_only": iters_local / (exp_ms * 1e-3),
             "kernel_ms_per_rank": k_all, "gather_ms_per_rank": g_all,
+            "expansions_per_step": iters_per_step, "accepted_nodes_per_step": acc_per_step,  # summed over ALL ranks
             "accepted_nodes_per_episode": float((summ["n_nodes"] - 1).mean()),
             "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
             "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters_local,
         }
+        out["hbm_probe"] = dict(HBM_MEASURED, peak_spec_GBps=HBM_PEAK_GBS,
+                                note="auvp_hbm_probe: best of `reps` launches; read = 8 x 16 B loads in flight per lane, copy = bytes read + written")
         if with_cpu:
             out["cpu_baseline"] = cpu_baseline(world, args.iters, args)
             out["cpu_baseline_all_cores"] = cpu_all
@@ -1087,11 +1214,25 @@ def main():
         if rank == 0 and isinstance(out.get("rrt_nn_long_horizon"), dict) and "roofline" in out["rrt_nn_long_horizon"]:
             # the headline's parent sampling (time bins) reads one node per iteration; the SAME path with nearest-neighbour
             # parent sampling streams the whole tree every iteration -- that side measurement is where the HBM roofline
-            # fraction of the path is visible
-            nl = out["rrt_nn_long_horizon"]["roofline"]
-            out["roofline"]["streaming_side_measurement"] = {
-                "name": "rrt_nn_long_horizon", "frac": nl["frac"], "achieved": nl["achieved"], "unit": nl["unit"],
-                "traffic": nl.get("traffic"), "kernel_ms": nl["kernel_ms"]}
+            # fraction of the path is visible.  Flat scalars: the driver's record keeps scalars of `roofline` only.
+            side = out["rrt_nn_long_horizon"]
+            nl = side["roofline"]
+            out["roofline"].update({
+                "nn_long_kernel": "rrt_explore_kernel<4,2,false> (nearest-neighbour parent sampling, max_traj_time 20000 s)",
+                "nn_long_episodes": side["episodes"], "nn_long_kernel_ms": nl["kernel_ms"],
+                "nn_long_alg_bytes": nl["algorithmic_bytes_per_launch"], "nn_long_achieved_GBps": nl["achieved"],
+                "nn_long_frac": nl["frac"], "nn_long_frac_of_measured": nl.get("frac_of_measured"),
+                "nn_long_traffic": nl.get("traffic"), "nn_long_traffic_raw": nl.get("traffic_raw"),
+                "nn_long_mirror_bytes": side["xy_mirror_working_set_bytes"], "nn_long_iters_per_s": side["value"],
+                "nn_long_valu_issue_frac": nl.get("valu_issue_frac")})
+        if rank == 0:
+            # the other configurations as flat scalars too (value of each side measurement; details in its own object)
+            for name, key in (("astar", "side_astar_cells_per_s"), ("planner_rrt", "side_planner_steps_per_s"),
+                              ("config5", "side_config5_steps_per_s"), ("rrt_1024_replicas", "side_replicas_expansions_per_s"),
+                              ("single_episode", "side_single_episode_us_per_expansion")):
+                v = out.get(name)
+                if isinstance(v, dict):
+                    out["roofline"][key] = v.get("us_per_expansion" if name == "single_episode" else "value")
     if rank == 0:
         print(json.dumps(out))
     if world_size > 1:

@@ -178,22 +178,40 @@ int auvp_prrt_observation(auvp_handle* h, int32_t episode, double* rrt_grid, int
 /* RRTEnv.step (gym_rrt/envs/rrt_env.py:182-247) for every environment with NOTHING crossing PCIe: bucket_ids_dev [E]
  * (chosen_grid_cell_idx per environment, -1 = skip; DEVICE memory, e.g. an agent's output) -> generate_one_node, then
  * the observation arrays (as auvp_prrt_observation_dev; rrt_grid_dev may be NULL to skip them) and the step's outcome:
- * reward_dev [E] i64 = 300 R_FOUND_PATH / 0 R_CREATE_NODE / -1 R_INVALID_NODE (0 for an environment that had already
- * finished: it is skipped), done_dev [E] u8 (may be NULL).  Only ENQUEUES on the handle's stream: follow with
- * auvp_stream_sync (or order other work on auvp_stream) before reading results. */
+ * reward_dev [E] i64 = 300 R_FOUND_PATH / 0 R_CREATE_NODE / -1 R_INVALID_NODE; 0 for an environment that had already
+ * finished or that the caller skipped with -1 (neither is touched; a skipped one keeps its done flag), done_dev [E] u8
+ * (may be NULL).  An episode that fails on the device (tree / point capacity, a bucket id outside the grid) is flagged
+ * done, rewarded 0 and reported by auvp_prrt_env_check -- the host loop (auvp_prrt_step) shows the same failure as
+ * summary.status < 0.  Two launches per step (the outcome is written by the planner launch itself).  Only ENQUEUES on the
+ * handle's stream: follow with auvp_stream_sync (or order other work on auvp_stream) before reading results. */
 int auvp_prrt_env_step_dev(auvp_handle* h, const int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev,
                            void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev);
-/* stand-in agent for device-resident runs: every live environment picks, uniformly, one of the buckets has_node_dev
- * [E,n_buckets] marks occupied (finished environments: -1); its randomness is its own (counter-based on `seed`), not
- * the planner's stream.  Enqueues only. */
+/* the same step with the stand-in agent of auvp_prrt_policy_random_dev INSIDE the planner launch: bucket_ids_dev [E]
+ * receives what it picked (still two launches per step; measurements and tests of the device-resident loop) */
+int auvp_prrt_env_step_agent_dev(auvp_handle* h, uint64_t seed, int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev,
+                                 void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev);
+/* stand-in agent for device-resident runs as a launch of its own: every live environment picks, uniformly, one of its
+ * occupied buckets -- read from the planner's own list of occupied buckets, the set the observation's has_node array marks
+ * (rrt_env.py:250-265); has_node_dev is accepted for compatibility and not read -- finished environments get -1; its
+ * randomness is its own (counter-based on `seed`), not the planner's stream.  Enqueues only. */
 int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uint64_t seed, int32_t* bucket_ids_dev);
+/* waits for the stream, then: *status = status (< 0) of the first episode that failed on the device inside the
+ * device-resident loop since the batch was created, *env (may be NULL) = its index; 0 = none */
+int auvp_prrt_env_check(auvp_handle* h, int32_t* status, int32_t* env);
 /* the handle's HIP stream (hipStream_t) and a wait for everything enqueued on it */
 void* auvp_stream(auvp_handle* h);
 int auvp_stream_sync(auvp_handle* h);
+/* HIP-event time of a region of the handle's stream that the caller brackets around enqueue-only calls
+ * (auvp_prrt_env_step_dev, auvp_graph_launch ...): mark(h, 0) before, mark(h, 1) after; elapsed_ms waits for the second
+ * mark and returns the device time between the two (measurement infrastructure: no reference counterpart) */
+int auvp_stream_mark(auvp_handle* h, int32_t which);
+int auvp_stream_elapsed_ms(auvp_handle* h, double* ms);
 /* hipGraph capture of a launch-bound step loop: everything the enqueue-only entry points (auvp_prrt_policy_random_dev,
  * auvp_prrt_env_step_dev, the caller's own kernels on auvp_stream) put on the stream between begin and end is recorded
  * instead of run; auvp_graph_launch replays it n_times back to back (enqueue only).  The loop's step counter lives in
- * HBM, so every replay of the stand-in agent draws anew.  Run one un-captured step first. */
+ * HBM, so every replay of the stand-in agent draws anew.  Run one un-captured step first.  A graph holds the device
+ * pointers of the batch (and of the caller's arrays) it was captured with: creating a new batch (auvp_prrt_create_batch,
+ * auvp_prrt_replan_particles) destroys the handle's graphs, and auvp_graph_launch of such an id fails with AUVP_ERR_STATE. */
 int auvp_graph_begin(auvp_handle* h);
 int auvp_graph_end(auvp_handle* h, int32_t* graph_id);
 int auvp_graph_launch(auvp_handle* h, int32_t graph_id, int32_t n_times);
@@ -305,6 +323,13 @@ int auvp_cost_paths(auvp_handle* h, int32_t n_paths, const int32_t* off, const d
  * that path ran */
 int auvp_nn_closest_batch(auvp_handle* h, int32_t n_nodes, const double* xy, int32_t n_queries, const double* q,
                           int32_t force_exact, int32_t* out_index, int32_t* out_slow);
+/* Measured HBM streaming rates of this GPU (the roof bench.py quotes its bandwidth fractions against, beside the 8 TB/s
+ * datasheet figure): a read of `bytes` (>= 64 MB; use >= 4 GB to get past the 256 MB Infinity Cache) with eight 16-byte
+ * loads in flight per lane -- the access shape of the nearest-neighbour scan of get_closest_mps
+ * (path_planning/rrt_dubins.py:505-513) -- and a 16-byte copy of one half of the buffer onto the other; best of `reps`
+ * launches each, HIP events on the handle's stream.  GB/s = 1e9 bytes per second; copy counts bytes read + written.
+ * (No reference counterpart: measurement infrastructure of the boundary.) */
+int auvp_hbm_probe(auvp_handle* h, uint64_t bytes, int32_t reps, double* read_GBps, double* copy_GBps);
 /* portable sin/cos evaluated on the device (bit-exactness probe for auvp_math.h) */
 int auvp_sincos_dev(auvp_handle* h, int32_t n, const double* x, double* s, double* c);
 /* CPython random() stream of `seed` generated by the wave-level device MT19937 */
@@ -318,6 +343,11 @@ double auvp_last_kernel_ms(auvp_handle* h);
 /* of the last auvp_rrt_run: HIP-event times of its two launches (tree expansion; leaf ranking) and which expansion
  * kernel ran (4 = four episodes per wavefront, rrt_rows_kernel; 1 = rrt_explore_kernel) */
 int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_ms, int32_t* episodes_per_wave);
+/* of the last auvp_rrt_run's leaf pass (the qualifying-leaf bookkeeping of exploring, rrt_dubins.py:158-171 +
+ * cost.py:145-207), summed over the batch: out4 = {nodes its sweep visited (qualifying leaves and their ancestors), path
+ * points of those nodes (each evaluated once), path elements re-summed in the reference's leaf->root order, leaves
+ * re-summed}: the units of that kernel's compulsory-traffic figure */
+int auvp_rrt_last_leaf_stats(auvp_handle* h, int64_t* out4);
 int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds_bytes);
 
 /* Config 5 composition (BASELINE.json configs[4]): the particle filter of particleFilter.py:283-317 feeding one

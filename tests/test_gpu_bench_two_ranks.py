@@ -1,0 +1,58 @@
+"""bench.py's N > 1 path on a ONE-GPU box: `--gpus 2` under AUVP_BENCH_ONE_GPU=1 starts two ranks (fresh children of a
+fresh child of this test: nothing that has touched the GPU is ever exec'ed) that share GPU 0 and talk over gloo -- RCCL
+cannot put two ranks on one device -- so spawn_ranks, the episode sharding (seed = global episode id), the sharded side
+measurements (configs 3, 4, 5), the result gathers and the per-rank fields of the JSON line all run where the driver
+looks.  The RCCL transport itself is covered by tests/test_gpu_gather_rccl.py (world size 1 here, 2 on a 2-GPU box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(gpus, episodes, extra=(), one_gpu=False):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    if one_gpu:
+        env["AUVP_BENCH_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0",
+           "--episodes", str(episodes), "--iters", "300", "--no-cpu"] + list(extra)
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE JSON line, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_gpu_shard_the_batch_and_report_per_rank():
+    two = _bench(2, 64, one_gpu=True)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["config"]["parallelism"] == "episodes sharded x2"
+    assert two["config"]["episodes_per_gpu"] == 64
+    assert len(two["kernel_ms_per_rank"]) == 2 and all(k > 0 for k in two["kernel_ms_per_rank"])
+    assert len(two["gather_ms_per_rank"]) == 2
+    assert "gloo" in (two["config"]["gather"] or "") and "AUVP_BENCH_ONE_GPU" in (two["config"]["gather_note"] or "")
+    assert len(two["config"]["workload"]) <= 120 and "parent sampling" in two["config"]["workload"]
+    # the sharded side measurements ran on both ranks and report per rank
+    for side, field in (("astar", "search_launch_ms_per_rank"), ("planner_rrt", "plan_launch_ms_per_rank")):
+        assert "error" not in two[side], two[side]
+        assert len(two[side][field]) == 2
+    assert two["astar"]["instances_this_rank"] == 512 and two["planner_rrt"]["episodes_this_rank"] == 256
+    assert "error" not in two["config5"], two["config5"]
+    # the same 128 episodes (seeds = global episode ids 0..127) on one rank: same expansions, same trees
+    one = _bench(1, 128, extra=["--no-extra"])
+    assert one["n_gpus"] == 1 and one["config"]["parallelism"] == "episodes sharded x1"
+    assert two["expansions_per_step"] == one["expansions_per_step"] == 128 * 300
+    assert two["accepted_nodes_per_step"] == one["accepted_nodes_per_step"] > 0
+    # roofline object: flat scalars the driver's record keeps
+    rf = one["roofline"]
+    for k in ("frac", "kernel_ms", "leaf_kernel_ms", "leaf_compulsory_bytes", "leaf_frac", "pass_8d_frac", "hbm_measured_GBps",
+              "frac_of_measured"):
+        assert isinstance(rf[k], float) and rf[k] > 0, k
+    assert rf["frac"] <= 1.0 and rf["leaf_frac"] <= 1.0
+    assert 1000.0 < rf["hbm_measured_GBps"] < 8000.0  # a measured HBM read rate, below the datasheet peak

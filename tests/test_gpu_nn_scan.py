@@ -87,6 +87,31 @@ def test_near_ties_take_the_reference_path(ctx):
             assert got[0] == want
 
 
+def test_near_tie_before_duplicated_minimum_in_one_lane(ctx):
+    """positions b, a, a at indices i, i + 64, i + 128 -- ONE lane's subsequence of the scan -- with d2(b) one ulp above d2(a)
+    and equal rounded roots: the lane ends with its smallest value held twice, and the near-tie must still be seen (the second
+    smallest DISTINCT value is what the lane tracks).  The reference keeps index i (strict < on the rounded root)."""
+    rng = np.random.default_rng(13)
+    for a, b in _near_tie_cases(rng, 8):
+        for n, i in ((200, 5), (700, 3), (1400, 512 + 60), (130, 1)):
+            for order in ((b, a, a), (a, b, a), (a, a, b), (b, a, a, a)):
+                xy = rng.uniform(5, 50, size=(max(n, i + 64 * len(order) + 1), 2))
+                for k, p in enumerate(order):
+                    xy[i + 64 * k] = p
+                q = np.zeros((1, 2))
+                want = reference_closest(xy, q[0])
+                assert want == i
+                got, slow = ctx.nn_closest(xy, q)
+                assert got[0] == want and slow[0], (n, i, len(order))
+                got, _ = ctx.nn_closest(xy, q, force_exact=True)
+                assert got[0] == want
+    # the same duplicated minimum WITHOUT a near-tie stays on the fast path
+    xy = rng.uniform(5, 50, size=(300, 2))
+    xy[7] = xy[71] = xy[135] = np.array([1.75, 0.0])
+    got, slow = ctx.nn_closest(xy, np.zeros((1, 2)))
+    assert got[0] == 7 and not slow[0]
+
+
 def test_exploring_nn_forced_exact_equals_scan(ctx, orc, monkeypatch):
     """the exploring loop in nearest-neighbour mode: scan path == forced-exact path == checker, bit for bit"""
     from auv_sim_amd import synth
