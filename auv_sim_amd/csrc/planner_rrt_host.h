@@ -17,7 +17,6 @@ struct PrrtState {
   DevBuf work;  // work counter of the four-episodes-per-wavefront kernel (planner_rows_kernel.h)
   bool use_rows = false;  // decided once per batch: the two kernels keep the generator's lazy state in different block phases
   const char* last_kernel = "";
-  DevBuf loop_step;  // device word: steps of the device-resident env loop so far (mixed into the stand-in agent's draws)
   DevBuf env_err;    // device int32[2]: {status, environment} of the first episode that failed inside the device-resident loop
   // captured step graphs of the device-resident loop (auvp_graph_*).  A graph holds raw device pointers (this batch's
   // buffers and the caller's observation / reward arrays): it dies with the batch it was captured for -- prrt_configure
@@ -156,7 +155,8 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
   B.start = S.start.as<double>(); B.goal = S.goal.as<double>();
   B.st_log = nullptr;
   B.env_flags = 0; B._pad_env = 0; B.env_done = nullptr; B.env_reward = nullptr; B.env_done_out = nullptr;
-  B.env_bucket_out = nullptr; B.env_loop_step = nullptr; B.env_agent_seed = 0ull; B.env_err = nullptr;
+  B.env_bucket_out = nullptr; B.env_agent_seed = 0ull; B.env_err = nullptr;
+  B.env_obs_grid = nullptr; B.env_obs_has = nullptr; B.env_obs_num = nullptr;
   if (flags & AUVP_FLAG_ITER_LOG) {
     HIPCHK(h, S.st_log.reserve((size_t)E * p->max_step * 8 * sizeof(int32_t)));
     HIPCHK(h, hipMemsetAsync(S.st_log.p, 0xff, (size_t)E * p->max_step * 8 * sizeof(int32_t), h->stream));
@@ -183,8 +183,6 @@ static int prrt_plant(auvp_handle* h, PrrtState& S, int32_t E) {
   HIPCHK(h, hipMemsetAsync(S.bcount.p, 0, (size_t)E * S.P.n_buckets * sizeof(int32_t), h->stream));
   HIPCHK(h, S.env_done.reserve((size_t)E));
   HIPCHK(h, hipMemsetAsync(S.env_done.p, 0, (size_t)E, h->stream));
-  HIPCHK(h, S.loop_step.reserve(sizeof(unsigned long long)));
-  HIPCHK(h, hipMemsetAsync(S.loop_step.p, 0, sizeof(unsigned long long), h->stream));
   HIPCHK(h, S.env_err.reserve(2 * sizeof(int32_t)));
   HIPCHK(h, hipMemsetAsync(S.env_err.p, 0, 2 * sizeof(int32_t), h->stream));
   S.thetas_ready = false;
@@ -373,8 +371,7 @@ void* auvp_prrt_summaries_dev(auvp_handle* h) {
 // RRTEnv observation arrays (gym_rrt/envs/rrt_env.py:250-295) for every episode, written to
 // caller-owned DEVICE buffers: rrt_grid [E,n_buckets,4] f64 = cell.x, cell.y, subsection.theta,
 // len(node_array); has_node [E,n_buckets] i64; num_nodes [E,n_buckets] i64.
-static int prrt_observation_enqueue(auvp_handle* h, PrrtState& S, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev,
-                                    unsigned long long* tick = nullptr) {
+static int prrt_observation_enqueue(auvp_handle* h, PrrtState& S, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev) {
   if (!S.thetas_ready) {
     // subsection thetas exactly as Grid_cell_RRT builds them (grid_cell_rrt.py:49-55); once per batch
     std::vector<double> th(S.P.S);
@@ -394,7 +391,7 @@ static int prrt_observation_enqueue(auvp_handle* h, PrrtState& S, void* rrt_grid
   const int grid = (int)std::min<long long>((total + 255) / 256, 65535LL * 16);
   hipLaunchKernelGGL(auvp::prrt_observation_kernel, dim3(grid), dim3(256), 0, h->stream, S.P, S.B, S.thetas.as<double>(), S.E,
                      reinterpret_cast<double*>(rrt_grid_dev), reinterpret_cast<long long*>(has_node_dev),
-                     reinterpret_cast<long long*>(num_nodes_dev), tick);
+                     reinterpret_cast<long long*>(num_nodes_dev));
   HIPCHK(h, hipGetLastError());
   return AUVP_OK;
 }
@@ -411,63 +408,61 @@ int auvp_prrt_observation_dev(auvp_handle* h, void* rrt_grid_dev, void* has_node
 }
 
 // ---- the device-resident RRTEnv loop: every call below only ENQUEUES on the handle's stream (auvp_stream_sync waits) ----
-// One environment step = TWO launches: generate_one_node for every live environment with the step's outcome (reward, done
-// flag) written by the same launch -- and, for auvp_prrt_env_step_agent_dev, the stand-in agent's pick made inside it --
-// then the observation arrays, whose launch also advances the loop's step counter.  (Batches the four-episodes-per-wavefront
-// kernel serves keep the agent and the outcome as small launches of their own.)
-static int prrt_env_step_enqueue(auvp_handle* h, PrrtState& S, const int32_t* bucket_ids_dev, bool agent, uint64_t agent_seed,
-                                 int32_t* bucket_out_dev, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev,
-                                 int64_t* reward_dev, uint8_t* done_dev) {
+// One environment step = generate_one_node for every live environment, with the step's outcome (reward, done flag) written
+// by the same launch and -- AUVP_ENV_AGENT -- the stand-in agent's pick made inside it.  The observation arrays are either
+// rewritten whole by a second launch (E x n_buckets entries, what the reference env rebuilds after every node) or --
+// AUVP_ENV_OBS_DELTA -- updated in place by the planner launch itself: a step changes ONE bucket per environment.  (Batches
+// the four-episodes-per-wavefront kernel serves keep the agent and the outcome as small launches of their own and always
+// rewrite the observation.)
+static int prrt_env_step_enqueue(auvp_handle* h, PrrtState& S, int32_t flags, uint64_t agent_seed, int32_t* bucket_ids_dev,
+                                 void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev) {
+  const bool agent = (flags & AUVP_ENV_AGENT) != 0;
+  const bool delta = (flags & AUVP_ENV_OBS_DELTA) != 0 && rrt_grid_dev != nullptr;
   auvp::PrrtBuffers& B = S.B;
   B.env_done = S.env_done.as<uint8_t>(); B.env_reward = reinterpret_cast<long long*>(reward_dev); B.env_done_out = done_dev;
-  B.env_bucket_out = bucket_out_dev; B.env_loop_step = S.loop_step.as<unsigned long long>(); B.env_agent_seed = agent_seed;
-  B.env_err = S.env_err.as<int32_t>();
+  B.env_bucket_out = bucket_ids_dev; B.env_agent_seed = agent_seed; B.env_err = S.env_err.as<int32_t>();
+  B.env_obs_grid = reinterpret_cast<double*>(rrt_grid_dev); B.env_obs_has = reinterpret_cast<long long*>(has_node_dev);
+  B.env_obs_num = reinterpret_cast<long long*>(num_nodes_dev);
   const int32_t* own = B.step_bucket;
+  B.step_bucket = bucket_ids_dev;
   int rc;
+  bool full_obs = rrt_grid_dev != nullptr && !delta;
   if (!S.use_rows) {
-    B.env_flags = PRRT_ENV_OUTCOME | (agent ? PRRT_ENV_AGENT : 0);
-    if (!agent) B.step_bucket = bucket_ids_dev;
+    B.env_flags = PRRT_ENV_OUTCOME | (agent ? PRRT_ENV_AGENT : 0) | (delta ? PRRT_ENV_DELTA : 0);
     rc = prrt_launch(h, S, 1, false);
   } else {
     B.env_flags = 0;
+    full_obs = rrt_grid_dev != nullptr;
     if (agent) {
       hipLaunchKernelGGL(auvp::prrt_policy_random_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, B, S.E,
-                         (unsigned long long)agent_seed, S.loop_step.as<unsigned long long>(), bucket_out_dev);
+                         (unsigned long long)agent_seed, bucket_ids_dev);
       HIPCHK(h, hipGetLastError());
     }
-    const int32_t* ids = agent ? bucket_out_dev : bucket_ids_dev;
-    B.step_bucket = ids;
     rc = prrt_launch(h, S, 1, false);
     if (rc == AUVP_OK) {
-      hipLaunchKernelGGL(auvp::prrt_env_outcome_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, B, S.E, ids);
+      hipLaunchKernelGGL(auvp::prrt_env_outcome_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, B, S.E, bucket_ids_dev);
       rc = hipGetLastError() == hipSuccess ? AUVP_OK : fail(h, AUVP_ERR_HIP, "prrt_env_outcome_kernel launch");
     }
   }
   B.step_bucket = own;
   B.env_flags = 0;
   if (rc != AUVP_OK) return rc;
-  if (rrt_grid_dev) return prrt_observation_enqueue(h, S, rrt_grid_dev, has_node_dev, num_nodes_dev, S.loop_step.as<unsigned long long>());
-  hipLaunchKernelGGL(auvp::prrt_env_tick_kernel, dim3(1), dim3(1), 0, h->stream, S.loop_step.as<unsigned long long>());
-  HIPCHK(h, hipGetLastError());
+  if (full_obs) return prrt_observation_enqueue(h, S, rrt_grid_dev, has_node_dev, num_nodes_dev);
   return AUVP_OK;
 }
 
 int auvp_prrt_env_step_dev(auvp_handle* h, const int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev, void* num_nodes_dev,
                            int64_t* reward_dev, uint8_t* done_dev) {
-  if (!h || !bucket_ids_dev || !reward_dev) return AUVP_ERR_ARG;
-  PrrtState& S = *prrt_of(h);
-  if (!S.ready) return fail(h, AUVP_ERR_STATE, "auvp_prrt_create_batch not called");
-  HIPCHK(h, hipSetDevice(h->device));
-  return prrt_env_step_enqueue(h, S, bucket_ids_dev, false, 0, nullptr, rrt_grid_dev, has_node_dev, num_nodes_dev, reward_dev, done_dev);
+  return auvp_prrt_env_step_ex_dev(h, 0, 0, const_cast<int32_t*>(bucket_ids_dev), rrt_grid_dev, has_node_dev, num_nodes_dev, reward_dev, done_dev);
 }
 
-int auvp_prrt_env_step_agent_dev(auvp_handle* h, uint64_t seed, int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev,
-                                 void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev) {
-  if (!h || !bucket_ids_dev || !reward_dev) return AUVP_ERR_ARG;
+int auvp_prrt_env_step_ex_dev(auvp_handle* h, int32_t flags, uint64_t agent_seed, int32_t* bucket_ids_dev, void* rrt_grid_dev,
+                              void* has_node_dev, void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev) {
+  if (!h || !bucket_ids_dev || !reward_dev || (flags & ~(AUVP_ENV_AGENT | AUVP_ENV_OBS_DELTA))) return AUVP_ERR_ARG;
   PrrtState& S = *prrt_of(h);
   if (!S.ready) return fail(h, AUVP_ERR_STATE, "auvp_prrt_create_batch not called");
   HIPCHK(h, hipSetDevice(h->device));
-  return prrt_env_step_enqueue(h, S, nullptr, true, seed, bucket_ids_dev, rrt_grid_dev, has_node_dev, num_nodes_dev, reward_dev, done_dev);
+  return prrt_env_step_enqueue(h, S, flags, agent_seed, bucket_ids_dev, rrt_grid_dev, has_node_dev, num_nodes_dev, reward_dev, done_dev);
 }
 
 int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uint64_t seed, int32_t* bucket_ids_dev) {
@@ -479,7 +474,7 @@ int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uin
   auvp::PrrtBuffers B = S.B;
   B.env_done = S.env_done.as<uint8_t>();
   hipLaunchKernelGGL(auvp::prrt_policy_random_kernel, dim3((S.E + 255) / 256), dim3(256), 0, h->stream, B, S.E, (unsigned long long)seed,
-                     S.loop_step.as<unsigned long long>(), bucket_ids_dev);
+                     bucket_ids_dev);
   HIPCHK(h, hipGetLastError());
   return AUVP_OK;
 }

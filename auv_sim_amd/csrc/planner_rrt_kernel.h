@@ -65,12 +65,18 @@ struct PrrtBuffers {
   long long* env_reward;      // [E]
   uint8_t* env_done_out;      // [E] optional copy of env_done for the caller
   int32_t* env_bucket_out;    // [E] PRRT_ENV_AGENT: the bucket the agent picked (-1: finished environment)
-  const unsigned long long* env_loop_step;  // device word: steps of the loop so far (mixed into the agent's draws)
   unsigned long long env_agent_seed;
   int32_t* env_err;           // [2] {status, environment} of the first episode that failed on the device (0: none)
+  // PRRT_ENV_DELTA: the caller's observation arrays (rrt_env.py:250-295) hold the previous step's observation and this
+  // launch updates the entries of the ONE bucket per environment whose node_array grew (a step adds at most one node):
+  // rrt_grid[e][b][3] = has_node... -- one launch per environment step instead of a rewrite of all E x n_buckets entries
+  double* env_obs_grid;       // [E][n_buckets][4]
+  long long* env_obs_has;     // [E][n_buckets] (may be null)
+  long long* env_obs_num;     // [E][n_buckets] (may be null)
 };
 #define PRRT_ENV_OUTCOME 1
 #define PRRT_ENV_AGENT 2
+#define PRRT_ENV_DELTA 4
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   x += 0x9e3779b97f4a7c15ull;
@@ -81,11 +87,13 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 // The stand-in agent of the device-resident loop (tests and measurements; a real agent writes step_bucket itself): every
 // live environment picks one of its occupied buckets uniformly -- entry `want` of the planner's own list of occupied
 // buckets, the same set the observation's has_node array marks (rrt_env.py:250-265) -- with a counter-based generator of its
-// own (splitmix64 of seed / environment / call number: the agent's randomness, not the planner's stream).  -1 for a
+// own (splitmix64 of seed / environment / the environment's step count: the agent's randomness, not the planner's stream;
+// the count lives in the episode's record in HBM, so a captured graph of one step draws anew at every replay).  -1 for a
 // finished environment (the step skips it), 0 when nothing is occupied.
-__device__ __forceinline__ int prrt_agent_pick(const PrrtBuffers& B, int e, bool finished, unsigned long long seed, unsigned long long call) {
+__device__ __forceinline__ int prrt_agent_pick(const PrrtBuffers& B, int e, bool finished, unsigned long long seed) {
   if (finished) return -1;
   const int n_occ = B.summary[e].n_occ;
+  const unsigned long long call = (unsigned long long)(uint32_t)B.summary[e].steps;
   if (n_occ <= 0) return 0;
   const int want = (int)(splitmix64(seed ^ splitmix64(((unsigned long long)e << 32) | (call & 0xffffffffull))) % (unsigned long long)n_occ);
   return B.occupied[(size_t)e * B.cap_nodes + want];
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
   if (P.step_mode) {
     if (env) env_was = uni((int)B.env_done[ep]) != 0;
     if (env && (B.env_flags & PRRT_ENV_AGENT)) {
-      step_bucket = uni(prrt_agent_pick(B, ep, env_was, B.env_agent_seed, *B.env_loop_step));
+      step_bucket = uni(prrt_agent_pick(B, ep, env_was, B.env_agent_seed));
       if (lane == 0) B.env_bucket_out[ep] = step_bucket;
     } else {
       step_bucket = uni(B.step_bucket[ep]);
@@ -257,6 +265,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
   int n_nodes = uni(sum.n_nodes), n_points = uni(sum.n_points), n_occ = uni(sum.n_occ), step = uni(sum.steps);
   int done = uni(sum.done), status = uni(sum.status);
   int last_accepted = 0, last_new = -1;
+  int last_bk = -1, last_cnt = 0;  // bucket of the node the last step added and that bucket's new size (PRRT_ENV_DELTA)
   int prev_n_arc = -1;
   bool have_prev_arc = false;
   const int step_end = P.step_mode ? step + 1 : P.max_step;
@@ -555,6 +564,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
       n_nodes++;
       n_points += cnt;
       last_accepted = 1; last_new = me;
+      last_bk = bk; last_cnt = c_before + 1;
     }
     // ---------------------------------------------------------------- connect_to_goal_curve_alt(mps_list[-1]) (:374-423)
     const int last = n_nodes - 1;
@@ -695,7 +705,16 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
     sum.done = done; sum.last_accepted = last_accepted; sum.last_new_node = last_new;
     sum.rng_after = after; sum.n_draw32 = drawn;
     if (!done) { sum.path_len = 0; }
-    if (env) prrt_env_outcome(B, ep, false, false, status, done, last_accepted);
+    if (env) {
+      prrt_env_outcome(B, ep, false, false, status, done, last_accepted);
+      if ((B.env_flags & PRRT_ENV_DELTA) && last_accepted && last_bk >= 0) {
+        // the observation of this environment changes in one bucket: len(node_array), has_node, node count
+        const size_t at = (size_t)ep * P.n_buckets + (size_t)last_bk;
+        B.env_obs_grid[at * 4 + 3] = (double)last_cnt;
+        if (B.env_obs_has) B.env_obs_has[at] = 1;
+        if (B.env_obs_num) B.env_obs_num[at] = last_cnt;
+      }
+    }
   }
 }
 
@@ -892,10 +911,7 @@ __global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, 
 // The reference rebuilds these three O(#buckets) Python lists after every node.
 __global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, PrrtBuffers B, const double* __restrict__ thetas,
                                                                int n_episodes, double* __restrict__ rrt_grid,
-                                                               long long* __restrict__ has_node, long long* __restrict__ num_nodes,
-                                                               unsigned long long* __restrict__ loop_step_tick) {
-  // (device-resident loop: this launch closes the step -- everything that reads the loop's step counter ran before it)
-  if (loop_step_tick && blockIdx.x == 0 && threadIdx.x == 0) *loop_step_tick = *loop_step_tick + 1ull;
+                                                               long long* __restrict__ has_node, long long* __restrict__ num_nodes) {
   const long long total = (long long)n_episodes * P.n_buckets;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(i % P.n_buckets);
@@ -925,16 +941,11 @@ __global__ __launch_bounds__(256) void prrt_env_outcome_kernel(PrrtBuffers B, in
   prrt_env_outcome(B, e, was, skipped, s.status, s.done, s.last_accepted);
 }
 
-// the loop's step counter lives in HBM (the stand-in agent mixes it into its draws): a captured graph of one step can be
-// replayed, every replay sees the next value.  One thread, after everything of the step that reads the counter.
-__global__ void prrt_env_tick_kernel(unsigned long long* __restrict__ loop_step) { *loop_step = *loop_step + 1ull; }
-
 __global__ __launch_bounds__(256) void prrt_policy_random_kernel(PrrtBuffers B, int n_episodes, unsigned long long seed,
-                                                                 const unsigned long long* __restrict__ loop_step,
                                                                  int32_t* __restrict__ bucket_out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_episodes) return;
-  bucket_out[e] = prrt_agent_pick(B, e, B.env_done[e] != 0, seed, *loop_step);
+  bucket_out[e] = prrt_agent_pick(B, e, B.env_done[e] != 0, seed);
 }
 
 }  // namespace auvp

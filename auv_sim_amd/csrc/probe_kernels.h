@@ -78,18 +78,20 @@ __global__ __launch_bounds__(64) void nn_probe_kernel(const double2* __restrict_
 }
 
 // ---- HBM streaming probes: the MEASURED roof the bench's bandwidth fractions are quoted against -------------------------
-// Read probe: every lane keeps eight 16-byte loads in flight (the access shape of the nearest-neighbour scan: 1 KB per
-// wave-instruction, 8 KB per wave and trip), grid-stride over 32-KB chunks per workgroup; the values are folded into one
-// word per lane that is stored only if it equals a value the memset pattern cannot produce (keeps the loads alive).
+// Read probe: every lane keeps U (8 or 16) 16-byte loads in flight (U = 8 is the access shape of the nearest-neighbour scan:
+// 1 KB per wave-instruction, 8 KB per wave and trip), grid-stride over U x 4-KB chunks per workgroup; the values are folded
+// into one word per lane that is stored only if it equals a value the memset pattern cannot produce (keeps the loads
+// alive).  The host tries both depths at four and eight workgroups per CU and reports the best rate.
+template <int U>
 __global__ __launch_bounds__(256) void hbm_read_probe_kernel(const uint4* __restrict__ src, unsigned long long n16, uint32_t* __restrict__ sink) {
-  const unsigned long long chunk = 256ull * 8ull;  // uint4 elements per workgroup and trip
+  const unsigned long long chunk = 256ull * (unsigned long long)U;  // uint4 elements per workgroup and trip
   uint4 acc = make_uint4(0u, 0u, 0u, 0u);
   for (unsigned long long c0 = (unsigned long long)blockIdx.x * chunk; c0 + chunk <= n16; c0 += (unsigned long long)gridDim.x * chunk) {
-    uint4 q[8];
+    uint4 q[U];
 #pragma unroll
-    for (int u = 0; u < 8; u++) q[u] = src[c0 + (unsigned long long)u * 256ull + threadIdx.x];
+    for (int u = 0; u < U; u++) q[u] = src[c0 + (unsigned long long)u * 256ull + threadIdx.x];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { acc.x ^= q[u].x; acc.y += q[u].y; acc.z ^= q[u].z; acc.w += q[u].w; }
+    for (int u = 0; u < U; u++) { acc.x ^= q[u].x; acc.y += q[u].y; acc.z ^= q[u].z; acc.w += q[u].w; }
   }
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) sink[blockIdx.x] = acc.x;
 }
@@ -205,8 +207,8 @@ int auvp_nn_closest_batch(auvp_handle* h, int32_t n_nodes, const double* xy, int
 int auvp_hbm_probe(auvp_handle* h, uint64_t bytes, int32_t reps, double* read_GBps, double* copy_GBps) {
   if (!h || reps <= 0 || !read_GBps) return AUVP_ERR_ARG;
   HIPCHK(h, hipSetDevice(h->device));
-  // whole 32-KB chunks; at least 64 MB so that the launch is long against its own start-up
-  const unsigned long long chunk_b = 256ull * 8ull * 16ull;
+  // whole 64-KB chunks; at least 64 MB so that the launch is long against its own start-up
+  const unsigned long long chunk_b = 256ull * 16ull * 16ull;
   unsigned long long nb = (bytes < (64ull << 20) ? (64ull << 20) : bytes) / chunk_b * chunk_b;
   DevBuf buf, sink;
   HIPCHK(h, buf.reserve((size_t)nb));
@@ -233,8 +235,19 @@ int auvp_hbm_probe(auvp_handle* h, uint64_t bytes, int32_t reps, double* read_GB
     *out = best;
     return AUVP_OK;
   };
-  int rc = timed([&] { hipLaunchKernelGGL(hbm_read_probe_kernel, dim3(grid), dim3(256), 0, h->stream, buf.as<uint4>(), n16, sink.as<uint32_t>()); },
-                 (double)nb, read_GBps);
+  int rc = AUVP_OK;
+  double best_read = 0.0;
+  for (int wgs = 4; wgs <= 8 && rc == AUVP_OK; wgs *= 2) {
+    const int g = n_cu * wgs;
+    double r8 = 0.0, r16 = 0.0;
+    rc = timed([&] { hipLaunchKernelGGL(hbm_read_probe_kernel<8>, dim3(g), dim3(256), 0, h->stream, buf.as<uint4>(), n16, sink.as<uint32_t>()); },
+               (double)nb, &r8);
+    if (rc == AUVP_OK)
+      rc = timed([&] { hipLaunchKernelGGL(hbm_read_probe_kernel<16>, dim3(g), dim3(256), 0, h->stream, buf.as<uint4>(), n16 / 4096ull * 4096ull, sink.as<uint32_t>()); },
+                 (double)(n16 / 4096ull * 4096ull) * 16.0, &r16);
+    best_read = std::max(best_read, std::max(r8, r16));
+  }
+  *read_GBps = best_read;
   if (rc != AUVP_OK) return rc;
   if (copy_GBps) {
     const unsigned long long half16 = (n16 / 2ull) / 1024ull * 1024ull;

@@ -51,7 +51,7 @@ class RRTEnvBatch:
         self._L.auvp_prrt_observation.argtypes = [C.c_void_p, C.c_int32, _lib._dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         self._L.auvp_prrt_observation_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         self._L.auvp_prrt_env_step_dev.argtypes = [C.c_void_p] * 7
-        self._L.auvp_prrt_env_step_agent_dev.argtypes = [C.c_void_p, C.c_uint64] + [C.c_void_p] * 6
+        self._L.auvp_prrt_env_step_ex_dev.argtypes = [C.c_void_p, C.c_int32, C.c_uint64] + [C.c_void_p] * 6
         self._L.auvp_prrt_env_check.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         self._L.auvp_prrt_policy_random_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         self._L.auvp_stream_sync.argtypes = [C.c_void_p]
@@ -191,19 +191,20 @@ class RRTEnvBatch:
         """RRTEnv.step for all environments with the agent's choices already in device memory (`bucket_dev`: int32 [E] torch
         tensor on this GPU, default: the buffer policy_random_device fills; -1 skips an environment: reward 0, done flag
         unchanged).  `agent_seed` (int): the stand-in agent picks inside the planner launch instead and `bucket` receives its
-        choices.  Enqueues the step (two launches: planner step + outcome, observation arrays) on the planner's stream and
-        returns the device tensors; call sync() before reading them from another stream or the host.  The planner's stream is
-        not torch's: an agent that wrote `bucket_dev` on torch's current stream synchronises that stream
+        choices.  `observe`: True = the observation arrays are rewritten whole by a second launch; "delta" = the planner
+        launch updates the one bucket per environment that changed in the arrays of device_buffers() (which hold the previous
+        observation): one launch per step; False = no observation.  Enqueues on the planner's stream and returns the device
+        tensors; call sync() before reading them from another stream or the host.  The planner's stream is not torch's: an
+        agent that wrote `bucket_dev` on torch's current stream synchronises that stream
         (torch.cuda.current_stream().synchronize()) before this call."""
         self._enter("device")
         d = self.device_buffers()
-        obs = (C.c_void_p(d["rrt_grid"].data_ptr()) if observe else None, C.c_void_p(d["has_node"].data_ptr()),
-               C.c_void_p(d["num_nodes"].data_ptr()), C.c_void_p(d["reward"].data_ptr()), C.c_void_p(d["done"].data_ptr()))
-        if agent_seed is not None:
-            self._ctx._chk(self._L.auvp_prrt_env_step_agent_dev(self._ctx.h, int(agent_seed), C.c_void_p(d["bucket"].data_ptr()), *obs))
-        else:
-            b = d["bucket"] if bucket_dev is None else bucket_dev
-            self._ctx._chk(self._L.auvp_prrt_env_step_dev(self._ctx.h, C.c_void_p(b.data_ptr()), *obs))
+        flags = (1 if agent_seed is not None else 0) | (2 if observe == "delta" else 0)
+        b = d["bucket"] if (bucket_dev is None or agent_seed is not None) else bucket_dev
+        self._ctx._chk(self._L.auvp_prrt_env_step_ex_dev(
+            self._ctx.h, flags, int(agent_seed or 0), C.c_void_p(b.data_ptr()),
+            C.c_void_p(d["rrt_grid"].data_ptr()) if observe else None, C.c_void_p(d["has_node"].data_ptr()),
+            C.c_void_p(d["num_nodes"].data_ptr()), C.c_void_p(d["reward"].data_ptr()), C.c_void_p(d["done"].data_ptr())))
         return d
 
     def sync(self):

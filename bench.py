@@ -725,46 +725,53 @@ def bench_rrt_env(local_rank, n_env=512, n_steps=60):
            "envs": n_env, "steps": n_steps, "ms_per_batched_step": 1e3 * dt / n_steps, "buckets": nb,
            "observation_bytes_per_step": int(n_env * nb * (32 + 8 + 8)), "nodes_created": created,
            "note": "includes the numpy policy on the host and the download of the full observation arrays"}
-    # the same environments with NOTHING crossing PCIe (what row f1 is for): two launches per step -- generate_one_node for
-    # every live environment with the stand-in agent's pick made inside the launch and the outcome (reward, done flag) written
-    # by it, then the observation arrays -- enqueued back to back on the planner's stream; one wait at the end
-    env2 = RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=list(range(n_env)), max_nodes=8 * n_steps + 16, freq=10, device=local_rank)
-    env2.reset()
-    d = env2.device_buffers()
+    # the same environments with NOTHING crossing PCIe (what row f1 is for): ONE launch per step -- generate_one_node for every
+    # live environment with the stand-in agent's pick made inside the launch, the outcome (reward, done flag) written by it
+    # and the observation arrays updated in place (a step changes one bucket per environment) -- enqueued back to back on the
+    # planner's stream; one wait at the end.  Beside it: the same loop with the observation arrays rewritten whole every step
+    # (two launches; what the reference env rebuilds after every node), and the one-launch step as a hipGraph of 16 steps.
+    def device_loop(observe, n2, graph_steps=0):
+        env2 = RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=list(range(n_env)), max_nodes=4 * n_steps + 64, freq=10, device=local_rank)
+        env2.reset()
+        d = env2.device_buffers()
 
-    def one_step():
-        env2.step_device(agent_seed=5)
-    for _ in range(3):
-        one_step()
-    env2.sync()
-    n2 = 3 * n_steps
-    t0 = time.perf_counter()
-    dev_ms = env2.timed(lambda: [one_step() for _ in range(n2)])
-    dt2 = time.perf_counter() - t0
-    # ... and the same step captured once as a hipGraph and replayed
-    gid = env2.capture_step(one_step)
-    env2.replay(gid, 3)
-    env2.sync()
-    t0 = time.perf_counter()
-    dev_ms3 = env2.timed(lambda: env2.replay(gid, n2))
-    dt3 = time.perf_counter() - t0
-    live = int((d["done"] == 0).sum().item())
-    nodes = int(d["num_nodes"].sum().item())
-    # algorithmic bytes of one batched step: observation arrays written (32 + 8 + 8 B per bucket) and the bucket counts the
-    # observation kernel reads (4 B) per environment and bucket; the planner step itself (~0.33 KB per
-    # environment) is noise next to them
-    abytes = float(n_env) * nb * (32 + 8 + 8 + 4) + n_env * 330.0
-    out["device_resident"] = {
-        "metric": "RRTEnv steps/s, device-resident loop (planner step with agent + outcome inside, observation kernel; no host transfer)",
-        "value": n_env * n2 / dt2, "unit": "env-steps/s", "envs": n_env, "steps": n2, "ms_per_batched_step": 1e3 * dt2 / n2,
-        "device_ms_per_batched_step": dev_ms / n2, "launches_per_step": 2,
-        "envs_still_running_at_end": live, "nodes_in_all_trees": nodes,
-        "hipgraph_replay": {"value": n_env * n2 / dt3, "unit": "env-steps/s", "ms_per_batched_step": 1e3 * dt3 / n2,
-                            "device_ms_per_batched_step": dev_ms3 / n2,
-                            "note": "the same two-kernel step captured once on the planner's stream and replayed"},
-        "roofline": roofline(abytes, dev_ms / n2, "prrt_kernel (step mode: agent + generate_one_node + outcome) + prrt_observation_kernel",
-                             note="kernel_ms = HIP-event time of the enqueued loop / steps (device time incl. the boundary between "
-                                  "the two dependent launches, not host wall time); the observation write is the only HBM-sized term")}
+        def one_step():
+            env2.step_device(agent_seed=5, observe=observe)
+        for _ in range(3):
+            one_step()
+        env2.sync()
+        if graph_steps:
+            gid = env2.capture_step(lambda: [one_step() for _ in range(graph_steps)])
+            env2.replay(gid, 1)
+            env2.sync()
+            enqueue = lambda: env2.replay(gid, n2 // graph_steps)
+        else:
+            enqueue = lambda: [one_step() for _ in range(n2)]
+        t0 = time.perf_counter()
+        dev_ms = env2.timed(enqueue)
+        wall = time.perf_counter() - t0
+        env2.sync()
+        return {"value": n_env * n2 / wall, "unit": "env-steps/s", "steps": n2, "ms_per_batched_step": 1e3 * wall / n2,
+                "device_ms_per_batched_step": dev_ms / n2, "envs_still_running_at_end": int((d["done"] == 0).sum().item()),
+                "nodes_in_all_trees": int(d["num_nodes"].sum().item())}
+    n2 = 3 * n_steps - (3 * n_steps) % 16
+    one = device_loop("delta", n2)
+    full = device_loop(True, n2)
+    graph = device_loop("delta", n2, graph_steps=16)
+    # algorithmic bytes of one batched step, one-launch form: the planner step (~0.33 KB per environment) + the
+    # changed observation entries (8 + 8 + 8 B) + reward / flags / bucket (8 + 1 + 1 + 4 B); full rewrite: + 52 B per bucket
+    ab_one = n_env * (330.0 + 24 + 14)
+    ab_full = float(n_env) * nb * (32 + 8 + 8 + 4) + n_env * 330.0
+    out["device_resident"] = dict(one, **{
+        "metric": "RRTEnv steps/s, device-resident loop, ONE launch per step (agent + generate_one_node + outcome + in-place observation update)",
+        "envs": n_env, "launches_per_step": 1,
+        "full_observation_rewrite": dict(full, launches_per_step=2,
+                                         roofline=roofline(ab_full, full["device_ms_per_batched_step"], "prrt_kernel (step mode) + prrt_observation_kernel",
+                                                           note="the observation rewrite (49 MB per step) is the HBM-sized term")),
+        "hipgraph_replay": dict(graph, steps_per_graph=16, note="the one-launch step captured 16 x on the planner's stream and replayed"),
+        "roofline": roofline(ab_one, one["device_ms_per_batched_step"], "prrt_kernel<4,true> (step mode: agent + generate_one_node + outcome + observation delta)",
+                             note="kernel_ms = HIP-event time of the enqueued loop / steps (device time, not host wall time); 512 waves, "
+                                  "one dependent fp64 chain each: a latency figure")})
     return out
 
 

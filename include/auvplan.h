@@ -182,18 +182,28 @@ int auvp_prrt_observation(auvp_handle* h, int32_t episode, double* rrt_grid, int
  * finished or that the caller skipped with -1 (neither is touched; a skipped one keeps its done flag), done_dev [E] u8
  * (may be NULL).  An episode that fails on the device (tree / point capacity, a bucket id outside the grid) is flagged
  * done, rewarded 0 and reported by auvp_prrt_env_check -- the host loop (auvp_prrt_step) shows the same failure as
- * summary.status < 0.  Two launches per step (the outcome is written by the planner launch itself).  Only ENQUEUES on the
+ * summary.status < 0.  Two launches per step (the outcome is written by the planner launch itself, the observation arrays
+ * by a second one; see AUVP_ENV_OBS_DELTA below for one).  Only ENQUEUES on the
  * handle's stream: follow with auvp_stream_sync (or order other work on auvp_stream) before reading results. */
 int auvp_prrt_env_step_dev(auvp_handle* h, const int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev,
                            void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev);
-/* the same step with the stand-in agent of auvp_prrt_policy_random_dev INSIDE the planner launch: bucket_ids_dev [E]
- * receives what it picked (still two launches per step; measurements and tests of the device-resident loop) */
-int auvp_prrt_env_step_agent_dev(auvp_handle* h, uint64_t seed, int32_t* bucket_ids_dev, void* rrt_grid_dev, void* has_node_dev,
-                                 void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev);
+/* the same step with options (flags):
+ *   AUVP_ENV_AGENT      the stand-in agent of auvp_prrt_policy_random_dev picks INSIDE the planner launch; bucket_ids_dev [E]
+ *                       is then an OUTPUT (what it picked, -1 for finished environments)
+ *   AUVP_ENV_OBS_DELTA  rrt_grid_dev / has_node_dev / num_nodes_dev hold the observation of the previous step (or of
+ *                       auvp_prrt_observation_dev after the reset) and are UPDATED IN PLACE by the planner launch: a step adds
+ *                       at most one node per environment, so one bucket's len(node_array) / has_node / node count changes
+ *                       (rrt_env.py:250-295 rebuilds all three lists after every node) -- ONE launch per environment step
+ * flags = 0 is auvp_prrt_env_step_dev. */
+#define AUVP_ENV_AGENT 1
+#define AUVP_ENV_OBS_DELTA 2
+int auvp_prrt_env_step_ex_dev(auvp_handle* h, int32_t flags, uint64_t agent_seed, int32_t* bucket_ids_dev, void* rrt_grid_dev,
+                              void* has_node_dev, void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev);
 /* stand-in agent for device-resident runs as a launch of its own: every live environment picks, uniformly, one of its
  * occupied buckets -- read from the planner's own list of occupied buckets, the set the observation's has_node array marks
  * (rrt_env.py:250-265); has_node_dev is accepted for compatibility and not read -- finished environments get -1; its
- * randomness is its own (counter-based on `seed`), not the planner's stream.  Enqueues only. */
+ * randomness is its own (counter-based on `seed`, the environment and the environment's step count), not the planner's
+ * stream.  Enqueues only. */
 int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uint64_t seed, int32_t* bucket_ids_dev);
 /* waits for the stream, then: *status = status (< 0) of the first episode that failed on the device inside the
  * device-resident loop since the batch was created, *env (may be NULL) = its index; 0 = none */
@@ -208,7 +218,7 @@ int auvp_stream_mark(auvp_handle* h, int32_t which);
 int auvp_stream_elapsed_ms(auvp_handle* h, double* ms);
 /* hipGraph capture of a launch-bound step loop: everything the enqueue-only entry points (auvp_prrt_policy_random_dev,
  * auvp_prrt_env_step_dev, the caller's own kernels on auvp_stream) put on the stream between begin and end is recorded
- * instead of run; auvp_graph_launch replays it n_times back to back (enqueue only).  The loop's step counter lives in
+ * instead of run; auvp_graph_launch replays it n_times back to back (enqueue only).  Every environment's step count lives in
  * HBM, so every replay of the stand-in agent draws anew.  Run one un-captured step first.  A graph holds the device
  * pointers of the batch (and of the caller's arrays) it was captured with: creating a new batch (auvp_prrt_create_batch,
  * auvp_prrt_replan_particles) destroys the handle's graphs, and auvp_graph_launch of such an id fails with AUVP_ERR_STATE. */

@@ -188,42 +188,48 @@ def _small_env(E=16, max_nodes=100, seeds=None):
     return RRTEnvBatch(auv, shark, bnd, 5, 1, obstacles, seeds=seeds or list(range(E)), max_nodes=max_nodes, freq=10)
 
 
-def test_agent_inside_the_step_launch_equals_agent_as_its_own_launch():
-    """auvp_prrt_env_step_agent_dev (the stand-in agent picks inside the planner launch: two launches per step) against
-    policy_random_device + step_device (three): same picks, rewards, flags, observations and trees, eager and as a graph"""
-    n_steps = 70
+def test_one_launch_step_equals_the_three_launch_step():
+    """The device-resident step in its forms -- agent as its own launch + planner step + observation rewrite (three launches);
+    agent inside the planner launch (two); agent inside and the observation arrays updated in place by the planner launch
+    (one: a step changes one bucket per environment); the one-launch step captured as a hipGraph, one and eight steps per
+    graph -- gives the same picks, rewards, flags, observation arrays and trees"""
+    n_steps = 73
     out = []
-    for fused, graph in ((False, False), (True, False), (True, True)):
+    for fused, observe, graph in ((False, True, 0), (True, True, 0), (True, "delta", 0), (True, "delta", 1), (True, "delta", 8)):
         env = _small_env(E=24, max_nodes=n_steps + 8)
         env.reset()
         d = env.device_buffers()
 
         def one_step():
             if fused:
-                env.step_device(agent_seed=11)
+                env.step_device(agent_seed=11, observe=observe)
             else:
                 env.policy_random_device(seed=11)
-                env.step_device()
+                env.step_device(observe=observe)
         one_step()
+        env.sync()
         picks = [d["bucket"].cpu().numpy().copy()]
         if graph:
-            gid = env.capture_step(one_step)
-            env.replay(gid, n_steps - 1)
+            gid = env.capture_step(lambda: [one_step() for _ in range(graph)])
+            assert (n_steps - 1) % graph == 0
+            env.replay(gid, (n_steps - 1) // graph)
         else:
             for _ in range(n_steps - 1):
                 one_step()
-                if not graph:
-                    env.sync()
-                    picks.append(d["bucket"].cpu().numpy().copy())
+                env.sync()
+                picks.append(d["bucket"].cpu().numpy().copy())
         env.sync()
         out.append((d["num_nodes"].cpu().numpy().copy(), d["reward"].cpu().numpy().copy(), d["done"].cpu().numpy().copy(),
-                    d["rrt_grid"].cpu().numpy().copy(), [env.tree(e)["nodes"] for e in (0, 23)], picks))
-    a, b, c = out
+                    d["rrt_grid"].cpu().numpy().copy(), d["has_node"].cpu().numpy().copy(), [env.tree(e)["nodes"] for e in (0, 23)], picks))
+    a = out[0]
     assert a[0].sum() > 24 * 5
-    for x in (b, c):
-        assert np.array_equal(a[0], x[0]) and np.array_equal(a[1], x[1]) and np.array_equal(a[2], x[2]) and np.array_equal(a[3], x[3])
-        assert all(np.array_equal(p, q) for p, q in zip(a[4], x[4]))
-    assert all(np.array_equal(p, q) for p, q in zip(a[5], b[5]))   # the agent's picks, step by step
+    assert np.array_equal(a[4], (a[0] > 0).astype(np.int64)) and np.array_equal(a[3][:, :, 3], a[0].astype(np.float64))
+    for x in out[1:]:
+        for k in range(5):
+            assert np.array_equal(a[k], x[k]), k
+        assert all(np.array_equal(p, q) for p, q in zip(a[5], x[5]))
+    for x in out[1:3]:
+        assert len(x[6]) == n_steps and all(np.array_equal(p, q) for p, q in zip(a[6], x[6]))   # the agent's picks, step by step
 
 
 def test_skipped_and_failed_environments_in_the_device_loop():
@@ -266,7 +272,7 @@ def test_graphs_die_with_their_batch_and_modes_do_not_mix():
     env.reset()
 
     def one_step():
-        env.step_device(agent_seed=3)
+        env.step_device(agent_seed=3, observe="delta")
     one_step()
     gid = env.capture_step(one_step)
     env.replay(gid, 3)
@@ -280,7 +286,7 @@ def test_graphs_die_with_their_batch_and_modes_do_not_mix():
     assert rc == -4                                      # ... and the library destroyed the graph (AUVP_ERR_STATE)
     st, reward, done, _ = env.step(np.array([int(np.flatnonzero(h)[0]) for h in env.state["has_node"]]))
     with pytest.raises(RuntimeError):
-        env.step_device(agent_seed=3)                    # device stepping inside a host episode
+        env.step_device(agent_seed=3, observe="delta")   # device stepping inside a host episode
     env.reset()
     one_step()                                           # a fresh episode may choose again
     gid2 = env.capture_step(one_step)
