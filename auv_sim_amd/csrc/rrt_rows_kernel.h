@@ -265,6 +265,18 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       if (!__any(on)) break;
       const int n = on ? ((n_total - c0) < RW_C ? (n_total - c0) : RW_C) : 0;
       const int nwin = 3 * n;
+#ifdef AUVP_ROWS_PAD
+      // EXPERIMENT ONLY (tools/rows_pass_probe.py, profiles/r4_rows_packing.md; never defined in the product build): AUVP_ROWS_PAD
+      // extra vector instructions per steer pass -- independent fp64 adds on four registers, results unused -- to measure what
+      // a pass can afford to carry before packing the rows' sub-arcs stops paying
+      {
+        double pd0 = cth, pd1 = cx, pd2 = cy, pd3 = ctt;
+#pragma unroll
+        for (int q = 0; q < AUVP_ROWS_PAD / 4; q++)
+          asm volatile("v_add_f64 %0, %0, 1.0\n\tv_add_f64 %1, %1, 1.0\n\tv_add_f64 %2, %2, 1.0\n\tv_add_f64 %3, %3, 1.0"
+                       : "+v"(pd0), "+v"(pd1), "+v"(pd2), "+v"(pd3));
+      }
+#endif
       const int b0 = first_pass ? base : 0;  // later passes start at the (advanced) head of the stream
       if (pass != 0) make_window(on, nwin, b0);
       // "taken" predicate for every possible start offset, 48 bits per row

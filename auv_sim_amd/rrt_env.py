@@ -245,9 +245,9 @@ class RRTEnvBatch:
 
     def replay(self, graph_id, n_times=1):
         """n_times replays of a captured step, back to back on the planner's stream (enqueue only)"""
-        self._enter("device")
         if int(graph_id) not in self._graphs:
             raise _lib.AuvpError(-4, "graph %d was not captured since the last reset()" % int(graph_id))
+        self._enter("device")
         self._ctx._chk(self._L.auvp_graph_launch(self._ctx.h, int(graph_id), int(n_times)))
 
     def tree(self, e):
