@@ -356,6 +356,70 @@ __device__ __forceinline__ void cost_accumulate(int n_valid, double tv, int hab,
   wave_sync();
 }
 
+// cost_element in two halves, for callers that evaluate several elements per lane (the leaf pass): cost_pre does the index
+// arithmetic (time bin, cell, habitat-mask cell; LDS tables only when grid_lds is given), the CALLER then issues the two
+// global reads of every element back to back -- prob[tb][c] and the habitat mask word -- and cost_post finishes.  Same
+// decisions and the same floats as cost_element (which stays the one-element form).
+struct CostPre {
+  int tb, c, midx;  // time bin (-1: none: the element is skipped), cell (-1: none), habitat-mask cell (-1: outside / no mask grid)
+};
+__device__ __forceinline__ CostPre cost_pre(const WorldDev& W, const RrtTables& S, int bin_lo, int bin_hi, double x, double y, double t,
+                                            const double* grid_lds) {
+  CostPre q;
+  q.tb = -1; q.c = -1; q.midx = -1;
+  if (W.bins_sorted) {
+    if (bin_hi > bin_lo) {
+      int i = (int)auvp_floor((t - W.bins_t1_0) * W.bins_inv_len) + 1;
+      i = i < bin_lo ? bin_lo : (i > bin_hi - 1 ? bin_hi - 1 : i);
+      const double2 bi = *reinterpret_cast<const double2*>(&S.bins[i][0]);
+      const double pm = i > bin_lo ? S.bins[i - 1][1] : -__builtin_inf();
+      if (pm < t && bi.y >= t) {
+        if (bi.x <= t) q.tb = i;
+      } else {
+        while (i > bin_lo && S.bins[i - 1][1] >= t) i--;
+        while (i < bin_hi && S.bins[i][1] < t) i++;
+        if (i < bin_hi && S.bins[i][0] <= t) q.tb = i;
+      }
+    }
+  } else {
+    for (int b = bin_hi - 1; b >= bin_lo; b--) {
+      const double2 r = *reinterpret_cast<const double2*>(&S.bins[b][0]);
+      q.tb = (t >= r.x && t <= r.y) ? b : q.tb;
+    }
+  }
+  if (q.tb >= 0) {
+    q.c = cell_lookup(W, x, y, grid_lds);
+    if (W.hg_n > 0) {
+      const double fx = auvp_floor((x - W.hg_x0) * W.hg_inv_w), fy = auvp_floor((y - W.hg_y0) * W.hg_inv_h);
+      if (fx >= 0.0 && fy >= 0.0 && fx < (double)W.hg_n && fy < (double)W.hg_n) q.midx = (int)fy * W.hg_n + (int)fx;
+    }
+  }
+  return q;
+}
+__device__ __forceinline__ void cost_post(const WorldDev& W, const RrtTables& S, double w3, double x, double y, const CostPre& q,
+                                          double prob, unsigned long long m, double& tv, int& hab) {
+  tv = 0.0;
+  hab = -1;
+  if (q.tb >= 0) {
+    if (q.c >= 0) tv = w3 * prob;
+    if (W.hg_n > 0) {
+      while (m) {
+        const int h = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        const double2 hxy = *reinterpret_cast<const double2*>(&S.hab[h][0]);
+        const double ddx = hxy.x - x, ddy = hxy.y - y;
+        if (ddx * ddx + ddy * ddy <= S.hab[h][3]) { hab = h; break; }
+      }
+    } else {
+      for (int h = W.n_habitats - 1; h >= 0; h--) {
+        const double2 hxy = *reinterpret_cast<const double2*>(&S.hab[h][0]);
+        const double ddx = hxy.x - x, ddy = hxy.y - y;
+        hab = (ddx * ddx + ddy * ddy <= S.hab[h][3]) ? h : hab;
+      }
+    }
+  }
+}
+
 // evaluate + accumulate up to 64 elements given by value (the standalone cost probe)
 __device__ __forceinline__ void cost_pass(const WorldDev& W, const RrtTables& S, int bin_lo, int bin_hi, double w3,
                                           int n_valid, double x, double y, double t, double* term, CostAcc& acc) {
@@ -1115,8 +1179,21 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
       if (j0 + 128 < n_slots) { sa = fetch(j0 + 128 + lane); sb = fetch(j0 + 192 + lane); }
       double tva = 0.0, tvb = 0.0;
       int haba = -1, habb = -1;
-      if (ca.v) cost_element(W, St, 0, W.n_bins, P.w[2], ca.xy.x, ca.xy.y, ca.t, tva, haba, true, grid_lds);
-      if (cb.v) cost_element(W, St, 0, W.n_bins, P.w[2], cb.xy.x, cb.xy.y, cb.t, tvb, habb, true, grid_lds);
+      {
+        // both elements' index arithmetic first, then their four dependent global reads (prob, habitat mask) back to back
+        CostPre qa, qb;
+        qa.tb = -1; qa.c = -1; qa.midx = -1; qb = qa;
+        if (ca.v) qa = cost_pre(W, St, 0, W.n_bins, ca.xy.x, ca.xy.y, ca.t, grid_lds);
+        if (cb.v) qb = cost_pre(W, St, 0, W.n_bins, cb.xy.x, cb.xy.y, cb.t, grid_lds);
+        double pra = 0.0, prb = 0.0;
+        unsigned long long mka = 0ull, mkb = 0ull;
+        if (qa.c >= 0) pra = W.prob[(size_t)qa.tb * W.n_cells + qa.c];
+        if (qb.c >= 0) prb = W.prob[(size_t)qb.tb * W.n_cells + qb.c];
+        if (qa.midx >= 0) mka = W.hg_mask[qa.midx];
+        if (qb.midx >= 0) mkb = W.hg_mask[qb.midx];
+        cost_post(W, St, P.w[2], ca.xy.x, ca.xy.y, qa, pra, mka, tva, haba);
+        cost_post(W, St, P.w[2], cb.xy.x, cb.xy.y, qb, prb, mkb, tvb, habb);
+      }
       if (ca.v) {
         if (tva != 0.0) atomicAdd(&c_S[ca.o], tva);
         if (haba >= 0) { atomicAdd(&c_hits[ca.o], 1); atomicOr(&c_vis[ca.o], 1ull << haba); }
