@@ -30,6 +30,7 @@ namespace auvp {
 constexpr int PRW_WAVES = 4;       // waves per workgroup (16 episodes in flight per workgroup)
 constexpr int PRW_MAX_FREQ = 15;   // sub-arcs of a steer: lanes 0..14 of the row (lane 15: the parent's end / entry angle)
 constexpr int PRW_LDS_PER_EP = 624 * 4;
+constexpr int PRW_NO_ARC = -0x7fffffff;
 
 __device__ __forceinline__ uint32_t rows_word(const RowRng& r, uint32_t j) {
   uint32_t k = r.pslot + j;  // pslot < 624, j < avail <= 624: one wrap
@@ -63,8 +64,11 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
   int ep = -1;
   bool live = false, more = true;
   int n_nodes = 0, n_points = 0, n_occ = 0, step = 0, done = 0, status = 0, last_accepted = 0, last_new = -1;
-  int prev_n_arc = -1, step_end = 0, step_bucket = 0;
-  bool have_prev_arc = false;
+  // prev_n_arc: the goal arc's sample count of the episode's previous step; PRW_NO_ARC = none evaluated yet.  In step mode a
+  // row is done with its episode after ONE trip (`stepped`): no end-of-step counter, and the caller's bucket is read where it
+  // is used -- three row-uniform registers fewer across the step than rounds 3's step_end / step_bucket / have_prev_arc
+  int prev_n_arc = PRW_NO_ARC;
+  bool stepped = false;
 
   for (;;) {
     // ---------------------------------------------------------------- rows without an episode take the next one
@@ -78,9 +82,8 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         if (e >= n_episodes) { more = false; }
         else {
           ep = e;
-          step_bucket = P.step_mode ? B.step_bucket[e] : 0;
           // step mode: an episode whose bucket is < 0 is not touched at all
-          skip = P.step_mode && step_bucket < 0;
+          skip = P.step_mode && B.step_bucket[e] < 0;
         }
       }
       const bool load = need && more && !skip;
@@ -98,8 +101,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
             const int32_t* og = B.occupied + (size_t)ep * capn;
             for (int i = rl; i < n_occ; i += 16) occl[i] = (uint16_t)og[i];
           }
-          last_accepted = 0; last_new = -1; prev_n_arc = -1; have_prev_arc = false;
-          step_end = P.step_mode ? step + 1 : P.max_step;
+          last_accepted = 0; last_new = -1; prev_n_arc = PRW_NO_ARC; stepped = false;
           // whole 16-word blocks are regenerated in place (rrt_rows_kernel.h): the frontier must sit on a block boundary,
           // which every state this kernel or the host's seeding writes does
           if (((rng.pslot + rng.avail) & 15u) != 0u) status = -7;
@@ -117,14 +119,11 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
     auto epq = [&]() { int v = ep < 0 ? 0 : ep; asm volatile("" : "+v"(v)); return (size_t)v; };
 #define en (epq() * (size_t)capn)
 #define eb (epq() * (size_t)P.n_buckets)
-#define nodeF (B.node_f + en * 4)
-#define nodeI (reinterpret_cast<int4*>(B.node_i) + en)
-#define nnext (B.node_next + en)
-#define bcount (B.bucket_counts + eb)
-#define bhead (B.bucket_head + eb)
+#define nodes (B.nodes + en)
+#define buckets (B.buckets + eb)
 
     // a row takes part in this step if its episode is still running
-    bool act = live && status == 0 && !done && step < step_end;
+    bool act = live && status == 0 && !done && (P.step_mode ? !stepped : step < P.max_step);
 
     // per-row _randbelow(n): getrandbits(bit_length(n)) until < n, one 32-bit output per try; lanes 0..7 try eight at once
     auto randbelow = [&](bool on, uint32_t n) -> uint32_t {
@@ -151,7 +150,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       // ---------------------------------------------------------------- bucket + node choice (:186, :214-223)
       int b = 0;
       if (P.step_mode) {
-        b = step_bucket;
+        if (act) b = B.step_bucket[ep];
         if (act && b >= P.n_buckets) { status = -1; act = false; }
       } else {
         if (act && n_occ == 0) { status = -1; act = false; }
@@ -159,26 +158,26 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         if (act) b = occ_bytes ? (int)occl[oi] : B.occupied[en + oi];
       }
       int cnt_b = 0, head_b = 0;
-      if (act) { cnt_b = bcount[b]; head_b = bhead[b]; }
+      if (act) { const int2 bw = buckets[b]; cnt_b = prrt_bucket_count(bw, B.bucket_epoch); head_b = bw.y; }
       last_accepted = act ? 0 : last_accepted;
       last_new = act ? -1 : last_new;
       // generate_one_node on an empty bucket: (False, None) (:214-220): the step is used up, nothing else happens
       const bool empty_b = act && cnt_b == 0;
-      if (empty_b) { step++; act = false; }
+      if (empty_b) { step++; stepped = true; act = false; }
       const uint32_t rsel = randbelow(act, (uint32_t)cnt_b);
       // the rsel-th member of the bucket in creation order is count - 1 - rsel steps from the head of its list
       int par = act ? head_b : 0;
       {
         int hops = act ? cnt_b - 1 - (int)rsel : 0;
         while (__any(hops > 0)) {
-          if (hops > 0) { par = nnext[par]; hops--; }
+          if (hops > 0) { par = nodes[par].next; hops--; }
         }
       }
       // ---------------------------------------------------------------- steer (:251-289)
       double cx = 0.0, cy = 0.0, cth = 0.0, ctt = 0.0;
       if (act) {
-        const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 4);
-        const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 4 + 2);
+        const double2 a = *reinterpret_cast<const double2*>(&nodes[par].x);
+        const double2 c = *reinterpret_cast<const double2*>(&nodes[par].theta);
         cx = a.x; cy = a.y; cth = c.x; ctt = c.y;
       }
       const double px0 = cx, py0 = cy;
@@ -252,8 +251,9 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       const bool wr = taken && act;
       if (wr) {
         const int rank = __popc(tmask & ((1u << rl) - 1u));
-        const size_t gi = (size_t)ep * capp * 4 + (size_t)(n_points + rank);  // speculative: kept only if the node is accepted
-        B.points[gi] = mx; B.points[gi + capp] = my; B.points[gi + 2 * capp] = th; B.points[gi + 3 * capp] = mtt;
+        // speculative: kept only if the node is accepted.  One 32-byte record per point, a steer's points contiguous
+        double2* pr = reinterpret_cast<double2*>(B.points + ((size_t)ep * capp + (size_t)(n_points + rank)) * 4);
+        pr[0] = make_double2(mx, my); pr[1] = make_double2(th, mtt);
       }
       // the row's state after the steer = the prefix values of its last sub-arc
       // (sin, cos of the row's final angle -- lane n - 1's, or the entry angle's on lane 15 for a steer without sub-arcs --
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           pre_bk = (rrow * P.cols + col) * P.S + sub;
         }
         if (pre_err) pre_bk = -1;
-        if (pre_bk >= 0) { pre_c = bcount[pre_bk]; pre_h = bhead[pre_bk]; }
+        if (pre_bk >= 0) { const int2 bw = buckets[pre_bk]; pre_c = prrt_bucket_count(bw, B.bucket_epoch); pre_h = bw.y; }
       }
 
       // ---------------------------------------------------------------- check_collision_free (:435-458)
@@ -352,20 +352,22 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         if (pre_err) { status = -1; ok = false; act = false; }
         else {
           const int bk = pre_bk, c_before = pre_c, h_before = pre_h;
-          if (rl == 0) {
-            double* nf = nodeF + (size_t)me * 4;
-            *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
-            *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
-            nodeI[me] = make_int4(step, par, n_points, cnt);
-            B.node_bucket[en + me] = bk;
-            if (bk >= 0) {
-              nnext[me] = c_before > 0 ? h_before : -1;
-              bhead[bk] = me;
-              bcount[bk] = c_before + 1;
-              if (c_before == 0) {  // first node of the bucket (:157-159)
-                B.occupied[en + n_occ] = bk;
-                if (occ_bytes) occl[n_occ] = (uint16_t)bk;
-              }
+          if (rl < 4) {
+            // the node's 64-byte record: lanes 0..3 of the row store one 16-byte quarter each -- ONE store instruction and one
+            // full line per accepted node (rounds 1-3: seven stores into six arrays)
+            const int nx = (bk >= 0 && c_before > 0) ? h_before : -1;
+            int4 q;
+            if (rl == 0) q = make_int4(__double2loint(cx), __double2hiint(cx), __double2loint(cy), __double2hiint(cy));
+            else if (rl == 1) q = make_int4(__double2loint(cth), __double2hiint(cth), __double2loint(ctt), __double2hiint(ctt));
+            else if (rl == 2) q = make_int4(step, par, n_points, cnt);
+            else q = make_int4(bk, nx, 0, 0);
+            reinterpret_cast<int4*>(&nodes[me])[rl] = q;
+          }
+          if (rl == 0 && bk >= 0) {
+            buckets[bk] = prrt_bucket_word(c_before + 1, me, B.bucket_epoch);
+            if (c_before == 0) {  // first node of the bucket (:157-159)
+              B.occupied[en + n_occ] = bk;
+              if (occ_bytes) occl[n_occ] = (uint16_t)bk;
             }
           }
           if (c_before == 0) n_occ++;
@@ -379,10 +381,10 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       // step's evaluation, which was "not free" (or planning would have ended): its result is reused
       const int lastn = n_nodes - 1;
       double lx = cx, ly = cy, th0 = cth;
-      const bool eval = act && (ok || !have_prev_arc);
+      const bool eval = act && (ok || prev_n_arc == PRW_NO_ARC);
       if (eval && !ok) {
-        const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)lastn * 4);
-        lx = a.x; ly = a.y; th0 = nodeF[(size_t)lastn * 4 + 2];
+        const double2 a = *reinterpret_cast<const double2*>(&nodes[lastn].x);
+        lx = a.x; ly = a.y; th0 = nodes[lastn].theta;
       }
       int n_arc = act ? prev_n_arc : -1;
       bool free_ = false;
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           bool walking = true;
           while (__any(walking)) {
             if (walking) {
-              const int4 r = nodeI[m];
+              const int4 r = *reinterpret_cast<const int4*>(&nodes[m].step);
               if (r.y < 0) walking = false;
               else { L += r.w + 1; m = r.y; }
             }
@@ -465,11 +467,11 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           }
         }
       }
-      if (act) { prev_n_arc = n_arc; have_prev_arc = true; step++; }
+      if (act) { prev_n_arc = n_arc; stepped = true; step++; }
     }
 
     // ---------------------------------------------------------------- rows whose episode is finished store it
-    const bool fin = live && (status != 0 || done || step >= step_end);
+    const bool fin = live && (status != 0 || done || (P.step_mode ? stepped : step >= P.max_step));
     if (__any(fin)) {
       const unsigned long long drawn = rng.drawn;
       wave_sync();
@@ -502,10 +504,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
 
 #undef en
 #undef eb
-#undef nodeF
-#undef nodeI
-#undef nnext
-#undef bcount
-#undef bhead
+#undef nodes
+#undef buckets
 }  // namespace auvp
 #endif

@@ -12,8 +12,13 @@ struct PrrtState {
   int E = 0;
   auvp::PrrtParamsDev P{};
   auvp::PrrtBuffers B{};
-  DevBuf node_f, node_i, node_bucket, points, occupied, bcount, bhead, nnext, mt, rng_state, start, goal, step_bucket, summary, st_log,
+  DevBuf nodes, node_bucket, points, occupied, buckets, mt, rng_state, start, goal, step_bucket, summary, st_log,
       tmp_off, tmp_out, env_done, thetas;
+  // the bucket table's current epoch (PrrtBuffers::bucket_epoch): a new batch on the same allocation takes the next one; the
+  // table is cleared when the allocation changes or the 8-bit tag would wrap
+  int bucket_epoch = 0;
+  void* bucket_alloc = nullptr;
+  size_t bucket_alloc_bytes = 0;
   DevBuf work;  // work counter of the four-episodes-per-wavefront kernel (planner_rows_kernel.h)
   bool use_rows = false;  // decided once per batch: the two kernels keep the generator's lazy state in different block phases
   const char* last_kernel = "";
@@ -132,24 +137,21 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
   double cp = (double)p->max_step * (double)(nfreq > 0 ? nfreq : 1) + 64;  // every taken sub-arc is stored
   if (cp > 2.0e9) return fail(h, AUVP_ERR_ARG, "point capacity too large");
   B.cap_points = (int32_t)cp;
+  if (B.cap_nodes >= (1 << 24)) return fail(h, AUVP_ERR_ARG, "max_step %d: a bucket's size is kept in 24 bits", p->max_step);
   const size_t cn = (size_t)E * B.cap_nodes;
-  HIPCHK(h, S.node_f.reserve(cn * 4 * sizeof(double)));
-  HIPCHK(h, S.node_i.reserve(cn * 4 * sizeof(int32_t)));
+  HIPCHK(h, S.nodes.reserve(cn * sizeof(auvp::PrrtNode)));
   HIPCHK(h, S.node_bucket.reserve(cn * sizeof(int32_t)));
   HIPCHK(h, S.points.reserve((size_t)E * B.cap_points * 4 * sizeof(double)));
   HIPCHK(h, S.occupied.reserve(cn * sizeof(int32_t)));
-  HIPCHK(h, S.bcount.reserve((size_t)E * P.n_buckets * sizeof(int32_t)));
-  HIPCHK(h, S.bhead.reserve((size_t)E * P.n_buckets * sizeof(int32_t)));
-  HIPCHK(h, S.nnext.reserve(cn * sizeof(int32_t)));
+  HIPCHK(h, S.buckets.reserve((size_t)E * P.n_buckets * sizeof(int2)));
   HIPCHK(h, S.mt.reserve((size_t)E * 624 * sizeof(uint32_t)));
   HIPCHK(h, S.rng_state.reserve((size_t)E * 4 * sizeof(int32_t)));
   HIPCHK(h, S.summary.reserve((size_t)E * sizeof(auvp::PrrtSummary)));
   HIPCHK(h, S.step_bucket.reserve((size_t)E * sizeof(int32_t)));
   HIPCHK(h, S.start.reserve((size_t)E * 4 * sizeof(double)));
   HIPCHK(h, S.goal.reserve((size_t)E * 2 * sizeof(double)));
-  B.node_f = S.node_f.as<double>(); B.node_i = S.node_i.as<int32_t>(); B.node_bucket = S.node_bucket.as<int32_t>();
-  B.points = S.points.as<double>(); B.occupied = S.occupied.as<int32_t>(); B.bucket_counts = S.bcount.as<int32_t>();
-  B.bucket_head = S.bhead.as<int32_t>(); B.node_next = S.nnext.as<int32_t>();
+  B.nodes = S.nodes.as<auvp::PrrtNode>(); B.node_bucket = S.node_bucket.as<int32_t>();
+  B.points = S.points.as<double>(); B.occupied = S.occupied.as<int32_t>(); B.buckets = S.buckets.as<int2>();
   B.mt = S.mt.as<uint32_t>(); B.rng_state = S.rng_state.as<int32_t>(); B.summary = S.summary.as<auvp::PrrtSummary>();
   B.step_bucket = S.step_bucket.as<int32_t>();
   B.start = S.start.as<double>(); B.goal = S.goal.as<double>();
@@ -180,7 +182,17 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
 // mps_list = [start]; add_node_to_grid(start)  (:53,:108-159): one thread per episode places the start node with the
 // kernel's own add_node_to_grid arithmetic (starts / goals / generator states are already on the device)
 static int prrt_plant(auvp_handle* h, PrrtState& S, int32_t E) {
-  HIPCHK(h, hipMemsetAsync(S.bcount.p, 0, (size_t)E * S.P.n_buckets * sizeof(int32_t), h->stream));
+  {
+    // every bucket of the new batch is empty: a fresh epoch does that without touching the table (E x n_buckets x 8 bytes);
+    // the table itself is cleared when its allocation changed or the 8-bit tag wraps (tag 0 is never current)
+    const size_t need = (size_t)E * S.P.n_buckets * sizeof(int2);
+    if (S.bucket_alloc != S.buckets.p || need > S.bucket_alloc_bytes || S.bucket_epoch >= 255) {
+      HIPCHK(h, hipMemsetAsync(S.buckets.p, 0, need, h->stream));
+      S.bucket_alloc = S.buckets.p; S.bucket_alloc_bytes = need; S.bucket_epoch = 0;
+    }
+    S.bucket_epoch++;
+    S.B.bucket_epoch = S.bucket_epoch;
+  }
   HIPCHK(h, S.env_done.reserve((size_t)E));
   HIPCHK(h, hipMemsetAsync(S.env_done.p, 0, (size_t)E, h->stream));
   HIPCHK(h, S.env_err.reserve(2 * sizeof(int32_t)));
@@ -294,16 +306,17 @@ int auvp_prrt_tree(auvp_handle* h, int32_t ep, double* nodes4, int32_t* node_i4,
   auvp::PrrtSummary s;
   HIPCHK(h, hipMemcpy(&s, S.B.summary + ep, sizeof s, hipMemcpyDeviceToHost));
   const size_t N = (size_t)s.n_nodes, NP = (size_t)s.n_points, capp = (size_t)S.B.cap_points;
-  if (nodes4) HIPCHK(h, hipMemcpy(nodes4, S.B.node_f + (size_t)ep * S.B.cap_nodes * 4, N * 4 * sizeof(double), hipMemcpyDeviceToHost));
-  if (node_i4) HIPCHK(h, hipMemcpy(node_i4, S.B.node_i + (size_t)ep * S.B.cap_nodes * 4, N * 4 * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (node_bucket) HIPCHK(h, hipMemcpy(node_bucket, S.B.node_bucket + (size_t)ep * S.B.cap_nodes, N * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (points4 && NP) {
-    std::vector<double> col(NP);
-    for (int c = 0; c < 4; c++) {
-      HIPCHK(h, hipMemcpy(col.data(), S.B.points + ((size_t)ep * 4 + c) * capp, NP * sizeof(double), hipMemcpyDeviceToHost));
-      for (size_t i = 0; i < NP; i++) points4[4 * i + c] = col[i];
+  if (nodes4 || node_i4 || node_bucket) {
+    std::vector<auvp::PrrtNode> rec(N);
+    HIPCHK(h, hipMemcpy(rec.data(), S.B.nodes + (size_t)ep * S.B.cap_nodes, N * sizeof(auvp::PrrtNode), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+      const auvp::PrrtNode& r = rec[i];
+      if (nodes4) { nodes4[4 * i] = r.x; nodes4[4 * i + 1] = r.y; nodes4[4 * i + 2] = r.theta; nodes4[4 * i + 3] = r.t; }
+      if (node_i4) { node_i4[4 * i] = r.step; node_i4[4 * i + 1] = r.parent; node_i4[4 * i + 2] = r.pt_off; node_i4[4 * i + 3] = r.pt_cnt; }
+      if (node_bucket) node_bucket[i] = r.bucket;
     }
   }
+  if (points4 && NP) HIPCHK(h, hipMemcpy(points4, S.B.points + (size_t)ep * capp * 4, NP * 4 * sizeof(double), hipMemcpyDeviceToHost));
   return AUVP_OK;
 }
 
@@ -317,20 +330,16 @@ int auvp_prrt_node(auvp_handle* h, int32_t ep, int32_t node, double* node4, int3
   if (node < 0 || node >= S.B.cap_nodes) return fail(h, AUVP_ERR_ARG, "node %d outside 0..%d", node, S.B.cap_nodes - 1);
   HIPCHK(h, hipSetDevice(h->device));
   const size_t at = (size_t)ep * S.B.cap_nodes + (size_t)node, capp = (size_t)S.B.cap_points;
-  int32_t ni[4];
-  HIPCHK(h, hipMemcpy(ni, S.B.node_i + at * 4, sizeof ni, hipMemcpyDeviceToHost));
-  if (node4) HIPCHK(h, hipMemcpy(node4, S.B.node_f + at * 4, 4 * sizeof(double), hipMemcpyDeviceToHost));
-  if (node_i4) memcpy(node_i4, ni, sizeof ni);
-  if (node_bucket) HIPCHK(h, hipMemcpy(node_bucket, S.B.node_bucket + at, sizeof(int32_t), hipMemcpyDeviceToHost));
-  const int off = ni[2], cnt = ni[3];
+  auvp::PrrtNode r;
+  HIPCHK(h, hipMemcpy(&r, S.B.nodes + at, sizeof r, hipMemcpyDeviceToHost));
+  if (node4) { node4[0] = r.x; node4[1] = r.y; node4[2] = r.theta; node4[3] = r.t; }
+  if (node_i4) { node_i4[0] = r.step; node_i4[1] = r.parent; node_i4[2] = r.pt_off; node_i4[3] = r.pt_cnt; }
+  if (node_bucket) *node_bucket = r.bucket;
+  const int off = r.pt_off, cnt = r.pt_cnt;
   if (points4 && cnt > 0) {
     if (cnt > cap_points) return fail(h, AUVP_ERR_CAPACITY, "node has %d points, buffer holds %d", cnt, cap_points);
     if (off < 0 || (size_t)off + (size_t)cnt > capp) return fail(h, AUVP_ERR_STATE, "node record out of range");
-    std::vector<double> col((size_t)cnt);
-    for (int c = 0; c < 4; c++) {  // the points are four SoA columns per episode
-      HIPCHK(h, hipMemcpy(col.data(), S.B.points + ((size_t)ep * 4 + c) * capp + off, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost));
-      for (int i = 0; i < cnt; i++) points4[4 * (size_t)i + c] = col[i];
-    }
+    HIPCHK(h, hipMemcpy(points4, S.B.points + ((size_t)ep * capp + (size_t)off) * 4, (size_t)cnt * 4 * sizeof(double), hipMemcpyDeviceToHost));
   }
   return AUVP_OK;
 }
@@ -344,7 +353,12 @@ int auvp_prrt_grid(auvp_handle* h, int32_t ep, int32_t* occupied, int32_t* bucke
   HIPCHK(h, hipMemcpy(&s, S.B.summary + ep, sizeof s, hipMemcpyDeviceToHost));
   if (dims4) { dims4[0] = S.P.rows; dims4[1] = S.P.cols; dims4[2] = S.P.S; dims4[3] = s.n_occ; }
   if (occupied && s.n_occ) HIPCHK(h, hipMemcpy(occupied, S.B.occupied + (size_t)ep * S.B.cap_nodes, (size_t)s.n_occ * sizeof(int32_t), hipMemcpyDeviceToHost));
-  if (bucket_counts) HIPCHK(h, hipMemcpy(bucket_counts, S.B.bucket_counts + (size_t)ep * S.P.n_buckets, (size_t)S.P.n_buckets * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (bucket_counts) {
+    std::vector<int2> tab((size_t)S.P.n_buckets);
+    HIPCHK(h, hipMemcpy(tab.data(), S.B.buckets + (size_t)ep * S.P.n_buckets, tab.size() * sizeof(int2), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tab.size(); i++)
+      bucket_counts[i] = (int32_t)((uint32_t)tab[i].x >> 24) == S.B.bucket_epoch ? (tab[i].x & 0xffffff) : 0;
+  }
   return AUVP_OK;
 }
 

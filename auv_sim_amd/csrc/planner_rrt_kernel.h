@@ -36,19 +36,27 @@ struct PrrtSummary {  // must match auvp_prrt_summary in include/auvplan.h
   unsigned long long n_draw32;
 };
 
+// One tree node = one 64-byte line (round 4; rounds 1-3 kept node_f / node_i / node_bucket / node_next as four arrays, and
+// the L2 hands every store instruction's sectors on to memory, so an accepted node cost four partial-line writes: see
+// profiles/r4_config5_traffic.md).  `length` stays 0 (:232) and is not stored.
+struct alignas(64) PrrtNode {
+  double x, y, theta, t;                  // the state
+  int32_t step, parent, pt_off, pt_cnt;   // step it was created in, parent node, its run of path points
+  int32_t bucket, next, _p0, _p1;         // its bucket; the member added to that bucket before it (-1: it was the first)
+};
+static_assert(sizeof(PrrtNode) == 64, "PrrtNode is one line");
+
 struct PrrtBuffers {
-  int32_t cap_nodes, cap_points, max_pts, _pad;
-  double* node_f;        // [E][cap_nodes][4]  x, y, theta, traj_t   (length stays 0, :232)
-  int32_t* node_i;       // [E][cap_nodes][4]  step, parent, pt_off, pt_cnt
-  int32_t* node_bucket;  // [E][cap_nodes]
-  double* points;        // [E][4][cap_points] SoA x, y, theta, traj_t
+  int32_t cap_nodes, cap_points, max_pts, bucket_epoch;
+  PrrtNode* nodes;       // [E][cap_nodes]
+  int32_t* node_bucket;  // [E][cap_nodes] compact copy of PrrtNode::bucket: what prrt_kernel's bucket-id scan reads (written by prrt_kernel only)
+  double* points;        // [E][cap_points][4] x, y, theta, traj_t of the stored path points (a node's run is contiguous)
   int32_t* occupied;     // [E][cap_nodes]
-  int32_t* bucket_counts;  // [E][n_buckets]
-  // member lists of the buckets, newest first: bucket_head[b] = the last node added to bucket b (valid while its count
-  // is > 0), node_next[m] = the member added before m (-1: m was the first).  Member k of the reference's node_array
-  // (creation order) is count - 1 - k steps from the head.
-  int32_t* bucket_head;    // [E][n_buckets]
-  int32_t* node_next;      // [E][cap_nodes]
+  // [E][n_buckets] {epoch << 24 | len(node_array), head}: the bucket's size -- valid when its top byte equals bucket_epoch,
+  // else the bucket is empty: a new batch bumps the epoch instead of clearing the table (a clear every 255 batches) -- and
+  // the last node added to it.  The buckets' member lists run newest first: head, then PrrtNode::next.  Member k of the
+  // reference's node_array (creation order) is count - 1 - k steps from the head.
+  int2* buckets;
   uint32_t* mt;          // [E][624] generator words (lazy in-place format between launches)
   int32_t* rng_state;    // [E][4] pslot, avail, drawn_lo, drawn_hi
   const double* start;   // [E][4] x, y, theta, traj_t
@@ -74,6 +82,10 @@ struct PrrtBuffers {
   long long* env_obs_has;     // [E][n_buckets] (may be null)
   long long* env_obs_num;     // [E][n_buckets] (may be null)
 };
+__device__ __forceinline__ int prrt_bucket_count(int2 w, int epoch) {
+  return (int)((uint32_t)w.x >> 24) == epoch ? (w.x & 0xffffff) : 0;
+}
+__device__ __forceinline__ int2 prrt_bucket_word(int count, int head, int epoch) { return make_int2((epoch << 24) | count, head); }
 #define PRRT_ENV_OUTCOME 1
 #define PRRT_ENV_AGENT 2
 #define PRRT_ENV_DELTA 4
@@ -241,14 +253,12 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
 
   const int capn = B.cap_nodes;
   const size_t capp = (size_t)B.cap_points;
-  double* nodeF = B.node_f + (size_t)ep * capn * 4;
-  int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)ep * capn;
+  PrrtNode* nodes = B.nodes + (size_t)ep * capn;
   int32_t* nbucket = B.node_bucket + (size_t)ep * capn;
   double* ptF = B.points + (size_t)ep * capp * 4;
   int32_t* occupied = B.occupied + (size_t)ep * capn;
-  int32_t* bcount = B.bucket_counts + (size_t)ep * P.n_buckets;
-  int32_t* bhead = B.bucket_head + (size_t)ep * P.n_buckets;
-  int32_t* nnext = B.node_next + (size_t)ep * capn;
+  int2* buckets = B.buckets + (size_t)ep * P.n_buckets;
+  const int epoch = B.bucket_epoch;
   PrrtSummary& sum = B.summary[ep];
   const double gx = readfirst_f64(B.goal[2 * (size_t)ep]), gy = readfirst_f64(B.goal[2 * (size_t)ep + 1]);
   const bool logst = (P.flags & 1) != 0 && B.st_log != nullptr;
@@ -284,8 +294,9 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
       if (n_occ == 0) { status = -1; break; }
       b = uni(occupied[rng_randbelow(rng, (uint32_t)n_occ)]);
     }
-    const int cnt_b = uni(bcount[b]);
-    const int head_b = bhead[b];  // (requested with the count; used only when the bucket is not empty)
+    const int2 bw = buckets[b];  // size and head in one read
+    const int cnt_b = uni(prrt_bucket_count(bw, epoch));
+    const int head_b = bw.y;  // (used only when the bucket is not empty)
     last_accepted = 0; last_new = -1;
     if (cnt_b == 0) {  // generate_one_node on an empty bucket: (False, None) (:214-220, input() not reproduced)
       if (logst && lane == 0) {
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
     const int hops = cnt_b - 1 - rsel;
     if (hops <= 6) {
       par = uni(head_b);
-      for (int q = 0; q < hops; q++) par = uni(nnext[par]);
+      for (int q = 0; q < hops; q++) par = uni(nodes[par].next);
     }
     // ... else a scan of the bucket ids: 256 are requested at a time so their loads overlap (one dependent round trip per
     // 256 nodes instead of per 64)
@@ -334,8 +345,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
     // ---------------------------------------------------------------- steer (:251-289)
     double cx, cy, cth, ctt;
     {
-      const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 4);
-      const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 4 + 2);
+      const double2 a = *reinterpret_cast<const double2*>(&nodes[par].x);
+      const double2 c = *reinterpret_cast<const double2*>(&nodes[par].theta);
       cx = readfirst_f64(a.x); cy = readfirst_f64(a.y); cth = readfirst_f64(c.x); ctt = readfirst_f64(c.y);
     }
     int n_total;
@@ -411,7 +422,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
         if (taken) {
           int rank = __popcll(tmask & ((1ull << lane) - 1ull));
           size_t gi = (size_t)(n_points + cnt + rank);
-          ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * capp + gi] = myth; ptF[3 * capp + gi] = mt_;
+          double2* pr = reinterpret_cast<double2*>(ptF + gi * 4);
+          pr[0] = make_double2(mx, my); pr[1] = make_double2(myth, mt_);
           pts[cnt + rank + 1][0] = mx;
           pts[cnt + rank + 1][1] = my;
         }
@@ -491,7 +503,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
         if (taken) {
           int rank = __popcll(tmask & ((1ull << lane) - 1ull));
           size_t gi = (size_t)(n_points + cnt + rank);
-          ptF[gi] = mx; ptF[capp + gi] = my; ptF[2 * capp + gi] = myth; ptF[3 * capp + gi] = mt_;
+          double2* pr = reinterpret_cast<double2*>(ptF + gi * 4);
+          pr[0] = make_double2(mx, my); pr[1] = make_double2(myth, mt_);
           pts[cnt + rank + 1][0] = mx;
           pts[cnt + rank + 1][1] = my;
         }
@@ -545,18 +558,24 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
       }
       if (__any(idx_err)) { status = -1; break; }
       bk = uni(bk);
-      const int c_before = bk >= 0 ? uni(bcount[bk]) : -1;
-      const int h_before = bk >= 0 ? uni(bhead[bk]) : -1;
+      int2 bwn = make_int2(0, 0);
+      if (bk >= 0) bwn = buckets[bk];
+      const int c_before = bk >= 0 ? uni(prrt_bucket_count(bwn, epoch)) : -1;
+      const int h_before = bk >= 0 ? uni(bwn.y) : -1;
+      if (lane < 4) {
+        // the node's 64-byte record: lanes 0..3 store one 16-byte quarter each, ONE store instruction for the line
+        const int nx = (bk >= 0 && c_before > 0) ? h_before : -1;
+        int4 q;
+        if (lane == 0) q = make_int4(__double2loint(cx), __double2hiint(cx), __double2loint(cy), __double2hiint(cy));
+        else if (lane == 1) q = make_int4(__double2loint(cth), __double2hiint(cth), __double2loint(ctt), __double2hiint(ctt));
+        else if (lane == 2) q = make_int4(step, par, n_points, cnt);
+        else q = make_int4(bk, nx, 0, 0);
+        reinterpret_cast<int4*>(&nodes[me])[lane] = q;
+      }
       if (lane == 0) {
-        double* nf = nodeF + (size_t)me * 4;
-        *reinterpret_cast<double2*>(nf) = make_double2(cx, cy);
-        *reinterpret_cast<double2*>(nf + 2) = make_double2(cth, ctt);
-        nodeI[me] = make_int4(step, par, n_points, cnt);
         nbucket[me] = bk;
         if (bk >= 0) {
-          nnext[me] = c_before > 0 ? h_before : -1;
-          bhead[bk] = me;
-          bcount[bk] = c_before + 1;
+          buckets[bk] = prrt_bucket_word(c_before + 1, me, epoch);
           if (c_before == 0) occupied[n_occ] = bk;  // first node of the bucket (:157-159)
         }
       }
@@ -571,8 +590,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
     double lx, ly, th0, ltt;
     if (ok) { lx = cx; ly = cy; th0 = cth; ltt = ctt; }
     else {
-      const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)last * 4);
-      const double2 c = *reinterpret_cast<const double2*>(nodeF + (size_t)last * 4 + 2);
+      const double2 a = *reinterpret_cast<const double2*>(&nodes[last].x);
+      const double2 c = *reinterpret_cast<const double2*>(&nodes[last].theta);
       lx = readfirst_f64(a.x); ly = readfirst_f64(a.y); th0 = readfirst_f64(c.x); ltt = readfirst_f64(c.y);
     }
     int n_arc = -1, arc_free = 0;
@@ -661,7 +680,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
               done = 1;
               int L = 1 + n_arc;
               for (int m = last;;) {
-                const int4 r = nodeI[m];
+                const int4 r = *reinterpret_cast<const int4*>(&nodes[m].step);
                 const int gp = uni(r.y);
                 if (gp < 0) break;
                 L += uni(r.w) + 1;
@@ -729,8 +748,7 @@ __global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, co
   if (!s.done || s.path_len <= 0) return;
   const int capn = B.cap_nodes;
   const size_t capp = (size_t)B.cap_points;
-  const double* nodeF = B.node_f + (size_t)ep * capn * 4;
-  const int4* nodeI = reinterpret_cast<const int4*>(B.node_i) + (size_t)ep * capn;
+  const PrrtNode* nodes = B.nodes + (size_t)ep * capn;
   const double* ptF = B.points + (size_t)ep * capp * 4;
   double* o = out + 5 * (size_t)offsets[ep];
   const double x_C = s.arc[0], y_C = s.arc[1], radius = s.arc[2], ang_vel = s.arc[3], th0 = s.arc[4];
@@ -743,28 +761,29 @@ __global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, co
     double* e = o + 5 * (size_t)(1 + (n_arc - 1 - i));
     e[0] = x_C + radius * sa; e[1] = y_C - radius * ca; e[2] = a; e[3] = 0.0; e[4] = 0.0;
     if (i == n_arc - 1) {
-      o[0] = e[0]; o[1] = e[1]; o[2] = a; o[3] = nodeF[(size_t)s.last_node * 4 + 3]; o[4] = s.arc[5];
+      o[0] = e[0]; o[1] = e[1]; o[2] = a; o[3] = nodes[s.last_node].t; o[4] = s.arc[5];
     }
   }
   if (n_arc == 0 && lane == 0) {
-    const double* nf = nodeF + (size_t)s.last_node * 4;
-    o[0] = nf[0]; o[1] = nf[1]; o[2] = nf[2]; o[3] = nf[3]; o[4] = s.arc[5];
+    const PrrtNode& nf = nodes[s.last_node];
+    o[0] = nf.x; o[1] = nf.y; o[2] = nf.theta; o[3] = nf.t; o[4] = s.arc[5];
   }
   int pos = 1 + n_arc;
   for (int m = s.last_node;;) {
-    const int4 r = nodeI[m];
+    const int4 r = *reinterpret_cast<const int4*>(&nodes[m].step);
     if (r.y < 0) break;
     const int cnt = r.w, off = r.z;
     for (int k = lane; k < cnt; k += 64) {
       double* e = o + 5 * (size_t)(pos + (cnt - 1 - k));
       size_t gi = (size_t)off + k;
-      e[0] = ptF[gi]; e[1] = ptF[capp + gi]; e[2] = ptF[2 * capp + gi]; e[3] = ptF[3 * capp + gi]; e[4] = 0.0;
+      const double2 p0 = *reinterpret_cast<const double2*>(ptF + gi * 4), p1 = *reinterpret_cast<const double2*>(ptF + gi * 4 + 2);
+      e[0] = p0.x; e[1] = p0.y; e[2] = p1.x; e[3] = p1.y; e[4] = 0.0;
     }
     pos += cnt;
     if (lane == 0) {
-      const double* nf = nodeF + (size_t)r.y * 4;
+      const PrrtNode& nf = nodes[r.y];
       double* e = o + 5 * (size_t)pos;
-      e[0] = nf[0]; e[1] = nf[1]; e[2] = nf[2]; e[3] = nf[3]; e[4] = 0.0;
+      e[0] = nf.x; e[1] = nf.y; e[2] = nf.theta; e[3] = nf.t; e[4] = 0.0;
     }
     pos++;
     m = r.y;
@@ -777,9 +796,6 @@ __global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuf
   if (e >= n_episodes) return;
   const double* st = B.start + 4 * (size_t)e;
   const double sx = st[0], sy = st[1], sth = st[2], stt = st[3];
-  double* nf = B.node_f + (size_t)e * B.cap_nodes * 4;
-  nf[0] = sx; nf[1] = sy; nf[2] = sth; nf[3] = stt;
-  reinterpret_cast<int4*>(B.node_i)[(size_t)e * B.cap_nodes] = make_int4(0, -1, 0, 0);
   // same index arithmetic as the step kernel (int(y / cs), int(x / cs), floor(theta / delta_theta))
   int row = (int)(sy / P.cell), col = (int)(sx / P.cell);
   bool err = false;
@@ -795,13 +811,16 @@ __global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuf
     bk = (row * P.cols + col) * P.S + sub;
   }
   if (err) bk = -1;
+  PrrtNode n0;
+  n0.x = sx; n0.y = sy; n0.theta = sth; n0.t = stt;
+  n0.step = 0; n0.parent = -1; n0.pt_off = 0; n0.pt_cnt = 0;
+  n0.bucket = bk; n0.next = -1; n0._p0 = 0; n0._p1 = 0;
+  B.nodes[(size_t)e * B.cap_nodes] = n0;
   B.node_bucket[(size_t)e * B.cap_nodes] = bk;
   if (bk >= 0) {
-    B.bucket_counts[(size_t)e * P.n_buckets + bk] = 1;
+    B.buckets[(size_t)e * P.n_buckets + bk] = prrt_bucket_word(1, 0, B.bucket_epoch);
     B.occupied[(size_t)e * B.cap_nodes] = bk;
-    B.bucket_head[(size_t)e * P.n_buckets + bk] = 0;
   }
-  B.node_next[(size_t)e * B.cap_nodes] = -1;
   PrrtSummary s;
   s.status = err ? -1 : 0; s.n_nodes = 1; s.n_points = 0; s.n_occ = bk >= 0 ? 1 : 0; s.steps = 0; s.done = 0;
   s.path_len = 0; s.last_node = 0; s.last_accepted = 0; s.last_new_node = -1; s.n_arc = 0; s._pad = 0;
@@ -916,7 +935,7 @@ __global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, 
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int b = (int)(i % P.n_buckets);
     const int k = b % P.S, cell = b / P.S, col = cell % P.cols, row = cell / P.cols;
-    const int c = B.bucket_counts[i];
+    const int c = prrt_bucket_count(B.buckets[i], B.bucket_epoch);
     double4 v;
     v.x = P.rect[0] + col * P.cell;  // env_btm_left_corner.x + col * cell_side_length (rrt_dubins.py:91)
     v.y = P.rect[1] + row * P.cell;

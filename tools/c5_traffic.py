@@ -50,9 +50,9 @@ bucket_sec, hop_reads, spec_pts = [], [], []
 for e in sample:
     t = pb.tree(int(e), summ[int(e)])
     bk = np.asarray(t["node_bucket"])
-    bucket_sec.append(len(np.unique(bk[bk >= 0] // 16)))
+    bucket_sec.append(len(np.unique(bk[bk >= 0] // 8)))  # 8-byte words: eight buckets per 64-B sector
 scale = E / float(len(sample))
-bsec = float(np.sum(bucket_sec)) * scale  # distinct 64-B sectors of a [n_buckets] int32 array an episode's accepted nodes fall into
+bsec = float(np.sum(bucket_sec)) * scale  # distinct 64-B sectors of the [n_buckets] table an episode's accepted nodes fall into
 
 rows = []
 
@@ -65,17 +65,16 @@ def row(name, what, alg_r, alg_w, sec_r, sec_w, acc_r, acc_w):
 row("mt + rng_state", "624 words + 4 per episode, read at pickup, stored at the end", E * 2512.0, E * 2512.0, E * 2560.0, E * 2560.0, E * 2560.0, E * 2560.0)
 row("summary", "136-B record per episode, read at pickup, stored at the end", E * 136.0, E * 136.0, E * 192.0, E * 192.0, E * 192.0, E * 192.0)
 row("goal + start", "16 + 32 B per episode", E * 48.0, 0.0, E * 128.0, 0.0, E * 128.0, 0.0)
-# per step: bucket size + head of the chosen bucket, of the new node's bucket (accepted or not: requested before the collision test)
-row("bucket_counts + bucket_head (two arrays)", "4 + 4 B of the chosen bucket and of the new node's bucket per step; 4 + 4 B stored per accepted node",
-    steps * 16.0, nodes * 8.0, 2 * bsec * SEC, 2 * bsec * SEC, steps * 4 * SEC, nodes * 2 * SEC)
-row("node_next", "member-list hops of the node choice (~1 per step) + 4 B stored per node", steps * 4.0, nodes * 4.0, sectors(nodes * 4 / E).sum() * E / 1.0 if False else np.ceil(nodes / E * 4 / SEC) * SEC * E,
-    np.ceil(nodes / E * 4 / SEC) * SEC * E, steps * SEC, nodes * SEC)
-row("node_f", "parent record 32 B per step (+ the last node's 24 B when the step's node was rejected); 32 B stored per node",
-    steps * 32.0, nodes * 32.0, np.ceil((nodes / E + 1) * 32 / SEC) * SEC * E, np.ceil((nodes / E + 1) * 32 / SEC) * SEC * E, steps * SEC, nodes * SEC)
-row("node_i + node_bucket + occupied", "16 + 4 (+ 4 for a first bucket member) B stored per node; links read by the final path walk", 0.0, nodes * 24.0,
-    0.0, (np.ceil((nodes / E + 1) * 16 / SEC) + np.ceil((nodes / E + 1) * 4 / SEC) * 2) * SEC * E, 0.0, nodes * 3 * SEC)
-row("points (4 SoA columns)", "x, y, theta, t of every taken sub-arc, stored speculatively per step (rejected steers are overwritten)",
-    0.0, pts * 32.0, 0.0, 4 * np.ceil(pts / E * 8 / SEC) * SEC * E, 0.0, steps * 4 * SEC)
+# per step: the 8-byte {size, head} word of the chosen bucket and of the new node's bucket (requested before the collision test)
+row("buckets ({size | epoch, head}, 8 B per bucket)", "the chosen bucket's and the new node's bucket's word per step; one word stored per accepted node",
+    steps * 16.0, nodes * 8.0, 2 * bsec * SEC, 2 * bsec * SEC, steps * 2 * SEC, nodes * SEC)
+row("nodes (64-B records)", "parent state 32 B per step, member-list hops 4 B each (~1 per step), the last node's state when the step's node was "
+    "rejected, links read by the final path walk; one 64-B record stored per accepted node (one store instruction)",
+    steps * 36.0, nodes * 64.0, (nodes + E) * SEC, (nodes + E) * SEC, steps * 2 * SEC, nodes * SEC)
+row("occupied", "4 B stored per first member of a bucket (the list itself is read from its LDS copy)", 0.0, float(summ["n_occ"].sum()) * 4.0,
+    0.0, np.ceil(summ["n_occ"] * 4 / SEC).sum() * SEC, 0.0, float(summ["n_occ"].sum()) * SEC)
+row("points (32-B records)", "x, y, theta, t of every taken sub-arc, stored speculatively per step (rejected steers are overwritten)",
+    0.0, pts * 32.0, 0.0, np.ceil(pts / E * 32 / SEC) * SEC * E, 0.0, steps * 3 * SEC)
 row("obstacle tile (os_*)", "7 KB shared by every episode: L1 / L2 hits", 0.0, 0.0, 7168.0, 0.0, 0.0, 0.0)
 
 tot = np.array([[r[2], r[3], r[4], r[5], r[6], r[7]] for r in rows]).sum(axis=0)
@@ -87,8 +86,8 @@ for r in rows:
 lines.append("| **sum** | | **%.1f / %.1f** | **%.1f / %.1f** | **%.1f / %.1f** |" % tuple(tot / 1e6))
 hdr = ("config 5 plan launch (%s): %d episodes, %.0f planner steps, %.0f accepted nodes (%.1f per episode), %.0f stored path points "
        "(%.1f per episode), %d buckets per episode; SURVEY 8(d) algorithmic bytes (bench.planner_bytes) = %.1f MB; "
-       "memset of bucket_counts before the launch: %.1f MB (not in the launch's counters)"
-       % (ctx.prrt_last_kernel(), E, steps, nodes, nodes / E, pts, pts / E, nb, bench.planner_bytes(summ) / 1e6, E * nb * 4 / 1e6))
+       "the bucket table (%.1f MB) is not cleared between batches (epoch tag)"
+       % (ctx.prrt_last_kernel(), E, steps, nodes, nodes / E, pts, pts / E, nb, bench.planner_bytes(summ) / 1e6, E * nb * 8 / 1e6))
 out = hdr + "\n\n" + "\n".join(lines) + "\n"
 print(out)
 print("plan launch %.3f ms, replan (seeding + planting) %.3f ms, filter %.3f ms" % (rp.plan_ms, rp.replan_ms, rp.pf_ms))
