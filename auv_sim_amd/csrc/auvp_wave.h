@@ -93,6 +93,13 @@ struct WaveRng {
   unsigned long long drawn;  // 32-bit outputs consumed so far
 };
 
+// random.random() from two tempered outputs: (a * 2^26 + b) / 2^53 with a < 2^27, b < 2^26.  Every step of that expression is
+// exact (a 53-bit integer, then a power-of-two scale), so any exact evaluation gives the same double: a * 2^-27 and b * 2^-53
+// are exact, their sum is a multiple of 2^-53 below 1 -- one multiply and one fused multiply-add instead of multiply, add, multiply.
+__device__ __forceinline__ double py_random_from(uint32_t a27, uint32_t b26) {
+  return __builtin_fma((double)a27, 0x1p-27, (double)b26 * 0x1p-53);
+}
+
 __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   y ^= (y >> 11);
   y ^= (y << 7) & 0x9d2c5680u;
@@ -132,7 +139,7 @@ __device__ __forceinline__ uint32_t rng_word(const WaveRng& r, uint32_t j) {
 // random.random() number `j` ahead (consumes words 2j, 2j+1)
 __device__ __forceinline__ double rng_random_at(const WaveRng& r, uint32_t j) {
   uint32_t a = rng_word(r, 2u * j) >> 5, b = rng_word(r, 2u * j + 1u) >> 6;
-  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+  return py_random_from(a, b);
 }
 
 __device__ __forceinline__ void rng_advance_words(WaveRng& r, uint32_t nwords) {
@@ -152,7 +159,13 @@ __device__ __forceinline__ double rng_next_random(WaveRng& r) {
 }
 
 // random.uniform(a, b) = a + (b-a) * random()
-__device__ __forceinline__ double py_uniform(double a, double b, double u) { return a + (b - a) * u; }
+// A literal 0.0 lower end (most calls): 0.0 + (b - 0.0) * u = RN(b * u) + 0.0; b - 0.0 is b and adding +0.0 to a rounded product
+// is exact, so ONE fused multiply-add with a +0.0 addend returns the same double, sign of zero included ((-0.0) + (+0.0) = +0.0
+// both ways) -- one vector instruction instead of two.
+__device__ __forceinline__ double py_uniform(double a, double b, double u) {
+  if (__builtin_constant_p(a) && a == 0.0) return __builtin_fma(b, u, 0.0);
+  return a + (b - a) * u;
+}
 
 }  // namespace auvp
 #endif

@@ -112,7 +112,7 @@ __device__ __forceinline__ double rows_random_at(const RowRng& r, uint32_t j) {
   k = k >= 624u ? k - 624u : k;
   const uint32_t k1 = (k + 1u == 624u) ? 0u : k + 1u;
   const uint32_t a = mt_temper(r.s[k]) >> 5, b = mt_temper(r.s[k1]) >> 6;
-  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+  return py_random_from(a, b);
 }
 __device__ __forceinline__ void rows_advance(RowRng& r, bool on, uint32_t nwords) {
   if (on) {
