@@ -46,7 +46,7 @@ __host__ __device__ inline int prrt_rows_occ_bytes(int n_buckets, int max_step) 
 }
 
 __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes,
-                                                                      int* __restrict__ work_counter, int occ_bytes) {
+                                                                      int* __restrict__ work_counter, int work_base, int occ_bytes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = (int)(threadIdx.x >> 6);
   const int lane = lane_id();
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
     if (__any(!live && more)) {
       const bool need = !live && more;
       int e = 0;
-      if (need && rl == 0) e = atomicAdd(work_counter, 1);
+      if (need && rl == 0) e = atomicAdd(work_counter, 1) - work_base;
       e = row_read(e, rowbase);
       bool skip = false;
       if (need) {

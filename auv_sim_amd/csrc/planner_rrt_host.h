@@ -19,7 +19,11 @@ struct PrrtState {
   int bucket_epoch = 0;
   void* bucket_alloc = nullptr;
   size_t bucket_alloc_bytes = 0;
-  DevBuf work;  // work counter of the four-episodes-per-wavefront kernel (planner_rows_kernel.h)
+  // work counter of the four-episodes-per-wavefront kernel (planner_rows_kernel.h).  It is never reset between launches: a
+  // launch hands out ids counter - work_base, and every one of its rows ends with exactly one pull that finds no episode, so
+  // the next launch's base is known on the host (no fill launch per plan / step)
+  DevBuf work;
+  int work_base = 0;
   bool use_rows = false;  // decided once per batch: the two kernels keep the generator's lazy state in different block phases
   const char* last_kernel = "";
   DevBuf env_err;    // device int32[2]: {status, environment} of the first episode that failed inside the device-resident loop
@@ -71,12 +75,17 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     block_used = auvp::PRW_WAVES * 64;
     const int occ_bytes = auvp::prrt_rows_occ_bytes(S.P.n_buckets, S.P.max_step);
     lds_used = (size_t)per_wg * (auvp::PRW_LDS_PER_EP + occ_bytes);
-    le = S.work.reserve(sizeof(int));
-    if (le == hipSuccess) le = hipMemsetAsync(S.work.p, 0, sizeof(int), h->stream);
+    if (!S.work.p || S.work_base > (1 << 30)) {
+      le = S.work.reserve(sizeof(int));
+      if (le == hipSuccess) le = hipMemsetAsync(S.work.p, 0, sizeof(int), h->stream);
+      S.work_base = 0;
+    } else le = hipSuccess;
     if (le == hipSuccess) le = hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::prrt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
     if (le == hipSuccess) {
-      hipLaunchKernelGGL(auvp::prrt_rows_kernel, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, S.work.as<int>(), occ_bytes);
+      hipLaunchKernelGGL(auvp::prrt_rows_kernel, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, S.work.as<int>(),
+                         S.work_base, occ_bytes);
       le = hipGetLastError();
+      S.work_base += S.E + grid_used * per_wg;  // every episode once + one empty pull per row
     }
   } else if (lat) {
     if (O <= 64) le = launch(auvp::prrt_kernel<1, true>);
@@ -194,11 +203,11 @@ static int prrt_plant(auvp_handle* h, PrrtState& S, int32_t E) {
     S.B.bucket_epoch = S.bucket_epoch;
   }
   HIPCHK(h, S.env_done.reserve((size_t)E));
-  HIPCHK(h, hipMemsetAsync(S.env_done.p, 0, (size_t)E, h->stream));
   HIPCHK(h, S.env_err.reserve(2 * sizeof(int32_t)));
-  HIPCHK(h, hipMemsetAsync(S.env_err.p, 0, 2 * sizeof(int32_t), h->stream));
   S.thetas_ready = false;
-  hipLaunchKernelGGL(auvp::prrt_init_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, S.P, S.B, (int)E);
+  // (the planting launch also clears the device-resident loop's finished flags and error word: no fill launches)
+  hipLaunchKernelGGL(auvp::prrt_init_kernel, dim3((E + 255) / 256), dim3(256), 0, h->stream, S.P, S.B, (int)E, S.env_done.as<uint8_t>(),
+                     S.env_err.as<int32_t>());
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
   S.E = E;

@@ -791,9 +791,12 @@ __global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, co
 }
 
 // Planner_RRT.__init__ (:34-75): mps_list = [start]; add_node_to_grid(start).  One thread per episode.
-__global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
+__global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuffers B, int n_episodes, uint8_t* __restrict__ env_done,
+                                                        int32_t* __restrict__ env_err) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0 && env_err) { env_err[0] = 0; env_err[1] = 0; }
   if (e >= n_episodes) return;
+  if (env_done) env_done[e] = 0;
   const double* st = B.start + 4 * (size_t)e;
   const double sx = st[0], sy = st[1], sth = st[2], stt = st[3];
   // same index arithmetic as the step kernel (int(y / cs), int(x / cs), floor(theta / delta_theta))

@@ -85,8 +85,12 @@ for key, (needles, units_field) in MEAS.items():
     try:
         if side is None:
             j = json.loads(open(os.path.join(src, "pmc@headline@FETCH_SIZE.json")).read().strip().splitlines()[-1])
-            rec["units"] = j["expansions_per_s_kernel_only"] * j["roofline"]["kernel_ms"] * 1e-3
-            rec["algorithmic_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
+            rec["units"] = j["expansions_per_step"]
+            # whole pass (expansion + leaf launch): SURVEY 8(d) B_exp x expansions; per kernel: roofline.algorithmic_bytes_per_launch
+            # (expansion kernel) and roofline.leaf_compulsory_bytes
+            rec["algorithmic_bytes_per_launch"] = j["roofline"]["pass_8d_bytes"]
+            rec["expansion_kernel_algorithmic_bytes"] = j["roofline"]["algorithmic_bytes_per_launch"]
+            rec["leaf_kernel_compulsory_bytes"] = j["roofline"]["leaf_compulsory_bytes"]
         else:
             j = json.loads(open(os.path.join(src, "pmc@%s@FETCH_SIZE.json" % key)).read().strip().splitlines()[-1])[side]
             rec["units"] = j[units_field]
