@@ -116,6 +116,8 @@ def load():
     L.auvp_last_launch.argtypes = [vp, _ip, _ip, _ip]
     L.auvp_rrt_last_launch_parts.argtypes = [vp, _dp, _dp, _ip]
     L.auvp_rrt_last_leaf_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.auvp_rrt_last_kernel.argtypes = [vp]
+    L.auvp_rrt_last_kernel.restype = C.c_char_p
     L.auvp_hbm_probe.argtypes = [vp, C.c_uint64, C.c_int32, _dp, _dp]
     _lib = L
     return L
@@ -327,6 +329,10 @@ class Context:
         a, b, k = C.c_double(), C.c_double(), C.c_int32()
         self._chk(self.L.auvp_rrt_last_launch_parts(self.h, C.byref(a), C.byref(b), C.byref(k)))
         return a.value, b.value, k.value
+
+    def last_rrt_kernel(self):
+        """name of the expansion kernel the last rrt_run launched (rrt_rows_kernel / rrt_explore_kernel / rrt_duo_kernel)"""
+        return (self.L.auvp_rrt_last_kernel(self.h) or b"").decode()
 
     def last_leaf_stats(self):
         """of the last rrt_run's leaf pass, summed over the batch: nodes visited, their path points, path elements re-summed

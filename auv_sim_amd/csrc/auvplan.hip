@@ -18,6 +18,7 @@
 #include "../../include/auvplan.h"
 #include "rrt_explore_kernel.h"
 #include "rrt_rows_kernel.h"
+#include "rrt_duo_kernel.h"
 
 using namespace auvp;
 
@@ -47,6 +48,7 @@ struct auvp_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
   double last_expand_ms = 0.0, last_leaf_ms = 0.0;
   int last_rows = 0;
+  const char* last_rrt_kernel = "";
   std::string err;
   // world
   bool have_world = false;
@@ -739,7 +741,27 @@ int auvp_rrt_run(auvp_handle* h) {
                        rp.total <= 160 * 1024;
   const bool use_rows = rows_ok && (rows_env ? atoi(rows_env) != 0 : E > 24 * n_cu_);
   int grid_used = grid, block_used = xw * 64, lds_used = (int)lds;
-  if (use_rows) {
+  // latency runs (at most four episodes per CU: one episode, config 2's 1 024 replicas): two wavefronts per episode
+  // (rrt_duo_kernel.h).  AUVP_DUO=1 / 0 force it on (limits permitting) / off.
+  const char* duo_env = getenv("AUVP_DUO");
+  const bool duo_ok = P.mode == 0 && !diag && nfreq <= DUO_MAX_FREQ && nfreq >= 1 && O_ <= 256 && h->max_pts <= 64;
+  const bool use_duo = duo_ok && !use_rows && (duo_env ? atoi(duo_env) != 0 : false);  // (bring-up: opt-in)
+  h->last_rrt_kernel = use_rows ? "rrt_rows_kernel" : (use_duo ? "rrt_duo_kernel" : "rrt_explore_kernel");
+  if (use_duo) {
+    int eps_wg = (E + n_cu_ - 1) / n_cu_;
+    eps_wg = eps_wg < 1 ? 1 : (eps_wg > DUO_EP ? DUO_EP : eps_wg);
+    const int jd = O_ <= 64 ? 1 : (O_ <= 128 ? 2 : 4);
+    const int dl = duo_lds_bytes(P.K, h->max_pts, jd * 64, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), eps_wg);
+    if (dl > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %d B > 160 KiB (K=%d)", dl, P.K);
+    grid_used = (E + eps_wg - 1) / eps_wg; block_used = eps_wg * 128; lds_used = dl;
+    auto launch_duo = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dl);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), dl, h->stream, h->W, PR, B, (int)E, h->max_pts);
+      return hipGetLastError();
+    };
+    le = jd == 1 ? launch_duo(rrt_duo_kernel<1>) : (jd == 2 ? launch_duo(rrt_duo_kernel<2>) : launch_duo(rrt_duo_kernel<4>));
+  } else if (use_rows) {
     // a workgroup of up to 12 waves (48 episodes) fills one CU; a batch that cannot give every CU such a workgroup is
     // spread over all CUs with fewer waves per workgroup instead of leaving CUs idle
     int n_cu = 256;
@@ -936,6 +958,8 @@ int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_m
   if (episodes_per_wave) *episodes_per_wave = h->last_rows ? 4 : 1;
   return AUVP_OK;
 }
+
+const char* auvp_rrt_last_kernel(auvp_handle* h) { return h ? h->last_rrt_kernel : ""; }
 
 int auvp_rrt_last_leaf_stats(auvp_handle* h, int64_t* out4) {
   if (!h || !out4) return AUVP_ERR_ARG;

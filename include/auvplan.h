@@ -353,6 +353,11 @@ double auvp_last_kernel_ms(auvp_handle* h);
 /* of the last auvp_rrt_run: HIP-event times of its two launches (tree expansion; leaf ranking) and which expansion
  * kernel ran (4 = four episodes per wavefront, rrt_rows_kernel; 1 = rrt_explore_kernel) */
 int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_ms, int32_t* episodes_per_wave);
+/* name of the expansion kernel the last auvp_rrt_run launched: "rrt_rows_kernel" (four episodes per wavefront: batches of
+ * more than 24 episodes per CU), "rrt_explore_kernel" (one), "rrt_duo_kernel" (two wavefronts per episode: batches of at
+ * most four episodes per CU in time-bin mode -- the helper wavefront produces the half of an iteration that depends only on
+ * the random stream, rrt_dubins.py:121-127,252-281, one iteration ahead) */
+const char* auvp_rrt_last_kernel(auvp_handle* h);
 /* of the last auvp_rrt_run's leaf pass (the qualifying-leaf bookkeeping of exploring, rrt_dubins.py:158-171 +
  * cost.py:145-207), summed over the batch: out4 = {nodes its sweep visited (qualifying leaves and their ancestors), path
  * points of those nodes (each evaluated once), path elements re-summed in the reference's leaf->root order, leaves
