@@ -745,7 +745,9 @@ int auvp_rrt_run(auvp_handle* h) {
   // (rrt_duo_kernel.h).  AUVP_DUO=1 / 0 force it on (limits permitting) / off.
   const char* duo_env = getenv("AUVP_DUO");
   const bool duo_ok = P.mode == 0 && !diag && nfreq <= DUO_MAX_FREQ && nfreq >= 1 && O_ <= 256 && h->max_pts <= 64;
-  const bool use_duo = duo_ok && !use_rows && (duo_env ? atoi(duo_env) != 0 : false);  // (bring-up: opt-in)
+  // Measured (tools/duo_probe.py, M expansions/s one vs two wavefronts per episode): 1 episode 0.25 vs 0.32, 256: 62 vs 80,
+  // 1 024: 227 vs 271 (config 2's replicas, 64 obstacles: 241 vs 283), 2 048: 409 vs 435, 4 096: 621 vs 485
+  const bool use_duo = duo_ok && !use_rows && (duo_env ? atoi(duo_env) != 0 : E <= 8 * n_cu_);
   h->last_rrt_kernel = use_rows ? "rrt_rows_kernel" : (use_duo ? "rrt_duo_kernel" : "rrt_explore_kernel");
   if (use_duo) {
     int eps_wg = (E + n_cu_ - 1) / n_cu_;

@@ -406,6 +406,9 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
         if (++spins > DUO_SPIN_LIMIT) { give_up(); status = -9; break; }
         __builtin_amdgcn_s_sleep(1);
       }
+#ifdef AUVP_DUO_DIAG
+      n_cand += spins;  // EXPERIMENT ONLY (tools/duo_probe.py): polls main spent waiting for its packets, reported as n_candidates
+#endif
     }
     if (uni(status)) break;
     if (lane == 0) duo_poke(&ctl->valid_seq, it + 1);  // the helper may build the next packet now
@@ -427,13 +430,17 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
       if (lane < DUO_CS) phi_l[lane] = phi;  // untaken / idle lanes add an exact 0.0
       wave_sync();
       if (lane == 0) {
+        // eight entries per LDS round trip: four 16-byte reads up front, eight chained additions, four writes (entries past n
+        // hold exact zeros; this wavefront has registers to spare and nothing else to do meanwhile)
         double th = cth;
-#pragma unroll 2
-        for (int s = 0; s < n; s += 2) {
-          double2 v = *reinterpret_cast<double2*>(phi_l + s);
-          th = th + v.x; v.x = th;
-          th = th + v.y; v.y = th;
-          *reinterpret_cast<double2*>(phi_l + s) = v;
+        for (int s = 0; s < n; s += 8) {
+          double2 v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<double2*>(phi_l + s + 2 * k);
+#pragma unroll
+          for (int k = 0; k < 4; k++) { th = th + v[k].x; v[k].x = th; th = th + v[k].y; v[k].y = th; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) *reinterpret_cast<double2*>(phi_l + s + 2 * k) = v[k];
         }
       }
       wave_sync();
@@ -457,12 +464,14 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
       if (lane < 4) {
         double acc = lane == 0 ? cx : (lane == 1 ? cy : (lane == 2 ? ctt : clen));
         double* row = inc + lane * DUO_CS;
-#pragma unroll 2
-        for (int s = 0; s < n; s += 2) {
-          double2 v = *reinterpret_cast<double2*>(row + s);
-          acc = acc + v.x; v.x = acc;
-          acc = acc + v.y; v.y = acc;
-          *reinterpret_cast<double2*>(row + s) = v;
+        for (int s = 0; s < n; s += 8) {
+          double2 v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = *reinterpret_cast<double2*>(row + s + 2 * k);
+#pragma unroll
+          for (int k = 0; k < 4; k++) { acc = acc + v[k].x; v[k].x = acc; acc = acc + v[k].y; v[k].y = acc; }
+#pragma unroll
+          for (int k = 0; k < 4; k++) *reinterpret_cast<double2*>(row + s + 2 * k) = v[k];
         }
       }
       wave_sync();

@@ -473,7 +473,7 @@ def bench_single_episode(ctx, world, args, reps=3):
         if i:
             ms.append(ctx.last_kernel_ms())
     k_ms = float(np.mean(ms))
-    return {"metric": "single-episode latency (seed 7)", "kernel_ms": k_ms, "iters": int(summ[0]["iters_run"]),
+    return {"metric": "single-episode latency (seed 7)", "kernel": ctx.last_rrt_kernel(), "kernel_ms": k_ms, "iters": int(summ[0]["iters_run"]),
             "expansions_per_s": float(summ[0]["iters_run"]) / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / float(summ[0]["iters_run"])}
 
 
@@ -498,11 +498,11 @@ def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0, mode=None, kw=No
     k_ms = float(np.mean(ms))
     iters = float(summ["iters_run"].sum())
     out = {"value": iters / (k_ms * 1e-3), "unit": "expansions/s", "episodes": n_ep, "kernel_ms": k_ms, "mode": mode,
+           "kernel": ctx.last_rrt_kernel(),
            "accept_rate": float((summ["n_nodes"] - 1).sum()) / iters,
            "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters,
            "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
-           "roofline": rrt_pass_rooflines(ctx, summ, meas, float(np.mean(ems)), float(np.mean(lms)),
-                                          "rrt_rows_kernel" if ctx.last_launch_parts()[2] == 4 else "rrt_explore_kernel")}
+           "roofline": rrt_pass_rooflines(ctx, summ, meas, float(np.mean(ems)), float(np.mean(lms)), ctx.last_rrt_kernel())}
     if cpu_seconds > 0:
         from oracle import orc
         w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
@@ -529,8 +529,8 @@ def bench_rrt_o64(ctx, args, n_ep=None):
 
 
 def bench_rrt_replicas(ctx, args, n_ep=1024):
-    """SURVEY 8(d) config 2, throughput test: 1 024 replicas of the 64-obstacle episode (seeds 0..1023) -- one wavefront per
-    SIMD, so this is the one-episode kernel running as many latency chains as the chip has SIMDs."""
+    """SURVEY 8(d) config 2, throughput test: 1 024 replicas of the 64-obstacle episode (seeds 0..1023): as many latency chains
+    as the chip has SIMDs -- rrt_duo_kernel, two wavefronts per episode (one per SIMD and a helper beside it)."""
     out = _rrt_batch(ctx, bench_world(64, args.grid), n_ep, args)
     out["metric"] = "RRT.exploring expansions/s, %d replicas, 64 obstacles, %dx%d cells" % (n_ep, args.grid, args.grid)
     return out
@@ -1166,7 +1166,7 @@ def main():
         exp_ms = float(np.mean([p[0] for p in parts[-args.steps:]]))
         leaf_ms = float(np.mean([p[1] for p in parts[-args.steps:]]))
         per_wave = parts[-1][2]
-        kname = "rrt_rows_kernel" if per_wave == 4 else "rrt_explore_kernel"
+        kname = ctx.last_rrt_kernel()
         wl = "RRT.exploring %d obst %dx%d cells %d iters x %d episodes/GPU, %s parent sampling" % (
             args.obstacles, args.grid, args.grid, args.iters, E, args.mode)
         out = {

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Latency runs with one (rrt_explore_kernel) and two (rrt_duo_kernel) wavefronts per episode: one episode, 64 / 256 / 1 024
+episodes of the headline world, and config 2's 1 024 replicas (64 obstacles).  Run on a GPU box."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from auv_sim_amd import _lib  # noqa: E402
+
+ctx = _lib.Context(0)
+iters = 10000
+os.environ["AUVP_ROWS"] = "0"
+for obst, E in ((256, 1), (256, 64), (256, 256), (256, 1024), (64, 1024), (256, 2048), (256, 4096)):
+    world = bench.bench_world(obst, 200)
+    ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+    init = np.zeros((E, 6))
+    init[:, 0], init[:, 1] = world["start"]
+    res = []
+    for duo in ("0", "1"):
+        os.environ["AUVP_DUO"] = duo
+        ctx.rrt_prepare(init, np.arange(E, dtype=np.uint64) + 7, iters, mode="timebin", **bench.RRT_KW)
+        ms = []
+        for i in range(3):
+            ctx.rrt_run()
+            if i:
+                ms.append(ctx.last_launch_parts()[0])
+        s = ctx.summaries()
+        assert (s["status"] >= 0).all(), np.unique(s["status"])
+        res.append((ctx.last_rrt_kernel(), float(np.mean(ms)), float(s["iters_run"].sum())))
+        if os.environ.get("AUVPLAN_LIBRARY") and duo == "1":
+            print("   diag build: main polled %.2f times per iteration waiting for its packet" % (float(s["n_candidates"].sum()) / float(s["iters_run"].sum())))
+    (k0, m0, n0), (k1, m1, n1) = res
+    print("O=%d E=%d: %s %.2f ms = %.1f M exp/s (%.2f us per expansion of one episode) | %s %.2f ms = %.1f M exp/s (%.2f us)"
+          % (obst, E, k0, m0, n0 / m0 / 1e3, 1e3 * m0 / iters, k1, m1, n1 / m1 / 1e3, 1e3 * m1 / iters))
