@@ -203,6 +203,9 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
       return true;
     };
     int i = 0;
+#ifdef AUVP_DUO_DIAG
+    unsigned long long diag_build = 0ull;  // EXPERIMENT ONLY: shader clocks spent building packets (waits excluded)
+#endif
     for (;;) {
       // ---- wait: main accepts packet i - 1 (then packet i may be built), or wants it redone, or is done
       {
@@ -224,6 +227,9 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
         }
       }
       // ---------------------------------------------------------------- build packet i
+#ifdef AUVP_DUO_DIAG
+      const unsigned long long t_build0 = __builtin_amdgcn_s_memtime();
+#endif
       sp_pslot = rng.pslot; sp_drawn = rng.drawn;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       int ver = uni(duo_peek(&ctl->ver));
@@ -364,6 +370,9 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) duo_poke64(&q->tag, duo_tag(epoch, i));
+#ifdef AUVP_DUO_DIAG
+      diag_build += __builtin_amdgcn_s_memtime() - t_build0;
+#endif
       i++;  // (a KeyError packet: main stops at it, or asks for a redo first)
     }
   helper_end:
@@ -374,6 +383,9 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
       rng_ensure(rng, 2u);
       const double after = rng_random_at(rng, 0u);
       if (lane == 0) { ctl->final_after = after; ctl->final_drawn = drawn; }
+#ifdef AUVP_DUO_DIAG
+      if (lane == 0) ctl->_pad = (int)(diag_build >> 8);
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) duo_poke(&ctl->helper_done, 1);
     }
@@ -383,6 +395,9 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
   // =========================================================================================================== MAIN
   int next_chunk = 0;
   int n_nodes = 1, n_points = 0, status = 0, n_cand = 0, it = 0, my_epoch = 0;
+#ifdef AUVP_DUO_DIAG
+  unsigned long long diag_work = 0ull;
+#endif
   for (; it < P.max_iter; it++) {
     // ---------------------------------------------------------------- the iteration's packet
     DuoPacket* q = packet(it);
@@ -406,11 +421,11 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
         if (++spins > DUO_SPIN_LIMIT) { give_up(); status = -9; break; }
         __builtin_amdgcn_s_sleep(1);
       }
-#ifdef AUVP_DUO_DIAG
-      n_cand += spins;  // EXPERIMENT ONLY (tools/duo_probe.py): polls main spent waiting for its packets, reported as n_candidates
-#endif
     }
     if (uni(status)) break;
+#ifdef AUVP_DUO_DIAG
+    const unsigned long long t_work0 = __builtin_amdgcn_s_memtime();  // EXPERIMENT ONLY (tools/duo_probe.py)
+#endif
     if (lane == 0) duo_poke(&ctl->valid_seq, it + 1);  // the helper may build the next packet now
     if (uni(q->status) != 0) { status = uni(q->status); break; }  // KeyError (:124)
     const int par = uni(q->par), n_total = uni(q->n_total);
@@ -575,6 +590,9 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) duo_poke(&ctl->done_seq, it + 1);
+#ifdef AUVP_DUO_DIAG
+    diag_work += __builtin_amdgcn_s_memtime() - t_work0;
+#endif
   }
   // ---- the episode is over: the helper posts the stream position, main writes the record ----
   if (lane == 0) duo_poke(&ctl->stop, 1);
@@ -594,6 +612,10 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
     s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;
     s.best_length = 0.0;
     s.rng_after = ctl->final_after; s.leaf_elems = 0; s.n_draw32 = ctl->final_drawn; s.nn_scanned = 0ull;
+#ifdef AUVP_DUO_DIAG
+    s.n_candidates = (int)(diag_work >> 8);                       // main: clocks / 256 at work (packet waits excluded)
+    s.nn_scanned = (unsigned long long)(uint32_t)ctl->_pad;       // helper: clocks / 256 building packets
+#endif
   }
 }
 

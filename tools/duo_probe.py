@@ -31,7 +31,8 @@ for obst, E in ((256, 1), (256, 64), (256, 256), (256, 1024), (64, 1024), (256, 
         assert (s["status"] >= 0).all(), np.unique(s["status"])
         res.append((ctx.last_rrt_kernel(), float(np.mean(ms)), float(s["iters_run"].sum())))
         if os.environ.get("AUVPLAN_LIBRARY") and duo == "1":
-            print("   diag build: main polled %.2f times per iteration waiting for its packet" % (float(s["n_candidates"].sum()) / float(s["iters_run"].sum())))
+            print("   diag build: per iteration, main works %.0f clocks, the helper builds for %.0f clocks (s_memtime, 100 MHz ticks x ... : ratio matters)"
+                  % (256.0 * float(s["n_candidates"].sum()) / float(s["iters_run"].sum()), 256.0 * float(s["nn_scanned"].sum()) / float(s["iters_run"].sum())))
     (k0, m0, n0), (k1, m1, n1) = res
     print("O=%d E=%d: %s %.2f ms = %.1f M exp/s (%.2f us per expansion of one episode) | %s %.2f ms = %.1f M exp/s (%.2f us)"
           % (obst, E, k0, m0, n0 / m0 / 1e3, 1e3 * m0 / iters, k1, m1, n1 / m1 / 1e3, 1e3 * m1 / iters))
