@@ -1,6 +1,7 @@
 """rrt_duo_kernel (two wavefronts per episode: a helper produces the half of an iteration that depends only on the random
-stream one iteration ahead, rrt_duo_kernel.h) against rrt_explore_kernel and the checker, bit for bit: summaries, trees,
-path points, bin sizes, returned paths -- including the stream position the episode ends at."""
+stream one iteration ahead, rrt_duo_kernel.h) and rrt_trio_kernel (three: stream, geometry, tree -- a pipeline over the
+iterations with speculative stages, rrt_trio_kernel.h) against rrt_explore_kernel and the checker, bit for bit: summaries,
+trees, path points, bin sizes, returned paths -- including the stream position the episode ends at."""
 import numpy as np
 import pytest
 
@@ -25,8 +26,9 @@ def ctx():
     c.close()
 
 
+@pytest.mark.parametrize("kernel", ["duo", "trio"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_duo_equals_one_wavefront_per_episode(ctx, orc, monkeypatch, name):
+def test_helper_wavefronts_equal_one_wavefront_per_episode(ctx, orc, monkeypatch, name, kernel):
     from auv_sim_amd import synth
     c = CASES[name]
     world = synth.make_world(**c["world"])
@@ -39,9 +41,10 @@ def test_duo_equals_one_wavefront_per_episode(ctx, orc, monkeypatch, name):
     out = {}
     monkeypatch.setenv("AUVP_ROWS", "0")
     for duo in ("1", "0"):
-        monkeypatch.setenv("AUVP_DUO", duo)
+        monkeypatch.setenv("AUVP_DUO", duo if kernel == "duo" else "0")
+        monkeypatch.setenv("AUVP_TRIO", duo if kernel == "trio" else "0")
         summ = ctx.rrt_explore_batch(init, seeds, n_iter, **kw).copy()
-        assert ctx.last_rrt_kernel() == ("rrt_duo_kernel" if duo == "1" else "rrt_explore_kernel")
+        assert ctx.last_rrt_kernel() == ("rrt_%s_kernel" % kernel if duo == "1" else "rrt_explore_kernel")
         sample = range(E) if E <= 16 else range(0, E, 37)
         trees = {e: ctx.tree(e, summ[e]) for e in sample}
         bins = {e: ctx.bin_sizes(e) for e in sample} if hasattr(ctx, "bin_sizes") else {}

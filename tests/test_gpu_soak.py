@@ -16,3 +16,12 @@ def test_random_cases_match_the_checker(seed):
                        cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_helper_wavefront_kernels_random_cases():
+    """rrt_duo_kernel / rrt_trio_kernel (speculative stages whose redo paths depend on the timing between wavefronts) against
+    rrt_explore_kernel over random worlds, parameters, batch sizes and budgets, every case repeated"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "experiments", "soak_duo.py"), "60", "11"],
+                       cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Latency runs with one (rrt_explore_kernel) and two (rrt_duo_kernel) wavefronts per episode: one episode, 64 / 256 / 1 024
-episodes of the headline world, and config 2's 1 024 replicas (64 obstacles).  Run on a GPU box."""
+"""Latency runs with one (rrt_explore_kernel), two (rrt_duo_kernel) and three (rrt_trio_kernel) wavefronts per episode: one
+episode, 64 / 256 / 1 024 episodes of the headline world, and config 2's 1 024 replicas (64 obstacles).  Run on a GPU box."""
 import os
 import sys
 
@@ -19,8 +19,8 @@ for obst, E in ((256, 1), (256, 64), (256, 256), (256, 1024), (64, 1024), (256, 
     init = np.zeros((E, 6))
     init[:, 0], init[:, 1] = world["start"]
     res = []
-    for duo in ("0", "1"):
-        os.environ["AUVP_DUO"] = duo
+    for duo, trio in (("0", "0"), ("1", "0"), ("0", "1")):
+        os.environ["AUVP_DUO"], os.environ["AUVP_TRIO"] = duo, trio
         ctx.rrt_prepare(init, np.arange(E, dtype=np.uint64) + 7, iters, mode="timebin", **bench.RRT_KW)
         ms = []
         for i in range(3):
@@ -30,9 +30,11 @@ for obst, E in ((256, 1), (256, 64), (256, 256), (256, 1024), (64, 1024), (256, 
         s = ctx.summaries()
         assert (s["status"] >= 0).all(), np.unique(s["status"])
         res.append((ctx.last_rrt_kernel(), float(np.mean(ms)), float(s["iters_run"].sum())))
-        if os.environ.get("AUVPLAN_LIBRARY") and duo == "1":
-            print("   diag build: per iteration, main works %.0f clocks, the helper builds for %.0f clocks (s_memtime, 100 MHz ticks x ... : ratio matters)"
-                  % (256.0 * float(s["n_candidates"].sum()) / float(s["iters_run"].sum()), 256.0 * float(s["nn_scanned"].sum()) / float(s["iters_run"].sum())))
-    (k0, m0, n0), (k1, m1, n1) = res
-    print("O=%d E=%d: %s %.2f ms = %.1f M exp/s (%.2f us per expansion of one episode) | %s %.2f ms = %.1f M exp/s (%.2f us)"
-          % (obst, E, k0, m0, n0 / m0 / 1e3, 1e3 * m0 / iters, k1, m1, n1 / m1 / 1e3, 1e3 * m1 / iters))
+        if os.environ.get("AUVPLAN_LIBRARY") and trio == "1":
+            w = s["nn_scanned"].astype(np.uint64)
+            n_it = float(s["iters_run"].sum())
+            print("   diag build (trio): %.3f flushes per iteration; clocks at work per iteration: H %.0f, M %.0f, T %.0f"
+                  % (float(s["n_candidates"].sum()) / n_it, 256.0 * float((w & np.uint64(0xfffff)).sum()) / n_it,
+                     256.0 * float(((w >> np.uint64(20)) & np.uint64(0xfffff)).sum()) / n_it, 256.0 * float((w >> np.uint64(40)).sum()) / n_it))
+    print("O=%d E=%d: " % (obst, E) + " | ".join("%s %.2f ms = %.1f M exp/s (%.2f us)" % (k.replace("rrt_", "").replace("_kernel", ""), m, n / m / 1e3, 1e3 * m / iters)
+                                                  for k, m, n in res))
