@@ -750,8 +750,8 @@ int auvp_rrt_run(auvp_handle* h) {
   // 1 024: 227 vs 271 (config 2's replicas, 64 obstacles: 241 vs 283), 2 048: 409 vs 435, 4 096: 621 vs 485
   const bool use_duo = duo_ok && !use_rows && (duo_env ? atoi(duo_env) != 0 : E <= 8 * n_cu_);
   // ... and three (rrt_trio_kernel.h: stream, geometry, tree -- a pipeline over the iterations) for at most four episodes per
-  // CU.  Measured (tools/duo_probe.py, M expansions/s, one / two / three wavefronts per episode): 1 episode 0.25 / 0.32 / 0.38,
-  // 256: 62 / 80 / 86, 1 024: 227 / 271 / 286 (config 2's replicas: 241 / 284 / 290), 2 048: 409 / 435 / 288.
+  // CU.  Measured (tools/duo_probe.py, M expansions/s, one / two / three wavefronts per episode): 1 episode 0.25 / 0.32 / 0.40,
+  // 256: 61 / 80 / 95, 1 024: 226 / 271 / 303 (config 2's replicas: 239 / 282 / 309), 2 048: 406 / 434 / 304.
   // AUVP_TRIO=1 / 0 force it on (limits permitting) / off; an explicit AUVP_DUO=1 takes precedence.
   const char* trio_env = getenv("AUVP_TRIO");
   const bool use_trio = duo_ok && !use_rows && (trio_env ? atoi(trio_env) != 0 : (E <= TRIO_EP * n_cu_ && !(duo_env && atoi(duo_env) != 0)));
@@ -762,14 +762,20 @@ int auvp_rrt_run(auvp_handle* h) {
     const int jd = O_ <= 64 ? 1 : (O_ <= 128 ? 2 : 4);
     const int dl = trio_lds_bytes(P.K, jd * 64, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), eps_wg);
     if (dl > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %d B > 160 KiB (K=%d)", dl, P.K);
-    grid_used = (E + eps_wg - 1) / eps_wg; block_used = eps_wg * 192; lds_used = dl;
+    // the parent lookup as a fourth wavefront per episode (rrt_trio_kernel<J, 4>) where every episode has a CU to itself: one
+    // episode 2.52 -> 2.49 us per expansion, 256 episodes 95 -> 100 M/s (1 024: 303 -> 262 M/s, so not there).  AUVP_QUAD=1 / 0
+    const char* quad_env = getenv("AUVP_QUAD");
+    const bool quad = quad_env ? atoi(quad_env) != 0 : E <= n_cu_;
+    grid_used = (E + eps_wg - 1) / eps_wg; block_used = eps_wg * (quad ? 256 : 192); lds_used = dl;
+    if (quad) h->last_rrt_kernel = "rrt_trio_kernel<4 wavefronts>";
     auto launch_trio = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, dl);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), dl, h->stream, h->W, PR, B, (int)E);
       return hipGetLastError();
     };
-    le = jd == 1 ? launch_trio(rrt_trio_kernel<1>) : (jd == 2 ? launch_trio(rrt_trio_kernel<2>) : launch_trio(rrt_trio_kernel<4>));
+    if (quad) le = jd == 1 ? launch_trio(rrt_trio_kernel<1, 4>) : (jd == 2 ? launch_trio(rrt_trio_kernel<2, 4>) : launch_trio(rrt_trio_kernel<4, 4>));
+    else le = jd == 1 ? launch_trio(rrt_trio_kernel<1, 3>) : (jd == 2 ? launch_trio(rrt_trio_kernel<2, 3>) : launch_trio(rrt_trio_kernel<4, 3>));
   } else if (use_duo) {
     int eps_wg = (E + n_cu_ - 1) / n_cu_;
     eps_wg = eps_wg < 1 ? 1 : (eps_wg > DUO_EP ? DUO_EP : eps_wg);

@@ -40,8 +40,10 @@ constexpr int TRIO_GEN = 1248;      // generator ring, words
 constexpr int TRIO_HIST = 8;        // appends T remembers (bin, size before): more than can be pending
 
 struct TrioPacket {  // H -> M (and T: ver, rb, rejects, status)
-  unsigned long long tag;
+  unsigned long long tag;    // the packet is complete (what M waits for)
+  unsigned long long tag_s;  // four-wavefront form: the stream part is complete, the parent lookup (L) is still to come
   int ver, status, rb, rejects, n_total, par;
+  int ri, _p0;
   unsigned long long tmask;
   double cx, cy, cth, ctt, clen;  // the parent's record
   double ud[DUO_CS], uf[DUO_CS], uv[DUO_CS];  // the taken sub-arcs' random() numbers: dist, diff, v (M turns them into radius, phi, v)
@@ -55,12 +57,13 @@ struct TrioGeo {  // M -> T
   double px[DUO_CS], py[DUO_CS], pt[DUO_CS], pth[DUO_CS], pv[DUO_CS], pl[DUO_CS];  // its path points, in order
 };
 
-struct TrioCtl {
+struct TrioCtl {  // (the first eight words are what the waits look at: read as two 16-byte pieces, one LDS round trip)
   int ver;            // appends so far (T)
   int done_seq;       // T has finished iterations < done_seq
   int epoch;          // bumped by T: everything from iteration restart_k on is redone
   int restart_k;
   int stop, abort, h_done, m_done;
+  int l_done, _pc0, _pc1, _pc2;
   double final_after;
   unsigned long long final_drawn;
   int hist_bin[TRIO_HIST], hist_cb[TRIO_HIST];  // append number a (1-based) -> bin, size before; slot a & 7
@@ -112,14 +115,29 @@ __device__ __forceinline__ void ring_advance(RingRng& r, uint32_t n) {
   r.drawn += n;
 }
 
-template <int J>
-__global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
+// the control words of an episode as the waits see them: one look = one LDS round trip (a lone wavefront pays ~100 clocks per
+// dependent LDS access, and a wait that looked at stop, abort, epoch and done_seq one after the other cost ~400 per iteration)
+struct TrioView { int ver, done_seq, epoch, restart_k, stop, abort; };
+__device__ __forceinline__ TrioView trio_look(const TrioCtl* c) {
+  __asm__ volatile("" ::: "memory");
+  const int4 a = *reinterpret_cast<const int4*>(&c->ver);
+  const int2 b = *reinterpret_cast<const int2*>(&c->stop);
+  __asm__ volatile("" ::: "memory");
+  TrioView v;
+  v.ver = uni(a.x); v.done_seq = uni(a.y); v.epoch = uni(a.z); v.restart_k = uni(a.w); v.stop = uni(b.x); v.abort = uni(b.y);
+  return v;
+}
+
+// NW = 3: H, M, T.  NW = 4: the parent lookup -- the member's id out of the bin's list, then its record: two dependent global
+// reads, ~1 200 clocks of H's ~5 000 that nothing in H covers -- is a wavefront of its own (L) between H and M.
+template <int J, int NW>
+__global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const RrtTables S = rrt_tables_view(smem, W.n_habitats, W.n_poly);
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
-  const int n_ep_wg = (int)(blockDim.x / 192);
-  const int eidx = wave / 3, role = wave - 3 * eidx;  // role 0: M (geometry), 1: H (stream), 2: T (tree)
+  const int n_ep_wg = (int)(blockDim.x / (64 * NW));
+  const int eidx = wave / NW, role = wave - NW * eidx;  // role 0: M (geometry), 1: H (stream), 2: T (tree), 3: L (parent lookup)
   const int K = P.K;
   const int tables_b = (rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins) + 15) & ~15;
   const int per_ep = trio_per_episode_bytes(K);
@@ -178,8 +196,9 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
     for (int i = lane; i < K + 2; i += 64) bin_count[i] = 0;
     if (lane == 0) {
       ctl->ver = 0; ctl->done_seq = 0; ctl->epoch = 0; ctl->restart_k = 0; ctl->stop = 0; ctl->abort = 0; ctl->h_done = 0; ctl->m_done = 0;
+      ctl->l_done = NW == 4 ? 0 : 1;
       ctl->final_after = 0.0; ctl->final_drawn = 0ull;
-      for (int k = 0; k < TRIO_RING; k++) { packet(k)->tag = 0ull; geo(k)->tag = 0ull; }
+      for (int k = 0; k < TRIO_RING; k++) { packet(k)->tag = 0ull; packet(k)->tag_s = 0ull; geo(k)->tag = 0ull; }
       for (int k = 0; k < TRIO_HIST; k++) { ctl->hist_bin[k] = -1; ctl->hist_cb[k] = 1; }
     }
     wave_sync();
@@ -241,21 +260,23 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
     };
     for (;;) {
       // ---- wait for a free slot (T has finished iteration k - TRIO_RING), a new epoch, or the end
-      int done = 0;
+      int done = 0, snap_ver = 0;
       {
         int spins = 0;
         for (;;) {
-          if (uni(duo_peek(&ctl->stop)) || uni(duo_peek(&ctl->abort))) goto h_end;
-          const int e2 = uni(duo_peek(&ctl->epoch));
-          if (e2 != epoch) {
+          TrioView cv = trio_look(ctl);
+          if (cv.stop || cv.abort) goto h_end;
+          if (cv.epoch != epoch) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            epoch = e2;
-            k = uni(duo_peek(&ctl->restart_k));
+            cv = trio_look(ctl);  // (restart_k is written before the epoch)
+            epoch = cv.epoch;
+            k = cv.restart_k;
             uint32_t cs; unsigned long long dr;
             sp_get(k, cs, dr);
             rewind_to(cs, dr);
           }
-          done = uni(duo_peek(&ctl->done_seq));
+          done = cv.done_seq;
+          snap_ver = cv.ver;
           if (k < P.max_iter && done >= k - (TRIO_RING - 1)) break;
           if (++spins > DUO_SPIN_LIMIT) { give_up(); goto h_end; }
           __builtin_amdgcn_s_sleep(1);
@@ -273,8 +294,9 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
       const unsigned long long t_b0 = __builtin_amdgcn_s_memtime();  // EXPERIMENT ONLY (tools/duo_probe.py)
 #endif
       sp_set(k, rng.cslot, rng.drawn);
+      // (the snapshot of `ver` is the one the wait just took -- BEFORE any look at the bins: an append after it is checked by T)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      int ver = uni(duo_peek(&ctl->ver));
+      int ver = snap_ver;
       bool synced = false;
       int status = 0, rb = 0, cnt = 0, f = -1, rejects = 0;
       double u_me = 0.0;
@@ -335,11 +357,13 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
       }
       if (again) continue;
       TrioPacket* q = packet(k);
-      int n_total = 0, par = 0;
+      int n_total = 0, par = 0, ri_out = 0;
       unsigned long long tmask = 0ull;
       if (status == 0) {
         const int ri = uni((int)py_uniform(0.0, (double)cnt, readlane_f64(u_me, f + 1)));
-        const int par_v = duo_bin_member(bins, rb, ri, capn);
+        ri_out = ri;
+        int par_v = 0;
+        if (NW == 3) par_v = duo_bin_member(bins, rb, ri, capn);
         int base = uni(f + 2);
         n_total = uni((int)auvp_floor(py_uniform(0.0, Q.freq, readlane_f64(u_me, base)) / 1));
         base += 1;
@@ -373,9 +397,12 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
         }
         // the parent's record is requested here, between the predicate and the fixed point: its id (requested before the window)
         // has had the predicate's time to arrive, and the record has the fixed point's
-        par = uni(par_v);
-        const double* pr = nodeF + (size_t)par * 8;
-        const double p0 = duo_ld_f64(pr), p1 = duo_ld_f64(pr + 1), p2 = duo_ld_f64(pr + 2), p3 = duo_ld_f64(pr + 3), p4 = duo_ld_f64(pr + 4);
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
+        if (NW == 3) {
+          par = uni(par_v);
+          const double* pr = nodeF + (size_t)par * 8;
+          p0 = duo_ld_f64(pr); p1 = duo_ld_f64(pr + 1); p2 = duo_ld_f64(pr + 2); p3 = duo_ld_f64(pr + 3); p4 = duo_ld_f64(pr + 4);
+        }
         const bool active = lane < n;
         int cbelow = lane;
         unsigned long long win;
@@ -399,15 +426,16 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
         if (taken) { ud = uw[mypos]; uf = uw[mypos + 1]; uv = uw[mypos + 2]; }
         wave_sync();  // (u_win is read by every lane above)
         if (lane < DUO_CS) { q->ud[lane] = ud; q->uf[lane] = uf; q->uv[lane] = uv; }
-        if (lane == 0) { q->cx = p0; q->cy = p1; q->cth = p2; q->ctt = p3; q->clen = p4; }
+        if (NW == 3 && lane == 0) { q->cx = p0; q->cy = p1; q->cth = p2; q->ctt = p3; q->clen = p4; }
         ring_advance(rng, (uint32_t)(2 * (base + used)));
       }
       if (lane == 0) {
         q->ver = ver; q->status = status; q->rb = rb; q->rejects = rejects;
-        q->n_total = n_total; q->par = par; q->tmask = tmask;
+        q->n_total = n_total; q->tmask = tmask; q->ri = ri_out;
+        if (NW == 3) q->par = par;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) duo_poke64(&q->tag, duo_tag(epoch, k));
+      if (lane == 0) duo_poke64(NW == 3 ? &q->tag : &q->tag_s, duo_tag(epoch, k));
 #ifdef AUVP_DUO_DIAG
       diag_h += __builtin_amdgcn_s_memtime() - t_b0;
 #endif
@@ -431,6 +459,48 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
     return;
   }
 
+  if (NW == 4 && role == 3) {
+    // ================================================================================================ L: the parent lookup
+    int epoch = 0, k = 0;
+    for (;;) {
+      TrioPacket* q = nullptr;
+      {
+        int spins = 0;
+        for (;;) {
+          q = packet(k);
+          const unsigned long long tg = duo_peek64(&q->tag_s);
+          TrioView cv = trio_look(ctl);
+          if (cv.stop || cv.abort) goto l_end;
+          if (cv.epoch != epoch) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            cv = trio_look(ctl);
+            epoch = cv.epoch;
+            k = cv.restart_k;
+            continue;
+          }
+          if (k < P.max_iter && tg == duo_tag(epoch, k)) break;
+          if (++spins > DUO_SPIN_LIMIT) { give_up(); goto l_end; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      if (uni(q->status) == 0) {
+        // the ri-th member of bin rb and its record (T wrote both before the `ver` the packet was built from -- or T redoes the
+        // packet: a read that raced with a later append is clamped into the episode's storage and thrown away)
+        const int par = uni(duo_bin_member(bins, uni(q->rb), uni(q->ri), capn));
+        const double* pr = nodeF + (size_t)par * 8;
+        const double p0 = duo_ld_f64(pr), p1 = duo_ld_f64(pr + 1), p2 = duo_ld_f64(pr + 2), p3 = duo_ld_f64(pr + 3), p4 = duo_ld_f64(pr + 4);
+        if (lane == 0) { q->par = par; q->cx = p0; q->cy = p1; q->cth = p2; q->ctt = p3; q->clen = p4; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) duo_poke64(&q->tag, duo_tag(epoch, k));
+      k++;
+    }
+  l_end:
+    if (lane == 0) duo_poke(&ctl->l_done, 1);
+    return;
+  }
+
   if (role == 0) {
     // =================================================================================================== M: the geometry
     int epoch = 0, k = 0;
@@ -442,15 +512,18 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
       {
         int spins = 0;
         for (;;) {
-          if (uni(duo_peek(&ctl->stop)) || uni(duo_peek(&ctl->abort))) goto m_end;
-          const int e2 = uni(duo_peek(&ctl->epoch));
-          if (e2 != epoch) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            epoch = e2;
-            k = uni(duo_peek(&ctl->restart_k));
-          }
           q = packet(k);
-          if (k < P.max_iter && duo_peek64(&q->tag) == duo_tag(epoch, k)) break;
+          const unsigned long long tg = duo_peek64(&q->tag);  // (issued with the control words: one round trip)
+          TrioView cv = trio_look(ctl);
+          if (cv.stop || cv.abort) goto m_end;
+          if (cv.epoch != epoch) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            cv = trio_look(ctl);
+            epoch = cv.epoch;
+            k = cv.restart_k;
+            continue;
+          }
+          if (k < P.max_iter && tg == duo_tag(epoch, k)) break;
           if (++spins > DUO_SPIN_LIMIT) { give_up(); goto m_end; }
           __builtin_amdgcn_s_sleep(1);
         }
@@ -705,7 +778,7 @@ __global__ __launch_bounds__(TRIO_EP * 192, 1) void rrt_trio_kernel(WorldDev W, 
   if (lane == 0) duo_poke(&ctl->stop, 1);
   {
     int spins = 0;
-    while (!uni(duo_peek(&ctl->h_done)) || !uni(duo_peek(&ctl->m_done))) {
+    while (!uni(duo_peek(&ctl->h_done)) || !uni(duo_peek(&ctl->m_done)) || !uni(duo_peek(&ctl->l_done))) {
       if (++spins > DUO_SPIN_LIMIT) { status = -9; break; }
       __builtin_amdgcn_s_sleep(1);
     }

@@ -29,12 +29,13 @@ for c in range(n_cases):
     init[:, 2] = rng.uniform(-3, 3, E)
     seeds = rng.integers(0, 2 ** 40, E).astype(np.uint64)
     ref = None
-    for kern, rep in (("explore", 1), ("duo", 2), ("trio", 3)):
+    for kern, rep in (("explore", 1), ("duo", 2), ("trio", 3), ("quad", 3)):
         os.environ["AUVP_DUO"] = "1" if kern == "duo" else "0"
-        os.environ["AUVP_TRIO"] = "1" if kern == "trio" else "0"
+        os.environ["AUVP_TRIO"] = "1" if kern in ("trio", "quad") else "0"
+        os.environ["AUVP_QUAD"] = "1" if kern == "quad" else "0"
         for _ in range(rep):
             s = ctx.rrt_explore_batch(init, seeds, n_iter, **kw).copy()
-            assert ctx.last_rrt_kernel() == "rrt_%s_kernel" % kern, ctx.last_rrt_kernel()
+            assert ctx.last_rrt_kernel().startswith("rrt_%s_kernel" % ("trio" if kern == "quad" else kern)), ctx.last_rrt_kernel()
             trees = [ctx.tree(e, s[e]) for e in range(min(E, 3))]
             if ref is None:
                 ref = (s, trees)

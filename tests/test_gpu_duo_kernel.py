@@ -26,7 +26,7 @@ def ctx():
     c.close()
 
 
-@pytest.mark.parametrize("kernel", ["duo", "trio"])
+@pytest.mark.parametrize("kernel", ["duo", "trio", "quad"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_helper_wavefronts_equal_one_wavefront_per_episode(ctx, orc, monkeypatch, name, kernel):
     from auv_sim_amd import synth
@@ -42,9 +42,10 @@ def test_helper_wavefronts_equal_one_wavefront_per_episode(ctx, orc, monkeypatch
     monkeypatch.setenv("AUVP_ROWS", "0")
     for duo in ("1", "0"):
         monkeypatch.setenv("AUVP_DUO", duo if kernel == "duo" else "0")
-        monkeypatch.setenv("AUVP_TRIO", duo if kernel == "trio" else "0")
+        monkeypatch.setenv("AUVP_TRIO", duo if kernel in ("trio", "quad") else "0")
+        monkeypatch.setenv("AUVP_QUAD", "1" if kernel == "quad" else "0")
         summ = ctx.rrt_explore_batch(init, seeds, n_iter, **kw).copy()
-        assert ctx.last_rrt_kernel() == ("rrt_%s_kernel" % kernel if duo == "1" else "rrt_explore_kernel")
+        assert ctx.last_rrt_kernel().startswith("rrt_%s_kernel" % ("trio" if kernel == "quad" else kernel) if duo == "1" else "rrt_explore_kernel")
         sample = range(E) if E <= 16 else range(0, E, 37)
         trees = {e: ctx.tree(e, summ[e]) for e in sample}
         bins = {e: ctx.bin_sizes(e) for e in sample} if hasattr(ctx, "bin_sizes") else {}

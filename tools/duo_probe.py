@@ -19,8 +19,8 @@ for obst, E in ((256, 1), (256, 64), (256, 256), (256, 1024), (64, 1024), (256, 
     init = np.zeros((E, 6))
     init[:, 0], init[:, 1] = world["start"]
     res = []
-    for duo, trio in (("0", "0"), ("1", "0"), ("0", "1")):
-        os.environ["AUVP_DUO"], os.environ["AUVP_TRIO"] = duo, trio
+    for duo, trio, quad in (("0", "0", "0"), ("1", "0", "0"), ("0", "1", "0"), ("0", "1", "1")):
+        os.environ["AUVP_DUO"], os.environ["AUVP_TRIO"], os.environ["AUVP_QUAD"] = duo, trio, quad
         ctx.rrt_prepare(init, np.arange(E, dtype=np.uint64) + 7, iters, mode="timebin", **bench.RRT_KW)
         ms = []
         for i in range(3):
@@ -36,5 +36,5 @@ for obst, E in ((256, 1), (256, 64), (256, 256), (256, 1024), (64, 1024), (256, 
             print("   diag build (trio): %.3f flushes per iteration; clocks at work per iteration: H %.0f, M %.0f, T %.0f"
                   % (float(s["n_candidates"].sum()) / n_it, 256.0 * float((w & np.uint64(0xfffff)).sum()) / n_it,
                      256.0 * float(((w >> np.uint64(20)) & np.uint64(0xfffff)).sum()) / n_it, 256.0 * float((w >> np.uint64(40)).sum()) / n_it))
-    print("O=%d E=%d: " % (obst, E) + " | ".join("%s %.2f ms = %.1f M exp/s (%.2f us)" % (k.replace("rrt_", "").replace("_kernel", ""), m, n / m / 1e3, 1e3 * m / iters)
+    print("O=%d E=%d: " % (obst, E) + " | ".join("%s %.2f ms = %.1f M exp/s (%.2f us)" % (k.replace("rrt_", "").replace("_kernel", "").replace("<4 wavefronts>", "4"), m, n / m / 1e3, 1e3 * m / iters)
                                                   for k, m, n in res))
