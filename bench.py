@@ -427,7 +427,12 @@ def timed_steps(ranks, step, steps, warmup):
 RRT_KW = dict(freq=30, bin_interval=5, v=2, max_traj_time=500.0, weights=(-3, -3, -4))
 
 
-def rrt_pass_rooflines(ctx, summ, meas, exp_ms, leaf_ms, kname, **extra):
+SIDE_KEEP = ("bound", "achieved", "peak", "unit", "frac", "kernel", "kernel_ms", "algorithmic_bytes_per_launch", "frac_of_measured",
+             "valu_issue_frac", "traffic", "traffic_raw", "bytes_per_expansion", "leaf_kernel_ms", "leaf_compulsory_bytes", "leaf_frac",
+             "pass_kernel_ms", "pass_8d_frac")
+
+
+def rrt_pass_rooflines(ctx, summ, meas, exp_ms, leaf_ms, kname, compact=False, **extra):
     """One pass of RRT.exploring = two launches.  Returns the roofline of the DOMINANT kernel (the tree expansion: its own
     algorithmic bytes over its own HIP-event time) with the leaf pass and the whole-pass SURVEY 8(d) figure beside it as
     flat scalars (the driver's record keeps scalars of this object, not nested dicts):
@@ -459,6 +464,8 @@ def rrt_pass_rooflines(ctx, summ, meas, exp_ms, leaf_ms, kname, **extra):
                  **extra)
     if HBM_MEASURED.get("read_GBps"):
         r["leaf_frac_of_measured"] = leaf_ach / HBM_MEASURED["read_GBps"]
+    if compact:  # side measurements: the scalars that matter, no prose (the headline's object explains the fields)
+        r = {k: r[k] for k in SIDE_KEEP if k in r}
     return r
 
 
@@ -502,7 +509,7 @@ def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0, mode=None, kw=No
            "accept_rate": float((summ["n_nodes"] - 1).sum()) / iters,
            "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters,
            "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
-           "roofline": rrt_pass_rooflines(ctx, summ, meas, float(np.mean(ems)), float(np.mean(lms)), ctx.last_rrt_kernel())}
+           "roofline": rrt_pass_rooflines(ctx, summ, meas, float(np.mean(ems)), float(np.mean(lms)), ctx.last_rrt_kernel(), compact=True)}
     if cpu_seconds > 0:
         from oracle import orc
         w = orc.WorldArrays(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
