@@ -1011,6 +1011,7 @@ int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds
 #include "probe_kernels.h"
 #include "planner_rrt_kernel.h"
 #include "planner_rows_kernel.h"
+#include "planner_duo_kernel.h"
 #include "planner_rrt_host.h"
 
 namespace {

@@ -66,6 +66,9 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
   int grid_used = grid, block_used = wg_waves * 64;
   size_t lds_used = lds;
   S.last_kernel = "prrt_kernel";
+  const char* denv = getenv("AUVP_PRRT_DUO");
+  const bool use_duo = !S.use_rows && step_mode == 0 && lat && !(S.P.flags & AUVP_FLAG_ITER_LOG) && nfreq <= auvp::DUO_MAX_FREQ && O <= 256 &&
+                       S.B.max_pts <= auvp::DUO_CS + 2 && (denv ? atoi(denv) != 0 : false);  // (bring-up: opt-in)
   if (S.use_rows) {
     // persistent rows (four episodes per wavefront) fed from a device counter: as many workgroups as fit the chip at
     // three per CU (one wave per SIMD each), fewer when the batch is smaller
@@ -87,6 +90,23 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
       le = hipGetLastError();
       S.work_base += S.E + grid_used * per_wg;  // every episode once + one empty pull per row
     }
+  } else if (use_duo) {
+    // two wavefronts per episode (planner_duo_kernel.h): plan-mode latency runs of at most four episodes per CU
+    S.last_kernel = "prrt_duo_kernel";
+    int eps_wg = (S.E + n_cu_l - 1) / n_cu_l;
+    eps_wg = eps_wg < 1 ? 1 : (eps_wg > auvp::PDUO_EP ? auvp::PDUO_EP : eps_wg);
+    grid_used = (S.E + eps_wg - 1) / eps_wg;
+    block_used = eps_wg * 128;
+    lds_used = (size_t)eps_wg * auvp::pduo_per_episode_bytes(S.B.max_pts);
+    auto launch_duo = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E);
+      return hipGetLastError();
+    };
+    if (O <= 64) le = launch_duo(auvp::prrt_duo_kernel<1>);
+    else if (O <= 128) le = launch_duo(auvp::prrt_duo_kernel<2>);
+    else le = launch_duo(auvp::prrt_duo_kernel<4>);
   } else if (lat) {
     if (O <= 64) le = launch(auvp::prrt_kernel<1, true>);
     else if (O <= 128) le = launch(auvp::prrt_kernel<2, true>);
