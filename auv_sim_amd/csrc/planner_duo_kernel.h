@@ -47,6 +47,11 @@ struct PduoCtl {  // (first eight words: what the waits look at)
   int stop, abort, helper_done, final_step;  // final_step: the last step main executed (the stream ends after its draws)
   double final_after;
   unsigned long long final_drawn;
+  // three-wavefront form: the goal arc (connect_to_goal_curve_alt, :374-423) of step k is evaluated by a wavefront of its own
+  // (G) while main steers and collision-tests step k + 1; main waits for the verdict before it inserts
+  unsigned long long arc_tag;  // request: {0, step + 1}, written last
+  double arc_lx, arc_ly, arc_th0;
+  int arc_last, arc_done_seq, arc_free, g_done;  // arc_done_seq: requests of steps < arc_done_seq are decided; arc_free: the latest verdict
 };
 
 __host__ __device__ inline int pduo_per_episode_bytes(int max_pts) {
@@ -98,14 +103,118 @@ __device__ __forceinline__ uint32_t pduo_randbelow(WaveRng& r, uint32_t n, int& 
   }
 }
 
+// connect_to_goal_curve_alt(mps_list[-1]) (:374-423) from the node (lx, ly, th0) = node `last`: true when the arc to the goal is
+// free -- then the planning is over and the result record gets the arc and the length of the path (the walk to the root).
+// n_arc_out: number of arc samples (-1: no arc: bearing error above pi / 2 or degenerate).
 template <int J>
-__global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
+__device__ __forceinline__ bool prrt_goal_arc(const PrrtParamsDev& P, const double (&ox)[J], const double (&oy)[J], const double (&ot)[J],
+                                              const double (&orr)[J], double gx, double gy, double lx, double ly, double th0,
+                                              const PrrtNode* nodes, int last, PrrtSummary& sum, int& n_arc_out) {
+  const int lane = lane_id();
+  int n_arc = -1;
+  bool is_free = false;
+  {
+      const double theta = auvp_atan2(gy - ly, gx - lx);
+      const double diff = prrt_angle_wrap(theta - th0);
+      if (!(auvp_fabs(diff) > AUVP_PI / 2)) {
+        const double r_G = auvp_hypot(gx - lx, gy - ly);
+        const double phi_G = theta;
+        if (phi_G - th0 != 0) {
+          double phi = 2 * prrt_angle_wrap(phi_G - th0);
+          const double sn0 = auvp_sin(phi_G - th0);
+          if (sn0 != 0) {
+            const double radius = r_G / (2 * sn0);
+            double length = radius * phi;
+            if (phi > AUVP_PI) { phi -= 2 * AUVP_PI; length = -radius * phi; }
+            else if (phi < -AUVP_PI) { phi += 2 * AUVP_PI; length = -radius * phi; }
+            const double ang_vel = phi / (length / P.exp_rate);
+            double s0, c0;
+            auvp_sincos(th0, &s0, &c0);
+            const double x_C = lx - radius * s0;
+            const double y_C = ly + radius * c0;
+            const double ne = auvp_floor(length / P.exp_rate);
+            n_arc = (ne >= 0 && ne < 1e8) ? (int)ne + 1 : 0;
+            n_arc = uni(n_arc);
+            bool free_ = true;
+            for (int i0 = 0; i0 < n_arc && free_; i0 += 64) {
+              const int nv = (n_arc - i0) < 64 ? (n_arc - i0) : 64;
+              const int i = i0 + lane;
+              double ax = 0.0, ay = 0.0;
+              bool outside = false;
+              if (lane < nv) {
+                double sa, ca;
+                auvp_sincos(ang_vel * i + th0, &sa, &ca);
+                ax = x_C + radius * sa;
+                ay = y_C - radius * ca;
+                const bool wx = (ax >= P.rect[0]) && (ax <= P.rect[2]);
+                const bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
+                outside = !(wx && wy);
+              }
+              if (__any(outside)) { free_ = false; break; }
+              const double rad = auvp_fabs(radius), dth = auvp_fabs(ang_vel) * (double)(nv - 1);
+              double bx0, by0, bx1, by1;
+              if (dth < AUVP_PI) {
+                const double x0 = readlane_f64(ax, 0), y0 = readlane_f64(ay, 0);
+                const double x1 = readlane_f64(ax, nv - 1), y1 = readlane_f64(ay, nv - 1);
+                double sag = rad * dth * dth * 0.125;
+                sag = sag < 2.0 * rad ? sag : 2.0 * rad;
+                bx0 = (x0 < x1 ? x0 : x1) - sag; bx1 = (x0 < x1 ? x1 : x0) + sag;
+                by0 = (y0 < y1 ? y0 : y1) - sag; by1 = (y0 < y1 ? y1 : y0) + sag;
+              } else {
+                bx0 = x_C - rad; bx1 = x_C + rad; by0 = y_C - rad; by1 = y_C + rad;
+              }
+              const double cxm = (bx0 + bx1) * 0.5, cym = (by0 + by1) * 0.5;
+              const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + rad + 1.0);
+              const double hx = (bx1 - bx0) * 0.5 + slack, hy = (by1 - by0) * 0.5 + slack;
+              bool hitl = false;
+#pragma unroll
+              for (int j = 0; j < J; j++) {
+                const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
+                unsigned long long cm = __ballot(cand);
+                while (cm) {
+                  const int l = __ffsll((long long)cm) - 1;
+                  cm &= cm - 1ull;
+                  const double oxl = readlane_f64(ox[j], l), oyl = readlane_f64(oy[j], l), otl = readlane_f64(ot[j], l);
+                  const double ex = ax - oxl, ey = ay - oyl;
+                  hitl |= (lane < nv) && (ex * ex + ey * ey <= otl);
+                }
+              }
+              if (__any(hitl)) free_ = false;
+            }
+            if (free_) {
+              is_free = true;
+              int L = 1 + n_arc;
+              for (int m = last;;) {
+                const int4 r = *reinterpret_cast<const int4*>(&nodes[m].step);
+                const int gp = uni(r.y);
+                if (gp < 0) break;
+                L += uni(r.w) + 1;
+                m = gp;
+              }
+              if (lane == 0) {
+                sum.path_len = L; sum.last_node = last; sum.n_arc = n_arc;
+                sum.arc[0] = x_C; sum.arc[1] = y_C; sum.arc[2] = radius; sum.arc[3] = ang_vel; sum.arc[4] = th0;
+                sum.arc[5] = length;
+              }
+            }
+          }
+        }
+      }
+  }
+  n_arc_out = n_arc;
+  return is_free;
+}
+
+// NW = 2: helper + main.  NW = 3: helper + main + goal-arc wavefront.
+template <int J, int NW>
+__global__ __launch_bounds__(PDUO_EP * 64 * NW, 1) void prrt_duo_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
-  const int n_ep_wg = (int)(blockDim.x >> 7);
+  const int n_ep_wg = (int)(blockDim.x / (64 * NW));
+  const int eidx = wave / NW, role = wave - NW * eidx;  // role 0: main, 1: helper, 2: goal arc
   const int per_ep = pduo_per_episode_bytes(B.max_pts);
-  unsigned char* eb = smem + (size_t)(wave >> 1) * per_ep;
+  unsigned char* eb = smem + (size_t)eidx * per_ep;
   uint32_t* mt = reinterpret_cast<uint32_t*>(eb);
   eb += 624 * 4;
   double(*pts)[2] = reinterpret_cast<double(*)[2]>(eb);
@@ -117,8 +226,8 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
   auto packet = [&](int k) -> PduoPacket* { return reinterpret_cast<PduoPacket*>(pk_base + (size_t)(k & 1) * PK_STRIDE); };
   (void)n_ep_wg;
 
-  const int ep = (int)blockIdx.x * (int)(blockDim.x >> 7) + (wave >> 1);
-  const bool helper = (wave & 1) != 0;
+  const int ep = (int)blockIdx.x * n_ep_wg + eidx;
+  const bool helper = role == 1;
   const bool valid_ep = ep < n_episodes;
   const size_t eps = (size_t)(valid_ep ? ep : 0);
   const int capn = B.cap_nodes;
@@ -131,13 +240,14 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
   const int epoch_b = B.bucket_epoch;
   PrrtSummary& sum = B.summary[eps];
   const int step0 = uni(sum.steps);
-  if (!helper) {
+  if (role == 0) {
     if (lane == 0) {
+      ctl->arc_tag = 0ull; ctl->arc_done_seq = step0; ctl->arc_free = 0; ctl->g_done = NW == 3 ? 0 : 1;
       ctl->ver = sum.n_nodes; ctl->n_occ = sum.n_occ; ctl->valid_seq = step0; ctl->redo_epoch = 0; ctl->stop = 0; ctl->abort = 0;
       ctl->helper_done = 0; ctl->final_step = step0 - 1; ctl->final_after = 0.0; ctl->final_drawn = 0ull;
       packet(0)->tag = 0ull; packet(1)->tag = 0ull;
     }
-  } else {
+  } else if (role == 1) {
     for (int i = lane; i < 624; i += 64) mt[i] = B.mt[eps * 624 + i];
   }
   __threadfence_block();
@@ -153,21 +263,30 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
     rng.avail = (uint32_t)uni(B.rng_state[4 * eps + 1]);
     rng.drawn = ((unsigned long long)(uint32_t)uni(B.rng_state[4 * eps + 2])) | ((unsigned long long)(uint32_t)uni(B.rng_state[4 * eps + 3]) << 32);
     int epoch = 0;
-    uint32_t sp_pslot = rng.pslot;             // stream position at the start of the latest packet
-    unsigned long long sp_drawn = rng.drawn;
+    // stream positions at the first word of the latest packet (slot cur & 1) and of the one before (the other slot): main can
+    // ask for the latest to be rebuilt, and -- three-wavefront form -- the planning can end one step BEFORE the latest packet
+    // main had accepted (a free goal arc drops the step in progress)
+    uint32_t spp0 = rng.pslot, spp1 = rng.pslot;
+    unsigned long long spd0 = rng.drawn, spd1 = rng.drawn;
     int cur = step0 - 1;                        // the latest packet started
-    auto rewind = [&]() {
-      rng.avail = (uint32_t)uni((int)(rng.avail + (uint32_t)(rng.drawn - sp_drawn)));
-      rng.pslot = sp_pslot; rng.drawn = sp_drawn;
+    unsigned long long hold_drawn = rng.drawn;  // oldest position a rewind may ask for: generation stays within 624 words of it
+    auto rewind_to = [&](int kk) {
+      const uint32_t ps = (kk & 1) ? spp1 : spp0;
+      const unsigned long long dr = (kk & 1) ? spd1 : spd0;
+      rng.avail = (uint32_t)uni((int)(rng.avail + (uint32_t)(rng.drawn - dr)));
+      rng.pslot = ps; rng.drawn = dr;
     };
     auto ensure = [&](uint32_t need) -> bool {
       while (rng.avail < need) {
-        if ((rng.drawn - sp_drawn) + rng.avail + 64ull > 624ull) return false;
+        if ((rng.drawn - hold_drawn) + rng.avail + 64ull > 624ull) return false;
         rng_ensure(rng, rng.avail + 1u);
       }
       return true;
     };
     int k = step0;
+#ifdef AUVP_DUO_DIAG
+    unsigned long long diag_h = 0ull;
+#endif
     for (;;) {
       PduoView cv;
       {
@@ -177,8 +296,8 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
           if (cv.stop || cv.abort) goto helper_end;
           if (cv.redo_epoch != epoch) {  // packet k - 1 is rebuilt from its first word
             epoch = cv.redo_epoch;
-            rewind();
             k -= 1;
+            rewind_to(k);
             break;
           }
           if (k < P.max_step && cv.valid_seq >= k) break;
@@ -187,8 +306,12 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
         }
       }
       // ---------------------------------------------------------------- build packet k (from the snapshot `cv` just taken)
+#ifdef AUVP_DUO_DIAG
+      const unsigned long long t_h0 = __builtin_amdgcn_s_memtime();  // EXPERIMENT ONLY (tools/prrt_duo_probe.py)
+#endif
       cur = k;
-      sp_pslot = rng.pslot; sp_drawn = rng.drawn;
+      if (k & 1) { spp1 = rng.pslot; spd1 = rng.drawn; } else { spp0 = rng.pslot; spd0 = rng.drawn; }
+      hold_drawn = k > step0 ? ((k & 1) ? spd0 : spd1) : rng.drawn;  // (the packet before this one, while there is one)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const int ver = cv.ver, n_occ = cv.n_occ;
       PduoPacket* q = packet(k);
@@ -198,7 +321,7 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
       if (n_occ <= 0) status = -1;
       if (status == 0) {
         bool ok1 = true;
-        const uint32_t oi = pduo_randbelow(rng, (uint32_t)n_occ, rmin, ok1, sp_drawn);
+        const uint32_t oi = pduo_randbelow(rng, (uint32_t)n_occ, rmin, ok1, hold_drawn);
         fits = ok1;
         if (fits) {
           int bb = duo_ld_i32(occupied + (oi < (uint32_t)capn ? oi : 0u));
@@ -210,7 +333,7 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
           else {
             int dummy = 0x7fffffff;
             bool ok2 = true;
-            const int rsel = (int)pduo_randbelow(rng, (uint32_t)cnt_b, dummy, ok2, sp_drawn);
+            const int rsel = (int)pduo_randbelow(rng, (uint32_t)cnt_b, dummy, ok2, hold_drawn);
             fits = ok2;
             if (fits) {
               // the rsel-th member (creation order) of bucket b: count - 1 - rsel steps from the head of its list, or -- further
@@ -296,6 +419,9 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) duo_poke64(&q->tag, duo_tag(epoch, k));
+#ifdef AUVP_DUO_DIAG
+      diag_h += __builtin_amdgcn_s_memtime() - t_h0;
+#endif
       k++;
     }
   helper_end:
@@ -304,7 +430,7 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
       // or begun beyond it is undone)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const int fs = uni(duo_peek(&ctl->final_step));
-      if (cur > fs) rewind();
+      if (cur > fs) rewind_to(fs + 1);  // (fs + 1 is the latest packet or the one before it)
       const unsigned long long drawn = rng.drawn;
       for (int i = lane; i < 624; i += 64) B.mt[eps * 624 + i] = mt[i];
       if (lane == 0) {
@@ -318,13 +444,16 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
       rng_ensure(peek, 2u);  // may generate ahead in LDS only; the stored words above are untouched
       const double after = rng_random_at(peek, 0u);
       if (lane == 0) { ctl->final_after = after; ctl->final_drawn = drawn; }
+#ifdef AUVP_DUO_DIAG
+      if (lane == 0) ctl->arc_lx = (double)diag_h;
+#endif
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) duo_poke(&ctl->helper_done, 1);
     }
     return;
   }
 
-  // =========================================================================================================== MAIN
+  // ================================================================================================ MAIN / GOAL ARC
   double ox[J], oy[J], ot[J], orr[J];
 #pragma unroll
   for (int j = 0; j < J; j++) {
@@ -336,11 +465,77 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
     orr[j] = ot[j] >= 0.0 ? auvp_sqrt(ot[j]) * (1.0 + 0x1p-30) + 0x1p-40 : -__builtin_inf();
   }
   const double gx = readfirst_f64(B.goal[2 * eps]), gy = readfirst_f64(B.goal[2 * eps + 1]);
+  if (NW == 3 && role == 2) {
+    // ---- G: the goal arcs main asks for, one at a time (main takes a verdict before it posts the next request)
+#ifdef AUVP_DUO_DIAG
+    unsigned long long diag_g = 0ull;
+#endif
+    for (int n = 0;; n++) {
+      int spins = 0;
+      bool stop = false;
+      for (;;) {
+        const unsigned long long tg = duo_peek64(&ctl->arc_tag);
+        const PduoView cv = pduo_look(ctl);
+        if (cv.stop || cv.abort) { stop = true; break; }
+        if (tg == duo_tag(0, n)) break;
+        if (++spins > DUO_SPIN_LIMIT) { give_up(); stop = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (stop) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double lx = readfirst_f64(ctl->arc_lx), ly = readfirst_f64(ctl->arc_ly), th0 = readfirst_f64(ctl->arc_th0);
+      const int last = uni(ctl->arc_last);
+      int n_arc = -1;
+#ifdef AUVP_DUO_DIAG
+      const unsigned long long t_g0 = __builtin_amdgcn_s_memtime();
+#endif
+      const bool is_free = prrt_goal_arc<J>(P, ox, oy, ot, orr, gx, gy, lx, ly, th0, nodes, last, sum, n_arc);
+#ifdef AUVP_DUO_DIAG
+      diag_g += __builtin_amdgcn_s_memtime() - t_g0;
+#endif
+      if (lane == 0) ctl->arc_free = is_free ? 1 : 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) duo_poke(&ctl->arc_done_seq, n + 1);
+    }
+#ifdef AUVP_DUO_DIAG
+    if (lane == 0) ctl->arc_ly = (double)diag_g;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) duo_poke(&ctl->g_done, 1);
+    return;
+  }
   int n_nodes = uni(sum.n_nodes), n_points = uni(sum.n_points), n_occ = uni(sum.n_occ), step = step0;
   int done = uni(sum.done), status = uni(sum.status);
   int last_accepted = 0, last_new = -1, last_bk = -2, my_epoch = 0;
   int prev_n_arc = -1;
   bool have_prev_arc = false;
+  // three-wavefront form: the arc request in flight (at most one), the step in progress, what the previous step reported
+#ifdef AUVP_DUO_DIAG
+  unsigned long long diag_m = 0ull, diag_w = 0ull;
+#endif
+  bool arc_pending = false, in_step = false;
+  int arc_reqs = 0, prev_acc = 0, prev_new = -1;
+  // the verdict of the request in flight.  A free arc ends the planning at the step that posted it: a step in progress (its
+  // steer, its collision test -- never an insert: the verdict is taken before) is dropped, the stream ends before its draws
+  auto take_verdict = [&]() {
+    if (!arc_pending) return;
+    int spins = 0;
+    while (uni(duo_peek(&ctl->arc_done_seq)) < arc_reqs) {
+      if (uni(duo_peek(&ctl->abort)) || ++spins > DUO_SPIN_LIMIT) { give_up(); status = -9; arc_pending = false; return; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    arc_pending = false;
+    if (uni(duo_peek(&ctl->arc_free)) != 0) {
+      done = 1;
+      if (in_step) {
+        status = 0;
+        last_accepted = prev_acc; last_new = prev_new;
+        if (lane == 0) ctl->final_step = step - 1;
+        in_step = false;
+      }
+    }
+  };
   auto lane_f64 = [](double v, int src) {
     const long long bits = __double_as_longlong(v);
     const int lo = __shfl((int)(bits & 0xffffffffll), src, 64), hi = __shfl((int)(bits >> 32), src, 64);
@@ -374,12 +569,20 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
       }
     }
     if (uni(status)) break;
+#ifdef AUVP_DUO_DIAG
+    const unsigned long long t_m0 = __builtin_amdgcn_s_memtime();
+#endif
     if (lane == 0) duo_poke(&ctl->valid_seq, step + 1);  // the helper may build the next packet now
+    in_step = true;
+    prev_acc = last_accepted; prev_new = last_new;
     if (uni(q->status) != 0) { status = uni(q->status); break; }
     last_accepted = 0; last_new = -1;
     if (lane == 0) ctl->final_step = step;  // (this step's draws count from here on)
     if (uni(q->kind) == 1) {  // generate_one_node on an empty bucket: (False, None) (:214-220)
+      take_verdict();
+      if (done || uni(status)) break;
       step++;
+      in_step = false;
       continue;
     }
     const int par = uni(q->par), n_total = uni(q->n_total);
@@ -454,6 +657,16 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
     }
     int me = -1;
     last_bk = -2;
+#ifdef AUVP_DUO_DIAG
+    const unsigned long long t_m1 = __builtin_amdgcn_s_memtime();
+    diag_m += t_m1 - t_m0;
+#endif
+    take_verdict();  // (before anything of this step reaches the tree)
+#ifdef AUVP_DUO_DIAG
+    const unsigned long long t_m2 = __builtin_amdgcn_s_memtime();
+    diag_w += t_m2 - t_m1;
+#endif
+    if (done || uni(status)) break;
     if (ok) {
       if (n_nodes >= capn) { status = -2; break; }
       me = n_nodes;
@@ -512,103 +725,30 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
     }
     int n_arc = -1;
     if (!ok && have_prev_arc) n_arc = prev_n_arc;
-    else {
-      const double theta = auvp_atan2(gy - ly, gx - lx);
-      const double diff = prrt_angle_wrap(theta - th0);
-      if (!(auvp_fabs(diff) > AUVP_PI / 2)) {
-        const double r_G = auvp_hypot(gx - lx, gy - ly);
-        const double phi_G = theta;
-        if (phi_G - th0 != 0) {
-          double phi = 2 * prrt_angle_wrap(phi_G - th0);
-          const double sn0 = auvp_sin(phi_G - th0);
-          if (sn0 != 0) {
-            const double radius = r_G / (2 * sn0);
-            double length = radius * phi;
-            if (phi > AUVP_PI) { phi -= 2 * AUVP_PI; length = -radius * phi; }
-            else if (phi < -AUVP_PI) { phi += 2 * AUVP_PI; length = -radius * phi; }
-            const double ang_vel = phi / (length / P.exp_rate);
-            double s0, c0;
-            auvp_sincos(th0, &s0, &c0);
-            const double x_C = lx - radius * s0;
-            const double y_C = ly + radius * c0;
-            const double ne = auvp_floor(length / P.exp_rate);
-            n_arc = (ne >= 0 && ne < 1e8) ? (int)ne + 1 : 0;
-            n_arc = uni(n_arc);
-            bool free_ = true;
-            for (int i0 = 0; i0 < n_arc && free_; i0 += 64) {
-              const int nv = (n_arc - i0) < 64 ? (n_arc - i0) : 64;
-              const int i = i0 + lane;
-              double ax = 0.0, ay = 0.0;
-              bool outside = false;
-              if (lane < nv) {
-                double sa, ca;
-                auvp_sincos(ang_vel * i + th0, &sa, &ca);
-                ax = x_C + radius * sa;
-                ay = y_C - radius * ca;
-                const bool wx = (ax >= P.rect[0]) && (ax <= P.rect[2]);
-                const bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
-                outside = !(wx && wy);
-              }
-              if (__any(outside)) { free_ = false; break; }
-              const double rad = auvp_fabs(radius), dth = auvp_fabs(ang_vel) * (double)(nv - 1);
-              double bx0, by0, bx1, by1;
-              if (dth < AUVP_PI) {
-                const double x0 = readlane_f64(ax, 0), y0 = readlane_f64(ay, 0);
-                const double x1 = readlane_f64(ax, nv - 1), y1 = readlane_f64(ay, nv - 1);
-                double sag = rad * dth * dth * 0.125;
-                sag = sag < 2.0 * rad ? sag : 2.0 * rad;
-                bx0 = (x0 < x1 ? x0 : x1) - sag; bx1 = (x0 < x1 ? x1 : x0) + sag;
-                by0 = (y0 < y1 ? y0 : y1) - sag; by1 = (y0 < y1 ? y1 : y0) + sag;
-              } else {
-                bx0 = x_C - rad; bx1 = x_C + rad; by0 = y_C - rad; by1 = y_C + rad;
-              }
-              const double cxm = (bx0 + bx1) * 0.5, cym = (by0 + by1) * 0.5;
-              const double slack = 0x1p-30 * (auvp_fabs(bx0) + auvp_fabs(bx1) + auvp_fabs(by0) + auvp_fabs(by1) + rad + 1.0);
-              const double hx = (bx1 - bx0) * 0.5 + slack, hy = (by1 - by0) * 0.5 + slack;
-              bool hitl = false;
-#pragma unroll
-              for (int j = 0; j < J; j++) {
-                const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
-                unsigned long long cm = __ballot(cand);
-                while (cm) {
-                  const int l = __ffsll((long long)cm) - 1;
-                  cm &= cm - 1ull;
-                  const double oxl = readlane_f64(ox[j], l), oyl = readlane_f64(oy[j], l), otl = readlane_f64(ot[j], l);
-                  const double ex = ax - oxl, ey = ay - oyl;
-                  hitl |= (lane < nv) && (ex * ex + ey * ey <= otl);
-                }
-              }
-              if (__any(hitl)) free_ = false;
-            }
-            if (free_) {
-              done = 1;
-              int L = 1 + n_arc;
-              for (int m = last;;) {
-                const int4 r = *reinterpret_cast<const int4*>(&nodes[m].step);
-                const int gp = uni(r.y);
-                if (gp < 0) break;
-                L += uni(r.w) + 1;
-                m = gp;
-              }
-              if (lane == 0) {
-                sum.path_len = L; sum.last_node = last; sum.n_arc = n_arc;
-                sum.arc[0] = x_C; sum.arc[1] = y_C; sum.arc[2] = radius; sum.arc[3] = ang_vel; sum.arc[4] = th0;
-                sum.arc[5] = length;
-              }
-            }
-          }
-        }
-      }
+    else if (NW == 2) {
+      if (prrt_goal_arc<J>(P, ox, oy, ot, orr, gx, gy, lx, ly, th0, nodes, last, sum, n_arc)) done = 1;
+    } else {
+      // the arc of this step goes to G; main goes on with the next step and picks the verdict up before its insert
+      if (lane == 0) { ctl->arc_lx = lx; ctl->arc_ly = ly; ctl->arc_th0 = th0; ctl->arc_last = last; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) duo_poke64(&ctl->arc_tag, duo_tag(0, arc_reqs));
+      arc_reqs++;
+      arc_pending = true;
     }
     prev_n_arc = n_arc; have_prev_arc = true;
     step++;
+    in_step = false;
+#ifdef AUVP_DUO_DIAG
+    diag_m += __builtin_amdgcn_s_memtime() - t_m2;
+#endif
   }
+  take_verdict();  // (the last step's arc; or the one in flight when a later step failed: a free arc ends the planning before it)
   // ---- the planning is over: the helper stores the generator where it ended, main the record ----
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane == 0) duo_poke(&ctl->stop, 1);
   {
     int spins = 0;
-    while (!uni(duo_peek(&ctl->helper_done))) {
+    while (!uni(duo_peek(&ctl->helper_done)) || !uni(duo_peek(&ctl->g_done))) {
       if (++spins > DUO_SPIN_LIMIT) { status = -9; break; }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -619,6 +759,9 @@ __global__ __launch_bounds__(PDUO_EP * 128, 1) void prrt_duo_kernel(WorldDev W, 
     sum.done = done; sum.last_accepted = last_accepted; sum.last_new_node = last_new;
     sum.rng_after = ctl->final_after; sum.n_draw32 = ctl->final_drawn;
     if (!done) sum.path_len = 0;
+#ifdef AUVP_DUO_DIAG
+    if (!done) { sum.arc[0] = (double)diag_m; sum.arc[1] = (double)diag_w; sum.arc[2] = ctl->arc_lx; sum.arc[3] = ctl->arc_ly; sum.arc[4] = (double)my_epoch; }
+#endif
   }
 }
 

@@ -92,11 +92,14 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     }
   } else if (use_duo) {
     // two wavefronts per episode (planner_duo_kernel.h): plan-mode latency runs of at most four episodes per CU
-    S.last_kernel = "prrt_duo_kernel";
+    // AUVP_PRRT_TRIO=1: the goal arc as a third wavefront
+    const char* tenv = getenv("AUVP_PRRT_TRIO");
+    const bool trio = tenv ? atoi(tenv) != 0 : false;
+    S.last_kernel = trio ? "prrt_duo_kernel<3 wavefronts>" : "prrt_duo_kernel";
     int eps_wg = (S.E + n_cu_l - 1) / n_cu_l;
     eps_wg = eps_wg < 1 ? 1 : (eps_wg > auvp::PDUO_EP ? auvp::PDUO_EP : eps_wg);
     grid_used = (S.E + eps_wg - 1) / eps_wg;
-    block_used = eps_wg * 128;
+    block_used = eps_wg * (trio ? 192 : 128);
     lds_used = (size_t)eps_wg * auvp::pduo_per_episode_bytes(S.B.max_pts);
     auto launch_duo = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
@@ -104,9 +107,15 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
       hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E);
       return hipGetLastError();
     };
-    if (O <= 64) le = launch_duo(auvp::prrt_duo_kernel<1>);
-    else if (O <= 128) le = launch_duo(auvp::prrt_duo_kernel<2>);
-    else le = launch_duo(auvp::prrt_duo_kernel<4>);
+    if (trio) {
+      if (O <= 64) le = launch_duo(auvp::prrt_duo_kernel<1, 3>);
+      else if (O <= 128) le = launch_duo(auvp::prrt_duo_kernel<2, 3>);
+      else le = launch_duo(auvp::prrt_duo_kernel<4, 3>);
+    } else {
+      if (O <= 64) le = launch_duo(auvp::prrt_duo_kernel<1, 2>);
+      else if (O <= 128) le = launch_duo(auvp::prrt_duo_kernel<2, 2>);
+      else le = launch_duo(auvp::prrt_duo_kernel<4, 2>);
+    }
   } else if (lat) {
     if (O <= 64) le = launch(auvp::prrt_kernel<1, true>);
     else if (O <= 128) le = launch(auvp::prrt_kernel<2, true>);

@@ -22,19 +22,22 @@ def _fields_equal(a, b):
 
 
 def _plan(ctx, w, starts, goals, seeds, max_step, duo, monkeypatch, **kw):
+    """duo: 0 = prrt_kernel, 2 / 3 = prrt_duo_kernel with two / three wavefronts per episode"""
     from auv_sim_amd._prrt_lib import PlannerBatch
     monkeypatch.setenv("AUVP_PRRT_ROWS", "0")
     monkeypatch.setenv("AUVP_PRRT_DUO", "1" if duo else "0")
+    monkeypatch.setenv("AUVP_PRRT_TRIO", "1" if duo == 3 else "0")
     pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, **kw)
     s = pb.plan().copy()
     ctx.L.auvp_prrt_last_kernel.restype = C.c_char_p
-    assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == ("prrt_duo_kernel" if duo else "prrt_kernel")
+    assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == {0: "prrt_kernel", 2: "prrt_duo_kernel", 3: "prrt_duo_kernel<3 wavefronts>"}[duo]
     return pb, s
 
 
+@pytest.mark.parametrize("waves", [2, 3])
 @pytest.mark.parametrize("n_ep,freq,max_step,n_obst,subs", [(37, 10, 400, 256, 2), (64, 15, 250, 64, 1), (5, 3, 300, 256, 4), (1, 10, 2000, 256, 1),
                                                            (130, 30, 150, 128, 2), (9, 10, 1, 64, 1)])
-def test_duo_equals_one_wavefront_per_episode(ctx, orc, n_ep, freq, max_step, n_obst, subs, monkeypatch):
+def test_duo_equals_one_wavefront_per_episode(ctx, orc, n_ep, freq, max_step, n_obst, subs, waves, monkeypatch):
     from auv_sim_amd import synth
     from oracle import orc_planner as op
     w = synth.make_rect_world(seed=3, n_obstacles=n_obst)
@@ -47,14 +50,14 @@ def test_duo_equals_one_wavefront_per_episode(ctx, orc, n_ep, freq, max_step, n_
         goals[0] = [w["start"][0] + 6.0, w["start"][1] + 1.0]
     seeds = np.arange(n_ep, dtype=np.uint64) + 11
     kw = dict(freq=freq, cell=5, subs=subs)
-    pa, a = _plan(ctx, w, starts, goals, seeds, max_step, False, monkeypatch, **kw)
+    pa, a = _plan(ctx, w, starts, goals, seeds, max_step, 0, monkeypatch, **kw)
     ta = [pa.tree(e, a[e]) for e in range(n_ep)]
     ga = [pa.grid(e) for e in range(n_ep)]
     paths_a = pa.paths(a)
     # continue every unfinished episode by three generate_one_node steps (one-wavefront kernel): the generator state it finds
     nxt = np.array([int(g[0][0]) if len(g[0]) else 0 for g in ga], dtype=np.int32)
     cont_a = [pa.step(nxt).copy() for _ in range(3)][-1]
-    pb, b = _plan(ctx, w, starts, goals, seeds, max_step, True, monkeypatch, **kw)
+    pb, b = _plan(ctx, w, starts, goals, seeds, max_step, waves, monkeypatch, **kw)
     assert (a["status"] >= 0).all(), np.unique(a["status"])
     assert _fields_equal(a, b), [n for n in a.dtype.names if not np.array_equal(a[n], b[n])]
     paths_b = pb.paths(b)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Config 4 (512 Planner_RRT.planning(2000) episodes) with one / two / three wavefronts per episode.  With a diagnostic build
+(AUVPLAN_LIBRARY=<lib built with -DAUVP_DUO_DIAG>) also the shader clocks per step each wavefront spends at work."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from auv_sim_amd import _lib, synth  # noqa: E402
+from auv_sim_amd._prrt_lib import PlannerBatch  # noqa: E402
+
+ctx = _lib.Context(0)
+w = synth.make_rect_world(seed=3, n_obstacles=256)
+ctx.set_world(obstacles=w["obstacles"])
+for n in (1, 64, 512, 1024):
+    starts = np.tile(np.array([w["start"][0], w["start"][1], 0.0, 0.0]), (n, 1))
+    goals = np.tile(w["goal"], (n, 1))
+    seeds = np.arange(n, dtype=np.uint64)
+    out = []
+    for duo, trio in (("0", "0"), ("1", "0"), ("1", "1")):
+        os.environ["AUVP_PRRT_DUO"], os.environ["AUVP_PRRT_TRIO"] = duo, trio
+        ms = []
+        for i in range(3):
+            pb = PlannerBatch(ctx, starts, goals, w["rect"], 2000, seeds=seeds, freq=10, cell=5, subs=1)
+            s = pb.plan()
+            if i:
+                ms.append(ctx.last_kernel_ms())
+        out.append("%s %.2f ms (%.2f us/step)" % (ctx.prrt_last_kernel(), np.mean(ms), 1e3 * np.mean(ms) / max(s["steps"].max(), 1)))
+        if os.environ.get("AUVPLAN_LIBRARY") and duo == "1":
+            nd = s["done"] == 0
+            st = float(s["steps"][nd].sum())
+            a = s["arc"][nd]
+            print("   diag (%s): per step main works %.0f clocks and waits %.0f for arc verdicts, helper builds for %.0f, arc wavefront %.0f; redos per step %.3f"
+                  % (ctx.prrt_last_kernel(), a[:, 0].sum() / st, a[:, 1].sum() / st, a[:, 2].sum() / st, a[:, 3].sum() / st, a[:, 4].sum() / st))
+    print("E=%d: " % n + " | ".join(out))
