@@ -515,8 +515,14 @@ __global__ __launch_bounds__(PDUO_EP * 64 * NW, 1) void prrt_duo_kernel(WorldDev
 #endif
   bool arc_pending = false, in_step = false;
   int arc_reqs = 0, prev_acc = 0, prev_new = -1;
-  // the verdict of the request in flight.  A free arc ends the planning at the step that posted it: a step in progress (its
-  // steer, its collision test -- never an insert: the verdict is taken before) is dropped, the stream ends before its draws
+  // what the insert of the step in progress replaced (three-wavefront form: that insert is taken back when the arc of the step
+  // before turns out free -- the planning ended there)
+  bool un_ins = false, un_occ = false;
+  int un_bk = -1, un_cnt = 0;
+  int2 un_word = make_int2(0, 0);
+  // the verdict of the request in flight.  A free arc ends the planning at the step that posted it: the step in progress is
+  // dropped -- its insert, if it got that far, is taken back (bucket word and the three counters; what it appended lies past
+  // them) -- and the stream ends before its draws
   auto take_verdict = [&]() {
     if (!arc_pending) return;
     int spins = 0;
@@ -532,6 +538,13 @@ __global__ __launch_bounds__(PDUO_EP * 64 * NW, 1) void prrt_duo_kernel(WorldDev
         status = 0;
         last_accepted = prev_acc; last_new = prev_new;
         if (lane == 0) ctl->final_step = step - 1;
+        if (un_ins) {
+          if (lane == 0 && un_bk >= 0) buckets[un_bk] = un_word;
+          if (un_occ) n_occ--;
+          n_nodes--;
+          n_points -= un_cnt;
+          un_ins = false;
+        }
         in_step = false;
       }
     }
@@ -574,6 +587,7 @@ __global__ __launch_bounds__(PDUO_EP * 64 * NW, 1) void prrt_duo_kernel(WorldDev
 #endif
     if (lane == 0) duo_poke(&ctl->valid_seq, step + 1);  // the helper may build the next packet now
     in_step = true;
+    un_ins = false;
     prev_acc = last_accepted; prev_new = last_new;
     if (uni(q->status) != 0) { status = uni(q->status); break; }
     last_accepted = 0; last_new = -1;
@@ -657,16 +671,6 @@ __global__ __launch_bounds__(PDUO_EP * 64 * NW, 1) void prrt_duo_kernel(WorldDev
     }
     int me = -1;
     last_bk = -2;
-#ifdef AUVP_DUO_DIAG
-    const unsigned long long t_m1 = __builtin_amdgcn_s_memtime();
-    diag_m += t_m1 - t_m0;
-#endif
-    take_verdict();  // (before anything of this step reaches the tree)
-#ifdef AUVP_DUO_DIAG
-    const unsigned long long t_m2 = __builtin_amdgcn_s_memtime();
-    diag_w += t_m2 - t_m1;
-#endif
-    if (done || uni(status)) break;
     if (ok) {
       if (n_nodes >= capn) { status = -2; break; }
       me = n_nodes;
@@ -706,6 +710,7 @@ __global__ __launch_bounds__(PDUO_EP * 64 * NW, 1) void prrt_duo_kernel(WorldDev
           if (c_before == 0) occupied[n_occ] = bk;
         }
       }
+      un_ins = true; un_occ = c_before == 0; un_bk = bk; un_cnt = cnt; un_word = bwn;
       if (c_before == 0) n_occ++;
       n_nodes++;
       n_points += cnt;
@@ -715,6 +720,16 @@ __global__ __launch_bounds__(PDUO_EP * 64 * NW, 1) void prrt_duo_kernel(WorldDev
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) { ctl->n_occ = n_occ; duo_poke(&ctl->ver, n_nodes); }
     }
+#ifdef AUVP_DUO_DIAG
+    const unsigned long long t_m1 = __builtin_amdgcn_s_memtime();
+    diag_m += t_m1 - t_m0;
+#endif
+    take_verdict();  // the arc of the step before: G had this whole step for it
+#ifdef AUVP_DUO_DIAG
+    const unsigned long long t_m2 = __builtin_amdgcn_s_memtime();
+    diag_w += t_m2 - t_m1;
+#endif
+    if (done || uni(status)) break;
     // ---------------------------------------------------------------- connect_to_goal_curve_alt(mps_list[-1]) (:374-423)
     const int last = n_nodes - 1;
     double lx, ly, th0;

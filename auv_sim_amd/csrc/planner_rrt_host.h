@@ -66,9 +66,11 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
   int grid_used = grid, block_used = wg_waves * 64;
   size_t lds_used = lds;
   S.last_kernel = "prrt_kernel";
+  // plan-mode latency runs of at most four episodes per CU: helper + main + goal-arc wavefronts per episode (planner_duo_kernel.h).
+  // AUVP_PRRT_DUO=0 / 1 forces the choice where the kernel's limits allow it; AUVP_PRRT_TRIO=0: two wavefronts (no goal-arc wavefront)
   const char* denv = getenv("AUVP_PRRT_DUO");
   const bool use_duo = !S.use_rows && step_mode == 0 && lat && !(S.P.flags & AUVP_FLAG_ITER_LOG) && nfreq <= auvp::DUO_MAX_FREQ && O <= 256 &&
-                       S.B.max_pts <= auvp::DUO_CS + 2 && (denv ? atoi(denv) != 0 : false);  // (bring-up: opt-in)
+                       S.B.max_pts <= auvp::DUO_CS + 2 && (denv ? atoi(denv) != 0 : S.E <= 4 * n_cu_l);
   if (S.use_rows) {
     // persistent rows (four episodes per wavefront) fed from a device counter: as many workgroups as fit the chip at
     // three per CU (one wave per SIMD each), fewer when the batch is smaller
@@ -91,10 +93,8 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
       S.work_base += S.E + grid_used * per_wg;  // every episode once + one empty pull per row
     }
   } else if (use_duo) {
-    // two wavefronts per episode (planner_duo_kernel.h): plan-mode latency runs of at most four episodes per CU
-    // AUVP_PRRT_TRIO=1: the goal arc as a third wavefront
     const char* tenv = getenv("AUVP_PRRT_TRIO");
-    const bool trio = tenv ? atoi(tenv) != 0 : false;
+    const bool trio = tenv ? atoi(tenv) != 0 : true;
     S.last_kernel = trio ? "prrt_duo_kernel<3 wavefronts>" : "prrt_duo_kernel";
     int eps_wg = (S.E + n_cu_l - 1) / n_cu_l;
     eps_wg = eps_wg < 1 ? 1 : (eps_wg > auvp::PDUO_EP ? auvp::PDUO_EP : eps_wg);

@@ -25,3 +25,12 @@ def test_helper_wavefront_kernels_random_cases():
                        cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_planner_helper_wavefronts_random_cases():
+    """prrt_duo_kernel with two and three wavefronts per Planner_RRT episode against prrt_kernel: random worlds, goals near and
+    far (plannings that end while the next step is already inserted), parameters and budgets, every case repeated"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "experiments", "soak_planner_duo.py"), "40", "5"],
+                       cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
