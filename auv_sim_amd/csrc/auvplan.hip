@@ -1012,6 +1012,7 @@ int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds
 #include "planner_rrt_kernel.h"
 #include "planner_rows_kernel.h"
 #include "planner_duo_kernel.h"
+#include "planner_pipe_kernel.h"
 #include "planner_rrt_host.h"
 
 namespace {

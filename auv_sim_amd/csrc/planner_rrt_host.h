@@ -66,8 +66,9 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
   int grid_used = grid, block_used = wg_waves * 64;
   size_t lds_used = lds;
   S.last_kernel = "prrt_kernel";
-  // plan-mode latency runs of at most four episodes per CU: helper + main + goal-arc wavefronts per episode (planner_duo_kernel.h).
-  // AUVP_PRRT_DUO=0 / 1 forces the choice where the kernel's limits allow it; AUVP_PRRT_TRIO=0: two wavefronts (no goal-arc wavefront)
+  // plan-mode latency runs of at most four episodes per CU: a pipeline of four wavefronts per episode (planner_pipe_kernel.h).
+  // AUVP_PRRT_DUO=0 / 1 forces the choice where the kernels' limits allow it; AUVP_PRRT_PIPE=0: the helper + main + goal-arc
+  // form of planner_duo_kernel.h, with AUVP_PRRT_TRIO=0 helper + main only
   const char* denv = getenv("AUVP_PRRT_DUO");
   const bool use_duo = !S.use_rows && step_mode == 0 && lat && !(S.P.flags & AUVP_FLAG_ITER_LOG) && nfreq <= auvp::DUO_MAX_FREQ && O <= 256 &&
                        S.B.max_pts <= auvp::DUO_CS + 2 && (denv ? atoi(denv) != 0 : S.E <= 4 * n_cu_l);
@@ -92,6 +93,23 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
       le = hipGetLastError();
       S.work_base += S.E + grid_used * per_wg;  // every episode once + one empty pull per row
     }
+  } else if (use_duo && (getenv("AUVP_PRRT_PIPE") ? atoi(getenv("AUVP_PRRT_PIPE")) != 0 : true)) {
+    // four wavefronts per episode, feed-forward (planner_pipe_kernel.h)
+    S.last_kernel = "prrt_pipe_kernel";
+    int eps_wg = (S.E + n_cu_l - 1) / n_cu_l;
+    eps_wg = eps_wg < 1 ? 1 : (eps_wg > auvp::PPIPE_EP ? auvp::PPIPE_EP : eps_wg);
+    grid_used = (S.E + eps_wg - 1) / eps_wg;
+    block_used = eps_wg * 256;
+    lds_used = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts);
+    auto launch_pipe = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E);
+      return hipGetLastError();
+    };
+    if (O <= 64) le = launch_pipe(auvp::prrt_pipe_kernel<1>);
+    else if (O <= 128) le = launch_pipe(auvp::prrt_pipe_kernel<2>);
+    else le = launch_pipe(auvp::prrt_pipe_kernel<4>);
   } else if (use_duo) {
     const char* tenv = getenv("AUVP_PRRT_TRIO");
     const bool trio = tenv ? atoi(tenv) != 0 : true;

@@ -33,13 +33,14 @@ for c in range(n_cases):
     goals[near] = starts[near, :2] + rng.uniform(-25, 25, (int(near.sum()), 2))
     seeds = rng.integers(0, 2 ** 40, E).astype(np.uint64)
     ref = None
-    for waves, rep in ((0, 1), (2, 2), (3, 3)):
+    for waves, rep in ((0, 1), (2, 2), (3, 3), (4, 3)):
         os.environ["AUVP_PRRT_DUO"] = "1" if waves else "0"
         os.environ["AUVP_PRRT_TRIO"] = "1" if waves == 3 else "0"
+        os.environ["AUVP_PRRT_PIPE"] = "1" if waves == 4 else "0"
         for _ in range(rep):
             pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, **kw)
             s = pb.plan().copy()
-            want = {0: "prrt_kernel", 2: "prrt_duo_kernel", 3: "prrt_duo_kernel<3 wavefronts>"}[waves]
+            want = {0: "prrt_kernel", 2: "prrt_duo_kernel", 3: "prrt_duo_kernel<3 wavefronts>", 4: "prrt_pipe_kernel"}[waves]
             assert ctx.prrt_last_kernel() == want, ctx.prrt_last_kernel()
             sample = sorted(set(rng.integers(0, E, 4).tolist())) if ref is None else ref[3]
             trees = [pb.tree(e, s[e]) for e in sample]

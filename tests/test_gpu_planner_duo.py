@@ -22,19 +22,20 @@ def _fields_equal(a, b):
 
 
 def _plan(ctx, w, starts, goals, seeds, max_step, duo, monkeypatch, **kw):
-    """duo: 0 = prrt_kernel, 2 / 3 = prrt_duo_kernel with two / three wavefronts per episode"""
+    """duo: 0 = prrt_kernel, 2 / 3 = prrt_duo_kernel with two / three wavefronts per episode, 4 = prrt_pipe_kernel"""
     from auv_sim_amd._prrt_lib import PlannerBatch
     monkeypatch.setenv("AUVP_PRRT_ROWS", "0")
     monkeypatch.setenv("AUVP_PRRT_DUO", "1" if duo else "0")
     monkeypatch.setenv("AUVP_PRRT_TRIO", "1" if duo == 3 else "0")
+    monkeypatch.setenv("AUVP_PRRT_PIPE", "1" if duo == 4 else "0")
     pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, **kw)
     s = pb.plan().copy()
     ctx.L.auvp_prrt_last_kernel.restype = C.c_char_p
-    assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == {0: "prrt_kernel", 2: "prrt_duo_kernel", 3: "prrt_duo_kernel<3 wavefronts>"}[duo]
+    assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == {0: "prrt_kernel", 2: "prrt_duo_kernel", 3: "prrt_duo_kernel<3 wavefronts>", 4: "prrt_pipe_kernel"}[duo]
     return pb, s
 
 
-@pytest.mark.parametrize("waves", [2, 3])
+@pytest.mark.parametrize("waves", [2, 3, 4])
 @pytest.mark.parametrize("n_ep,freq,max_step,n_obst,subs", [(37, 10, 400, 256, 2), (64, 15, 250, 64, 1), (5, 3, 300, 256, 4), (1, 10, 2000, 256, 1),
                                                            (130, 30, 150, 128, 2), (9, 10, 1, 64, 1)])
 def test_duo_equals_one_wavefront_per_episode(ctx, orc, n_ep, freq, max_step, n_obst, subs, waves, monkeypatch):

@@ -18,8 +18,8 @@ for n in (1, 64, 512, 1024):
     goals = np.tile(w["goal"], (n, 1))
     seeds = np.arange(n, dtype=np.uint64)
     out = []
-    for duo, trio in (("0", "0"), ("1", "0"), ("1", "1")):
-        os.environ["AUVP_PRRT_DUO"], os.environ["AUVP_PRRT_TRIO"] = duo, trio
+    for duo, trio, pipe in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1")):
+        os.environ["AUVP_PRRT_DUO"], os.environ["AUVP_PRRT_TRIO"], os.environ["AUVP_PRRT_PIPE"] = duo, trio, pipe
         ms = []
         for i in range(3):
             pb = PlannerBatch(ctx, starts, goals, w["rect"], 2000, seeds=seeds, freq=10, cell=5, subs=1)
@@ -27,7 +27,14 @@ for n in (1, 64, 512, 1024):
             if i:
                 ms.append(ctx.last_kernel_ms())
         out.append("%s %.2f ms (%.2f us/step)" % (ctx.prrt_last_kernel(), np.mean(ms), 1e3 * np.mean(ms) / max(s["steps"].max(), 1)))
-        if os.environ.get("AUVPLAN_LIBRARY") and duo == "1":
+        if os.environ.get("AUVPLAN_LIBRARY") and pipe == "1":
+            nd = s["done"] == 0
+            st = float(s["steps"][nd].sum())
+            a = s["arc"][nd]
+            print("   diag (%s): clocks per step at work: M %.0f, H %.0f, S %.0f, G %.0f; redos per step %.3f; nodes per step %.2f"
+                  % (ctx.prrt_last_kernel(), a[:, 0].sum() / st, a[:, 1].sum() / st, a[:, 2].sum() / st, a[:, 3].sum() / st, a[:, 4].sum() / st,
+                     s["n_nodes"][nd].sum() / st))
+        elif os.environ.get("AUVPLAN_LIBRARY") and duo == "1":
             nd = s["done"] == 0
             st = float(s["steps"][nd].sum())
             a = s["arc"][nd]
