@@ -52,8 +52,9 @@ struct PpipeSlot {
   double radius[DUO_CS], phi[DUO_CS];
   // ---- B (S)
   unsigned long long tagB;
-  int ok, cnt, bk, idx_err;      // collision free?  path points; bucket of the candidate node (-1: outside the table); index error
+  int ok, cnt, have_sc, _p1;     // collision free?  path points; sin_c / cos_c are there
   double cx, cy, cth, ctt;       // the candidate node
+  double sin_c, cos_c;           // sin / cos of its heading as the steer evaluated them
   double pts[DUO_CS][4];         // its path points (x, y, theta, t)
   // ---- C (G)
   unsigned long long tagC;
@@ -97,25 +98,31 @@ __device__ __forceinline__ PpipeView ppipe_look(const PpipeCtl* c) {
   return v;
 }
 
-// random._randbelow(n) on the ring generator, also reporting the smallest try that was thrown away (>= n; 0x7fffffff: none)
-__device__ __forceinline__ uint32_t ppipe_randbelow(RingRng& r, uint32_t n, int& rmin, bool& ok, unsigned long long floor_drawn) {
+// random._randbelow(n) on the ring generator; RMIN: also the smallest try that was thrown away (>= n; 0x7fffffff: none).
+// `more()` generates another block of words if the ring has room for it (false: it has not).
+template <bool RMIN, typename More>
+__device__ __forceinline__ uint32_t ppipe_randbelow(RingRng& r, uint32_t n, int& rmin, bool& ok, More&& more) {
   const int lane = lane_id();
   const int k = 32 - __clz((int)n);
   ok = true;
   for (;;) {
-    if (r.avail < 8u) {
-      if ((r.drawn - floor_drawn) + r.avail + 64ull > (unsigned long long)TRIO_GEN) { ok = false; return 0u; }
-      ring_generate64(r);
-    }
+    if (r.avail < 8u && !more()) { ok = false; return 0u; }
     uint32_t v = 0xffffffffu;
     if (lane < 8) v = ring_word(r, (uint32_t)lane) >> (32 - k);
     const unsigned long long okm = __ballot(lane < 8 && v < n);
     const int f = okm ? (__ffsll((long long)okm) - 1) : 8;
-    int mine = (lane < f) ? (int)(v & 0x7fffffffu) : 0x7fffffff;  // tries in front of the success (all eight when there is none) were >= n
-#pragma unroll
-    for (int o = 4; o >= 1; o >>= 1) { const int t = __shfl_xor(mine, o, 64); mine = t < mine ? t : mine; }
-    const int m0 = __builtin_amdgcn_readfirstlane(mine);
-    rmin = m0 < rmin ? m0 : rmin;
+    if (RMIN) {
+      // tries in front of the success (all eight when there is none) were >= n: their minimum over lanes 0..7 on the DPP path
+      int mine = (lane < f) ? (int)(v & 0x7fffffffu) : 0x7fffffff;
+      int t = __builtin_amdgcn_update_dpp(mine, mine, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+      mine = t < mine ? t : mine;
+      t = __builtin_amdgcn_update_dpp(mine, mine, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+      mine = t < mine ? t : mine;
+      t = __builtin_amdgcn_update_dpp(mine, mine, 0x141, 0xf, 0xf, false);     // row_half_mirror: lane i <-> 7 - i
+      mine = t < mine ? t : mine;
+      const int m0 = __builtin_amdgcn_readfirstlane(mine);
+      rmin = m0 < rmin ? m0 : rmin;
+    }
     if (okm) {
       const uint32_t res = (uint32_t)__builtin_amdgcn_readlane((int)v, f);
       ring_advance(r, (uint32_t)(f + 1));
@@ -125,12 +132,19 @@ __device__ __forceinline__ uint32_t ppipe_randbelow(RingRng& r, uint32_t n, int&
   }
 }
 
+// prrt_angle_wrap with its first pass free of branches (the same operations in the same order: the same double)
+__device__ __forceinline__ double ppipe_angle_wrap(double a) {
+  const double b = a > AUVP_PI ? a + (-2 * AUVP_PI) : (a < -AUVP_PI ? a + (2 * AUVP_PI) : a);
+  if (-AUVP_PI <= b && b <= AUVP_PI) return b;
+  return prrt_angle_wrap(b);
+}
+
 // connect_to_goal_curve_alt (:374-423) from (lx, ly, th0): the arc and whether it is free; nothing is written.
 // out[0..5] = x_C, y_C, radius, ang_vel, th0, length (as the result record holds them); n_arc -1: no arc.
 template <int J>
 __device__ __forceinline__ bool prrt_goal_arc_eval(const PrrtParamsDev& P, const double (&ox)[J], const double (&oy)[J], const double (&ot)[J],
                                                    const double (&orr)[J], double gx, double gy, double lx, double ly, double th0,
-                                                   int& n_arc_out, double (&out)[6]) {
+                                                   bool have_sc, double sin_th0, double cos_th0, int& n_arc_out, double (&out)[6]) {
   const int lane = lane_id();
   int n_arc = -1;
   bool is_free = false;
@@ -148,8 +162,8 @@ __device__ __forceinline__ bool prrt_goal_arc_eval(const PrrtParamsDev& P, const
         if (phi > AUVP_PI) { phi -= 2 * AUVP_PI; length = -radius * phi; }
         else if (phi < -AUVP_PI) { phi += 2 * AUVP_PI; length = -radius * phi; }
         const double ang_vel = phi / (length / P.exp_rate);
-        double s0, c0;
-        auvp_sincos(th0, &s0, &c0);
+        double s0 = sin_th0, c0 = cos_th0;  // (of th0, by auvp_sincos, when the caller has them already)
+        if (!have_sc) auvp_sincos(th0, &s0, &c0);
         const double x_C = lx - radius * s0;
         const double y_C = ly + radius * c0;
         const double ne = auvp_floor(length / P.exp_rate);
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       rng.gslot = 624u; rng.cslot = (uint32_t)(624 - ac); rng.avail = (uint32_t)ac;
       rng.drawn = ((unsigned long long)(uint32_t)uni(B.rng_state[4 * eps + 2])) | ((unsigned long long)(uint32_t)uni(B.rng_state[4 * eps + 3]) << 32);
     }
-    int epoch = 0, k = step0;
+    int epoch = 0;
     int cur = step0 - 1;  // the latest packet started
     // stream position at the first word of the packets in flight (slot k & 7): where a new epoch, or the end of the planning, rewinds to
     if (lane == 0)
@@ -297,12 +311,28 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       rng.avail = (uint32_t)uni((int)(rng.avail + (uint32_t)(rng.drawn - dr)));
       rng.cslot = cs; rng.drawn = dr;
     };
-    unsigned long long floor_drawn = rng.drawn;  // oldest position a rewind may ask for: every word since then stays in the ring
-    auto ensure = [&](uint32_t need) -> bool {
-      while (rng.avail < need) {
+    // oldest position a rewind may ask for (every word since then stays in the ring): the first word of the step M is at.  Kept
+    // lazily -- an older value only keeps more -- and looked up again when the ring seems full.
+    unsigned long long floor_drawn = rng.drawn;
+    int k = step0;
+    auto refresh_floor = [&]() {
+      const PpipeView v2 = ppipe_look(ctl);
+      const int md = v2.m_done < k ? v2.m_done : k;
+      uint32_t cs; unsigned long long dr;
+      sp_get(md, cs, dr);
+      floor_drawn = dr;
+    };
+    auto more = [&]() -> bool {
+      if ((rng.drawn - floor_drawn) + rng.avail + 64ull > (unsigned long long)TRIO_GEN) {
+        refresh_floor();
         if ((rng.drawn - floor_drawn) + rng.avail + 64ull > (unsigned long long)TRIO_GEN) return false;
-        ring_generate64(rng);
       }
+      ring_generate64(rng);
+      return true;
+    };
+    auto ensure = [&](uint32_t need) -> bool {
+      while (rng.avail < need)
+        if (!more()) return false;
       return true;
     };
 #ifdef AUVP_DUO_DIAG
@@ -333,12 +363,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
 #endif
       cur = k;
       sp_set(k, rng.cslot, rng.drawn);
-      {
-        // M is at step m_done (<= k): the start of that step's packet is the oldest position anyone can ask for
-        uint32_t cs; unsigned long long dr;
-        sp_get(cv.m_done, cs, dr);
-        floor_drawn = cv.m_done < k ? dr : rng.drawn;
-      }
+      if (rng.avail < 160u) (void)ensure(160u);  // (a step's words, generated in one go while nothing waits on them; as far as the ring has room)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const int ver = cv.ver, n_occ = cv.n_occ;
       PpipeSlot* q = slot_of(k);
@@ -349,7 +374,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       if (n_occ <= 0) status = -1;
       if (status == 0) {
         bool ok1 = true;
-        const uint32_t oi = ppipe_randbelow(rng, (uint32_t)n_occ, rmin, ok1, floor_drawn);
+        const uint32_t oi = ppipe_randbelow<true>(rng, (uint32_t)n_occ, rmin, ok1, more);
         fits = ok1;
         if (fits) {
           int bb = duo_ld_i32(occupied + (oi < (uint32_t)capn ? oi : 0u));
@@ -361,7 +386,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
           else {
             int dummy = 0x7fffffff;
             bool ok2 = true;
-            const int rsel = (int)ppipe_randbelow(rng, (uint32_t)cnt_b, dummy, ok2, floor_drawn);
+            const int rsel = (int)ppipe_randbelow<false>(rng, (uint32_t)cnt_b, dummy, ok2, more);
             fits = ok2;
             if (fits) {
               // the rsel-th member (creation order) of bucket b: count - 1 - rsel steps from the head of its list, or -- further
@@ -461,8 +486,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const int fs = uni(duo_peek(&ctl->final_step));
       if (cur > fs) rewind_to(fs + 1);
-      floor_drawn = rng.drawn;
-      (void)ensure(2u);
+      if (rng.avail < 2u) ring_generate64(rng);  // (nothing before this position is asked for again: the oldest block may go)
       const unsigned long long drawn = rng.drawn;
       const uint32_t a_out = rng.avail < 624u ? rng.avail : 624u;
       for (int o = lane; o < 624; o += 64) {
@@ -533,14 +557,20 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       const int a_status = uni(q->status), a_kind = uni(q->kind);
       int n_total = uni(q->n_total);
       n_total = n_total < 0 ? 0 : (n_total > DUO_MAX_FREQ ? DUO_MAX_FREQ : n_total);
-      const unsigned long long tmask = q->tmask & ((1ull << DUO_MAX_FREQ) - 1ull);
+      unsigned long long tmask;
+      {
+        // (a scalar: the loops over its bits and the lane reads they index stay on the scalar unit)
+        const unsigned long long tv = q->tmask & ((1ull << DUO_MAX_FREQ) - 1ull);
+        tmask = ((unsigned long long)(uint32_t)uni((int)(tv >> 32)) << 32) | (uint32_t)uni((int)(tv & 0xffffffffull));
+      }
       double cx = readfirst_f64(q->px), cy = readfirst_f64(q->py), cth = readfirst_f64(q->pth), ctt = readfirst_f64(q->ptt);
       double radius = 0.0, phi = 0.0;
       if (lane < DUO_CS) { radius = q->radius[lane]; phi = q->phi[lane]; }
       __asm__ volatile("" ::: "memory");
       if (duo_peek64(&q->tagA) != duo_tag(epoch, k)) continue;  // rewritten under the copy (a new epoch): look again
       if (lane == 0) duo_poke64(&q->tagB, 0ull);
-      int ok = 0, cnt = 0, bk = -1, idx_err = 0;
+      int ok = 0, cnt = 0, have_sc = 0;
+      double sin_c = 0.0, cos_c = 0.0;
       if (a_status == 0 && a_kind == 0) {
         // ---------------------------------------------------------------- steer, the half that needs the parent (:271-289)
         if (lane == 0) { spts[0][0] = cx; spts[0][1] = cy; }
@@ -548,13 +578,23 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
         if (n_total > 0) {
           const int n = n_total;
           const bool taken = (tmask >> lane) & 1ull;
+          // (a sub-arc that is not taken changes nothing, :262-271: the chains run over the taken ones)
           double th = cth, myth = cth;
-          for (int s = 0; s < n; s++) {
-            if ((tmask >> s) & 1ull) th = prrt_angle_wrap(th + readlane_f64(phi, s));
+          for (unsigned long long tm = tmask; tm; tm &= tm - 1ull) {
+            const int s = __ffsll((long long)tm) - 1;
+            th = ppipe_angle_wrap(th + readlane_f64(phi, s));
             if (lane == s) myth = th;
           }
+          (void)n;
           double sn, cs;
           auvp_sincos(myth, &sn, &cs);
+          {
+            // sin / cos of the candidate's heading for the goal arc (:395-396 takes them of the same angle): the last taken
+            // sub-arc's lane, or the idle lane with the entry angle
+            const int src = tmask ? (63 - __clzll((long long)tmask)) : (DUO_CS - 1);
+            sin_c = readlane_f64(sn, src); cos_c = readlane_f64(cs, src);
+            have_sc = 1;
+          }
           double dx = 0.0, dy = 0.0, dt = 0.0;
           {
             const unsigned long long below = tmask & ((1ull << lane) - 1ull);
@@ -567,7 +607,8 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
             }
           }
           double mx = 0.0, my = 0.0, mt_ = 0.0;
-          for (int s = 0; s < n; s++) {
+          for (unsigned long long tm = tmask; tm; tm &= tm - 1ull) {
+            const int s = __ffsll((long long)tm) - 1;
             cx = cx + readlane_f64(dx, s);
             cy = cy + readlane_f64(dy, s);
             ctt = ctt + readlane_f64(dt, s);
@@ -598,28 +639,10 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
           }
           ok = (!prrt_hits<J>(ox, oy, ot, orr, spts, P_n, bbx0, bby0, bbx1, bby1) && !__any(outside)) ? 1 : 0;
         }
-        if (ok) {
-          // the bucket of the candidate node (:291-320)
-          int row = (int)(cy / P.cell), col = (int)(cx / P.cell);
-          bool ie = false;
-          if (row < 0) { row += P.rows; ie |= row < 0; }
-          if (col < 0) { col += P.cols; ie |= col < 0; }
-          if (!ie && row < P.rows && col < P.cols) {
-            const double raw = cth / P.delta_theta;
-            int sub = (int)auvp_floor(raw);
-            if (sub < 0) sub = (int)(P.S + sub);
-            if (sub == P.S) sub -= 1;
-            if (sub < 0) { sub += P.S; ie |= sub < 0; }
-            ie |= sub >= P.S;
-            bk = (row * P.cols + col) * P.S + sub;
-          }
-          idx_err = __any(ie) ? 1 : 0;
-          bk = uni(bk);
-        }
       }
       if (lane == 0) {
-        q->ok = ok; q->cnt = cnt; q->bk = bk; q->idx_err = idx_err;
-        q->cx = cx; q->cy = cy; q->cth = cth; q->ctt = ctt;
+        q->ok = ok; q->cnt = cnt; q->have_sc = have_sc;
+        q->cx = cx; q->cy = cy; q->cth = cth; q->ctt = ctt; q->sin_c = sin_c; q->cos_c = cos_c;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) duo_poke64(&q->tagB, duo_tag(epoch, k));
@@ -662,15 +685,16 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
 #ifdef AUVP_DUO_DIAG
       const unsigned long long t_g0 = __builtin_amdgcn_s_memtime();
 #endif
-      const int ok = uni(q->ok), cnt = uni(q->cnt), idx_err = uni(q->idx_err);
+      const int ok = uni(q->ok), cnt = uni(q->cnt), have_sc = uni(q->have_sc);
       int par = uni(q->par);
       const double lx = readfirst_f64(q->cx), ly = readfirst_f64(q->cy), th0 = readfirst_f64(q->cth);
+      const double sin_c = readfirst_f64(q->sin_c), cos_c = readfirst_f64(q->cos_c);
       __asm__ volatile("" ::: "memory");
       if (duo_peek64(&q->tagB) != duo_tag(epoch, k)) continue;
       int n_arc = -1, is_free = 0, L = 0;
       double arc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-      if (ok && !idx_err) {
-        if (prrt_goal_arc_eval<J>(P, ox, oy, ot, orr, gx, gy, lx, ly, th0, n_arc, arc)) {
+      if (ok) {
+        if (prrt_goal_arc_eval<J>(P, ox, oy, ot, orr, gx, gy, lx, ly, th0, have_sc != 0, sin_c, cos_c, n_arc, arc)) {
           is_free = 1;
           // the path: the arc, the candidate node with its points, and the walk from its parent to the root
           L = 1 + n_arc + cnt + 1;
@@ -749,7 +773,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
 #endif
     // ---- the slot, copied out; then H may have it back
     const int a_status = uni(q->status), a_kind = uni(q->kind), par = uni(q->par), n_total = uni(q->n_total);
-    const int ok = uni(q->ok), cnt = uni(q->cnt), bk = uni(q->bk), idx_err = uni(q->idx_err);
+    const int ok = uni(q->ok), cnt = uni(q->cnt);
     const double cx = readfirst_f64(q->cx), cy = readfirst_f64(q->cy), cth = readfirst_f64(q->cth), ctt = readfirst_f64(q->ctt);
     const int is_free = uni(q->free_), n_arc = uni(q->n_arc), path_len = uni(q->path_len);
     double2 pa = make_double2(0.0, 0.0), pb = make_double2(0.0, 0.0);
@@ -772,7 +796,25 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     int me = -1;
     if (ok) {
       if (n_nodes >= capn) { status = -2; break; }
-      if (idx_err) { status = -1; break; }
+      // the bucket of the new node (:291-320)
+      int bk = -1;
+      {
+        int row = (int)(cy / P.cell), col = (int)(cx / P.cell);
+        bool ie = false;
+        if (row < 0) { row += P.rows; ie |= row < 0; }
+        if (col < 0) { col += P.cols; ie |= col < 0; }
+        if (!ie && row < P.rows && col < P.cols) {
+          const double raw = cth / P.delta_theta;
+          int sub = (int)auvp_floor(raw);
+          if (sub < 0) sub = (int)(P.S + sub);
+          if (sub == P.S) sub -= 1;
+          if (sub < 0) { sub += P.S; ie |= sub < 0; }
+          ie |= sub >= P.S;
+          bk = (row * P.cols + col) * P.S + sub;
+        }
+        if (__any(ie)) { status = -1; break; }
+        bk = uni(bk);
+      }
       me = n_nodes;
       int2 bwn = make_int2(0, 0);
       if (bk >= 0) bwn = buckets[bk];
