@@ -207,11 +207,21 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
     B.exp_log = S.exp_log.as<double>();
   }
   const int grid = (E + auvp::ASTAR_WAVES - 1) / auvp::ASTAR_WAVES;
+  bool pair = false;
   switch (P.variant) {
     case 0: hipLaunchKernelGGL(auvp::astar_kernel<0>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
     case 1: hipLaunchKernelGGL(auvp::astar_kernel<1>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
     case 2: hipLaunchKernelGGL(auvp::astar_kernel<2>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
-    default: hipLaunchKernelGGL(auvp::astar_kernel<3>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
+    default: {
+      // latency batches on a product grid: a second wavefront per instance (astar_kernel.h, PAIR); AUVP_ASTAR_PAIR=0 / 1 forces the choice
+      int n_cu = 256;
+      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+      const char* penv = getenv("AUVP_ASTAR_PAIR");
+      pair = S.W.g_ncol > 0 && (penv ? atoi(penv) != 0 : E <= (size_t)8 * (size_t)(n_cu > 0 ? n_cu : 256));
+      if (pair) hipLaunchKernelGGL((auvp::astar_kernel<3, true>), dim3(grid), dim3(auvp::ASTAR_WAVES * 128), 0, h->stream, S.W, P, B, (int)E);
+      else hipLaunchKernelGGL(auvp::astar_kernel<3>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E);
+      break;
+    }
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -219,7 +229,7 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  h->last_grid = grid; h->last_block = auvp::ASTAR_WAVES * 64; h->last_lds = 0;
+  h->last_grid = grid; h->last_block = auvp::ASTAR_WAVES * (pair ? 128 : 64); h->last_lds = 0;
   S.E = E;
   S.ready = true;
   return AUVP_OK;

@@ -59,6 +59,19 @@ __device__ __forceinline__ int astar_lower_bound(PtrT a, int n, double v, int g)
   while (g < n && a[g] < v) g++;
   return g;
 }
+// two of them at once (columns, rows): the entries on either side of both guesses are read together -- one round trip to the
+// table when the guesses are right (on a regular grid they are), the walks above otherwise
+template <typename PtrT>
+__device__ __forceinline__ void astar_lower_bound2(PtrT ax, int nx, double vx, int gx_, PtrT ay, int ny, double vy, int gy_, int& rx, int& ry) {
+  gx_ = gx_ < 0 ? 0 : (gx_ > nx ? nx : gx_);
+  gy_ = gy_ < 0 ? 0 : (gy_ > ny ? ny : gy_);
+  const double xl = gx_ > 0 ? ax[gx_ - 1] : 0.0, xh = gx_ < nx ? ax[gx_] : 0.0;
+  const double yl = gy_ > 0 ? ay[gy_ - 1] : 0.0, yh = gy_ < ny ? ay[gy_] : 0.0;
+  const bool okx = (gx_ == 0 || xl < vx) && (gx_ == nx || !(xh < vx));
+  const bool oky = (gy_ == 0 || yl < vy) && (gy_ == ny || !(yh < vy));
+  rx = okx ? gx_ : astar_lower_bound(ax, nx, vx, gx_);
+  ry = oky ? gy_ : astar_lower_bound(ay, ny, vy, gy_);
+}
 
 struct AstarParamsDev {
   int32_t variant, cap_nodes, cap_exp, flags;
@@ -132,9 +145,25 @@ constexpr int ASTAR_OPEN_CAP = 768;
 constexpr int ASTAR_MAX_BINS = 64;
 constexpr int ASTAR_LDS_OBST = 256, ASTAR_LDS_POLY = 64, ASTAR_LDS_GRID = 256;
 
+// PAIR (variant 3 on a product grid, latency batches): a second wavefront per instance evaluates what depends on the popped
+// node's position alone -- the cell of every neighbour, path length, time stamp and time bin, the visited / cell-info words
+// and the prob / topn table values -- while the first runs the bounds and collision tests (see the kernel).
+struct AstarPairBox {
+  int seq_m;      // the searching wavefront: expansion number + 1 whose node is posted
+  int seq_x;      // the second wavefront: expansion number + 1 whose results are posted
+  int stop, _p0;
+  double cx, cy, clen;
+  double len_[8], pr[8], tn[8];
+  int ts_[8], tb[8], key[8], flags[8];  // flags bit 0: visited index out of range
+  uint32_t ciw[8];
+};
+constexpr int ASTAR_SPIN_LIMIT = 1 << 24;
+
 // one instantiation per variant (VARIANT = AstarParamsDev::variant): the other variants' state and branches are gone
-template <int VARIANT>
-__global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W, AstarParamsDev P, AstarBuffers B, int n_inst) {
+template <int VARIANT, bool PAIR = false>
+__global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kernel(AstarWorldDev W, AstarParamsDev P, AstarBuffers B, int n_inst) {
+  static_assert(!PAIR || VARIANT == 3, "the paired form is variant 3's");
+  __shared__ AstarPairBox s_box[PAIR ? ASTAR_WAVES : 1];
   __shared__ int32_t s_hopen[ASTAR_WAVES][ASTAR_MAX_HAB];
   __shared__ int32_t s_hclosed[ASTAR_WAVES][ASTAR_MAX_HAB];
   __shared__ int32_t s_keys[ASTAR_WAVES][8];
@@ -148,7 +177,10 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   __shared__ double s_obs[3][ASTAR_LDS_OBST];  // x, y, T(size) of the first ASTAR_LDS_OBST obstacles
   __shared__ double s_poly[ASTAR_LDS_POLY][2];
   __shared__ double s_grid[ASTAR_LDS_GRID];    // product-grid edge tables gx0 | gx1 | gy0 | gy1 (when they fit)
-  const int wave = uni((int)(threadIdx.x >> 6));
+  const int wave_id = uni((int)(threadIdx.x >> 6));
+  // PAIR: wavefronts 0..3 search, wavefront 4 + ((i + 2) & 3) is the second wavefront of instance i (another SIMD than its partner's)
+  const bool second = PAIR && wave_id >= ASTAR_WAVES;
+  const int wave = second ? ((wave_id - ASTAR_WAVES + 2) & (ASTAR_WAVES - 1)) : wave_id;
   const int lane = lane_id();
   const int ep = (int)blockIdx.x * ASTAR_WAVES + wave;
   const int H = W.n_habitats, C = W.n_cells, T = W.n_bins;
@@ -164,9 +196,12 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     for (int i = threadIdx.x; i < 2 * W.n_poly; i += blockDim.x) (&s_poly[0][0])[i] = W.poly[i];
   if (grid_lds)
     for (int i = threadIdx.x; i < 2 * (W.g_ncol + W.g_nrow); i += blockDim.x) s_grid[i] = W.gx0[i];  // one contiguous upload
+  if (PAIR && threadIdx.x < ASTAR_WAVES) { s_box[threadIdx.x].seq_m = 0; s_box[threadIdx.x].seq_x = 0; s_box[threadIdx.x].stop = 0; }
   __syncthreads();
   if (ep >= n_inst) return;  // no workgroup barrier after this point
   constexpr int V = VARIANT;
+  AstarPairBox* box = &s_box[PAIR ? wave : 0];
+  (void)box;
   const int cap = P.cap_nodes;
   double4* rec = reinterpret_cast<double4*>(B.nodes + (size_t)ep * 8 * cap);  // two per node; 64-byte aligned
   // f once more, contiguous, behind the records of all instances (the scan of the variants without an open list in LDS)
@@ -189,10 +224,10 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   const double w2 = P.w[1], w3 = P.w[2], w4 = P.w[3];
   const bool logx = (P.flags & 1) != 0 && B.exp_log != nullptr;
 
-  for (int i = lane; i < H; i += 64) hopen[i] = i;
+  if (!second) for (int i = lane; i < H; i += 64) hopen[i] = i;
   int n_hopen = H, n_hclosed = 0;
   unsigned long long closedmask = 0ull;  // bit h: habitat h is in the closed list
-  if (lane == 0) {
+  if (lane == 0 && !second) {
     put_node(0, sx, sy, 0.0, 0.0, 0.0, 0.0, 0.0, -1, 0, 1);
   }
   wave_sync();
@@ -203,7 +238,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
   int32_t* oi_l = s_oi[wave];
   int n_list = 1;
   bool list_ok = V >= 2;  // astar.py / astar_real.py never close a cell: their open sets outgrow the list at once
-  if (lane == 0) { of_l[0] = 0.0; oi_l[0] = 0; }
+  if (lane == 0 && !second) { of_l[0] = 0.0; oi_l[0] = 0; }
   wave_sync();
 
   // neighbour offsets: lane k = lane >> 3 handles neighbour k, slice s = lane & 7
@@ -217,6 +252,91 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     offy = V == 0 ? ay[k8] : by[k8];
   }
 
+  if (PAIR && second) {
+    // ======================================================================================== the second wavefront (PAIR)
+    // per expansion, from the popped node's position and path length alone: for each of the eight neighbours (lane kk < 8
+    // = neighbour kk; the cell lookup on all 64 lanes as below) cell key, path length, time stamp, time bin, cell-info word,
+    // prob / topn values -- whether or not the neighbour becomes a child (the searching wavefront knows after its bounds and
+    // collision tests, which run meanwhile)
+    const int kk = lane & 7;
+    for (int e = 0;; e++) {
+      {
+        int spins = 0;
+        bool stop = false;
+        for (;;) {
+          const int sm = *reinterpret_cast<volatile int*>(&box->seq_m);
+          if (*reinterpret_cast<volatile int*>(&box->stop)) { stop = true; break; }
+          if (uni(sm) == e + 1) break;
+          if (++spins > ASTAR_SPIN_LIMIT) { stop = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (stop) break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double cxp = readfirst_f64(box->cx), cyp = readfirst_f64(box->cy), clen = readfirst_f64(box->clen);
+      const double qx = cxp + (double)offx, qy = cyp + (double)offy;
+      const double px = __shfl(qx, kk * 8, 64), py = __shfl(qy, kk * 8, 64);
+      int xi = (int)(px + 500), yi = (int)(py + 200);
+      if (xi < 0) xi += P.vx;
+      if (yi < 0) yi += P.vy;
+      const bool oob = xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy;
+      uint32_t ciw = 0u;
+      if (lane < 8 && !oob) ciw = cellinfo[(size_t)xi * P.vy + yi];
+      int key_grid = -1;
+      {
+        int gc = 0, gr = 0;
+        bool m = false;
+        auto lookup = [&](const auto* gx0, const auto* gx1, const auto* gy0, const auto* gy1) {
+          astar_lower_bound2(gx1, W.g_ncol, qx, (int)((qx - W.g_x1_0) * W.g_inv_dx), gy1, W.g_nrow, qy, (int)((qy - W.g_y1_0) * W.g_inv_dy), gc, gr);
+          const bool colj = s8 < 3;
+          const int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
+          const int n = colj ? W.g_ncol : W.g_nrow;
+          if (s8 < 6 && idx >= 0 && idx < n) {
+            const double a = colj ? gx0[idx] : gy0[idx], b = colj ? gx1[idx] : gy1[idx], v = colj ? qx : qy;
+            const double dd = auvp_fabs(a - b);
+            m = auvp_fabs(v - a) <= dd && auvp_fabs(v - b) <= dd;
+          }
+        };
+        if (grid_lds) lookup(s_grid, s_grid + W.g_ncol, s_grid + 2 * W.g_ncol, s_grid + 2 * W.g_ncol + W.g_nrow);
+        else lookup(W.gx0, W.gx1, W.gy0, W.gy1);
+        const unsigned long long bm = __ballot(m);
+        const unsigned g8 = (unsigned)((bm >> (k8 * 8)) & 0xffull);
+        const unsigned cm3 = g8 & 7u, rm3 = (g8 >> 3) & 7u;
+        if (cm3 && rm3) key_grid = (gr - 1 + (__ffs((int)rm3) - 1)) * W.g_ncol + (gc - 1 + (__ffs((int)cm3) - 1));
+      }
+      const int key = __shfl(key_grid, kk * 8, 64);
+      const double sq_ = astar_sqdist(cxp, cyp, px, py);
+      const bool lattice = sq_ == 100.0 || sq_ == 200.0;
+      double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
+      if (!__all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
+      const double len_ = clen + root_;
+      const double dist_left = auvp_fabs(limit - len_);
+      const int ts_ = (int)(P.velocity == 1.0 ? len_ : len_ / P.velocity);
+      int tb = -1;
+      {
+        const double tsn = (double)__shfl(ts_, k8, 64);
+        for (int t0 = 0; t0 < T; t0 += 8) {
+          const int t = t0 + s8;
+          bool m = false;
+          if (t < T) { const double2 bb = *reinterpret_cast<const double2*>(&s_bins[t][0]); m = tsn <= bb.y && tsn >= bb.x; }
+          const unsigned long long bm = __ballot(m);
+          const unsigned mine8 = (unsigned)((bm >> (8 * kk)) & 0xffull);
+          if (tb < 0 && mine8) tb = t0 + (__ffs((int)mine8) - 1);
+          if (__all(tb >= 0 || lane >= 8)) break;
+        }
+      }
+      const int ntop = (int)dist_left;
+      double pr = 0.0, tn = 0.0;
+      if (lane < 8 && tb >= 0 && key >= 0 && key < C && ntop >= 0 && ntop <= C) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; }
+      if (lane < 8) {
+        box->len_[lane] = len_; box->pr[lane] = pr; box->tn[lane] = tn;
+        box->ts_[lane] = ts_; box->tb[lane] = tb; box->key[lane] = key; box->flags[lane] = oob ? 1 : 0; box->ciw[lane] = ciw;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) *reinterpret_cast<volatile int*>(&box->seq_x) = e + 1;
+    }
+    return;
+  }
   while (n_open > 0) {
     // ------------------------------------------------------------ pop the first minimum f
     double bf = __builtin_inf();
@@ -239,7 +359,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     // then the lanes that hold it: almost always one
     {
       const bool have = bi != 0x7fffffff;
-      const double fmin = wave_min_f64(have ? bf : __builtin_inf());
+      const double fmin = wave_min_f64_dpp(have ? bf : __builtin_inf());
       const unsigned long long eq = __ballot(have && bf == fmin);
       if (__popcll(eq) == 1) {
         const int l = __ffsll((long long)eq) - 1;
@@ -284,6 +404,11 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       e[7] = (double)(int)(__double_as_longlong(cur_b.w) >> 32);
     }
     n_exp++;
+    if (PAIR) {
+      if (lane == 0) { box->cx = cxp; box->cy = cyp; box->clen = clen; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) *reinterpret_cast<volatile int*>(&box->seq_m) = n_exp;
+    }
     // ------------------------------------------------------------ neighbours: bounds, then collision
     const double qx = cxp + (double)offx, qy = cyp + (double)offy;
     // SOG: the visited/cell-info word of every neighbour is requested now (lane k < 8 = neighbour k), so the read is
@@ -291,7 +416,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     uint32_t ciw_early = 0u;
     double ex = 0.0, ey = 0.0;
     if (V >= 2) { ex = __shfl(qx, (lane & 7) * 8, 64); ey = __shfl(qy, (lane & 7) * 8, 64); }
-    if (V >= 2 && lane < 8) {
+    if (V >= 2 && lane < 8 && !PAIR) {
       int xi = (int)(ex + 500), yi = (int)(ey + 200);
       if (xi < 0) xi += P.vx;
       if (yi < 0) yi += P.vy;
@@ -428,7 +553,67 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       visited_count += opened;
       wave_sync();
     }
+    // the children's nodes once their inputs are known (variant 3): costs, stores, visited words, open-list append
+    auto finish_children = [&](const int kk, const bool mine, const double px, const double py, const double len_, const double dist_left,
+                               const int ts_, const size_t vi, const int key, const bool need_key, const double pr, const double tn,
+                               const int was) {
+      const double g_ = ccost - w4 * pr;
+      const double h_ = -w2 * dist_left - w3 * (double)H - w4 * tn;
+      const double f_ = g_ + h_;
+      const int open_ = was ? 0 : 1;
+      if (mine) {
+        const int c = n_nodes + __popc(childmask & ((1 << kk) - 1));
+        put_node(c, px, py, g_, h_, f_, g_, len_, cur, ts_, open_);
+        if (!was || need_key) cellinfo[vi] = ep_tag | 0x10000u | (uint32_t)(key + 1);  // visited from now on, key kept
+      }
+      const unsigned long long om = __ballot(mine && open_);
+      const int opened = __popcll(om);
+      if (list_ok) {
+        if (n_list + opened > ASTAR_OPEN_CAP) list_ok = false;
+        else {
+          if (mine && open_) {
+            const int q = n_list + __popcll(om & ((1ull << lane) - 1ull));
+            of_l[q] = f_; oi_l[q] = n_nodes + __popc(childmask & ((1 << kk) - 1));
+          }
+          n_list += opened;
+        }
+      }
+      n_open += opened;
+      visited_count += opened;
+      wave_sync();
+    };
     if (V == 3) {
+      if (PAIR) {
+        // the second wavefront's results of this expansion (it started when the popped node was posted)
+        {
+          int spins = 0;
+          while (uni(*reinterpret_cast<volatile int*>(&box->seq_x)) != n_exp) {
+            if (++spins > ASTAR_SPIN_LIMIT) { status = -9; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (status) break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int kk = lane & 7;
+        const bool mine = lane < 8 && ((childmask >> kk) & 1);
+        const double px = ex, py = ey;
+        const double len_ = box->len_[kk], pr_x = box->pr[kk], tn_x = box->tn[kk];
+        const int ts_ = box->ts_[kk], tb = box->tb[kk], key_x = box->key[kk], fl = box->flags[kk];
+        const uint32_t ciw = mine ? box->ciw[kk] : 0u;
+        const double dist_left = auvp_fabs(limit - len_);
+        const int ntop = (int)dist_left;
+        if (__any(mine && (fl & 1))) { status = -1; break; }
+        int xi = (int)(px + 500), yi = (int)(py + 200);
+        if (xi < 0) xi += P.vx;
+        if (yi < 0) yi += P.vy;
+        const size_t vi = (size_t)xi * P.vy + yi;
+        const bool ci_live = (ciw & 0xff000000u) == ep_tag;
+        const int key = mine ? key_x : 0;
+        const bool bad = mine && (tb < 0 || key < 0 || ntop > C);
+        if (__any(bad)) { status = -1; break; }
+        const int was = (mine && ci_live && (ciw & 0x10000u)) ? 1 : 0;
+        finish_children(kk, mine, px, py, len_, dist_left, ts_, vi, key, false, mine ? pr_x : 0.0, mine ? tn_x : 0.0, was);
+      } else {
       // get_cell_prob's cell of every neighbour on a product grid: lane (k8, s8) tests column gc-1+s8 (s8 < 3) or row
       // gr-4+s8 (3 <= s8 < 6) of neighbour k8 with the reference's own float predicate; the first matching row and the
       // first matching column give the first matching cell of the list (every (row, column) pair of matches is a match)
@@ -438,8 +623,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
         int gc = 0, gr = 0;
         bool m = false;
         auto lookup = [&](const auto* gx0, const auto* gx1, const auto* gy0, const auto* gy1) {
-          gc = astar_lower_bound(gx1, W.g_ncol, qx, (int)((qx - W.g_x1_0) * W.g_inv_dx));
-          gr = astar_lower_bound(gy1, W.g_nrow, qy, (int)((qy - W.g_y1_0) * W.g_inv_dy));
+          astar_lower_bound2(gx1, W.g_ncol, qx, (int)((qx - W.g_x1_0) * W.g_inv_dx), gy1, W.g_nrow, qy, (int)((qy - W.g_y1_0) * W.g_inv_dy), gc, gr);
           const bool colj = s8 < 3;
           const int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
           const int n = colj ? W.g_ncol : W.g_nrow;
@@ -462,12 +646,28 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       const int key_g = __shfl(key_grid, kk * 8, 64);
       const bool mine = lane < 8 && ((childmask >> kk) & 1);
       const double px = ex, py = ey;
-      const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
+      // (lattice steps: the squared distance is exactly 100 or 200 unless the coordinates carry fraction bits that the step
+      // rounded; the correctly rounded roots of those two are constants)
+      const double sq_ = astar_sqdist(cxp, cyp, px, py);
+      const bool lattice = sq_ == 100.0 || sq_ == 200.0;
+      double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
+      if (!__all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
+      const double len_ = clen + root_;
       const double dist_left = auvp_fabs(limit - len_);
       const int ts_ = (int)(P.velocity == 1.0 ? len_ : len_ / P.velocity);  // x / 1.0 is x: no division on the chain
+      // the first time bin that holds ts_ (:520-527): lane (k8, s8) tests bins s8, s8 + 8, .. for neighbour k8's time stamp
       int tb = -1;
-      for (int t = 0; t < T; t++) {
-        if ((double)ts_ <= s_bins[t][1] && (double)ts_ >= s_bins[t][0]) { tb = t; break; }
+      {
+        const double tsn = (double)__shfl(ts_, k8, 64);  // (lane kk < 8 holds child kk's)
+        for (int t0 = 0; t0 < T; t0 += 8) {
+          const int t = t0 + s8;
+          bool m = false;
+          if (t < T) { const double2 bb = *reinterpret_cast<const double2*>(&s_bins[t][0]); m = tsn <= bb.y && tsn >= bb.x; }
+          const unsigned long long bm = __ballot(m);
+          const unsigned mine8 = (unsigned)((bm >> (8 * (lane & 7))) & 0xffull);  // lane kk < 8: its own child's slices
+          if (tb < 0 && mine8) tb = t0 + (__ffs((int)mine8) - 1);
+          if (__all(tb >= 0 || lane >= 8)) break;
+        }
       }
       const int ntop = (int)dist_left;
       int xi = (int)(px + 500), yi = (int)(py + 200);
@@ -513,30 +713,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
       double pr = 0.0, tn = 0.0;
       int was = 0;
       if (mine) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; was = (ci_live && (ciw & 0x10000u)) ? 1 : 0; }
-      const double g_ = ccost - w4 * pr;
-      const double h_ = -w2 * dist_left - w3 * (double)H - w4 * tn;
-      const double f_ = g_ + h_;
-      const int open_ = was ? 0 : 1;
-      if (mine) {
-        const int c = n_nodes + __popc(childmask & ((1 << kk) - 1));
-        put_node(c, px, py, g_, h_, f_, g_, len_, cur, ts_, open_);
-        if (!was || need_key) cellinfo[vi] = ep_tag | 0x10000u | (uint32_t)(key + 1);  // visited from now on, key kept
+      finish_children(kk, mine, px, py, len_, dist_left, ts_, vi, key, need_key, pr, tn, was);
       }
-      const unsigned long long om = __ballot(mine && open_);
-      const int opened = __popcll(om);
-      if (list_ok) {
-        if (n_list + opened > ASTAR_OPEN_CAP) list_ok = false;
-        else {
-          if (mine && open_) {
-            const int q = n_list + __popcll(om & ((1ull << lane) - 1ull));
-            of_l[q] = f_; oi_l[q] = n_nodes + __popc(childmask & ((1 << kk) - 1));
-          }
-          n_list += opened;
-        }
-      }
-      n_open += opened;
-      visited_count += opened;
-      wave_sync();
     }
     int slot = 0;
     for (int k = 0; k < 8 && status == 0 && V <= 1; k++) {
@@ -567,6 +745,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64) void astar_kernel(AstarWorldDev W
     n_nodes += nch;
   }
 
+  if (PAIR && lane == 0) *reinterpret_cast<volatile int*>(&box->stop) = 1;
   for (int i = lane; i < n_hopen; i += 64) B.hab_left[(size_t)ep * (H > 0 ? H : 1) + i] = hopen[i];
   if (lane == 0) {
     AstarSummary& s = B.summary[ep];

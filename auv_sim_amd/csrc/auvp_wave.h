@@ -49,6 +49,28 @@ __device__ __forceinline__ double wave_min_f64(double v) {
   return v;
 }
 
+// the same minimum on the DPP path (a lone wavefront pays ~100 clocks per cross-lane LDS shuffle, twelve of them above): four
+// rotate steps inside the 16-lane rows, then the four row results.  Same comparison as wave_min_f64 ((t < v) ? t : v; the
+// order in which lanes meet differs, which matters only with a nan among the values).
+__device__ __forceinline__ double wave_min_f64_dpp(double v) {
+#define AUVP_ROW_ROR_MIN(N)                                                                                   \
+  do {                                                                                                        \
+    const long long b__ = __double_as_longlong(v);                                                            \
+    const int lo__ = __builtin_amdgcn_update_dpp(0, (int)(b__ & 0xffffffffll), 0x120 + (N), 0xf, 0xf, false); \
+    const int hi__ = __builtin_amdgcn_update_dpp(0, (int)(b__ >> 32), 0x120 + (N), 0xf, 0xf, false);          \
+    const double t__ = __longlong_as_double(((long long)hi__ << 32) | (unsigned int)lo__);                    \
+    v = (t__ < v) ? t__ : v;                                                                                  \
+  } while (0)
+  AUVP_ROW_ROR_MIN(8);
+  AUVP_ROW_ROR_MIN(4);
+  AUVP_ROW_ROR_MIN(2);
+  AUVP_ROW_ROR_MIN(1);
+#undef AUVP_ROW_ROR_MIN
+  const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+  const double ab = (b < a) ? b : a, cd = (d < c) ? d : c;
+  return (cd < ab) ? cd : ab;
+}
+
 __device__ __forceinline__ double wave_max_f64(double v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {

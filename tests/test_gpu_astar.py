@@ -78,12 +78,16 @@ def test_astar_batch_vs_oracle(ctx, orc, variant):
 
 @pytest.mark.parametrize("cells_as", ["product_grid", "shuffled_list", "column_major", "grid_14m_float_starts", "uneven_product_grid",
                                       "fine_grid_tables_in_hbm"])
-def test_sog_cell_lookup_paths(ctx, orc, cells_as):
+@pytest.mark.parametrize("wavefronts", ["two_per_instance", "one_per_instance"])
+def test_sog_cell_lookup_paths(ctx, orc, cells_as, wavefronts, monkeypatch):
     """get_cell_prob (astar_fixLenSOG.py:485-514) = the first cell of the LIST whose closed box holds the point; lattice
     points sit on cell edges, so up to four cells match and the list order decides.  A row-major product grid takes the
     arithmetic lookup (three rows and columns around the lower bounds), any other list the sweep over the cells."""
     from auv_sim_amd import synth
     from oracle import orc_astar as oa
+    # (latency batches on a product grid give every instance a second wavefront for what depends on the popped node's position
+    # alone, astar_kernel.h PAIR; both forms against the checker)
+    monkeypatch.setenv("AUVP_ASTAR_PAIR", "1" if wavefronts == "two_per_instance" else "0")
     rng = np.random.default_rng(23)
     # (80 x 80 cells of 2.5 m: the edge tables no longer fit the kernel's LDS budget and are read from memory)
     cell = 14.0 if cells_as == "grid_14m_float_starts" else (2.5 if cells_as == "fine_grid_tables_in_hbm" else 10.0)
