@@ -13,7 +13,7 @@ struct PrrtState {
   auvp::PrrtParamsDev P{};
   auvp::PrrtBuffers B{};
   DevBuf nodes, node_bucket, points, occupied, buckets, mt, rng_state, start, goal, step_bucket, summary, st_log,
-      tmp_off, tmp_out, env_done, thetas;
+      tmp_off, tmp_out, env_done, thetas, seeds;
   // the bucket table's current epoch (PrrtBuffers::bucket_epoch): a new batch on the same allocation takes the next one; the
   // table is cleared when the allocation changes or the 8-bit tag would wrap
   int bucket_epoch = 0;
@@ -273,20 +273,27 @@ int auvp_prrt_create_batch(auvp_handle* h, int32_t E, const double* starts, cons
   if ((rc = prrt_configure(h, S, E, p, flags))) return rc;
   if ((rc = upload(h, S.start, starts, (size_t)E * 4))) return rc;
   if ((rc = upload(h, S.goal, goals, (size_t)E * 2))) return rc;
-  // generator states
-  std::vector<uint32_t> words((size_t)E * 624);
-  std::vector<int32_t> rs((size_t)E * 4, 0);
-  for (int e = 0; e < E; e++) {
-    if (seeds) seed_mt(seeds[e], words.data() + (size_t)e * 624);
-    else {
+  // generator states: random.seed(seeds[e]) on the device (init_by_array, 64 generators per workgroup), or the caller's own
+  if (seeds) {
+    HIPCHK(h, S.seeds.reserve((size_t)E * sizeof(uint64_t)));
+    HIPCHK(h, hipMemcpyAsync(S.seeds.p, seeds, (size_t)E * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::prrt_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  auvp::PRRT_SEED_LDS));
+    hipLaunchKernelGGL(auvp::prrt_seed_kernel, dim3((E + 63) / 64), dim3(64), auvp::PRRT_SEED_LDS, h->stream,
+                       S.seeds.as<unsigned long long>(), S.B.mt, S.B.rng_state, (int)E);
+    HIPCHK(h, hipGetLastError());
+  } else {
+    std::vector<uint32_t> words((size_t)E * 624);
+    std::vector<int32_t> rs((size_t)E * 4, 0);
+    for (int e = 0; e < E; e++) {
       memcpy(words.data() + (size_t)e * 624, mt + (size_t)e * 624, 624 * sizeof(uint32_t));
       int idx = mt_index[e] < 0 ? 0 : (mt_index[e] > 624 ? 624 : mt_index[e]);
       rs[4 * (size_t)e] = idx == 624 ? 0 : idx;
       rs[4 * (size_t)e + 1] = 624 - idx;
     }
+    if ((rc = upload(h, S.mt, words.data(), words.size()))) return rc;
+    if ((rc = upload(h, S.rng_state, rs.data(), rs.size()))) return rc;
   }
-  if ((rc = upload(h, S.mt, words.data(), words.size()))) return rc;
-  if ((rc = upload(h, S.rng_state, rs.data(), rs.size()))) return rc;
   return prrt_plant(h, S, E);
 }
 
