@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/auvplan.h"
+#include "auvp_seed.h"
 #include "rrt_explore_kernel.h"
 #include "rrt_rows_kernel.h"
 #include "rrt_duo_kernel.h"
@@ -62,7 +63,7 @@ struct auvp_handle {
   RrtParamsDev P{};
   RrtBuffers B{};
   int max_pts = 0;
-  DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_init, d_summary, d_itlog_i, d_itlog_b,
+  DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_seeds, d_init, d_summary, d_itlog_i, d_itlog_b,
       d_leaf_c, d_leaf_i, d_phase, d_leaf_stats, d_node_c, d_node_q, d_node_xy, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
@@ -660,13 +661,17 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
     HIPCHK(h, hipMemsetAsync(h->d_phase.p, 0, (size_t)E * 5 * sizeof(unsigned long long), h->stream));
     B.phase_clocks = h->d_phase.as<unsigned long long>();
   }
-  // seeds -> MT states (host), uploaded once per batch
+  // seeds -> MT states, once per batch: random.seed(seeds[e]) on the device (auvp_seed.h)
   int rc;
   B.mt_index = nullptr;
   if (seeds) {
-    std::vector<uint32_t> mt((size_t)E * 624);
-    for (int e = 0; e < E; e++) seed_mt(seeds[e], mt.data() + (size_t)e * 624);
-    if ((rc = upload(h, h->d_mt, mt.data(), mt.size()))) return rc;
+    HIPCHK(h, h->d_mt.reserve((size_t)E * 624 * sizeof(uint32_t)));
+    if ((rc = upload(h, h->d_seeds, seeds, (size_t)E))) return rc;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::mt_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  auvp::MT_SEED_LDS));
+    hipLaunchKernelGGL(auvp::mt_seed_kernel, dim3((E + 63) / 64), dim3(64), auvp::MT_SEED_LDS, h->stream,
+                       h->d_seeds.as<unsigned long long>(), h->d_mt.as<uint32_t>(), (int32_t*)nullptr, (int)E);
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
   } else {
     if ((rc = upload(h, h->d_mt, states, (size_t)E * 624))) return rc;

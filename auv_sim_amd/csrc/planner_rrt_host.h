@@ -277,9 +277,9 @@ int auvp_prrt_create_batch(auvp_handle* h, int32_t E, const double* starts, cons
   if (seeds) {
     HIPCHK(h, S.seeds.reserve((size_t)E * sizeof(uint64_t)));
     HIPCHK(h, hipMemcpyAsync(S.seeds.p, seeds, (size_t)E * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::prrt_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  auvp::PRRT_SEED_LDS));
-    hipLaunchKernelGGL(auvp::prrt_seed_kernel, dim3((E + 63) / 64), dim3(64), auvp::PRRT_SEED_LDS, h->stream,
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::mt_seed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  auvp::MT_SEED_LDS));
+    hipLaunchKernelGGL(auvp::mt_seed_kernel, dim3((E + 63) / 64), dim3(64), auvp::MT_SEED_LDS, h->stream,
                        S.seeds.as<unsigned long long>(), S.B.mt, S.B.rng_state, (int)E);
     HIPCHK(h, hipGetLastError());
   } else {

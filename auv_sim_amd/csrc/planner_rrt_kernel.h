@@ -18,6 +18,7 @@
 #include "auvp_math.h"
 #include "auvp_types.h"
 #include "auvp_wave.h"
+#include "auvp_seed.h"
 
 namespace auvp {
 
@@ -866,36 +867,11 @@ __device__ inline void mt_seed_by_array(unsigned long long seed, uint32_t* mt) {
   mt[0] = 0x80000000u;
 }
 
-// init_by_array with the state as a column of an LDS tile: m[word * 65]
-__device__ __forceinline__ void mt_seed_by_array_column(unsigned long long seed, uint32_t* m) {
-  const uint32_t key[2] = {(uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)};
-  const int klen = key[1] ? 2 : 1;
-  uint32_t prev = 19650218u;
-  m[0] = prev;
-  for (int i = 1; i < 624; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; m[i * 65] = prev; }
-  int i = 1, j = 0;
-  prev = m[0];
-  for (int k = 624; k; k--) {
-    prev = (m[i * 65] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
-    m[i * 65] = prev;
-    i++; j++;
-    if (i >= 624) { m[0] = prev; i = 1; }
-    if (j >= klen) j = 0;
-  }
-  for (int k = 623; k; k--) {
-    prev = (m[i * 65] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-    m[i * 65] = prev;
-    i++;
-    if (i >= 624) { m[0] = prev; i = 1; }
-  }
-  m[0] = 0x80000000u;
-}
-
 // One wavefront seeds 64 generators at once.  init_by_array is a serial recurrence per generator (1 871 dependent steps), so
 // the work is one thread per episode -- but with the state column in LDS (a read-modify-write of global memory per step
 // made the round-2 kernel 0.3 ms for 12 500 episodes).  Layout mtl[word * 65 + thread]: conflict-free both for the
 // per-thread recurrence (bank = word + thread) and for the coalesced write-out (one episode's 624 words by 64 lanes).
-constexpr int PRRT_SEED_LDS = 624 * 65 * 4;
+constexpr int PRRT_SEED_LDS = MT_SEED_LDS;
 __global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, PrrtGoalMap M, const double* __restrict__ pf_state,
                                                                  int n_episodes) {
   extern __shared__ __align__(16) unsigned char seed_smem[];
@@ -925,28 +901,6 @@ __global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, 
   const int n_here = (n_episodes - e0) < 64 ? (n_episodes - e0) : 64;
   for (int q = 0; q < n_here; q++) {
     uint32_t* dst = B.mt + (size_t)(e0 + q) * 624;
-    for (int w = t; w < 624; w += 64) dst[w] = mtl[w * 65 + q];
-  }
-}
-
-// random.seed(seeds[e]) for every episode of a batch (auvp_prrt_create_batch with seeds: 2 us per generator on a host core,
-// 1.0 of the 1.4 ms a 512-episode batch took to create): the same column layout, 64 generators per workgroup
-__global__ __launch_bounds__(64) void prrt_seed_kernel(const unsigned long long* __restrict__ seeds, uint32_t* __restrict__ mt,
-                                                       int32_t* __restrict__ rng_state, int n_episodes) {
-  extern __shared__ __align__(16) unsigned char seed_smem[];
-  uint32_t* mtl = reinterpret_cast<uint32_t*>(seed_smem);
-  const int t = (int)threadIdx.x;
-  const int e0 = (int)blockIdx.x * 64;
-  const int e = e0 + t;
-  mt_seed_by_array_column(e < n_episodes ? seeds[e] : 0ull, mtl + t);
-  if (e < n_episodes) {
-    int32_t* rs = rng_state + 4 * (size_t)e;
-    rs[0] = 0; rs[1] = 0; rs[2] = 0; rs[3] = 0;  // a freshly seeded generator: nothing generated yet
-  }
-  __syncthreads();
-  const int n_here = (n_episodes - e0) < 64 ? (n_episodes - e0) : 64;
-  for (int q = 0; q < n_here; q++) {
-    uint32_t* dst = mt + (size_t)(e0 + q) * 624;
     for (int w = t; w < 624; w += 64) dst[w] = mtl[w * 65 + q];
   }
 }
