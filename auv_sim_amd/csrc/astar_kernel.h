@@ -258,14 +258,13 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     // = neighbour kk; the cell lookup on all 64 lanes as below) cell key, path length, time stamp, time bin, cell-info word,
     // prob / topn values -- whether or not the neighbour becomes a child (the searching wavefront knows after its bounds and
     // collision tests, which run meanwhile)
-    const int kk = lane & 7;
     for (int e = 0;; e++) {
       {
         int spins = 0;
         bool stop = false;
         for (;;) {
-          const int sm = *reinterpret_cast<volatile int*>(&box->seq_m);
-          if (*reinterpret_cast<volatile int*>(&box->stop)) { stop = true; break; }
+          const int sm = lds_peek(&box->seq_m);
+          if (lds_peek(&box->stop)) { stop = true; break; }
           if (uni(sm) == e + 1) break;
           if (++spins > ASTAR_SPIN_LIMIT) { stop = true; break; }
           __builtin_amdgcn_s_sleep(1);
@@ -274,66 +273,79 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
       const double cxp = readfirst_f64(box->cx), cyp = readfirst_f64(box->cy), clen = readfirst_f64(box->clen);
+      // every lane of group k8 works on neighbour k8 and lane (k8, 0) owns its row of results: no value crosses lanes except
+      // through ballots, and the table reads below are issued together -- three dependent round trips (edge tables + time
+      // bins; the rows / columns around the bounds; prob / topn) instead of a dozen
       const double qx = cxp + (double)offx, qy = cyp + (double)offy;
-      const double px = __shfl(qx, kk * 8, 64), py = __shfl(qy, kk * 8, 64);
-      int xi = (int)(px + 500), yi = (int)(py + 200);
+      int xi = (int)(qx + 500), yi = (int)(qy + 200);
       if (xi < 0) xi += P.vx;
       if (yi < 0) yi += P.vy;
       const bool oob = xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy;
       uint32_t ciw = 0u;
-      if (lane < 8 && !oob) ciw = cellinfo[(size_t)xi * P.vy + yi];
-      int key_grid = -1;
-      {
-        int gc = 0, gr = 0;
-        bool m = false;
-        auto lookup = [&](const auto* gx0, const auto* gx1, const auto* gy0, const auto* gy1) {
-          astar_lower_bound2(gx1, W.g_ncol, qx, (int)((qx - W.g_x1_0) * W.g_inv_dx), gy1, W.g_nrow, qy, (int)((qy - W.g_y1_0) * W.g_inv_dy), gc, gr);
-          const bool colj = s8 < 3;
-          const int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
-          const int n = colj ? W.g_ncol : W.g_nrow;
-          if (s8 < 6 && idx >= 0 && idx < n) {
-            const double a = colj ? gx0[idx] : gy0[idx], b = colj ? gx1[idx] : gy1[idx], v = colj ? qx : qy;
-            const double dd = auvp_fabs(a - b);
-            m = auvp_fabs(v - a) <= dd && auvp_fabs(v - b) <= dd;
-          }
-        };
-        if (grid_lds) lookup(s_grid, s_grid + W.g_ncol, s_grid + 2 * W.g_ncol, s_grid + 2 * W.g_ncol + W.g_nrow);
-        else lookup(W.gx0, W.gx1, W.gy0, W.gy1);
-        const unsigned long long bm = __ballot(m);
-        const unsigned g8 = (unsigned)((bm >> (k8 * 8)) & 0xffull);
-        const unsigned cm3 = g8 & 7u, rm3 = (g8 >> 3) & 7u;
-        if (cm3 && rm3) key_grid = (gr - 1 + (__ffs((int)rm3) - 1)) * W.g_ncol + (gc - 1 + (__ffs((int)cm3) - 1));
-      }
-      const int key = __shfl(key_grid, kk * 8, 64);
-      const double sq_ = astar_sqdist(cxp, cyp, px, py);
+      if (s8 == 0 && !oob) ciw = cellinfo[(size_t)xi * P.vy + yi];
+      const double sq_ = astar_sqdist(cxp, cyp, qx, qy);
       const bool lattice = sq_ == 100.0 || sq_ == 200.0;
       double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
       if (!__all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
       const double len_ = clen + root_;
       const double dist_left = auvp_fabs(limit - len_);
       const int ts_ = (int)(P.velocity == 1.0 ? len_ : len_ / P.velocity);
-      int tb = -1;
-      {
-        const double tsn = (double)__shfl(ts_, k8, 64);
-        for (int t0 = 0; t0 < T; t0 += 8) {
-          const int t = t0 + s8;
-          bool m = false;
-          if (t < T) { const double2 bb = *reinterpret_cast<const double2*>(&s_bins[t][0]); m = tsn <= bb.y && tsn >= bb.x; }
-          const unsigned long long bm = __ballot(m);
-          const unsigned mine8 = (unsigned)((bm >> (8 * kk)) & 0xffull);
-          if (tb < 0 && mine8) tb = t0 + (__ffs((int)mine8) - 1);
-          if (__all(tb >= 0 || lane >= 8)) break;
-        }
-      }
+      const double tsd = (double)ts_;
       const int ntop = (int)dist_left;
+      int key = -1, tb = -1;
+      auto tables = [&](const auto* gx0, const auto* gx1, const auto* gy0, const auto* gy1) {
+        // ---- round trip 1: the entries either side of both lower-bound guesses, and time bin s8
+        int gc = (int)((qx - W.g_x1_0) * W.g_inv_dx), gr = (int)((qy - W.g_y1_0) * W.g_inv_dy);
+        gc = gc < 0 ? 0 : (gc > W.g_ncol ? W.g_ncol : gc);
+        gr = gr < 0 ? 0 : (gr > W.g_nrow ? W.g_nrow : gr);
+        const double xl = gc > 0 ? gx1[gc - 1] : 0.0, xh = gc < W.g_ncol ? gx1[gc] : 0.0;
+        const double yl = gr > 0 ? gy1[gr - 1] : 0.0, yh = gr < W.g_nrow ? gy1[gr] : 0.0;
+        double2 bb = make_double2(0.0, 0.0);
+        if (s8 < T) bb = *reinterpret_cast<const double2*>(&s_bins[s8][0]);
+        const bool okx = (gc == 0 || xl < qx) && (gc == W.g_ncol || !(xh < qx));
+        const bool oky = (gr == 0 || yl < qy) && (gr == W.g_nrow || !(yh < qy));
+        if (!okx) gc = astar_lower_bound(gx1, W.g_ncol, qx, gc);
+        if (!oky) gr = astar_lower_bound(gy1, W.g_nrow, qy, gr);
+        // ---- round trip 2: column gc-1+s8 (s8 < 3) or row gr-4+s8 (3 <= s8 < 6) with the reference's own float predicate
+        const bool colj = s8 < 3;
+        const int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
+        const int n = colj ? W.g_ncol : W.g_nrow;
+        bool m = false;
+        if (s8 < 6 && idx >= 0 && idx < n) {
+          const double a = colj ? gx0[idx] : gy0[idx], b = colj ? gx1[idx] : gy1[idx], v = colj ? qx : qy;
+          const double dd = auvp_fabs(a - b);
+          m = auvp_fabs(v - a) <= dd && auvp_fabs(v - b) <= dd;
+        }
+        const unsigned long long bm = __ballot(m);
+        const unsigned g8 = (unsigned)((bm >> (k8 * 8)) & 0xffull);
+        const unsigned cm3 = g8 & 7u, rm3 = (g8 >> 3) & 7u;
+        if (cm3 && rm3) key = (gr - 1 + (__ffs((int)rm3) - 1)) * W.g_ncol + (gc - 1 + (__ffs((int)cm3) - 1));
+        // the first time bin that holds the time stamp (:520-527): bins 0..7 from the read above, further ones eight at a time
+        {
+          const unsigned long long tm = __ballot(s8 < T && tsd <= bb.y && tsd >= bb.x);
+          const unsigned t8 = (unsigned)((tm >> (k8 * 8)) & 0xffull);
+          if (t8) tb = __ffs((int)t8) - 1;
+        }
+        for (int t0 = 8; t0 < T && !__all(tb >= 0); t0 += 8) {
+          const int t = t0 + s8;
+          bool mt = false;
+          if (t < T) { const double2 b2 = *reinterpret_cast<const double2*>(&s_bins[t][0]); mt = tsd <= b2.y && tsd >= b2.x; }
+          const unsigned long long tm = __ballot(mt);
+          const unsigned t8 = (unsigned)((tm >> (k8 * 8)) & 0xffull);
+          if (tb < 0 && t8) tb = t0 + (__ffs((int)t8) - 1);
+        }
+      };
+      if (grid_lds) tables(s_grid, s_grid + W.g_ncol, s_grid + 2 * W.g_ncol, s_grid + 2 * W.g_ncol + W.g_nrow);
+      else tables(W.gx0, W.gx1, W.gy0, W.gy1);
+      // ---- round trip 3: the table values
       double pr = 0.0, tn = 0.0;
-      if (lane < 8 && tb >= 0 && key >= 0 && key < C && ntop >= 0 && ntop <= C) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; }
-      if (lane < 8) {
-        box->len_[lane] = len_; box->pr[lane] = pr; box->tn[lane] = tn;
-        box->ts_[lane] = ts_; box->tb[lane] = tb; box->key[lane] = key; box->flags[lane] = oob ? 1 : 0; box->ciw[lane] = ciw;
+      if (s8 == 0 && tb >= 0 && key >= 0 && key < C && ntop >= 0 && ntop <= C) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; }
+      if (s8 == 0) {
+        box->len_[k8] = len_; box->pr[k8] = pr; box->tn[k8] = tn;
+        box->ts_[k8] = ts_; box->tb[k8] = tb; box->key[k8] = key; box->flags[k8] = oob ? 1 : 0; box->ciw[k8] = ciw;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) *reinterpret_cast<volatile int*>(&box->seq_x) = e + 1;
+      if (lane == 0) lds_poke(&box->seq_x, e + 1);
     }
     return;
   }
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     if (PAIR) {
       if (lane == 0) { box->cx = cxp; box->cy = cyp; box->clen = clen; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) *reinterpret_cast<volatile int*>(&box->seq_m) = n_exp;
+      if (lane == 0) lds_poke(&box->seq_m, n_exp);
     }
     // ------------------------------------------------------------ neighbours: bounds, then collision
     const double qx = cxp + (double)offx, qy = cyp + (double)offy;
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         // the second wavefront's results of this expansion (it started when the popped node was posted)
         {
           int spins = 0;
-          while (uni(*reinterpret_cast<volatile int*>(&box->seq_x)) != n_exp) {
+          while (uni(lds_peek(&box->seq_x)) != n_exp) {
             if (++spins > ASTAR_SPIN_LIMIT) { status = -9; break; }
             __builtin_amdgcn_s_sleep(1);
           }
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     n_nodes += nch;
   }
 
-  if (PAIR && lane == 0) *reinterpret_cast<volatile int*>(&box->stop) = 1;
+  if (PAIR && lane == 0) lds_poke(&box->stop, 1);
   for (int i = lane; i < n_hopen; i += 64) B.hab_left[(size_t)ep * (H > 0 ? H : 1) + i] = hopen[i];
   if (lane == 0) {
     AstarSummary& s = B.summary[ep];

@@ -23,6 +23,16 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// Words in LDS that wavefronts of one workgroup hand to each other (flags, sequence numbers, tags).  A volatile access through a
+// generic pointer stays a FLAT instruction (address-space inference leaves volatile accesses alone): `flat_load ... sc0 sc1`
+// + `s_waitcnt vmcnt(0) lgkmcnt(0)` per poll -- every look at a flag also waits for the wavefront's outstanding global loads
+// and stores.  With the explicit LDS pointer they are ds_read / ds_write, which wait on the LDS counter alone.
+#define AUVP_LDS_PTR(T, p) ((volatile __attribute__((address_space(3))) T*)(p))
+__device__ __forceinline__ int lds_peek(const int* p) { return *AUVP_LDS_PTR(const int, p); }
+__device__ __forceinline__ void lds_poke(int* p, int v) { *AUVP_LDS_PTR(int, p) = v; }
+__device__ __forceinline__ unsigned long long lds_peek64(const unsigned long long* p) { return *AUVP_LDS_PTR(const unsigned long long, p); }
+__device__ __forceinline__ void lds_poke64(unsigned long long* p, unsigned long long v) { *AUVP_LDS_PTR(unsigned long long, p) = v; }
+
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   long long b = __double_as_longlong(v);
   int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane);

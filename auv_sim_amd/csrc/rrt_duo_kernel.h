@@ -70,10 +70,11 @@ __host__ __device__ inline int duo_lds_bytes(int K, int max_pts, int n_obst_slot
   return ((tables_bytes + 15) & ~15) + episodes * duo_per_episode_bytes(K, max_pts) + n_obst_slots * (8 + 8 + 8 + 4);
 }
 
-__device__ __forceinline__ int duo_peek(const int* p) { return *reinterpret_cast<const volatile int*>(p); }
-__device__ __forceinline__ void duo_poke(int* p, int v) { *reinterpret_cast<volatile int*>(p) = v; }
-__device__ __forceinline__ unsigned long long duo_peek64(const unsigned long long* p) { return *reinterpret_cast<const volatile unsigned long long*>(p); }
-__device__ __forceinline__ void duo_poke64(unsigned long long* p, unsigned long long v) { *reinterpret_cast<volatile unsigned long long*>(p) = v; }
+// hand-over words in LDS: auvp_wave.h's lds_peek / lds_poke
+__device__ __forceinline__ int duo_peek(const int* p) { return lds_peek(p); }
+__device__ __forceinline__ void duo_poke(int* p, int v) { lds_poke(p, v); }
+__device__ __forceinline__ unsigned long long duo_peek64(const unsigned long long* p) { return lds_peek64(p); }
+__device__ __forceinline__ void duo_poke64(unsigned long long* p, unsigned long long v) { lds_poke64(p, v); }
 __device__ __forceinline__ unsigned long long duo_tag(int epoch, int iteration) {
   return ((unsigned long long)(uint32_t)epoch << 32) | (unsigned long long)(uint32_t)(iteration + 1);
 }
