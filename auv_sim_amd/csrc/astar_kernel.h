@@ -146,8 +146,8 @@ constexpr int ASTAR_MAX_BINS = 64;
 constexpr int ASTAR_LDS_OBST = 256, ASTAR_LDS_POLY = 64, ASTAR_LDS_GRID = 256;
 
 // PAIR (variant 3 on a product grid, latency batches): a second wavefront per instance evaluates what depends on the popped
-// node's position alone -- the cell of every neighbour, path length, time stamp and time bin, the visited / cell-info words
-// and the prob / topn table values -- while the first runs the bounds and collision tests (see the kernel).
+// node's position alone -- the cell of every neighbour, path length, time stamp and time bin and the prob / topn table
+// values -- while the first runs the bounds and collision tests (see the kernel).
 struct AstarPairBox {
   int seq_m;      // the searching wavefront: expansion number + 1 whose node is posted
   int seq_x;      // the second wavefront: expansion number + 1 whose results are posted
@@ -155,7 +155,6 @@ struct AstarPairBox {
   double cx, cy, clen;
   double len_[8], pr[8], tn[8];
   int ts_[8], tb[8], key[8], flags[8];  // flags bit 0: visited index out of range
-  uint32_t ciw[8];
 };
 constexpr int ASTAR_SPIN_LIMIT = 1 << 24;
 
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         }
         if (stop) break;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");  // (it reads nothing the searching wavefront writes outside LDS)
       const double cxp = readfirst_f64(box->cx), cyp = readfirst_f64(box->cy), clen = readfirst_f64(box->clen);
       // every lane of group k8 works on neighbour k8 and lane (k8, 0) owns its row of results: no value crosses lanes except
       // through ballots, and the table reads below are issued together -- three dependent round trips (edge tables + time
@@ -281,8 +280,6 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       if (xi < 0) xi += P.vx;
       if (yi < 0) yi += P.vy;
       const bool oob = xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy;
-      uint32_t ciw = 0u;
-      if (s8 == 0 && !oob) ciw = cellinfo[(size_t)xi * P.vy + yi];
       const double sq_ = astar_sqdist(cxp, cyp, qx, qy);
       const bool lattice = sq_ == 100.0 || sq_ == 200.0;
       double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
@@ -342,9 +339,9 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       if (s8 == 0 && tb >= 0 && key >= 0 && key < C && ntop >= 0 && ntop <= C) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; }
       if (s8 == 0) {
         box->len_[k8] = len_; box->pr[k8] = pr; box->tn[k8] = tn;
-        box->ts_[k8] = ts_; box->tb[k8] = tb; box->key[k8] = key; box->flags[k8] = oob ? 1 : 0; box->ciw[k8] = ciw;
+        box->ts_[k8] = ts_; box->tb[k8] = tb; box->key[k8] = key; box->flags[k8] = oob ? 1 : 0;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // (the results are in LDS; its table reads have returned)
       if (lane == 0) lds_poke(&box->seq_x, e + 1);
     }
     return;
@@ -418,7 +415,9 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     n_exp++;
     if (PAIR) {
       if (lane == 0) { box->cx = cxp; box->cy = cyp; box->clen = clen; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      // (an LDS-only release: the partner reads the box and read-only tables, nothing this wavefront stores to memory -- a full
+      // workgroup release would wait here for the previous expansion's node stores to be acknowledged)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
       if (lane == 0) lds_poke(&box->seq_m, n_exp);
     }
     // ------------------------------------------------------------ neighbours: bounds, then collision
@@ -428,7 +427,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     uint32_t ciw_early = 0u;
     double ex = 0.0, ey = 0.0;
     if (V >= 2) { ex = __shfl(qx, (lane & 7) * 8, 64); ey = __shfl(qy, (lane & 7) * 8, 64); }
-    if (V >= 2 && lane < 8 && !PAIR) {
+    if (V >= 2 && lane < 8) {
       int xi = (int)(ex + 500), yi = (int)(ey + 200);
       if (xi < 0) xi += P.vx;
       if (yi < 0) yi += P.vy;
@@ -605,13 +604,13 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
           }
           if (status) break;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         const int kk = lane & 7;
         const bool mine = lane < 8 && ((childmask >> kk) & 1);
         const double px = ex, py = ey;
         const double len_ = box->len_[kk], pr_x = box->pr[kk], tn_x = box->tn[kk];
         const int ts_ = box->ts_[kk], tb = box->tb[kk], key_x = box->key[kk], fl = box->flags[kk];
-        const uint32_t ciw = mine ? box->ciw[kk] : 0u;
+        const uint32_t ciw = mine ? ciw_early : 0u;  // (requested before the bounds test; same index)
         const double dist_left = auvp_fabs(limit - len_);
         const int ntop = (int)dist_left;
         if (__any(mine && (fl & 1))) { status = -1; break; }
