@@ -101,79 +101,13 @@ AUVP_HD double auvp_cos(double x) {
 
 // atan(x), fdlibm-class: argument reduction to [0, 7/16] around 0.5, 1, 1.5, inf; odd polynomial
 // split into even/odd halves.  < 1 ulp (tests/test_portable_math.py).
-AUVP_HD double auvp_atan(double x) {
-  const double hi0 = 4.63647609000806093515e-01, hi1 = 7.85398163397448278999e-01,
-               hi2 = 9.82793723247329054082e-01, hi3 = 1.57079632679489655800e+00;
-  const double lo0 = 2.26987774529616870924e-17, lo1 = 3.06161699786838301793e-17,
-               lo2 = 1.39033110312309984516e-17, lo3 = 6.12323399573676603587e-17;
-  const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01,
-               a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
-               a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02,
-               a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
-               a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02,
-               a10 = 1.62858201153657823623e-02;
-  const int neg = x < 0.0;
-  double ax = auvp_fabs(x);
-  if (x != x) return x;
-  if (ax >= 0x1p66) {  // |x| >= 2^66: pi/2
-    double r = hi3 + lo3;
-    return neg ? -r : r;
-  }
-  // one division for whichever reduction applies: the lanes of a wavefront usually need different ones, and four divergent
-  // branches with a division each would run one after the other (same operations per lane either way)
-  int id;
-  double hi = 0.0, lo = 0.0, num = 0.0, den = 1.0;
-  if (ax < 0.4375) {
-    if (ax < 0x1p-27) return x;
-    id = -1;
-  } else if (ax < 0.6875) { id = 0; num = 2.0 * ax - 1.0; den = 2.0 + ax; hi = hi0; lo = lo0; }
-  else if (ax < 1.1875) { id = 1; num = ax - 1.0; den = ax + 1.0; hi = hi1; lo = lo1; }
-  else if (ax < 2.4375) { id = 2; num = ax - 1.5; den = 1.0 + 1.5 * ax; hi = hi2; lo = lo2; }
-  else { id = 3; num = -1.0; den = ax; hi = hi3; lo = lo3; }
-  if (id >= 0) ax = num / den;
-  double z = ax * ax;
-  double w = z * z;
-  double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
-  double s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
-  if (id < 0) {
-    double r = ax - ax * (s1 + s2);
-    return neg ? -r : r;
-  }
-  double r = hi - ((ax * (s1 + s2) - lo) - ax);
-  return neg ? -r : r;
-}
-
-// atan2(y, x) with the usual quadrant logic (finite inputs; infinities map through atan's limits).
-// Measured <= 1.2 ulp vs mpmath (the y/x rounding adds to atan's own error); glibc's atan2 is
-// nearly correctly rounded, so the two agree bit-for-bit on ~80 % of inputs and differ by one ulp
-// otherwise -- used only by Planner_RRT's goal connection, where it feeds floats, one
-// `abs(diff) > pi/2` test and one floor(length/exp_rate).
-AUVP_HD double auvp_atan2(double y, double x) {
-  const double pi = AUVP_PI, pi_lo = 1.2246467991473531772E-16, pio2 = AUVP_PIO2_HI;
-  if (x != x || y != y) return x + y;
-  if (y == 0.0) {
-    // atan2(+-0, +x) = +-0 ; atan2(+-0, -x) = +-pi
-    int xneg = (x < 0.0) || (x == 0.0 && __builtin_signbit(x));
-    if (!xneg) return y;
-    return __builtin_signbit(y) ? -pi : pi;
-  }
-  if (x == 0.0) return y < 0.0 ? -pio2 : pio2;
-  double ax = auvp_fabs(x), ay = auvp_fabs(y);
-  double z;
-  if (ax == __builtin_inf() || ay == __builtin_inf()) {
-    if (ax == ay) z = 0.5 * pio2;            // pi/4
-    else if (ay == __builtin_inf()) z = pio2;
-    else z = 0.0;
-  } else {
-    double q = ay / ax;
-    if (q >= 0x1p64) z = pio2 + 0.5 * pi_lo;
-    else if (x < 0.0 && q < 0x1p-64) z = 0.0;
-    else z = auvp_atan(q);
-  }
-  if (x > 0.0) return y < 0.0 ? -z : z;
-  double r = pi - (z - pi_lo);
-  return y < 0.0 ? -r : r;
-}
+#define AUVP_ATAN_FN auvp_atan
+#define AUVP_ATAN2_FN auvp_atan2
+#define AUVP_ATAN_K(c) (c)
+#include "auvp_atan_body.h"
+#undef AUVP_ATAN_FN
+#undef AUVP_ATAN2_FN
+#undef AUVP_ATAN_K
 
 // hypot(x, y) for finite, unexceptional magnitudes (|x|,|y| in ~[1e-140, 1e140]): Borges' fused
 // formulation -- sqrt of the fma'd sum of squares plus one exact-residual correction.

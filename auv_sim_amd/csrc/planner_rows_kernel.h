@@ -25,6 +25,24 @@
 #include "planner_rrt_kernel.h"
 #include "rrt_rows_kernel.h"
 
+// atan / atan2 with the argument-reduction constants materialised where they are used (auvp_atan_body.h): hoisted out of the
+// step loop they were this kernel's only spill (three 8-byte stores per wave at entry, four reloads per trip)
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ double auvp_late_f64() {
+  // the two halves as instruction literals inside a volatile asm: nothing loop-invariant is left outside to hoist and spill
+  unsigned a, b;
+  __asm__ volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(a), "=v"(b) : "i"(LO), "i"(HI));
+  return __longlong_as_double(((long long)b << 32) | (long long)a);
+}
+#define AUVP_LATE_BITS(c) __builtin_bit_cast(unsigned long long, (double)(c))
+#define AUVP_ATAN_FN auvp_atan_late
+#define AUVP_ATAN2_FN auvp_atan2_late
+#define AUVP_ATAN_K(c) auvp_late_f64<(unsigned)(AUVP_LATE_BITS(c) & 0xffffffffull), (unsigned)(AUVP_LATE_BITS(c) >> 32)>()
+#include "auvp_atan_body.h"
+#undef AUVP_ATAN_FN
+#undef AUVP_ATAN2_FN
+#undef AUVP_ATAN_K
+
 namespace auvp {
 
 constexpr int PRW_WAVES = 4;       // waves per workgroup (16 episodes in flight per workgroup)
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         n_arc = eval ? -1 : n_arc;
         const double2 goal = *reinterpret_cast<const double2*>(B.goal + 2 * (size_t)(ep < 0 ? 0 : ep));
         const double gx = goal.x, gy = goal.y;
-        const double theta = auvp_atan2(gy - ly, gx - lx);
+        const double theta = auvp_atan2_late(gy - ly, gx - lx);
         double diffg = theta - th0;
         for (int guard = 0; guard < 64; guard++) {  // angle_wrap
           const bool hi = diffg > AUVP_PI, lo = diffg < -AUVP_PI;
