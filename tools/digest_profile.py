@@ -39,7 +39,7 @@ RRT = ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel")
 MEAS = {
     "headline": (RRT, None),
     "astar": (("astar_kernel",), "cells_per_step"),
-    "planner_rrt": (("prrt_kernel", "prrt_rows_kernel"), "planner_steps_per_step"),
+    "planner_rrt": (("prrt_kernel", "prrt_rows_kernel", "prrt_pipe_kernel", "prrt_duo_kernel"), "planner_steps_per_step"),
     "rrt_nn": (RRT, "iters_per_launch"),
     "rrt_nn_long_horizon": (RRT, "iters_per_launch"),
     "config5": (("prrt_kernel", "prrt_rows_kernel"), "planner_steps_per_tracking_step"),
