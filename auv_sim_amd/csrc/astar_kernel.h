@@ -154,7 +154,7 @@ struct AstarPairBox {
   int stop, _p0;
   double cx, cy, clen;
   double len_[8], pr[8], tn[8];
-  int ts_[8], tb[8], key[8], flags[8];  // flags bit 0: visited index out of range
+  int ts_[8], tb[8], key[8];
 };
 constexpr int ASTAR_SPIN_LIMIT = 1 << 24;
 
@@ -276,10 +276,6 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       // through ballots, and the table reads below are issued together -- three dependent round trips (edge tables + time
       // bins; the rows / columns around the bounds; prob / topn) instead of a dozen
       const double qx = cxp + (double)offx, qy = cyp + (double)offy;
-      int xi = (int)(qx + 500), yi = (int)(qy + 200);
-      if (xi < 0) xi += P.vx;
-      if (yi < 0) yi += P.vy;
-      const bool oob = xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy;
       const double sq_ = astar_sqdist(cxp, cyp, qx, qy);
       const bool lattice = sq_ == 100.0 || sq_ == 200.0;
       double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
@@ -291,25 +287,34 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       const int ntop = (int)dist_left;
       int key = -1, tb = -1;
       auto tables = [&](const auto* gx0, const auto* gx1, const auto* gy0, const auto* gy1) {
-        // ---- round trip 1: the entries either side of both lower-bound guesses, and time bin s8
+        // ---- round trip 1: the entries either side of both lower-bound guesses, time bin s8, AND -- on the guess, which a
+        // regular grid makes right -- column gc-1+s8 (s8 < 3) or row gr-4+s8 (3 <= s8 < 6) for the reference's float predicate
         int gc = (int)((qx - W.g_x1_0) * W.g_inv_dx), gr = (int)((qy - W.g_y1_0) * W.g_inv_dy);
         gc = gc < 0 ? 0 : (gc > W.g_ncol ? W.g_ncol : gc);
         gr = gr < 0 ? 0 : (gr > W.g_nrow ? W.g_nrow : gr);
+        const bool colj = s8 < 3;
+        const int n = colj ? W.g_ncol : W.g_nrow;
+        const double v = colj ? qx : qy;
+        int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
         const double xl = gc > 0 ? gx1[gc - 1] : 0.0, xh = gc < W.g_ncol ? gx1[gc] : 0.0;
         const double yl = gr > 0 ? gy1[gr - 1] : 0.0, yh = gr < W.g_nrow ? gy1[gr] : 0.0;
         double2 bb = make_double2(0.0, 0.0);
         if (s8 < T) bb = *reinterpret_cast<const double2*>(&s_bins[s8][0]);
+        double a = 0.0, b = 0.0;
+        bool have = s8 < 6 && idx >= 0 && idx < n;
+        if (have) { a = colj ? gx0[idx] : gy0[idx]; b = colj ? gx1[idx] : gy1[idx]; }
         const bool okx = (gc == 0 || xl < qx) && (gc == W.g_ncol || !(xh < qx));
         const bool oky = (gr == 0 || yl < qy) && (gr == W.g_nrow || !(yh < qy));
-        if (!okx) gc = astar_lower_bound(gx1, W.g_ncol, qx, gc);
-        if (!oky) gr = astar_lower_bound(gy1, W.g_nrow, qy, gr);
-        // ---- round trip 2: column gc-1+s8 (s8 < 3) or row gr-4+s8 (3 <= s8 < 6) with the reference's own float predicate
-        const bool colj = s8 < 3;
-        const int idx = colj ? gc - 1 + s8 : gr - 4 + s8;
-        const int n = colj ? W.g_ncol : W.g_nrow;
+        if (__any(!okx || !oky)) {
+          // ---- a guess was off: the walk, and the rows / columns around the true bounds
+          if (!okx) gc = astar_lower_bound(gx1, W.g_ncol, qx, gc);
+          if (!oky) gr = astar_lower_bound(gy1, W.g_nrow, qy, gr);
+          idx = colj ? gc - 1 + s8 : gr - 4 + s8;
+          have = s8 < 6 && idx >= 0 && idx < n;
+          if (have) { a = colj ? gx0[idx] : gy0[idx]; b = colj ? gx1[idx] : gy1[idx]; }
+        }
         bool m = false;
-        if (s8 < 6 && idx >= 0 && idx < n) {
-          const double a = colj ? gx0[idx] : gy0[idx], b = colj ? gx1[idx] : gy1[idx], v = colj ? qx : qy;
+        if (have) {
           const double dd = auvp_fabs(a - b);
           m = auvp_fabs(v - a) <= dd && auvp_fabs(v - b) <= dd;
         }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       if (s8 == 0 && tb >= 0 && key >= 0 && key < C && ntop >= 0 && ntop <= C) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; }
       if (s8 == 0) {
         box->len_[k8] = len_; box->pr[k8] = pr; box->tn[k8] = tn;
-        box->ts_[k8] = ts_; box->tb[k8] = tb; box->key[k8] = key; box->flags[k8] = oob ? 1 : 0;
+        box->ts_[k8] = ts_; box->tb[k8] = tb; box->key[k8] = key;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  // (the results are in LDS; its table reads have returned)
       if (lane == 0) lds_poke(&box->seq_x, e + 1);
@@ -609,14 +614,14 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         const bool mine = lane < 8 && ((childmask >> kk) & 1);
         const double px = ex, py = ey;
         const double len_ = box->len_[kk], pr_x = box->pr[kk], tn_x = box->tn[kk];
-        const int ts_ = box->ts_[kk], tb = box->tb[kk], key_x = box->key[kk], fl = box->flags[kk];
+        const int ts_ = box->ts_[kk], tb = box->tb[kk], key_x = box->key[kk];
         const uint32_t ciw = mine ? ciw_early : 0u;  // (requested before the bounds test; same index)
         const double dist_left = auvp_fabs(limit - len_);
         const int ntop = (int)dist_left;
-        if (__any(mine && (fl & 1))) { status = -1; break; }
         int xi = (int)(px + 500), yi = (int)(py + 200);
         if (xi < 0) xi += P.vx;
         if (yi < 0) yi += P.vy;
+        if (__any(mine && (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy))) { status = -1; break; }
         const size_t vi = (size_t)xi * P.vy + yi;
         const bool ci_live = (ciw & 0xff000000u) == ep_tag;
         const int key = mine ? key_x : 0;
