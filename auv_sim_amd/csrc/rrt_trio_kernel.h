@@ -67,6 +67,10 @@ struct TrioCtl {  // (the first eight words are what the waits look at: read as 
   double final_after;
   unsigned long long final_drawn;
   int hist_bin[TRIO_HIST], hist_cb[TRIO_HIST];  // append number a (1-based) -> bin, size before; slot a & 7
+  // H's own: stream position at the first word of the packets in flight (slot k & 3).  In LDS because the compiler turns a
+  // register array under a computed index into a scratch array: 32 B per lane and a scratch read on H's chain per packet
+  unsigned long long sp_drawn[TRIO_RING];
+  uint32_t sp_cslot[TRIO_RING];
 };
 
 __host__ __device__ inline int trio_per_episode_bytes(int K) {
@@ -231,20 +235,20 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
     unsigned long long diag_h = 0ull;
 #endif
     // stream position at the first word of the packets in flight (slot k & 3): where a new epoch rewinds to
-    uint32_t sp_cslot[TRIO_RING];
-    unsigned long long sp_drawn[TRIO_RING];
-#pragma unroll
-    for (int q = 0; q < TRIO_RING; q++) { sp_cslot[q] = rng.cslot; sp_drawn[q] = 0ull; }
+    if (lane == 0)
+      for (int q = 0; q < TRIO_RING; q++) { ctl->sp_cslot[q] = rng.cslot; ctl->sp_drawn[q] = 0ull; }
+    wave_sync();
     unsigned long long floor_drawn = 0ull;  // stream position H may still have to return to (first word of the oldest unfinished iteration)
     auto sp_get = [&](int kk, uint32_t& cs, unsigned long long& dr) {
       const int q = kk & (TRIO_RING - 1);
-      cs = q == 0 ? sp_cslot[0] : (q == 1 ? sp_cslot[1] : (q == 2 ? sp_cslot[2] : sp_cslot[3]));
-      dr = q == 0 ? sp_drawn[0] : (q == 1 ? sp_drawn[1] : (q == 2 ? sp_drawn[2] : sp_drawn[3]));
+      cs = (uint32_t)uni((int)ctl->sp_cslot[q]);
+      const unsigned long long d = ctl->sp_drawn[q];
+      dr = ((unsigned long long)(uint32_t)uni((int)(d >> 32)) << 32) | (uint32_t)uni((int)(d & 0xffffffffull));
     };
     auto sp_set = [&](int kk, uint32_t cs, unsigned long long dr) {
       const int q = kk & (TRIO_RING - 1);
-      if (q == 0) { sp_cslot[0] = cs; sp_drawn[0] = dr; } else if (q == 1) { sp_cslot[1] = cs; sp_drawn[1] = dr; }
-      else if (q == 2) { sp_cslot[2] = cs; sp_drawn[2] = dr; } else { sp_cslot[3] = cs; sp_drawn[3] = dr; }
+      if (lane == 0) { ctl->sp_cslot[q] = cs; ctl->sp_drawn[q] = dr; }
+      wave_sync();
     };
     auto rewind_to = [&](uint32_t cs, unsigned long long dr) {
       rng.avail = (uint32_t)uni((int)(rng.avail + (uint32_t)(rng.drawn - dr)));
