@@ -38,6 +38,7 @@ for n in (1, 64, 512, 1024):
             nd = s["done"] == 0
             st = float(s["steps"][nd].sum())
             a = s["arc"][nd]
+            arc = a[:, 3].sum() / st if trio == "1" else 0.0  # (two wavefronts: main runs the arcs itself)
             print("   diag (%s): per step main works %.0f clocks and waits %.0f for arc verdicts, helper builds for %.0f, arc wavefront %.0f; redos per step %.3f"
-                  % (ctx.prrt_last_kernel(), a[:, 0].sum() / st, a[:, 1].sum() / st, a[:, 2].sum() / st, a[:, 3].sum() / st, a[:, 4].sum() / st))
+                  % (ctx.prrt_last_kernel(), a[:, 0].sum() / st, a[:, 1].sum() / st, a[:, 2].sum() / st, arc, a[:, 4].sum() / st))
     print("E=%d: " % n + " | ".join(out))
