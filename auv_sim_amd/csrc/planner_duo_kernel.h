@@ -20,7 +20,8 @@
 // (tests/test_gpu_planner_duo.py).
 //
 // Limits (the host falls back to prrt_kernel): plan mode (not the one-step mode of the environment), no step log,
-// freq <= 30, <= 256 obstacles, at most four episodes per CU.
+// freq <= 30, <= 256 obstacles, at most four episodes per CU.  Since planner_pipe_kernel.h (four wavefronts, feed-forward: the
+// default for these batches) this kernel is the selectable fallback (AUVP_PRRT_PIPE=0; AUVP_PRRT_TRIO=0 for two wavefronts).
 #ifndef AUVP_PLANNER_DUO_KERNEL_H
 #define AUVP_PLANNER_DUO_KERNEL_H
 #include "planner_rrt_kernel.h"
@@ -48,7 +49,8 @@ struct PduoCtl {  // (first eight words: what the waits look at)
   double final_after;
   unsigned long long final_drawn;
   // three-wavefront form: the goal arc (connect_to_goal_curve_alt, :374-423) of step k is evaluated by a wavefront of its own
-  // (G) while main steers and collision-tests step k + 1; main waits for the verdict before it inserts
+  // (G) while main runs step k + 1; main takes the verdict after that step's insert and takes the insert back when the arc
+  // was free (the planning ended at step k)
   unsigned long long arc_tag;  // request: {0, step + 1}, written last
   double arc_lx, arc_ly, arc_th0;
   int arc_last, arc_done_seq, arc_free, g_done;  // arc_done_seq: requests of steps < arc_done_seq are decided; arc_free: the latest verdict
