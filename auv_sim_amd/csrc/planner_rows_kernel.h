@@ -323,11 +323,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         // tight box of the row's points
         const double inf = __builtin_inf();
         double mnx = pv ? qx : inf, mxx = pv ? qx : -inf, mny = pv ? qy : inf, mxy = pv ? qy : -inf;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          mnx = __builtin_fmin(mnx, __shfl_xor(mnx, o, 16)); mxx = __builtin_fmax(mxx, __shfl_xor(mxx, o, 16));
-          mny = __builtin_fmin(mny, __shfl_xor(mny, o, 16)); mxy = __builtin_fmax(mxy, __shfl_xor(mxy, o, 16));
-        }
+        mnx = row_min_f64(mnx); mxx = row_max_f64(mxx); mny = row_min_f64(mny); mxy = row_max_f64(mxy);
         const double ts = 0x1p-30 * (auvp_fabs(mnx) + auvp_fabs(mxx) + auvp_fabs(mny) + auvp_fabs(mxy) + 1.0);
         const double tcx = (mnx + mxx) * 0.5, tcy = (mny + mxy) * 0.5;
         const double thx = (mxx - mnx) * 0.5 + ts, thy = (mxy - mny) * 0.5 + ts;

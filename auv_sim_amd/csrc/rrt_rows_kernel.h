@@ -57,6 +57,25 @@ __device__ __forceinline__ double row_read_f64(double v, int src_lane) {
   const int lo = __shfl((int)(b & 0xffffffffll), src_lane, 64), hi = __shfl((int)(b >> 32), src_lane, 64);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// minimum / maximum over the 16 lanes of a row, in every lane: four rotate steps on the DPP path (row_ror 8, 4, 2, 1) instead of
+// four xor shuffles -- `__shfl_xor` is a ds_bpermute per 32-bit half, an LDS round trip per step for a lone chain
+template <int N>
+__device__ __forceinline__ double row_ror_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0x120 + N, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x120 + N, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double row_min_f64(double v) {
+  v = __builtin_fmin(v, row_ror_f64<8>(v)); v = __builtin_fmin(v, row_ror_f64<4>(v));
+  v = __builtin_fmin(v, row_ror_f64<2>(v)); v = __builtin_fmin(v, row_ror_f64<1>(v));
+  return v;
+}
+__device__ __forceinline__ double row_max_f64(double v) {
+  v = __builtin_fmax(v, row_ror_f64<8>(v)); v = __builtin_fmax(v, row_ror_f64<4>(v));
+  v = __builtin_fmax(v, row_ror_f64<2>(v)); v = __builtin_fmax(v, row_ror_f64<1>(v));
+  return v;
+}
 // value of the previous lane of the row (DPP row_shr:1); lane 0 of every row gets `first`
 __device__ __forceinline__ double row_prev_f64(double v, double first) {
   const long long b = __double_as_longlong(v), f = __double_as_longlong(first);
@@ -426,11 +445,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
             mny = __builtin_fmin(mny, pty[q]); mxy = __builtin_fmax(mxy, pty[q]);
           }
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          mnx = __builtin_fmin(mnx, __shfl_xor(mnx, o, 16)); mxx = __builtin_fmax(mxx, __shfl_xor(mxx, o, 16));
-          mny = __builtin_fmin(mny, __shfl_xor(mny, o, 16)); mxy = __builtin_fmax(mxy, __shfl_xor(mxy, o, 16));
-        }
+        mnx = row_min_f64(mnx); mxx = row_max_f64(mxx); mny = row_min_f64(mny); mxy = row_max_f64(mxy);
         const double ts = 0x1p-30 * (auvp_fabs(mnx) + auvp_fabs(mxx) + auvp_fabs(mny) + auvp_fabs(mxy) + 1.0);
         tcx = (mnx + mxx) * 0.5; tcy = (mny + mxy) * 0.5;
         thx = (mxx - mnx) * 0.5 + ts; thy = (mxy - mny) * 0.5 + ts;
