@@ -49,46 +49,40 @@ __device__ __forceinline__ double readfirst_f64(double v) {
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// wave-wide min over lanes (values identical on return)
-__device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    double t = __shfl_xor(v, o, 64);
-    v = (t < v) ? t : v;
-  }
-  return v;
-}
-
-// the same minimum on the DPP path (a lone wavefront pays ~100 clocks per cross-lane LDS shuffle, twelve of them above): four
-// rotate steps inside the 16-lane rows, then the four row results.  Same comparison as wave_min_f64 ((t < v) ? t : v; the
-// order in which lanes meet differs, which matters only with a nan among the values).
-__device__ __forceinline__ double wave_min_f64_dpp(double v) {
-#define AUVP_ROW_ROR_MIN(N)                                                                                   \
+// wave-wide min / max over the lanes (values identical on return) on the DPP path: four rotate steps inside the 16-lane rows,
+// then the four row results.  (Rounds 1-3 used six xor shuffles: `__shfl_xor` of a double is two ds_bpermute, an LDS round trip
+// per step -- ~100 clocks each on a chain nothing else covers.)  Same comparison as before, (t < v) ? t : v; the order in which
+// lanes meet differs, which matters only with a nan among the values.
+#define AUVP_ROW_ROR_F64(v, N, out)                                                                           \
   do {                                                                                                        \
     const long long b__ = __double_as_longlong(v);                                                            \
     const int lo__ = __builtin_amdgcn_update_dpp(0, (int)(b__ & 0xffffffffll), 0x120 + (N), 0xf, 0xf, false); \
     const int hi__ = __builtin_amdgcn_update_dpp(0, (int)(b__ >> 32), 0x120 + (N), 0xf, 0xf, false);          \
-    const double t__ = __longlong_as_double(((long long)hi__ << 32) | (unsigned int)lo__);                    \
-    v = (t__ < v) ? t__ : v;                                                                                  \
+    out = __longlong_as_double(((long long)hi__ << 32) | (unsigned int)lo__);                                 \
   } while (0)
-  AUVP_ROW_ROR_MIN(8);
-  AUVP_ROW_ROR_MIN(4);
-  AUVP_ROW_ROR_MIN(2);
-  AUVP_ROW_ROR_MIN(1);
-#undef AUVP_ROW_ROR_MIN
+__device__ __forceinline__ double wave_min_f64(double v) {
+  double t;
+  AUVP_ROW_ROR_F64(v, 8, t); v = (t < v) ? t : v;
+  AUVP_ROW_ROR_F64(v, 4, t); v = (t < v) ? t : v;
+  AUVP_ROW_ROR_F64(v, 2, t); v = (t < v) ? t : v;
+  AUVP_ROW_ROR_F64(v, 1, t); v = (t < v) ? t : v;
   const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
   const double ab = (b < a) ? b : a, cd = (d < c) ? d : c;
   return (cd < ab) ? cd : ab;
 }
+__device__ __forceinline__ double wave_min_f64_dpp(double v) { return wave_min_f64(v); }
 
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    double t = __shfl_xor(v, o, 64);
-    v = (t > v) ? t : v;
-  }
-  return v;
+  double t;
+  AUVP_ROW_ROR_F64(v, 8, t); v = (t > v) ? t : v;
+  AUVP_ROW_ROR_F64(v, 4, t); v = (t > v) ? t : v;
+  AUVP_ROW_ROR_F64(v, 2, t); v = (t > v) ? t : v;
+  AUVP_ROW_ROR_F64(v, 1, t); v = (t > v) ? t : v;
+  const double a = readlane_f64(v, 0), b = readlane_f64(v, 16), c = readlane_f64(v, 32), d = readlane_f64(v, 48);
+  const double ab = (b > a) ? b : a, cd = (d > c) ? d : c;
+  return (cd > ab) ? cd : ab;
 }
+#undef AUVP_ROW_ROR_F64
 
 // sum over the 64 lanes in a fixed but unspecified order (NOT for sums whose rounding the reference defines): four
 // rotate-and-add steps inside the 16-lane rows on the DPP path (no LDS crossbar), then the four row totals
