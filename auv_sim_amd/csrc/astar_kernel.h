@@ -242,13 +242,15 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
 
   // neighbour offsets: lane k = lane >> 3 handles neighbour k, slice s = lane & 7
   const int k8 = lane >> 3, s8 = lane & 7;
-  int offx, offy;
+  int offx, offy, offx7, offy7;  // (offx7 / offy7: of neighbour lane & 7 -- the lane that owns child lane & 7 in the children's phase)
   {
     // astar.py:88 order vs the other variants' (astar_fixLen.py:146)
     const int ax[8] = {0, 0, -10, 10, 10, 10, -10, -10}, ay[8] = {-10, 10, 0, 0, 10, -10, 10, -10};
     const int bx[8] = {0, 0, -10, 10, -10, -10, 10, 10}, by[8] = {-10, 10, 0, 0, -10, 10, -10, 10};
     offx = V == 0 ? ax[k8] : bx[k8];
     offy = V == 0 ? ay[k8] : by[k8];
+    offx7 = V == 0 ? ax[lane & 7] : bx[lane & 7];
+    offy7 = V == 0 ? ay[lane & 7] : by[lane & 7];
   }
 
   if (PAIR && second) {
@@ -431,7 +433,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     // under way while the bounds and collision tests run; only the children's words are used
     uint32_t ciw_early = 0u;
     double ex = 0.0, ey = 0.0;
-    if (V >= 2) { ex = __shfl(qx, (lane & 7) * 8, 64); ey = __shfl(qy, (lane & 7) * 8, 64); }
+    // (neighbour lane & 7's position: the same sum its own lanes form -- no cross-lane read on the chain)
+    if (V >= 2) { ex = cxp + (double)offx7; ey = cyp + (double)offy7; }
     if (V >= 2 && lane < 8) {
       int xi = (int)(ex + 500), yi = (int)(ey + 200);
       if (xi < 0) xi += P.vx;

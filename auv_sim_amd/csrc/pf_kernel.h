@@ -116,7 +116,7 @@ __device__ __forceinline__ bool pf_angle_wrap(double& a) {
 
 template <int T>
 __device__ __forceinline__ double pf_block_max(double v, double* red, int tid) {
-  for (int o = 32; o; o >>= 1) { const double t = __shfl_xor(v, o); v = t > v ? t : v; }
+  v = auvp::wave_max_f64(v);  // (DPP path: auvp_wave.h)
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();

@@ -1299,12 +1299,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     double before = __shfl_up(pm, 1, 64);
     if (lane == 0) before = __builtin_inf();
     before = before < min_hi ? before : min_hi;
-    {
-      long long el = q ? (long long)elems : 0ll;
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) el += __shfl_xor(el, o, 64);
-      leaf_elems += el;
-    }
+    leaf_elems += q ? (long long)elems : 0ll;  // (per lane; summed over the wavefront once, where the record is written)
     const bool cand = q && (log_leaf || lo < before);
     unsigned long long cm = __ballot(cand);
     min_hi = readlane_f64(pm, 63) < min_hi ? readlane_f64(pm, 63) : min_hi;
@@ -1378,6 +1373,13 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     if (lane + 64 < qn) c_ids[lane] = carry;
     qn = qn > 64 ? qn - 64 : 0;
     wave_sync();
+  }
+  {
+    // (leaf_elems was kept per lane)
+    long long el = leaf_elems;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) el += __shfl_xor(el, o, 64);
+    leaf_elems = el;
   }
   if (lane == 0) {
     if (B.leaf_stats) {
