@@ -63,12 +63,28 @@ __host__ __device__ inline int prrt_rows_occ_bytes(int n_buckets, int max_step) 
   return (n_buckets <= 65535 && b <= 832) ? b : 0;
 }
 
+// the obstacle slot tables (auvp_types.h: os_x, os_y, os_t [256], os_r [256] float, os_box [16][4]) as an LDS tile behind the
+// episodes' blocks, where three workgroups per CU still fit (config 5: 3 x 54 272 B of the CU's 163 840): obstacle_hit runs for the
+// collision test and for every 16-sample pass of the goal arc, and each slot it looks into was four dependent L2 reads
+constexpr int PRW_OBST_TILE = RW_MAX_OBST * (8 + 8 + 4) + 16 * 32;  // x, y, r, slot boxes.  (t, needed with the exact tests only, stays in
+                                                                    // memory: with it three workgroups no longer fit a CU's LDS granules)
+template <bool OBST_LDS>
 __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes,
                                                                       int* __restrict__ work_counter, int work_base, int occ_bytes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = (int)(threadIdx.x >> 6);
   const int lane = lane_id();
   const int row = lane >> 4, rl = lane & 15, rowbase = lane & 48;
+  // obstacle tile (OBST_LDS): x | y | box | r
+  double* tl_x = reinterpret_cast<double*>(smem + (size_t)(PRW_WAVES * RW_ROWS) * (PRW_LDS_PER_EP + occ_bytes));
+  double* tl_y = tl_x + RW_MAX_OBST;
+  double* tl_box = tl_y + RW_MAX_OBST;
+  float* tl_r = reinterpret_cast<float*>(tl_box + 16 * 4);
+  if (OBST_LDS) {
+    for (int i = threadIdx.x; i < RW_MAX_OBST; i += blockDim.x) { tl_x[i] = W.os_x[i]; tl_y[i] = W.os_y[i]; tl_r[i] = W.os_r[i]; }
+    for (int i = threadIdx.x; i < 16 * 4; i += blockDim.x) tl_box[i] = W.os_box[i];
+    __syncthreads();
+  }
   unsigned char* ebase = smem + (size_t)(wave * RW_ROWS + row) * (PRW_LDS_PER_EP + occ_bytes);
   uint32_t* mt = reinterpret_cast<uint32_t*>(ebase);
   uint16_t* occl = reinterpret_cast<uint16_t*>(ebase + PRW_LDS_PER_EP);  // [max_step + 1] when occ_bytes != 0
@@ -327,7 +343,8 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         const double ts = 0x1p-30 * (auvp_fabs(mnx) + auvp_fabs(mxx) + auvp_fabs(mny) + auvp_fabs(mxy) + 1.0);
         const double tcx = (mnx + mxx) * 0.5, tcy = (mny + mxy) * 0.5;
         const double thx = (mxx - mnx) * 0.5 + ts, thy = (mxy - mny) * 0.5 + ts;
-        const double4 sbox = reinterpret_cast<const double4*>(W.os_box)[rl];  // lane rl: bounding box of obstacle slot rl
+        const double4 sbox = OBST_LDS ? reinterpret_cast<const double4*>(tl_box)[rl]
+                                      : reinterpret_cast<const double4*>(W.os_box)[rl];  // lane rl: bounding box of obstacle slot rl
         const bool slot_hit = on && !(sbox.z < mnx - ts || sbox.x > mxx + ts || sbox.w < mny - ts || sbox.y > mxy + ts);
         uint32_t sm = row_ballot(slot_hit, rowbase);
         bool hit = false;
@@ -336,7 +353,8 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           const int j0 = hs_ ? 16 * (__ffs((int)sm) - 1) : 0;
           sm &= sm - 1u;
           const int oi = j0 + rl;
-          const double oxj = W.os_x[oi], oyj = W.os_y[oi], orj = (double)W.os_r[oi], otj = W.os_t[oi];
+          const double oxj = OBST_LDS ? tl_x[oi] : W.os_x[oi], oyj = OBST_LDS ? tl_y[oi] : W.os_y[oi];
+          const double orj = (double)(OBST_LDS ? tl_r[oi] : W.os_r[oi]), otj = W.os_t[oi];
           const bool cand = hs_ && !(auvp_fabs(oxj - tcx) > thx + orj || auvp_fabs(oyj - tcy) > thy + orj);
           uint32_t cm = row_ballot(cand, rowbase);
           while (__any(cm != 0u)) {

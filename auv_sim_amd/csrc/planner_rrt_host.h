@@ -81,16 +81,25 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     block_used = auvp::PRW_WAVES * 64;
     const int occ_bytes = auvp::prrt_rows_occ_bytes(S.P.n_buckets, S.P.max_step);
     lds_used = (size_t)per_wg * (auvp::PRW_LDS_PER_EP + occ_bytes);
+    // the obstacle slot tables as an LDS tile where three workgroups per CU still fit beside it (AUVP_PRRT_OBST_LDS=0 / 1 overrides)
+    const char* oenv = getenv("AUVP_PRRT_OBST_LDS");
+    // (LDS is handed out in 1 280-byte granules on this GPU: three workgroups of 53 760 B fit a CU, three of 54 272 B do not)
+    auto granules = [](size_t b) { return (b + 1279) / 1280 * 1280; };
+    const bool obst_lds = oenv ? atoi(oenv) != 0 : 3 * granules(lds_used + auvp::PRW_OBST_TILE) <= (size_t)160 * 1024;
+    if (obst_lds) lds_used += auvp::PRW_OBST_TILE;
     if (!S.work.p || S.work_base > (1 << 30)) {
       le = S.work.reserve(sizeof(int));
       if (le == hipSuccess) le = hipMemsetAsync(S.work.p, 0, sizeof(int), h->stream);
       S.work_base = 0;
     } else le = hipSuccess;
-    if (le == hipSuccess) le = hipFuncSetAttribute(reinterpret_cast<const void*>(auvp::prrt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
+    auto launch_rows = [&](auto kern) -> hipError_t {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, S.work.as<int>(), S.work_base, occ_bytes);
+      return hipGetLastError();
+    };
     if (le == hipSuccess) {
-      hipLaunchKernelGGL(auvp::prrt_rows_kernel, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, S.work.as<int>(),
-                         S.work_base, occ_bytes);
-      le = hipGetLastError();
+      le = obst_lds ? launch_rows(auvp::prrt_rows_kernel<true>) : launch_rows(auvp::prrt_rows_kernel<false>);
       S.work_base += S.E + grid_used * per_wg;  // every episode once + one empty pull per row
     }
   } else if (use_duo && (getenv("AUVP_PRRT_PIPE") ? atoi(getenv("AUVP_PRRT_PIPE")) != 0 : true)) {
