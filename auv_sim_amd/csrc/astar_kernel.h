@@ -494,18 +494,27 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     // ------------------------------------------------------------ children, in neighbour order
     unsigned long long covm_v = 0ull;  // fixLen, lane k: bit set of the habitats that cover child k
     if (V == 2) {
-      // first loop of :350-363: habitat coverage update per new node (mutates the lists)
+      // first loop of :350-363: habitat coverage update per new node (mutates the lists).  Which habitats cover a child does
+      // not depend on the lists: all eight children at once, lane (k, s) = child k against habitats s, s + 8, .. (H <= 64) -- two
+      // rounds of table reads for ten habitats instead of eight serial ones with the child's position shuffled across lanes
+      {
+        unsigned long long cmine = 0ull;  // lane k < 8: the habitats that cover neighbour k
+        for (int h0 = 0; h0 < H; h0 += 8) {
+          const int hb = h0 + s8;
+          bool cov = false;
+          if (hb < H) {
+            const double ddx = qx - s_hab[hb][0], ddy = qy - s_hab[hb][1];
+            cov = ddx * ddx + ddy * ddy <= s_hab[hb][2];
+          }
+          const unsigned long long bm = __ballot(cov);
+          cmine |= ((bm >> (8 * (lane & 7))) & 0xffull) << h0;
+        }
+        if (lane < 8 && ((childmask >> lane) & 1)) covm_v = cmine;
+      }
       for (int k = 0; k < 8; k++) {
         if (!((childmask >> k) & 1)) continue;
-        const double px = __shfl(qx, k * 8, 64), py = __shfl(qy, k * 8, 64);
-        // which habitats cover this child: one lane per habitat (H <= 64)
-        bool cov = false;
-        if (lane < H) {
-          const double ddx = px - s_hab[lane][0], ddy = py - s_hab[lane][1];
-          cov = ddx * ddx + ddy * ddy <= s_hab[lane][2];
-        }
-        const unsigned long long cm = __ballot(cov);
-        if (lane == k) covm_v = cm;
+        const unsigned long long cm = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(covm_v >> 32), k) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(covm_v & 0xffffffffull), k);
         if ((cm & ~closedmask) == 0ull) continue;  // no open habitat covers it: the lists stay as they are (most children)
         unsigned long long removed = 0ull;
         if (lane == 0) {
@@ -540,7 +549,12 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       const double g_ = ccost - w2 * d2 - w3 * d3;
       const double h_ = -w2 * auvp_fabs(limit - 0.0) - w3 * (double)n_hopen;  // child.pathLen is still 0 (:401-403)
       const double f_ = g_ + h_;
-      const double len_ = clen + auvp_sqrt(astar_sqdist(cxp, cyp, px, py));
+      // (lattice steps: the squared distance is exactly 100 or 200 unless a coordinate carries fraction bits the step rounded)
+      const double sq_ = astar_sqdist(cxp, cyp, px, py);
+      const bool lattice = sq_ == 100.0 || sq_ == 200.0;
+      double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
+      if (!__all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
+      const double len_ = clen + root_;
       // visited bitmap (:414-416), numpy index semantics (negative wraps)
       int xi = (int)(px + 500), yi = (int)(py + 200);
       if (xi < 0) xi += P.vx;
