@@ -749,29 +749,18 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       finish_children(kk, mine, px, py, len_, dist_left, ts_, vi, key, need_key, pr, tn, was);
       }
     }
-    int slot = 0;
-    for (int k = 0; k < 8 && status == 0 && V <= 1; k++) {
-      if (!((childmask >> k) & 1)) continue;
-      const int c = n_nodes + slot;
-      slot++;
-      const double px = readfirst_f64(__shfl(qx, k * 8, 64)), py = readfirst_f64(__shfl(qy, k * 8, 64));
-      double g_, h_, f_, cost_ = 0.0, len_ = 0.0;
-      int ts_ = 0, open_ = 1;
-      if (V <= 1) {
-        g_ = cg + astar_sqdist(px, py, cxp, cyp);
-        h_ = astar_sqdist(px, py, gx, gy);
-        f_ = g_ + h_;
-      } else {
-        break;  // V >= 2 is handled above (lane-parallel children); not reached
-      }
-      if (lane == 0) {
-        put_node(c, px, py, g_, h_, f_, cost_, len_, cur, ts_, open_);
-      }
-      if (list_ok && open_) {
-        if (n_list + 1 > ASTAR_OPEN_CAP) list_ok = false;
-        else { if (lane == 0) { of_l[n_list] = f_; oi_l[n_list] = c; } n_list++; }
-      }
-      n_open += open_;
+    if (V <= 1 && status == 0) {
+      // children of astar.py / astar_real.py (:244-266 / :195-217), lane k < 8 = child of neighbour k: eight distinct lattice
+      // points, created in neighbour order (their indices by rank in the child mask); nothing is ever closed there, so a child is
+      // one record and one open flag.  (Their open sets outgrow the LDS list at once: list_ok is false from the start.)
+      const int kk = lane & 7;
+      const bool mine = lane < 8 && ((childmask >> kk) & 1);
+      const double px = cxp + (double)offx7, py = cyp + (double)offy7;
+      const double g_ = cg + astar_sqdist(px, py, cxp, cyp);
+      const double h_ = astar_sqdist(px, py, gx, gy);
+      const double f_ = g_ + h_;
+      if (mine) put_node(n_nodes + __popc(childmask & ((1 << kk) - 1)), px, py, g_, h_, f_, 0.0, 0.0, cur, 0, 1);
+      n_open += nch;
       wave_sync();
     }
     if (status) break;
