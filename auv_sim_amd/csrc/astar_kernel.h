@@ -96,7 +96,7 @@ struct AstarBuffers {
   // a pop reads one line, a child is four 16-byte stores), then [E][cap_nodes] f once more, contiguous, for the variants
   // whose pop scans every open node
   double* nodes;
-  int32_t* node_i;       // [E][cap_nodes] open flag
+  int32_t* node_i;       // [E][cap_nodes] (rounds 1-3: the open flag; round 4 folds it into the contiguous f copy -- a closed node's f there is a nan)
   // [E][vx*vy] one word per entry of the reference's visited_nodes array (variants 2,3):
   //   bits 31..24  epoch of the batch that wrote the word; a word of another epoch reads as "never touched", so a new
   //                batch needs no 360 KB-per-instance clear (the host bumps the epoch; a full clear every 255 batches)
@@ -205,12 +205,10 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
   double4* rec = reinterpret_cast<double4*>(B.nodes + (size_t)ep * 8 * cap);  // two per node; 64-byte aligned
   // f once more, contiguous, behind the records of all instances (the scan of the variants without an open list in LDS)
   double* nf = B.nodes + (size_t)n_inst * 8 * cap + (size_t)ep * cap;
-  int32_t* nopen = B.node_i + (size_t)ep * cap;
   auto put_node = [&](int c, double x, double y, double g, double hh, double f, double cost, double len, int par, int ts, int open) {
     rec[2 * (size_t)c] = make_double4(x, y, g, hh);
     rec[2 * (size_t)c + 1] = make_double4(f, cost, len, __longlong_as_double(((long long)ts << 32) | (long long)(uint32_t)par));
-    nf[c] = f;
-    nopen[c] = open;
+    nf[c] = open ? f : __builtin_nan("");  // (the scan's copy of f doubles as the open flag: a closed node's entry is a nan)
   };
   uint32_t* cellinfo = B.cellinfo ? B.cellinfo + (size_t)ep * P.vx * P.vy : nullptr;
   const uint32_t ep_tag = P.epoch << 24;
@@ -364,10 +362,19 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         if (bi == 0x7fffffff || f < bf || (f == bf && i < bi)) { bf = f; bi = i; bpos = q; }
       }
     } else {
-      for (int i = first_open + lane; i < n_nodes; i += 64) {
-        if (nopen[i]) {
-          double f = nf[i];
-          if (bi == 0x7fffffff || f < bf) { bf = f; bi = i; }
+      // (one read per node -- a closed node's f is a nan -- and four blocks of 64 in flight per lane; rounds 1-3 read an open flag
+      // and then, dependent on it, the f)
+      for (int i0 = first_open; i0 < n_nodes; i0 += 256) {
+        double fv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + 64 * u + lane;
+          fv[u] = i < n_nodes ? nf[i] : __builtin_nan("");
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const double f = fv[u];
+          if (f == f && (bi == 0x7fffffff || f < bf)) { bf = f; bi = i0 + 64 * u + lane; }
         }
       }
     }
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       n_list--;
       wave_sync();
     }
-    if (lane == 0) nopen[cur] = 0;
+    if (lane == 0) nf[cur] = __builtin_nan("");
     open_scanned += (unsigned long long)n_open;
     n_open--;
     if (cur == first_open) first_open++;
