@@ -158,6 +158,7 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
   if (S.world_version != h->world_version && (rc = astar_build_world(h, S))) return rc;
   auvp::AstarParamsDev& P = S.P;
   P.variant = p->variant; P.cap_nodes = p->cap_nodes; P.flags = flags;
+  if (getenv("AUVP_ASTAR_NO_LIST") && atoi(getenv("AUVP_ASTAR_NO_LIST")) != 0) P.flags |= AUVP_KFLAG_ASTAR_NO_LIST;
   P.cap_exp = (flags & AUVP_FLAG_ITER_LOG) ? p->cap_nodes : 0;
   for (int i = 0; i < 4; i++) { P.box[i] = p->box[i]; P.w[i] = p->w[i]; }
   P.velocity = p->velocity;

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
   double* of_l = s_of[wave];
   int32_t* oi_l = s_oi[wave];
   int n_list = 1;
-  bool list_ok = V >= 2;  // astar.py / astar_real.py never close a cell: their open sets outgrow the list at once
+  bool list_ok = V >= 2 && !(P.flags & AUVP_KFLAG_ASTAR_NO_LIST);  // astar.py / astar_real.py never close a cell: their open sets outgrow the list at once
   if (lane == 0 && !second) { of_l[0] = 0.0; oi_l[0] = 0; }
   wave_sync();
 

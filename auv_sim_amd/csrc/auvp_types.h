@@ -88,6 +88,8 @@ struct WorldDev {
 // kernel-internal bits of RrtParamsDev::flags (above the public AUVP_FLAG_* bits)
 #define AUVP_KFLAG_TIGHT_CULL 1024
 #define AUVP_KFLAG_NN_EXACT 2048  // nearest-neighbour scan: always rank the reference's way (sqrt per node); tests
+#define AUVP_KFLAG_ASTAR_NO_LIST 4096  // A* fixLen variants: pop by the scan of every node's f in memory from the start (what an open set larger than
+                                      // the LDS list falls back to); tests (AUVP_ASTAR_NO_LIST=1)
 
 struct RrtParamsDev {
   double dist_to_end, diff_max, freq, min_dist, bin_interval, v, max_traj_time, max_plan_time;

@@ -127,3 +127,30 @@ def test_astar_capacity_is_an_error_not_a_truncation(ctx):
     w = synth.make_lattice_world(seed=0, n_obstacles=10)
     r = _gpu_run(ctx, "astar", [(0.0, 0.0)], dict(obstacles=w["obstacles"], goal=(490.0, 490.0), box=w["box"]), cap_nodes=64)[0]
     assert r["status"] == -2 and not r["found"]
+
+
+@pytest.mark.parametrize("variant", ["astar_fixLen", "astar_fixLenSOG"])
+def test_pop_by_the_scan_of_every_node(ctx, orc, variant, monkeypatch):
+    """an open set that outgrows the 768-entry list the pop scans in LDS falls back to the scan of every node's f in memory,
+    where a closed node's f is a nan (nodes created closed -- their cell was visited already -- and popped ones).  Cells close
+    once visited, so the worlds of these tests never get there: AUVP_ASTAR_NO_LIST=1 takes the fallback from the first pop.
+    Both forms of the fixLenSOG kernel (one / two wavefronts per instance)."""
+    from auv_sim_amd import synth
+    from oracle import orc_astar as oa
+    monkeypatch.setenv("AUVP_ASTAR_NO_LIST", "1")
+    w = synth.make_world(seed=12, n_obstacles=32, obst_radius=(2.0, 6.0), n_habitats=8, hab_radius=(10.0, 25.0))
+    starts = np.array([(-280.0, -80.0), (-250.0, -60.0), (-270.0, -50.0)])
+    kw = dict(obstacles=w["obstacles"], polygon=w["polygon"], habitats=w["habitats"], limit=300.0, weights=(0, 10, 10, 100))
+    if variant == "astar_fixLenSOG":
+        kw.update(bins=w["bins"], cells=w["cells"], prob=w["prob"], velocity=1.0)
+    for pair in ("1", "0"):
+        monkeypatch.setenv("AUVP_ASTAR_PAIR", pair)
+        res = _gpu_run(ctx, variant, starts, kw, exp_log=True)
+        for e, r in enumerate(res):
+            o = oa.run(variant, starts[e], kind="portable", cap_nodes=20000, **kw)
+            assert r["status"] == o["status"], (e, r["status"], o["status"])
+            assert r["found"] == o["found"] and r["n_nodes"] == o["n_nodes"] and r["n_children"] == o["n_children"]
+            assert np.array_equal(r["expansions"], o["expansions"])
+            assert np.array_equal(r["path"], o["path"]) and np.array_equal(r["cost_list"], o["cost_list"])
+        if variant == "astar_fixLen":
+            break
