@@ -20,9 +20,11 @@
 // the tag, a writer clears the tag before it rewrites a part: a stage still working for an epoch that ended reads consistent --
 // if outdated -- values).  Measured: one episode 11.0 -> 5.5 ms per planning(2000), config 4 12.6 -> 7.3 ms.
 //
-// Why H may run three inserts ahead: an insert changes what H looked at only if it went into the bucket the packet chose, or it
-// occupied a new bucket AND `_randbelow(n_occ)` now comes out differently (planner_duo_kernel.h); M keeps the buckets of its last
-// eight inserts and checks every insert the packet's snapshot did not know.  On a conflict M starts a new epoch: H rewinds the
+// Why H may run three inserts ahead: an insert changes what H looked at only if it went into the bucket the packet chose AND
+// `_randbelow(len(bucket))` now comes out differently (members are kept in creation order, a new one goes to the end: the same
+// index is the same node unless the size's bit length changed or a thrown-away try is now below the size), or it occupied a new
+// bucket AND `_randbelow(n_occ)` now comes out differently (planner_duo_kernel.h); M keeps the buckets of its last eight inserts
+// and checks every insert the packet's snapshot did not know.  On a conflict M starts a new epoch: H rewinds the
 // generator to the first word of that step (the ring keeps 1 248 words: every word since the oldest unfinished step's start
 // stays available) and the stages start over from there.
 //
@@ -50,6 +52,8 @@ struct PpipeSlot {
   int ver, n_occ, rmin, status;  // the snapshot it was built from (nodes, occupied buckets); smallest rejected bucket try; 0 / -1 / -4
   int kind, b, par, n_total;     // kind 0: a steer follows; 1: the chosen bucket was empty (the step is used up)
   unsigned long long tmask;
+  int cnt_b, rmin2;              // the chosen bucket's size as H read it; smallest rejected member try (0x7fffffff: none)
+  int head_b, _pa1;              // ... and its newest member as H read it (>= ver: H saw an insert its snapshot does not cover)
   double px, py, pth, ptt;       // the parent's record
   double radius[DUO_CS], phi[DUO_CS];
   // ---- B (S)
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       const int ver = cv.ver, n_occ = cv.n_occ;
       PpipeSlot* q = slot_of(k);
       if (lane == 0) duo_poke64(&q->tagA, 0ull);  // (a stage of an epoch that ended may still be reading this part)
-      int status = 0, kind = 0, b = 0, par = 0, n_total = 0, rmin = 0x7fffffff;
+      int status = 0, kind = 0, b = 0, par = 0, n_total = 0, rmin = 0x7fffffff, rmin2 = 0x7fffffff, cnt_snap = 0, head_snap = 0;
       unsigned long long tmask = 0ull;
       bool fits = true;
       if (n_occ <= 0) status = -1;
@@ -386,9 +390,9 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
           const int cnt_b = uni(prrt_bucket_count(bw, epoch_b));
           if (cnt_b == 0) kind = 1;
           else {
-            int dummy = 0x7fffffff;
             bool ok2 = true;
-            const int rsel = (int)ppipe_randbelow<false>(rng, (uint32_t)cnt_b, dummy, ok2, more);
+            cnt_snap = cnt_b; head_snap = uni(bw.y);
+            const int rsel = (int)ppipe_randbelow<true>(rng, (uint32_t)cnt_b, rmin2, ok2, more);
             fits = ok2;
             if (fits) {
               // the rsel-th member (creation order) of bucket b: count - 1 - rsel steps from the head of its list, or -- further
@@ -471,6 +475,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       }
       if (lane == 0) {
         q->ver = ver; q->n_occ = n_occ; q->rmin = rmin; q->status = status; q->kind = kind; q->b = b; q->par = par; q->n_total = n_total;
+        q->cnt_b = cnt_snap; q->rmin2 = rmin2; q->head_b = head_snap;
         q->tmask = tmask;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -754,7 +759,14 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
           if (pv != n_nodes) {
             const int pn = uni(q->n_occ), qb = uni(q->b);
             const int newest = n_nodes - 1 - ((n_nodes - 1 - lane) & (PPIPE_HIST - 1));  // the node index lane l's entry belongs to
-            const bool touched = __any(lane < PPIPE_HIST && newest >= pv && newest >= 0 && hist == qb);
+            // inserts into the chosen bucket since the snapshot: its members are kept in creation order and a new one goes to the
+            // end, so `_randbelow(len)` (:223) picks the same node unless the size's bit length changed or a try the packet threw
+            // away (>= the old size) is below the new size -- the rule of the bucket choice, one level down
+            const int added = __popcll(__ballot(lane < PPIPE_HIST && newest >= pv && newest >= 0 && hist == qb));
+            const int c0 = uni(q->cnt_b), c2 = c0 + added;
+            // (a bucket word read AFTER one of those inserts may be ahead of the records it points to: nothing is published between a
+            // record and its bucket word -- such a packet is redone)
+            const bool touched = added > 0 && (uni(q->head_b) >= pv || (32 - __clz(c0)) != (32 - __clz(c2)) || uni(q->rmin2) < c2);
             conflict = pv > n_nodes || n_nodes - pv > PPIPE_HIST || uni(q->status) != 0 || touched ||
                        (pn != n_occ && ((32 - __clz(pn)) != (32 - __clz(n_occ)) || uni(q->rmin) < n_occ));
           }
