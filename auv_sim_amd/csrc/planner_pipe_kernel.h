@@ -84,8 +84,11 @@ struct PpipeCtl {  // (first eight words: what the waits look at)
   double diag[4];
 };
 
-__host__ __device__ inline int ppipe_per_episode_bytes(int max_pts) {
+// next_nodes > 0: the episode also keeps the member lists' `next` links (4 bytes per node) in LDS -- H walks count - 1 - r of
+// them per step, one dependent L2 read each otherwise
+__host__ __device__ inline int ppipe_per_episode_bytes(int max_pts, int next_nodes = 0) {
   int b = TRIO_GEN * 4;
+  b += (next_nodes * 4 + 15) & ~15;
   b += ((max_pts * 16) + 15) & ~15;
   b += (int)((sizeof(PpipeCtl) + 15) & ~(size_t)15);
   b += PPIPE_RING * (int)((sizeof(PpipeSlot) + 15) & ~(size_t)15);
@@ -234,16 +237,18 @@ __device__ __forceinline__ bool prrt_goal_arc_eval(const PrrtParamsDev& P, const
 }
 
 template <int J>
-__global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes) {
+__global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes, int next_lds) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
   const int n_ep_wg = (int)(blockDim.x / 256);
   const int eidx = wave >> 2, role = wave & 3;  // role 0: M, 1: H, 2: S, 3: G
-  const int per_ep = ppipe_per_episode_bytes(B.max_pts);
+  const int per_ep = ppipe_per_episode_bytes(B.max_pts, next_lds ? B.cap_nodes : 0);
   unsigned char* eb = smem + (size_t)eidx * per_ep;
   uint32_t* gen = reinterpret_cast<uint32_t*>(eb);
   eb += TRIO_GEN * 4;
+  int32_t* mnx = reinterpret_cast<int32_t*>(eb);  // [cap_nodes] when next_lds: node -> the bucket member created before it
+  if (next_lds) eb += (B.cap_nodes * 4 + 15) & ~15;
   double(*spts)[2] = reinterpret_cast<double(*)[2]>(eb);  // S: the candidate's points for the collision test
   eb += ((B.max_pts * 16) + 15) & ~15;
   PpipeCtl* ctl = reinterpret_cast<PpipeCtl*>(eb);
@@ -278,6 +283,10 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     const int p = uni(B.rng_state[4 * eps]), a = uni(B.rng_state[4 * eps + 1]);
     const int pc = p < 0 ? 0 : (p > 623 ? 623 : p), ac = a < 0 ? 0 : (a > 624 ? 624 : a);
     for (int r = lane; r < 624; r += 64) gen[r] = B.mt[eps * 624 + (size_t)((pc + r + ac) % 624)];
+  }
+  if (next_lds && valid_ep) {
+    const int n0 = uni(sum.n_nodes);
+    for (int i = (int)(threadIdx.x & 255u); i < n0 && i < capn; i += 256) mnx[i] = nodes[i].next;
   }
   __threadfence_block();
   __syncthreads();
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
                 pv = uni(bw.y);
                 pv = pv < 0 ? 0 : (pv >= capn ? capn - 1 : pv);
                 for (int h = 0; h < hops; h++) {
-                  int nx = uni(duo_ld_i32(&nodes[pv].next));
+                  int nx = uni(next_lds ? lds_peek(&mnx[pv]) : duo_ld_i32(&nodes[pv].next));
                   pv = nx < 0 ? 0 : (nx >= capn ? capn - 1 : nx);
                 }
               } else {
@@ -846,6 +855,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
         else if (lane == 2) r4 = make_int4(step, par, n_points, cnt);
         else r4 = make_int4(bk, nx, 0, 0);
         reinterpret_cast<int4*>(&nodes[me])[lane] = r4;
+        if (next_lds && lane == 3) mnx[me] = nx;
       }
       if (lane == 0) {
         nbucket[me] = bk;

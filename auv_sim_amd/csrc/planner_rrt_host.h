@@ -109,11 +109,15 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     eps_wg = eps_wg < 1 ? 1 : (eps_wg > auvp::PPIPE_EP ? auvp::PPIPE_EP : eps_wg);
     grid_used = (S.E + eps_wg - 1) / eps_wg;
     block_used = eps_wg * 256;
-    lds_used = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts);
+    // the member lists' next links in LDS where they fit beside the slots (AUVP_PRRT_NEXT_LDS=0 / 1 overrides)
+    const char* nenv = getenv("AUVP_PRRT_NEXT_LDS");
+    int next_lds = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, S.B.cap_nodes) <= (size_t)150 * 1024 ? 1 : 0;
+    if (nenv) next_lds = next_lds && atoi(nenv) != 0;
+    lds_used = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, next_lds ? S.B.cap_nodes : 0);
     auto launch_pipe = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
       if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E);
+      hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, next_lds);
       return hipGetLastError();
     };
     if (O <= 64) le = launch_pipe(auvp::prrt_pipe_kernel<1>);

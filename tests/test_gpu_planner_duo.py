@@ -75,3 +75,41 @@ def test_duo_equals_one_wavefront_per_episode(ctx, orc, n_ep, freq, max_step, n_
         r = op.planning(w["obstacles"], w["rect"], starts[e], goals[e], int(seeds[e]), max_step, freq, 5, subs, kind="portable")
         assert (b[e]["steps"], bool(b[e]["done"]), b[e]["n_nodes"], b[e]["n_points"]) == (r["steps"], bool(r["done"]), r["n_nodes"], r["n_points"])
         assert b[e]["rng_after"] == r["rng_after"]
+
+
+@pytest.mark.parametrize("next_lds", ["0", "1"])
+def test_pipeline_continues_a_tree_with_and_without_the_link_mirror(ctx, next_lds, monkeypatch):
+    """prrt_pipe_kernel keeps the member lists' next links in LDS where they fit (AUVP_PRRT_NEXT_LDS): a launch that finds a
+    partly grown tree copies the links it starts from; the mirror on and off give the one-wavefront kernel's result"""
+    from auv_sim_amd import synth
+    from auv_sim_amd._prrt_lib import PlannerBatch
+    w = synth.make_rect_world(seed=5, n_obstacles=128)
+    ctx.set_world(obstacles=w["obstacles"])
+    n_ep, max_step = 24, 500
+    rng = np.random.default_rng(77)
+    starts = np.tile(np.array([w["start"][0], w["start"][1], 0.0, 0.0]), (n_ep, 1))
+    starts[:, 2] = rng.uniform(-3.0, 3.0, n_ep)
+    goals = np.column_stack([rng.uniform(w["rect"][0] + 5, w["rect"][2] - 5, n_ep), rng.uniform(w["rect"][1] + 5, w["rect"][3] - 5, n_ep)])
+    seeds = np.arange(n_ep, dtype=np.uint64) + 501
+    res = []
+    for pipe in (0, 1):
+        monkeypatch.setenv("AUVP_PRRT_ROWS", "0")
+        monkeypatch.setenv("AUVP_PRRT_DUO", str(pipe))
+        monkeypatch.setenv("AUVP_PRRT_TRIO", "0")
+        monkeypatch.setenv("AUVP_PRRT_PIPE", str(pipe))
+        monkeypatch.setenv("AUVP_PRRT_NEXT_LDS", next_lds)
+        pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, freq=10, cell=5, subs=2)
+        for _ in range(40):  # a tree of up to 41 nodes grown by generate_one_node steps from the start's bucket
+            g = [pb.grid(e) for e in range(n_ep)]
+            pb.step(np.array([int(x[0][-1]) if len(x[0]) else 0 for x in g], dtype=np.int32))
+        s = pb.plan().copy()
+        ctx.L.auvp_prrt_last_kernel.restype = C.c_char_p
+        assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == ("prrt_pipe_kernel" if pipe else "prrt_kernel")
+        res.append((s, [pb.tree(e, s[e]) for e in range(n_ep)], pb.paths(s)))
+    (a, ta, pa_), (b, tb, pb_) = res
+    assert (a["n_nodes"] > 41).any()
+    assert _fields_equal(a, b), [n for n in a.dtype.names if not np.array_equal(a[n], b[n])]
+    for e in range(n_ep):
+        for k in ta[e]:
+            assert np.array_equal(ta[e][k], tb[e][k]), (e, k)
+        assert np.array_equal(pa_[e], pb_[e])
