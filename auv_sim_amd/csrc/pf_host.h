@@ -9,7 +9,7 @@ struct PfState {
   bool ready = false;
   int F = 0, N = 0, S = 0, A = 0;
   bool have_log = false;
-  DevBuf st, ent, llen, mt, mtpos, shark0, meas, shark, wl, mean, err, out_len, status, ndraw, updated, choice;
+  DevBuf st, ent, llen, mt, mtpos, shark0, meas, shark, mean, err, out_len, status, ndraw, updated, choice;
 };
 
 PfState* pf_of(auvp_handle* h) {
@@ -53,7 +53,7 @@ auvp::PfDev pf_dev(PfState& P) {
   D.st = P.st.as<double>(); D.ent = P.ent.as<int32_t>(); D.llen = P.llen.as<int32_t>();
   D.mt = P.mt.as<uint32_t>(); D.mtpos = P.mtpos.as<int32_t>();
   D.shark0 = P.shark0.as<double>(); D.meas = P.meas.as<double>(); D.shark = P.shark.as<double>();
-  D.wl = P.wl.as<double>(); D.mean = P.mean.as<double>(); D.err = P.err.as<double>(); D.out_len = P.out_len.as<int32_t>();
+  D.mean = P.mean.as<double>(); D.err = P.err.as<double>(); D.out_len = P.out_len.as<int32_t>();
   D.status = P.status.as<int32_t>(); D.ndraw = P.ndraw.as<unsigned long long>();
   return D;
 }
@@ -143,7 +143,6 @@ int auvp_pf_run(auvp_handle* h, int32_t n_steps, int32_t n_auv, int32_t phases, 
   int rc;
   if (A && (rc = upload(h, P.meas, meas, (size_t)S * F * A * 5))) return rc;
   if ((phases & auvp::PF_PHASE_MEAN) && (rc = upload(h, P.shark, shark_xy, (size_t)S * F * 2))) return rc;
-  HIPCHK(h, P.wl.reserve((size_t)F * std::max(A, 1) * N * sizeof(double)));
   HIPCHK(h, P.mean.reserve((size_t)S * F * 2 * sizeof(double)));
   HIPCHK(h, P.err.reserve((size_t)S * F * sizeof(double)));
   HIPCHK(h, P.out_len.reserve((size_t)S * F * sizeof(int32_t)));
@@ -162,11 +161,13 @@ int auvp_pf_run(auvp_handle* h, int32_t n_steps, int32_t n_auv, int32_t phases, 
     D.choice = P.choice.as<int32_t>();
   }
   const size_t lds = auvp::pf_lds_bytes(N);
-  // threads per filter: measured on MI355X at N = 1000 (4096 filters x 20 steps): 256 -> 11.6 ms, 1024 -> 14.4 ms
-  // (the step is bound by its ~100 workgroup barriers and the serial MT19937 / mean chains, which more waves make
-  // more expensive, not by the per-particle math)
+  // threads per filter, measured on MI355X at N = 1000 (4096 filters x 20 steps).  Round 1: 256 -> 11.6 ms, 1024 -> 14.4 ms
+  // (six barriers per MT19937 regeneration).  Round 4, regeneration without inner barriers: 256 threads (237 registers, one
+  // wavefront per SIMD and workgroup, two workgroups per CU by LDS) 9.2 ms -- one workgroup alone on a CU takes 0.94 of
+  // that: the step is a chain of dependent fp64 latencies, not issue bound (0.40 of the VALU issue slots); 512 threads held to
+  // 128 registers (four wavefronts per SIMD) 7.7 ms; 1024 (one workgroup per CU) 11.5 ms
 #ifndef AUVP_PF_THREADS
-#define AUVP_PF_THREADS 256
+#define AUVP_PF_THREADS 512
 #endif
   constexpr int T = AUVP_PF_THREADS, P1 = 1024 / T, P2 = 2048 / T;
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));

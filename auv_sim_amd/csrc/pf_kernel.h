@@ -1,5 +1,5 @@
 // pf_kernel.h -- the shark particle filter (particleFilter.py) on gfx950: one T-thread workgroup = one filter
-// (N particles, PPT consecutive list positions per thread; T = 256 measured fastest, pf_host.h), F filters per
+// (N particles, PPT consecutive list positions per thread; T = 512 measured fastest, pf_host.h), F filters per
 // launch, S steps per launch.
 //
 //   pf_create_kernel   Particle.__init__ x N                       particleFilter.py:44-53, 311-317
@@ -8,8 +8,9 @@
 //                      particleMean, meanError                     :153-177
 //
 // The reference draws from numpy's global legacy RandomState (its `random` is numpy.random, :8):
-// MT19937 state lives in LDS and is refilled by the workgroup in three data-parallel phases (the
-// recurrence reads 397 words ahead: [0,227) [227,454) [454,624) are independent inside a phase).  Draws
+// MT19937 state lives in LDS, two buffers: a refill reads the old state and writes the new one into the other
+// buffer, thread t forming words t, 227 + t and 454 + t (each needs old words and the thread's own previous
+// result: the recurrence reads 397 words ahead), so a regeneration has no barrier inside (round 4; six before).  Draws
 // whose count is data dependent (randint's masked rejection in random.choice) are taken a state block
 // at a time: temper, flag `word & mask <= rng`, block scan, the r-th accepted word is the r-th choice.
 //
@@ -39,7 +40,6 @@ struct PfDev {
   const double* shark0;    // [F][2]     (create)
   const double* meas;      // [S][F][A][5]
   const double* shark;     // [S][F][2]
-  double* wl;              // [F][A][N]  scratch: per-AUV weights
   double* mean;            // [S][F][2]
   double* err;             // [S][F]
   int32_t* out_len;        // [S][F]
@@ -56,8 +56,9 @@ struct PfDev {
 #define PF_PI 3.141592653589793
 
 struct PfRng {
-  uint32_t* mt;  // LDS [624]
-  int pos;       // uniform
+  uint32_t* mt;   // LDS [624]: the current state
+  uint32_t* alt;  // LDS [624]: the buffer the next regeneration writes
+  int pos;        // uniform
   unsigned long long drawn;
 };
 
@@ -66,35 +67,55 @@ __device__ __forceinline__ uint32_t pf_twist(uint32_t a, uint32_t b, uint32_t c)
   return c ^ (y >> 1) ^ ((y & 1u) ? PF_MAG : 0u);
 }
 
-// one MT19937 state regeneration by the whole workgroup; ends with a barrier
-__device__ __forceinline__ void pf_refill(uint32_t* mt, int tid) {
-  uint32_t v = 0;
-  if (tid < 227) v = pf_twist(mt[tid], mt[tid + 1], mt[tid + 397]);
-  __syncthreads();
-  if (tid < 227) mt[tid] = v;
-  __syncthreads();
-  if (tid < 227) v = pf_twist(mt[227 + tid], mt[228 + tid], mt[tid]);
-  __syncthreads();
-  if (tid < 227) mt[227 + tid] = v;
-  __syncthreads();
-  if (tid < 170) v = pf_twist(mt[454 + tid], mt[tid == 169 ? 0 : 455 + tid], mt[227 + tid]);
-  __syncthreads();
-  if (tid < 170) mt[454 + tid] = v;
-  __syncthreads();
+// one MT19937 state regeneration: thread t < 227 forms the new words t and 227 + t, t < 170 also 454 + t, from the old
+// state and its own results (word 623 needs the new word 0: thread 169 forms that one again) and writes them to the other
+// buffer -- no barrier inside; the CALLER's barrier publishes the new state (and separates this regeneration's reads
+// from the next one's writes to the same buffer).  With dst: the tempered words [0, take) go there as well.
+__device__ __forceinline__ void pf_refill(PfRng& r, int tid, uint32_t* dst = nullptr, int take = 0) {
+  const uint32_t* o = r.mt;
+  uint32_t* n = r.alt;
+  if (tid < 227) {
+    const uint32_t a = pf_twist(o[tid], o[tid + 1], o[tid + 397]);
+    const uint32_t b = pf_twist(o[227 + tid], o[228 + tid], a);
+    n[tid] = a;
+    n[227 + tid] = b;
+    if (tid < take) dst[tid] = mt_temper(a);
+    if (227 + tid < take) dst[227 + tid] = mt_temper(b);
+    if (tid < 170) {
+      const uint32_t nx = tid == 169 ? pf_twist(o[0], o[1], o[397]) : o[455 + tid];
+      const uint32_t c = pf_twist(o[454 + tid], nx, b);
+      n[454 + tid] = c;
+      if (454 + tid < take) dst[454 + tid] = mt_temper(c);
+    }
+  }
+  r.alt = r.mt;
+  r.mt = n;
+  r.pos = 0;
 }
 
 // the next `count` tempered outputs -> dst[0..count) (LDS); ends with a barrier
 template <int T>
 __device__ __forceinline__ void pf_gen_words(PfRng& r, uint32_t* dst, int count, int tid) {
+  static_assert(T >= 227, "a regeneration is one pass of 227 threads");
   int done = 0;
+  bool open = true;  // words written since the last barrier
   while (done < count) {
-    if (r.pos >= 624) { pf_refill(r.mt, tid); r.pos = 0; }
-    const int take = min(624 - r.pos, count - done);
-    for (int i = tid; i < take; i += T) dst[done + i] = mt_temper(r.mt[r.pos + i]);
-    r.pos += take;
-    done += take;
-    __syncthreads();
+    if (r.pos >= 624) {
+      const int take = min(624, count - done);
+      pf_refill(r, tid, dst + done, take);
+      r.pos = take;
+      done += take;
+      __syncthreads();
+      open = false;
+    } else {  // what is left of the current state: the regeneration that follows reads this buffer too, no barrier
+      const int take = min(624 - r.pos, count - done);
+      for (int i = tid; i < take; i += T) dst[done + i] = mt_temper(r.mt[r.pos + i]);
+      r.pos += take;
+      done += take;
+      open = true;
+    }
   }
+  if (open) __syncthreads();
   r.drawn += (unsigned long long)count;
 }
 
@@ -140,22 +161,23 @@ __device__ __forceinline__ int pf_block_scan(int v, int* red, int tid, int* tota
 }
 
 struct PfLds {
-  uint32_t* mt; int* red_i; double* red_d; double *sx, *sy, *sv, *sth, *sw; int* off; uint32_t* wbuf; int* slot;
+  uint32_t *mt, *mt2; int* red_i; double* red_d; double *sx, *sy, *sv, *sth, *sw; int* off; uint32_t* wbuf; int* slot;
 };
 __host__ __device__ inline size_t pf_lds_bytes(int N) {
   const size_t n2 = (size_t)(N + 2) & ~(size_t)1;
-  return 624 * 4 + 32 * 4 + 40 * 8 + 5 * n2 * 8 + n2 * 4 + (size_t)5 * n2 * 4;
+  return 2 * 624 * 4 + 32 * 4 + 40 * 8 + 5 * n2 * 8 + n2 * 4 + (size_t)5 * n2 * 4;
 }
 __device__ __forceinline__ PfLds pf_carve(unsigned char* smem, int N) {
   const size_t n2 = (size_t)(N + 2) & ~(size_t)1;
   PfLds L;
   L.mt = (uint32_t*)smem;
-  L.red_i = (int*)(L.mt + 624);
+  L.mt2 = L.mt + 624;
+  L.red_i = (int*)(L.mt2 + 624);
   L.red_d = (double*)(L.red_i + 32);  // red_i [0,16): reductions, 16: choice cursor
   L.sx = L.red_d + 40;                // red_d [0,16): reductions, 16..17: means
   L.sy = L.sx + n2; L.sv = L.sy + n2; L.sth = L.sv + n2; L.sw = L.sth + n2;
   L.off = (int*)(L.sw + n2);
-  L.wbuf = (uint32_t*)(L.off + n2);  // 5*n2 words: the RNG window, then the alias slots, then the drawn indices
+  L.wbuf = (uint32_t*)(L.off + n2);  // 5*n2 words: the RNG window, then the alias slots, then copy -> source particle (off: the drawn indices)
   L.slot = (int*)L.wbuf;
   return L;
 }
@@ -164,7 +186,7 @@ __global__ __launch_bounds__(PF_T) void pf_create_kernel(PfDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int f = blockIdx.x, tid = threadIdx.x, N = D.N;
   PfLds L = pf_carve(smem, N);
-  PfRng r{L.mt, D.mtpos[f], 0ull};
+  PfRng r{L.mt, L.mt2, D.mtpos[f], 0ull};
   for (int i = tid; i < 624; i += PF_T) L.mt[i] = D.mt[(size_t)f * 624 + i];
   __syncthreads();
   const double x0 = D.shark0[2 * f], y0 = D.shark0[2 * f + 1];
@@ -185,16 +207,18 @@ __global__ __launch_bounds__(PF_T) void pf_create_kernel(PfDev D) {
     }
     __syncthreads();
   }
-  for (int i = tid; i < 624; i += PF_T) D.mt[(size_t)f * 624 + i] = L.mt[i];
+  for (int i = tid; i < 624; i += PF_T) D.mt[(size_t)f * 624 + i] = r.mt[i];
   if (tid == 0) { D.mtpos[f] = r.pos; D.llen[f] = N; D.ndraw[f] += r.drawn; D.status[f] = PF_OK; }
 }
 
 template <int T, int PPT>
-__global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
+// (the register budget that lets the workgroups LDS admits be resident: two per CU up to 1024 particles = T / 128 wavefronts
+// per SIMD, one beyond)
+__global__ __launch_bounds__(T, (T * PPT <= 1024 ? 2 : 1) * T / 256) void pf_step_kernel(PfDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int f = blockIdx.x, tid = threadIdx.x, N = D.N, A = D.A;
   PfLds L = pf_carve(smem, N);
-  PfRng r{L.mt, D.mtpos[f], 0ull};
+  PfRng r{L.mt, L.mt2, D.mtpos[f], 0ull};
   double* st = D.st + (size_t)f * 5 * N;
   for (int i = tid; i < 624; i += T) L.mt[i] = D.mt[(size_t)f * 624 + i];
   for (int i = tid; i < N; i += T) {
@@ -207,11 +231,18 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
   int llen = D.llen[f];
   int status = D.status[f];
   __syncthreads();
+#ifdef AUVP_PF_DIAG  // clocks per section of the step, summed over the launch's steps -> err[k][f] (tools/pf_phases.py --clocks)
+  unsigned long long pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_t0 = __builtin_amdgcn_s_memtime();
+#define PF_STAMP(k) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pf_acc[k] += t_ - pf_t0; pf_t0 = t_; }
+#else
+#define PF_STAMP(k)
+#endif
 
   for (int s = 0; s < D.S; s++) {
     if (D.phases & PF_PHASE_UPDATE) {
       // ---- create_and_update: list position p consumes uniforms 2p, 2p+1 of this step
       pf_gen_words<T>(r, L.wbuf, 4 * N, tid);
+      PF_STAMP(0)
       double u0[PPT], u1[PPT];
 #pragma unroll
       for (int j = 0; j < PPT; j++) {
@@ -221,40 +252,42 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
       __syncthreads();
       for (int i = tid; i < llen; i += T) L.slot[i] = 0x7fffffff;
       __syncthreads();
-#pragma unroll
-      for (int j = 0; j < PPT; j++) if (p0 + j < N) atomicMin(&L.slot[e[j]], p0 + j);
-      __syncthreads();
+      // rounds: every pending position offers ((2048 - round) << 11 | position) to its object's slot with atomicMin -- a later
+      // round's offers are below every earlier one, so the table is not reset in between; the smallest pending position of an
+      // object is applied
+      static_assert(T * PPT <= 2048, "positions take 11 bits of a slot");
       int lead[PPT];
       unsigned pending = 0;
 #pragma unroll
-      for (int j = 0; j < PPT; j++) if (p0 + j < N) { lead[j] = L.slot[e[j]]; pending |= 1u << j; }
-      __syncthreads();
-      for (;;) {
+      for (int j = 0; j < PPT; j++) if (p0 + j < N) pending |= 1u << j;
+      for (int rd = 0;; rd++) {
+        const int kb = (2048 - rd) << 11;
+#pragma unroll
+        for (int j = 0; j < PPT; j++) if (pending >> j & 1u) atomicMin(&L.slot[e[j]], kb | (p0 + j));
+        __syncthreads();
         unsigned applied = 0;
 #pragma unroll
         for (int j = 0; j < PPT; j++) {
-          if ((pending >> j & 1u) && L.slot[e[j]] == p0 + j) {
-            const int q = lead[j];
-            double v = L.sv[q], th = L.sth[q];
-            v += 0.0 + 5.0 * u0[j];                                   // uniform(0, RANDOM_VELOCITY)
-            for (int d = 0; d < 900 && v > 5; d++) v += -5;           // velocity_wrap
-            th += -(PF_PI / 2) + (PF_PI / 2 - -(PF_PI / 2)) * u1[j];  // uniform(-RANDOM_THETA, RANDOM_THETA)
-            if (!pf_angle_wrap(th)) status = PF_ERR_ANGLE;
-            double sn, cs;
-            auvp_sincos(th, &sn, &cs);
-            L.sv[q] = v; L.sth[q] = th;
-            L.sx[q] += v * cs * .1;
-            L.sy[q] += v * sn * .1;
-            applied |= 1u << j;
+          if (pending >> j & 1u) {
+            const int top = L.slot[e[j]];
+            if (rd == 0) lead[j] = top & 2047;  // the object's state lives at its first position
+            if (top == (kb | (p0 + j))) {
+              const int q = lead[j];
+              double v = L.sv[q], th = L.sth[q];
+              v += 0.0 + 5.0 * u0[j];                                   // uniform(0, RANDOM_VELOCITY)
+              for (int d = 0; d < 900 && v > 5; d++) v += -5;           // velocity_wrap
+              th += -(PF_PI / 2) + (PF_PI / 2 - -(PF_PI / 2)) * u1[j];  // uniform(-RANDOM_THETA, RANDOM_THETA)
+              if (!pf_angle_wrap(th)) status = PF_ERR_ANGLE;
+              double sn, cs;
+              auvp_sincos(th, &sn, &cs);
+              L.sv[q] = v; L.sth[q] = th;
+              L.sx[q] += v * cs * .1;
+              L.sy[q] += v * sn * .1;
+              applied |= 1u << j;
+            }
           }
         }
         pending &= ~applied;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < PPT; j++) if (applied >> j & 1u) L.slot[e[j]] = 0x7fffffff;
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < PPT; j++) if (pending >> j & 1u) atomicMin(&L.slot[e[j]], p0 + j);
         if (!__syncthreads_or(pending != 0)) break;
       }
       // every position reads its object's state (leaders' slots are only read here)
@@ -270,12 +303,17 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
         for (int i = tid; i < N; i += T) { u[5 * i] = L.sx[i]; u[5 * i + 1] = L.sy[i]; u[5 * i + 2] = L.sv[i]; u[5 * i + 3] = L.sth[i]; u[5 * i + 4] = L.sw[i]; }
       }
       // positions are independent copies again after correct; until then the shared object id stays
+      PF_STAMP(1)
     }
 
     if (D.phases & PF_PHASE_WEIGHTS) {
       // ---- update_weights: per AUV measurement, weight of every particle (:285-300)
-      double* wl = D.wl + (size_t)f * A * N;
+      // (the per-AUV lists stay in registers: a particle's weight is the sum of its normalised entries in AUV order, :302-305)
+      double nw[PPT];
+#pragma unroll
+      for (int j = 0; j < PPT; j++) nw[j] = 0;
       for (int a = 0; a < A; a++) {
+        double wv[PPT];
         const double* m = D.meas + (((size_t)s * D.F + f) * A + a) * 5;
         const double mx = m[0], my = m[1], mth = m[2], auv_alpha = m[3], auv_range = m[4];
         double lmax = -__builtin_inf();
@@ -295,22 +333,19 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
             const double dr = pr - auv_range;
             const double fw = .001 + (1 / (100 * constant) * (auvp_pow_e((-(dr * dr)) / (20000))));
             const double w = fw * fa;
-            wl[(size_t)a * N + p] = w;
+            wv[j] = w;
             lmax = w > lmax ? w : lmax;
           }
         }
         const double den = pf_block_max<T>(lmax, L.red_d, tid);
         // normalize (:133-139) in place
 #pragma unroll
-        for (int j = 0; j < PPT; j++) { const int p = p0 + j; if (p < N) wl[(size_t)a * N + p] = (1 / den) * wl[(size_t)a * N + p]; }
+        for (int j = 0; j < PPT; j++) if (p0 + j < N) nw[j] += (1 / den) * wv[j];
       }
-      double nw[PPT], lmax = -__builtin_inf();
+      PF_STAMP(2)
+      double lmax = -__builtin_inf();
 #pragma unroll
-      for (int j = 0; j < PPT; j++) {
-        const int p = p0 + j;
-        nw[j] = 0;
-        if (p < N) { for (int a = 0; a < A; a++) nw[j] += wl[(size_t)a * N + p]; lmax = nw[j] > lmax ? nw[j] : lmax; }
-      }
+      for (int j = 0; j < PPT; j++) if (p0 + j < N) lmax = nw[j] > lmax ? nw[j] : lmax;
       const double fden = pf_block_max<T>(lmax, L.red_d, tid);
       // ---- correct (:179-252): 1..5 deep copies by weight class, then N index draws
       int k[PPT], ksum = 0;
@@ -327,13 +362,15 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
       }
       int total = 0;
       int run = pf_block_scan<T>(ksum, L.red_i, tid, &total);
+      // copy c of list_of_new_particles -> the particle it was copied from (at most five entries per particle)
+      int* inv = L.slot;
 #pragma unroll
-      for (int j = 0; j < PPT; j++) if (p0 + j < N) { L.off[p0 + j] = run; run += k[j]; }
-      if (tid == 0) L.off[N] = total;
+      for (int j = 0; j < PPT; j++) if (p0 + j < N) { for (int c = 0; c < k[j]; c++) inv[run + c] = p0 + j; run += k[j]; }
       const int len = total;
       __syncthreads();
       if (len == 0) { status = PF_ERR_EMPTY; break; }  // numpy raises ValueError
-      int* cho = L.slot;
+      PF_STAMP(3)
+      int* cho = L.off;
       if (len == 1) {
         for (int i = tid; i < N; i += T) cho[i] = 0;  // randint(0, 1): no draw
         __syncthreads();
@@ -343,7 +380,7 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
         mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
         int got = 0;
         while (got < N) {
-          if (r.pos >= 624) { pf_refill(r.mt, tid); r.pos = 0; }
+          if (r.pos >= 624) { pf_refill(r, tid); __syncthreads(); }
           const int avail = 624 - r.pos;
           // thread t looks at words [WPT t, WPT t + WPT) of the block (WPT T >= 624)
           constexpr int WPT = (624 + T - 1) / T;
@@ -375,6 +412,7 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
           __syncthreads();
         }
       }
+      PF_STAMP(4)
       if (D.choice) for (int i = tid; i < N; i += T) D.choice[((size_t)s * D.F + f) * N + i] = cho[i];
       // ---- the new list: position n = copy of the source of list_of_new_particles[cho[n]]
       double gx[PPT], gy[PPT], gv[PPT], gt[PPT], gw[PPT];
@@ -383,8 +421,7 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
         const int n = p0 + j;
         if (n < N) {
           const int x = cho[n];
-          int lo = 0, hi = N;  // largest p with off[p] <= x  (off[p] < off[p+1] for every p that made copies)
-          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (L.off[mid] <= x) lo = mid; else hi = mid; }
+          const int lo = inv[x];
           gx[j] = L.sx[lo]; gy[j] = L.sy[lo]; gv[j] = L.sv[lo]; gt[j] = L.sth[lo]; gw[j] = L.sw[lo];
           e[j] = x;
         }
@@ -398,6 +435,7 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
       llen = len;
       if (tid == 0) D.out_len[(size_t)s * D.F + f] = len;
       __syncthreads();
+      PF_STAMP(5)
     }
 
     if (D.phases & PF_PHASE_MEAN) {
@@ -426,11 +464,12 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
         D.err[(size_t)s * D.F + f] = auvp_sqrt((xd * xd) + (yd * yd));  // meanError (:169-177)
       }
       __syncthreads();
+      PF_STAMP(6)
     }
   }
 
   // ---- persist
-  for (int i = tid; i < 624; i += T) D.mt[(size_t)f * 624 + i] = L.mt[i];
+  for (int i = tid; i < 624; i += T) D.mt[(size_t)f * 624 + i] = r.mt[i];
   for (int i = tid; i < N; i += T) {
     st[i] = L.sx[i]; st[N + i] = L.sy[i]; st[2 * N + i] = L.sv[i]; st[3 * N + i] = L.sth[i]; st[4 * N + i] = L.sw[i];
   }
@@ -438,6 +477,10 @@ __global__ __launch_bounds__(T) void pf_step_kernel(PfDev D) {
   for (int j = 0; j < PPT; j++) if (p0 + j < N) D.ent[(size_t)f * N + p0 + j] = e[j];
   if (__syncthreads_or(status != PF_OK) && tid == 0 && D.status[f] == PF_OK) D.status[f] = status != PF_OK ? status : PF_ERR_ANGLE;
   if (tid == 0) { D.mtpos[f] = r.pos; D.llen[f] = llen; D.ndraw[f] += r.drawn; }
+#ifdef AUVP_PF_DIAG
+  if (tid == 0) for (int k = 0; k < 7 && k < D.S; k++) D.err[(size_t)k * D.F + f] = (double)pf_acc[k];
+#endif
+#undef PF_STAMP
 }
 
 }  // namespace auvp

@@ -931,13 +931,17 @@ def bench_particle_filter(device, with_cpu, n_filters=4096, n_particles=1000, n_
         return {"error": "filter status %s" % np.unique(st)}
     k_ms = float(np.mean(ms))
     units = float(F) * N * S
-    abytes = F * N * (2 * 44.0 + S * A * 24.0) + S * F * A * 40.0
+    abytes = F * N * 2 * 44.0 + S * F * (A * 40.0 + 28.0)  # particles in and out once per launch; measurements in, estimates out per step
+    pf_traffic = pmc_traffic("particle_filter", ["pf_step_kernel"], None)
     out = {"metric": "particle filter particle-steps/s (create_and_update + update_weights)", "value": units / (k_ms * 1e-3),
            "unit": "particle-steps/s", "filters": F, "particles": N, "steps": S, "auvs": A, "kernel_ms": k_ms,
            "draws32_per_filter_step": float(nd.mean()) / S,
            "config": "%d filters x %d particles x %d steps, %d AUV measurements per step" % (F, N, S, A),
-           "roofline": roofline(abytes, k_ms, "pf_step_kernel",
-                                note="state is LDS resident across the steps of a launch: barrier/latency bound, not HBM bound")}
+           "roofline": roofline(abytes, k_ms, "pf_step_kernel", pf_traffic,
+                                valu_issue_frac=pmc_valu_issue("particle_filter", "pf_step_kernel") if pf_traffic["traffic"] is not None else None,
+                                note="state is LDS resident across the steps of a launch; four wavefronts per SIMD of dependent fp64 "
+                                     "chains (atan2, exponentials, MT19937 blocks, ordered sums) between ~45 workgroup barriers per "
+                                     "step: issue and latency bound, not HBM")}
     if with_cpu:
         from oracle import orc_pf
         t0, n = time.perf_counter(), 0

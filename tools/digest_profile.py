@@ -43,6 +43,7 @@ MEAS = {
     "rrt_nn": (RRT, "iters_per_launch"),
     "rrt_nn_long_horizon": (RRT, "iters_per_launch"),
     "config5": (("prrt_kernel", "prrt_rows_kernel"), "planner_steps_per_tracking_step"),
+    "particle_filter": (("pf_step_kernel",), None),
 }
 
 

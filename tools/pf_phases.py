@@ -13,6 +13,17 @@ meas[..., 4] = rng.uniform(-np.pi, np.pi, size=(S, F, A))
 shark = shark0[None] + rng.uniform(-20, 20, size=(S, F, 2))
 key0, _ = _pf_lib.np_seed_state(0)
 mts = np.stack([np.roll(key0, f) ^ np.uint32(f) for f in range(F)])
+if "--clocks" in sys.argv:  # a -DAUVP_PF_DIAG build (AUVPLAN_LIBRARY=<.so>): s_memtime clocks per section and filter-step
+    Fx = int(sys.argv[sys.argv.index("--clocks") + 1]) if len(sys.argv) > sys.argv.index("--clocks") + 1 else 512
+    b = _pf_lib.FilterBatch(ctx, Fx, N).create(shark0[:Fx], mts[:Fx], 624)
+    b.run(meas=meas[:, :Fx], shark_xy=shark[:, :Fx])
+    _, err, _ = b.estimates()
+    names = ["update: words", "update: objects", "weights: per-AUV", "weights: sum, classes, scan", "correct: index draws", "correct: gather", "mean"]
+    tot = err[:7].mean(axis=1).sum() / S
+    for k, nm in enumerate(names):
+        print("%-30s %8.0f clocks per filter-step (%.0f %%)" % (nm, err[k].mean() / S, 100 * err[k].mean() / S / tot))
+    print("total %.0f; launch %.2f ms" % (tot, ctx.last_kernel_ms()))
+    sys.exit(0)
 for name, ph in [("all", 7), ("update", 1), ("weights", 2), ("mean", 4), ("upd+w", 3)]:
     for rep in range(2):
         b = _pf_lib.FilterBatch(ctx, F, N).create(shark0, mts, 624)
