@@ -977,14 +977,16 @@ def bench_shark_grid(device, with_cpu, n_side=200, n_sharks=32, n_pts=3000, reps
     T, G = grids.shape[0], grids.shape[1] * grids.shape[2]
     units = float(T) * G
     # compulsory traffic: the points once (24 B), the per-(bin, shark, cell) occupancy written and read once (8 + 8 B; the
-    # 81-cell window re-reads of the disc stencil are cache hits and are NOT counted), the output once (8 B)
+    # 81-cell window re-reads of the disc stencil come from LDS tiles and are NOT counted), the output once (8 B)
     abytes = len(pts) * 24.0 + T * n_sharks * G * (4.0 + 8.0 + 8.0) + units * 8.0
     out = {"metric": "SharkOccupancyGrid.convert output cells/s", "value": units / (k_ms * 1e-3), "unit": "grid cells/s",
            "bins": int(T), "grid": [int(grids.shape[1]), int(grids.shape[2])], "sharks": n_sharks, "kernel_ms": k_ms,
            "config": "%dx%d cells of 10 m, %d sharks x %d points, %d bins, detect range 50 m" % (n, n, n_sharks, n_pts, T),
            "roofline": roofline(abytes, k_ms, "sog_count/occ/grid_kernel",
-                                note="compulsory bytes only; the 81-cell stencil window is served by L2 (%.0f GB/s of cache reads)"
-                                     % (units * n_sharks * 81 * 8.0 / (k_ms * 1e-3) / 1e9))}
+                                pmc_traffic("shark_grid", ["sog_count_kernel", "sog_occ_kernel", "sog_grid_tile_c_kernel"], None),
+                                note="compulsory bytes only (three launches: count, occupancy, window sums); the 81-cell disc "
+                                     "windows are summed from LDS tiles, one LDS read per four of the %.1f G ordered fp64 additions"
+                                     % (units * n_sharks * 81 / 1e9))}
     if with_cpu:
         from oracle import orc_sog
         sub = 2

@@ -53,11 +53,18 @@ def test_dropin_class_matches_reference(path):
         assert list(celld[k].values()) == cv.tolist()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_random_inputs_match_oracle(ctx, orc, seed):
-    """ragged trajectories, points outside every cell, points on shared edges, a duplicated cell, sparse cell list"""
+@pytest.mark.parametrize("seed,detect,tile", [(1, 9.0, None), (2, 9.0, None), (3, 9.0, None),
+                                              # the three window-sum kernels (AUVP_SOG_TILE: 0 = per-cell sweep of L2, 1 = LDS tiles with
+                                              # the radius a compile-time constant up to 8 cells, 2 = LDS tiles, radius at run time)
+                                              (1, 9.0, "0"), (1, 9.0, "2"), (2, 30.0, "0"), (2, 30.0, "1"), (2, 30.0, "2"),
+                                              (1, 14.0, "1"), (1, 14.0, "2"), (3, 32.0, "1"), (1, 3.0, "1"), (1, 29.0, "1"), (1, 61.0, "1")])
+def test_random_inputs_match_oracle(ctx, orc, seed, detect, tile, monkeypatch):
+    """ragged trajectories, points outside every cell, points on shared edges, a duplicated cell, sparse cell list; window radii of
+    1 .. 21 cells (a tile wider than the whole grid included)"""
     from auv_sim_amd.sharkOccupancyGrid import convert_arrays
     from oracle import orc_sog
+    if tile is not None:
+        monkeypatch.setenv("AUVP_SOG_TILE", tile)
     rng = np.random.default_rng(seed)
     cs = [3.0, 7.5, 4.0][seed - 1]
     box = (-20.0, -10.0, 55.0, 47.0)
@@ -81,9 +88,9 @@ def test_random_inputs_match_oracle(ctx, orc, seed):
         t[rng.random(n) < 0.1] = 20.0  # exactly on a bin edge: the earlier bin takes it
         pts.append(np.stack([x, y, np.sort(t)], axis=1))
     pts = np.concatenate(pts)
-    ref = orc_sog.convert(cells, box, cs, 10.0, 9.0, traj_len, pts, kind="portable")
+    ref = orc_sog.convert(cells, box, cs, 10.0, detect, traj_len, pts, kind="portable")
     assert ref["status"] == 0
-    bins, grids = convert_arrays(ctx, cells, box, cs, 10.0, 9.0, traj_len, pts)
+    bins, grids = convert_arrays(ctx, cells, box, cs, 10.0, detect, traj_len, pts)
     assert np.array_equal(bins, ref["bins"])
     assert np.array_equal(grids, ref["grids"])
     assert grids.max() > 0

@@ -44,6 +44,7 @@ MEAS = {
     "rrt_nn_long_horizon": (RRT, "iters_per_launch"),
     "config5": (("prrt_kernel", "prrt_rows_kernel"), "planner_steps_per_tracking_step"),
     "particle_filter": (("pf_step_kernel",), None),
+    "shark_grid": (("sog_count_kernel", "sog_occ_kernel", "sog_grid_kernel", "sog_grid_tile_kernel", "sog_grid_tile_c_kernel"), None),
 }
 
 
