@@ -34,3 +34,20 @@ def test_planner_helper_wavefronts_random_cases():
                        cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+def test_particle_filter_random_cases():
+    """pf_step_kernel against the checker: particle counts 2 .. 2048, 1 .. 4 AUVs, 1 .. 12 steps, concentrated and spread weights"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "experiments", "soak_pf.py"), "80", "2"],
+                       cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatching" in r.stdout
+
+
+def test_shark_grid_random_cases():
+    """the three window-sum kernels of SharkOccupancyGrid.convert against the checker: grid shapes around the tile edges, sparse /
+    duplicated cell lists, radii 1 .. 14 cells"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "experiments", "soak_sog.py"), "40", "3"],
+                       cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout
