@@ -165,11 +165,12 @@ int auvp_pf_run(auvp_handle* h, int32_t n_steps, int32_t n_auv, int32_t phases, 
   // (six barriers per MT19937 regeneration).  Round 4, regeneration without inner barriers: 256 threads (237 registers, one
   // wavefront per SIMD and workgroup, two workgroups per CU by LDS) 9.2 ms -- one workgroup alone on a CU takes 0.94 of
   // that: the step is a chain of dependent fp64 latencies, not issue bound (0.40 of the VALU issue slots); 512 threads held to
-  // 128 registers (four wavefronts per SIMD) 7.7 ms; 1024 (one workgroup per CU) 11.5 ms
+  // 128 registers (four wavefronts per SIMD) 7.7 ms; 1024 (one workgroup per CU) 11.5 ms; 384 threads x 3 particles at 168
+  // registers (final kernel): 14.1 ms against 7.1 ms -- six wavefronts do not spread evenly over the four SIMDs
 #ifndef AUVP_PF_THREADS
 #define AUVP_PF_THREADS 512
 #endif
-  constexpr int T = AUVP_PF_THREADS, P1 = 1024 / T, P2 = 2048 / T;
+  constexpr int T = AUVP_PF_THREADS, P1 = (1024 + T - 1) / T, P2 = (2048 + T - 1) / T;
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   if (N <= 1024) {
     HIPCHK(h, hipFuncSetAttribute((const void*)auvp::pf_step_kernel<T, P1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

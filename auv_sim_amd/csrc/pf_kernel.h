@@ -214,7 +214,7 @@ __global__ __launch_bounds__(PF_T) void pf_create_kernel(PfDev D) {
 template <int T, int PPT>
 // (the register budget that lets the workgroups LDS admits be resident: two per CU up to 1024 particles = T / 128 wavefronts
 // per SIMD, one beyond)
-__global__ __launch_bounds__(T, (T * PPT <= 1024 ? 2 : 1) * T / 256) void pf_step_kernel(PfDev D) {
+__global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_step_kernel(PfDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int f = blockIdx.x, tid = threadIdx.x, N = D.N, A = D.A;
   PfLds L = pf_carve(smem, N);
@@ -252,16 +252,16 @@ __global__ __launch_bounds__(T, (T * PPT <= 1024 ? 2 : 1) * T / 256) void pf_ste
       __syncthreads();
       for (int i = tid; i < llen; i += T) L.slot[i] = 0x7fffffff;
       __syncthreads();
-      // rounds: every pending position offers ((2048 - round) << 11 | position) to its object's slot with atomicMin -- a later
+      // rounds: every pending position offers ((4096 - round) << 12 | position) to its object's slot with atomicMin -- a later
       // round's offers are below every earlier one, so the table is not reset in between; the smallest pending position of an
       // object is applied
-      static_assert(T * PPT <= 2048, "positions take 11 bits of a slot");
+      static_assert(T * PPT <= 4096, "positions take 12 bits of a slot");
       int lead[PPT];
       unsigned pending = 0;
 #pragma unroll
       for (int j = 0; j < PPT; j++) if (p0 + j < N) pending |= 1u << j;
       for (int rd = 0;; rd++) {
-        const int kb = (2048 - rd) << 11;
+        const int kb = (4096 - rd) << 12;
 #pragma unroll
         for (int j = 0; j < PPT; j++) if (pending >> j & 1u) atomicMin(&L.slot[e[j]], kb | (p0 + j));
         __syncthreads();
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(T, (T * PPT <= 1024 ? 2 : 1) * T / 256) void pf_ste
         for (int j = 0; j < PPT; j++) {
           if (pending >> j & 1u) {
             const int top = L.slot[e[j]];
-            if (rd == 0) lead[j] = top & 2047;  // the object's state lives at its first position
+            if (rd == 0) lead[j] = top & 4095;  // the object's state lives at its first position
             if (top == (kb | (p0 + j))) {
               const int q = lead[j];
               double v = L.sv[q], th = L.sth[q];
