@@ -125,11 +125,12 @@ __global__ __launch_bounds__(256) void sog_grid_kernel(SogDev D) {
 // additions in the reference's (row, column) order.  Tile column j is stored at (j % 4) * Q + j / 4: the 16 threads of a
 // tile row read consecutive doubles, and a thread's offset within its row is the same scalar for the whole wavefront.
 #define SOG_TH 16
+#define SOG_THREADS (16 * SOG_TH)
 #define SOG_TW 64
 __host__ __device__ constexpr int sog_tile_q(int count) { return (((SOG_TW + 2 * count + 1 + 3) / 4 + 7) / 8) * 8 + 4; }  // Q = 4 mod 8
 __host__ __device__ inline size_t sog_tile_bytes(int count) { return (size_t)2 * (SOG_TH + 2 * count) * 4 * sog_tile_q(count) * sizeof(double); }
 
-__global__ __launch_bounds__(256) void sog_grid_tile_kernel(SogDev D) {
+__global__ __launch_bounds__(SOG_THREADS) void sog_grid_tile_kernel(SogDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sog_smem[];
   const int count = D.count, Q = sog_tile_q(count), RS = 4 * Q, H = SOG_TH + 2 * count, P = SOG_TW + 2 * count + 1;
   double* buf0 = reinterpret_cast<double*>(sog_smem);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void sog_grid_tile_kernel(SogDev D) {
   const long long c2 = (long long)count * count;
   auto stage = [&](double* buf, int s) {
     const double* occ = D.occ + ((size_t)t * D.n_sharks + s) * G;
-    for (int idx = tid; idx < H * P; idx += 256) {
+    for (int idx = tid; idx < H * P; idx += SOG_THREADS) {
       const int r = idx / P, j = idx - r * P;
       const int gr = row0 - count + r, gc = col0 - count + j;
       const double v = (gr >= 0 && gr < D.rows && gc >= 0 && gc < D.cols) ? occ[(size_t)gr * D.cols + gc] : 0.0;
@@ -212,9 +213,9 @@ struct SogDisc {
 };
 
 template <int C>
-__global__ __launch_bounds__(256, C <= 5 ? 3 : 2) void sog_grid_tile_c_kernel(SogDev D) {  // (workgroups per CU LDS admits / registers)
+__global__ __launch_bounds__(SOG_THREADS, C <= 5 ? 3 : 2) void sog_grid_tile_c_kernel(SogDev D) {  // (workgroups per CU LDS admits / registers)
   extern __shared__ __attribute__((aligned(16))) unsigned char sog_smem[];
-  constexpr int Q = sog_tile_q(C), RS = 4 * Q, H = SOG_TH + 2 * C, P = SOG_TW + 2 * C + 1, NST = (H * P + 255) / 256;
+  constexpr int Q = sog_tile_q(C), RS = 4 * Q, H = SOG_TH + 2 * C, P = SOG_TW + 2 * C + 1, NST = (H * P + SOG_THREADS - 1) / SOG_THREADS;
   constexpr SogDisc<C> disc{};
   double* buf0 = reinterpret_cast<double*>(sog_smem);
   double* buf1 = buf0 + (size_t)H * RS;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, C <= 5 ? 3 : 2) void sog_grid_tile_c_kernel(So
   int src[NST], dst[NST];
 #pragma unroll
   for (int q = 0; q < NST; q++) {
-    const int idx = tid + 256 * q, r = idx / P, j = idx - r * P;
+    const int idx = tid + SOG_THREADS * q, r = idx / P, j = idx - r * P;
     const int gr = row0 - C + r, gc = col0 - C + j;
     src[q] = (idx < H * P && gr >= 0 && gr < D.rows && gc >= 0 && gc < D.cols) ? gr * D.cols + gc : -1;
     dst[q] = idx < H * P ? r * RS + (j & 3) * Q + (j >> 2) : -1;
@@ -424,7 +425,7 @@ extern "C" int auvp_sog_convert(auvp_handle* h, const double* cells, int32_t C, 
   auto launch_tile = [&](auto kern) -> hipError_t {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, tgrid, dim3(256), tile_lds, h->stream, D);
+    hipLaunchKernelGGL(kern, tgrid, dim3(SOG_THREADS), tile_lds, h->stream, D);
     return hipSuccess;
   };
   if (tiled) {
