@@ -12,27 +12,45 @@ namespace auvp {
 // with the state as a column of an LDS tile, m[word * 65] (a read-modify-write of global memory per step cost 4 x as much):
 // conflict-free both for the per-thread recurrence (bank = word + thread) and for the coalesced write-out
 constexpr int MT_SEED_LDS = 624 * 65 * 4;
+// `count` consecutive steps of one of init_by_array's two mixing loops over words [i0, i0 + count) (no wrap inside), eight
+// words read ahead of the dependent chain: a step needs the word's OLD value, which no earlier step of the run writes, so the
+// LDS reads leave the chain (round 4: the reads in the loop were 2/3 of the kernel's time)
+template <bool SECOND>
+__device__ __forceinline__ uint32_t mt_seed_run(uint32_t* m, int i0, int count, uint32_t prev, const uint32_t (&key)[2], int klen, int& j) {
+  int i = i0, left = count;
+  for (; left >= 8; left -= 8, i += 8) {
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) w[q] = m[(i + q) * 65];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (!SECOND) { prev = (w[q] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j; j++; if (j >= klen) j = 0; }
+      else prev = (w[q] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i + q);
+      m[(i + q) * 65] = prev;
+    }
+  }
+  for (; left > 0; left--, i++) {
+    if (!SECOND) { prev = (m[i * 65] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j; j++; if (j >= klen) j = 0; }
+    else prev = (m[i * 65] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+    m[i * 65] = prev;
+  }
+  return prev;
+}
+
 __device__ __forceinline__ void mt_seed_by_array_column(unsigned long long seed, uint32_t* m) {
   const uint32_t key[2] = {(uint32_t)(seed & 0xffffffffull), (uint32_t)(seed >> 32)};
   const int klen = key[1] ? 2 : 1;
   uint32_t prev = 19650218u;
   m[0] = prev;
   for (int i = 1; i < 624; i++) { prev = 1812433253u * (prev ^ (prev >> 30)) + (uint32_t)i; m[i * 65] = prev; }
-  int i = 1, j = 0;
-  prev = m[0];
-  for (int k = 624; k; k--) {
-    prev = (m[i * 65] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
-    m[i * 65] = prev;
-    i++; j++;
-    if (i >= 624) { m[0] = prev; i = 1; }
-    if (j >= klen) j = 0;
-  }
-  for (int k = 623; k; k--) {
-    prev = (m[i * 65] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-    m[i * 65] = prev;
-    i++;
-    if (i >= 624) { m[0] = prev; i = 1; }
-  }
+  // init_by_array: 624 steps over words 1 .. 623, 1 (the index wraps to 1 after 623; word 0 only ever receives copies and is
+  // set last), then 623 steps over words 2 .. 623, 1
+  int j = 0;
+  prev = 19650218u;  // = m[0]
+  prev = mt_seed_run<false>(m, 1, 623, prev, key, klen, j);
+  prev = mt_seed_run<false>(m, 1, 1, prev, key, klen, j);
+  prev = mt_seed_run<true>(m, 2, 622, prev, key, klen, j);
+  prev = mt_seed_run<true>(m, 1, 1, prev, key, klen, j);
   m[0] = 0x80000000u;
 }
 
