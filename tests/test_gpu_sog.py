@@ -57,10 +57,11 @@ def test_dropin_class_matches_reference(path):
                                               # the three window-sum kernels (AUVP_SOG_TILE: 0 = per-cell sweep of L2, 1 = LDS tiles with
                                               # the radius a compile-time constant up to 8 cells, 2 = LDS tiles, radius at run time)
                                               (1, 9.0, "0"), (1, 9.0, "2"), (2, 30.0, "0"), (2, 30.0, "1"), (2, 30.0, "2"),
-                                              (1, 14.0, "1"), (1, 14.0, "2"), (3, 32.0, "1"), (1, 3.0, "1"), (1, 29.0, "1"), (1, 61.0, "1")])
+                                              (1, 14.0, "1"), (1, 14.0, "2"), (3, 32.0, "1"), (1, 3.0, "1"), (1, 29.0, "1"), (1, 61.0, "1"),
+                                              (1, 100.0, None)])  # 34 cells: beyond the LDS tiles, the per-cell kernel by itself
 def test_random_inputs_match_oracle(ctx, orc, seed, detect, tile, monkeypatch):
     """ragged trajectories, points outside every cell, points on shared edges, a duplicated cell, sparse cell list; window radii of
-    1 .. 21 cells (a tile wider than the whole grid included)"""
+    1 .. 34 cells (a tile wider than the whole grid included)"""
     from auv_sim_amd.sharkOccupancyGrid import convert_arrays
     from oracle import orc_sog
     if tile is not None:
