@@ -715,8 +715,12 @@ def bench_rrt_env(local_rank, n_env=512, n_steps=60):
 
     def policy(st):
         # a random bucket among those that hold a node (what an agent that respects the action mask does)
+        # (vectorised: a Python loop over the environments took most of the step it was meant to drive)
         has = st["has_node"] != 0
-        return np.array([rng.choice(np.flatnonzero(h)) if h.any() else 0 for h in has], dtype=np.int64)
+        cnt = has.sum(axis=1)
+        k = (rng.random(len(has)) * np.maximum(cnt, 1)).astype(np.int64)
+        pick = (np.cumsum(has, axis=1, dtype=np.int32) > k[:, None]).argmax(axis=1)
+        return np.where(cnt > 0, pick, 0).astype(np.int64)
     st = env.reset()
     st, _, _, _ = env.step(policy(st))  # warm-up (allocations)
     torch.cuda.synchronize()
