@@ -95,7 +95,8 @@ for key, (needles, units_field) in MEAS.items():
             rec["leaf_kernel_compulsory_bytes"] = j["roofline"]["leaf_compulsory_bytes"]
         else:
             j = json.loads(open(os.path.join(src, "pmc@%s@FETCH_SIZE.json" % key)).read().strip().splitlines()[-1])[side]
-            rec["units"] = j[units_field]
+            if units_field:
+                rec["units"] = j[units_field]
             if "roofline" in j:
                 rec["algorithmic_bytes_per_launch"] = j["roofline"]["algorithmic_bytes_per_launch"]
     except Exception as e:
