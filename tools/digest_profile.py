@@ -31,7 +31,9 @@ for d in glob.glob(os.path.join(src, "trace*")):
             shutil.copy(f, os.path.join(dst, os.path.basename(f)))
 for f in glob.glob(os.path.join(src, "*.json")):
     if os.path.basename(f).startswith(("bench", "trace")):
-        shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+        d = os.path.join(dst, os.path.basename(f))
+        if not os.path.exists(d) or os.path.getmtime(f) > os.path.getmtime(d):  # (a later bench line may have been put there by hand)
+            shutil.copy2(f, d)
 
 # measurement key (= pass-directory name pmc@<key>@<counter>; "headline" or the side's name in the bench JSON) ->
 #   (kernel-name needles, field of the side's JSON holding its work units)
