@@ -113,7 +113,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       e = row_read(e, rowbase);
       bool skip = false;
       if (need) {
-        if (e >= n_episodes) { more = false; }
+        if ((unsigned)e >= (unsigned)n_episodes) { more = false; }  // (a negative id -- a base ahead of the counter -- ends the row too)
         else {
           ep = e;
           // step mode: an episode whose bucket is < 0 is not touched at all

@@ -24,6 +24,7 @@ struct PrrtState {
   // the next launch's base is known on the host (no fill launch per plan / step)
   DevBuf work;
   int work_base = 0;
+  bool work_memset = false;  // set by the first launch under stream capture: the counter is zeroed by a memset node per launch
   bool use_rows = false;  // decided once per batch: the two kernels keep the generator's lazy state in different block phases
   const char* last_kernel = "";
   DevBuf env_err;    // device int32[2]: {status, environment} of the first episode that failed inside the device-resident loop
@@ -87,9 +88,20 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     auto granules = [](size_t b) { return (b + 1279) / 1280 * 1280; };
     const bool obst_lds = oenv ? atoi(oenv) != 0 : 3 * granules(lds_used + auvp::PRW_OBST_TILE) <= (size_t)160 * 1024;
     if (obst_lds) lds_used += auvp::PRW_OBST_TILE;
-    if (!S.work.p || S.work_base > (1 << 30)) {
+    // The ids a launch hands out are counter - work_base.  Eager launches carry the base as an argument (no memset per
+    // launch).  A launch recorded into a hipGraph would freeze that argument while the counter keeps advancing on every
+    // replay, so from the first capture on this state zeroes the counter with a memset NODE in front of every launch and
+    // passes base 0 -- captured and eager launches alike (a replay may run between any two eager launches).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(h->stream, &cap);
+    if (cap != hipStreamCaptureStatusNone) S.work_memset = true;
+    if (!S.work.p) {
+      if (cap != hipStreamCaptureStatusNone) return fail(h, AUVP_ERR_STATE, "the rows work counter must exist before a stream capture (run one eager step first)");
       le = S.work.reserve(sizeof(int));
       if (le == hipSuccess) le = hipMemsetAsync(S.work.p, 0, sizeof(int), h->stream);
+      S.work_base = 0;
+    } else if (S.work_memset || S.work_base > (1 << 30)) {
+      le = hipMemsetAsync(S.work.p, 0, sizeof(int), h->stream);
       S.work_base = 0;
     } else le = hipSuccess;
     auto launch_rows = [&](auto kern) -> hipError_t {
@@ -100,7 +112,8 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     };
     if (le == hipSuccess) {
       le = obst_lds ? launch_rows(auvp::prrt_rows_kernel<true>) : launch_rows(auvp::prrt_rows_kernel<false>);
-      S.work_base += S.E + grid_used * per_wg;  // every episode once + one empty pull per row
+      // every episode once + one empty pull per row; a failed launch pulled nothing, a memset-fronted one restarts at 0
+      if (le == hipSuccess && !S.work_memset) S.work_base += S.E + grid_used * per_wg;
     }
   } else if (use_duo && (getenv("AUVP_PRRT_PIPE") ? atoi(getenv("AUVP_PRRT_PIPE")) != 0 : true)) {
     // four wavefronts per episode, feed-forward (planner_pipe_kernel.h)

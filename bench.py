@@ -90,6 +90,7 @@ def astar_bytes(summ, variant):
     return cells * per_cell + scanned * 8.0
 
 
+LATENCY_FRAC, LATENCY_VALU = 0.05, 0.25  # below both: `bound` = "latency"
 N_SIMD = 1024  # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 HBM_MEASURED = {"read_GBps": None, "copy_GBps": None}  # filled once per run by measure_hbm() (auvp_hbm_probe)
 
@@ -157,6 +158,10 @@ def roofline(abytes, k_ms, kernel, traffic=None, valu_issue_frac=None, **extra):
         r["valu_issue_frac"] = valu_issue_frac
         if valu_issue_frac > frac:
             r["bound"] = "valu_issue"
+    # neither roof is near: a launch of a few dependent chains (one episode, 1 024 replicas, a dense small tree) is bound
+    # by the latency of its serial chain, not by a throughput roof -- say so instead of "hbm" at a fraction of a few percent
+    if frac < LATENCY_FRAC and (valu_issue_frac is None or valu_issue_frac < LATENCY_VALU):
+        r["bound"] = "latency"
     r.update(traffic or {})
     r.update(extra)
     return r
@@ -283,6 +288,90 @@ def effective_cores(cap=64):
     if n > cap:
         n, how = cap, how + ", capped at %d" % cap
     return n, how
+
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the ONE line the driver parses: <= 4 KB of flat scalars; everything else goes to bench_sides.json next to bench.py
+# ----------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+SIDES_FILE = os.environ.get("AUVP_BENCH_SIDES", os.path.join(REPO, "bench_sides.json"))
+ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch",
+             "traffic_raw", "valu_issue_frac", "hbm_measured_GBps", "frac_of_measured", "bytes_per_expansion",
+             "leaf_kernel_ms", "leaf_compulsory_bytes", "leaf_frac", "leaf_valu_issue_frac", "leaf_traffic_raw",
+             "pass_kernel_ms", "pass_8d_frac", "pass_traffic_raw",
+             "nn_long_kernel_ms", "nn_long_alg_bytes", "nn_long_achieved_GBps", "nn_long_frac", "nn_long_frac_of_measured",
+             "nn_long_traffic", "nn_long_traffic_raw", "nn_long_episodes", "nn_long_valu_issue_frac",
+             "side_astar_cells_per_s", "side_planner_steps_per_s", "side_config5_steps_per_s",
+             "side_replicas_expansions_per_s", "side_single_episode_us_per_expansion", "side_pf_particle_steps_per_s",
+             "side_shark_grid_cells_per_s")
+CONFIG_KEEP = ("workload", "episodes_per_gpu", "iters", "obstacles", "cells", "parallelism", "gather", "rccl_ranks_seen")
+TOP_KEEP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+
+
+def _short(v, digits=7):
+    """scalars only, floats to `digits` significant digits (the full-precision values are in bench_sides.json)"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, (float, np.floating)):
+        return float("%.*g" % (digits, float(v)))
+    if isinstance(v, np.integer):
+        return int(v)
+    return None
+
+
+def compact_line(out, sides_file=None):
+    """The final stdout line: headline scalars, a FLAT `roofline` (scalars only), a flat `cpu_baseline`; <= LINE_LIMIT bytes.
+    Keys are dropped from the end of ROOF_KEEP (never `frac` / `achieved`) should a value ever push the line over."""
+    line = {k: _short(out.get(k)) for k in TOP_KEEP}
+    cfg = out.get("config") or {}
+    line["config"] = {k: _short(cfg.get(k)) for k in CONFIG_KEEP if k in cfg}
+    if isinstance(line["config"].get("workload"), str):
+        line["config"]["workload"] = line["config"]["workload"][:120]
+    roof = out.get("roofline") or {}
+    line["roofline"] = {k: _short(roof[k]) for k in ROOF_KEEP if k in roof and (k == "traffic" or _short(roof[k]) is not None)}
+    if isinstance(line["roofline"].get("kernel"), str):
+        line["roofline"]["kernel"] = line["roofline"]["kernel"][:48]
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = {k: _short(cb.get(k)) for k in ("value", "unit", "cores", "kind")}
+        c["sample"] = str(cb.get("sample", ""))[:160]
+        rr = cb.get("reference_recorded")
+        if isinstance(rr, dict):  # the reference Python itself, timed in the build container (it cannot travel)
+            c["reference_value"] = _short(rr.get("value"))
+            c["reference_cores"] = _short(rr.get("cores"))
+        allc = out.get("cpu_baseline_all_cores")
+        if isinstance(allc, dict):
+            c["all_cores_value"] = _short(allc.get("value"))
+            c["all_cores"] = _short(allc.get("cores"))
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = None
+    line["sides_file"] = os.path.basename(sides_file) if sides_file else None
+    drop = [k for k in reversed(ROOF_KEEP) if k not in ("bound", "achieved", "peak", "unit", "frac", "traffic")]
+    while len(json.dumps(line, separators=(",", ":"))) > LINE_LIMIT and drop:
+        line["roofline"].pop(drop.pop(0), None)
+    return line
+
+
+def emit(out):
+    """full record -> SIDES_FILE (and AUVP_BENCH_VERBOSE=1: stderr); compact line -> the LAST line of stdout"""
+    sides_file = SIDES_FILE
+    try:
+        with open(sides_file, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+    except OSError as e:
+        print("bench: could not write %s: %s" % (sides_file, e), file=sys.stderr)
+        sides_file = None
+    if os.environ.get("AUVP_BENCH_VERBOSE") == "1":
+        print(json.dumps(out), file=sys.stderr)
+    sys.stderr.flush()
+    s = json.dumps(compact_line(out, sides_file), separators=(",", ":"))
+    assert len(s) <= LINE_LIMIT, len(s)
+    sys.stdout.flush()
+    print(s, flush=True)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -1253,12 +1342,13 @@ def main():
             # the other configurations as flat scalars too (value of each side measurement; details in its own object)
             for name, key in (("astar", "side_astar_cells_per_s"), ("planner_rrt", "side_planner_steps_per_s"),
                               ("config5", "side_config5_steps_per_s"), ("rrt_1024_replicas", "side_replicas_expansions_per_s"),
-                              ("single_episode", "side_single_episode_us_per_expansion")):
+                              ("single_episode", "side_single_episode_us_per_expansion"),
+                              ("particle_filter", "side_pf_particle_steps_per_s"), ("shark_grid", "side_shark_grid_cells_per_s")):
                 v = out.get(name)
                 if isinstance(v, dict):
                     out["roofline"][key] = v.get("us_per_expansion" if name == "single_episode" else "value")
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if world_size > 1:
         dist.barrier()
         dist.destroy_process_group()

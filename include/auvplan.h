@@ -201,9 +201,10 @@ int auvp_prrt_env_step_ex_dev(auvp_handle* h, int32_t flags, uint64_t agent_seed
                               void* has_node_dev, void* num_nodes_dev, int64_t* reward_dev, uint8_t* done_dev);
 /* stand-in agent for device-resident runs as a launch of its own: every live environment picks, uniformly, one of its
  * occupied buckets -- read from the planner's own list of occupied buckets, the set the observation's has_node array marks
- * (rrt_env.py:250-265); has_node_dev is accepted for compatibility and not read -- finished environments get -1; its
- * randomness is its own (counter-based on `seed`, the environment and the environment's step count), not the planner's
- * stream.  Enqueues only. */
+ * (rrt_env.py:250-265); has_node_dev is accepted for compatibility, not read, and may be NULL -- finished environments get
+ * -1; its randomness is its own, not the planner's stream: a pure function of (`seed`, environment, the environment's step
+ * count in HBM), so a captured graph of one step draws anew at every replay, and calls repeated WITHOUT a step in between
+ * (or for an environment whose step did not run) return the same pick -- vary `seed` to redraw.  Enqueues only. */
 int auvp_prrt_policy_random_dev(auvp_handle* h, const int64_t* has_node_dev, uint64_t seed, int32_t* bucket_ids_dev);
 /* waits for the stream, then: *status = status (< 0) of the first episode that failed on the device inside the
  * device-resident loop since the batch was created, *env (may be NULL) = its index; 0 = none */

@@ -95,3 +95,59 @@ def test_workload_string_fits_the_drivers_record():
     assert '"workload": wl[:120]' in src
     wl = "RRT.exploring %d obst %dx%d cells %d iters x %d episodes/GPU, %s parent sampling" % (256, 200, 200, 10000, 12288, "plantime")
     assert len(wl) <= 120
+
+
+def test_final_line_is_compact_and_complete(tmp_path, monkeypatch):
+    """the driver parses the LAST stdout line: <= 4 KB, flat scalars, with roofline.frac and cpu_baseline.value; the full
+    record (every side measurement) goes to bench_sides.json.  Canned input: round 4's full 23.8 KB record."""
+    b = _bench()
+    full = json.load(open(os.path.join(REPO, "profiles", "r4e", "bench.json")))
+    assert len(json.dumps(full)) > 20000
+    monkeypatch.setattr(b, "SIDES_FILE", str(tmp_path / "bench_sides.json"))
+    import io
+    import contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        b.emit(full)
+    lines = buf.getvalue().strip().split("\n")
+    assert len(lines) == 1 and len(lines[0]) <= 4096
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] > 0 and line["unit"] == "expansions/s" and line["dtype"] == "f64" and line["vs_baseline"] is None
+    assert len(line["config"]["workload"]) <= 120 and "model" not in line["config"]
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "valu_issue", "latency") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and "traffic" in r
+    assert all(not isinstance(v, (dict, list)) for v in r.values())            # flat scalars only
+    assert "nn_long_frac" in r and "side_astar_cells_per_s" in r and "leaf_kernel_ms" in r
+    c = line["cpu_baseline"]
+    assert c["value"] > 0 and c["cores"] == 1 and c["kind"] == "port" and c["sample"] and c["reference_value"] > 0
+    assert all(not isinstance(v, (dict, list)) for v in c.values())
+    assert line["sides_file"] == "bench_sides.json"
+    assert json.load(open(tmp_path / "bench_sides.json")) == full               # nothing is lost: the sides are in the file
+    # values keep 7 significant digits
+    assert abs(line["value"] / full["value"] - 1.0) < 1e-6
+
+
+def test_final_line_survives_oversized_fields_and_missing_parts():
+    b = _bench()
+    out = {"metric": "m", "value": 1.0, "unit": "expansions/s", "n_gpus": 8, "steps": 2, "warmup": 1, "ms_per_step": 3.0,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "w" * 500, "gather_note": "x" * 9000, "rccl_comm_info_per_rank": [[8, i, 8] for i in range(8)]},
+           "roofline": dict({"bound": "hbm", "achieved": 1.0, "peak": 8000.0, "unit": "GB/s", "frac": 1.25e-4, "traffic": None,
+                             "kernel": "k" * 300, "traffic_source": "s" * 5000}, **{k: "y" * 200 for k in b.ROOF_KEEP[6:]}),
+           "cpu_baseline": None}
+    line = b.compact_line(out, None)
+    s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= 4096 and json.loads(s)["roofline"]["frac"] == 1.25e-4 and line["cpu_baseline"] is None
+    assert "gather_note" not in line["config"] and "traffic_source" not in line["roofline"] and line["roofline"]["traffic"] is None
+
+
+def test_bound_names_the_roof_that_binds():
+    b = _bench()
+    assert b.roofline(8e7, 1.0, "k")["bound"] == "latency"                        # 0.01 of HBM, no counters: a dependent chain
+    assert b.roofline(8e7, 1.0, "k", valu_issue_frac=0.1)["bound"] == "latency"
+    assert b.roofline(8e7, 1.0, "k", valu_issue_frac=0.6)["bound"] == "valu_issue"
+    assert b.roofline(6e9, 1.0, "k", valu_issue_frac=0.3)["bound"] == "hbm"

@@ -15,7 +15,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(gpus, episodes, extra=(), one_gpu=False):
+    """-> the full record (bench_sides.json) with the parsed final stdout line under "_line" """
+    import tempfile
     env = dict(os.environ)
+    sides = os.path.join(tempfile.mkdtemp(prefix="auvp_bench_"), "bench_sides.json")
+    env["AUVP_BENCH_SIDES"] = sides
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     if one_gpu:
@@ -26,7 +30,19 @@ def _bench(gpus, episodes, extra=(), one_gpu=False):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, "rank 0 prints ONE JSON line, got %d" % len(lines)
-    return json.loads(lines[0])
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0], "the JSON line is the LAST line of stdout"
+    assert len(lines[0]) <= 4096, "the line the driver parses stays under 4 KB (%d)" % len(lines[0])
+    line = json.loads(lines[0])
+    assert line["sides_file"] == "bench_sides.json"
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    rf = line["roofline"]
+    assert rf["frac"] > 0 and rf["achieved"] > 0 and rf["peak"] == 8000.0 and "traffic" in rf and rf["kernel_ms"] > 0
+    assert all(not isinstance(v, (dict, list)) for v in rf.values())
+    full = json.load(open(sides))
+    assert abs(full["value"] / line["value"] - 1.0) < 1e-6 and full["n_gpus"] == line["n_gpus"]
+    full["_line"] = line
+    return full
 
 
 def test_two_ranks_on_one_gpu_shard_the_batch_and_report_per_rank():

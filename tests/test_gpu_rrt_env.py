@@ -127,7 +127,7 @@ def test_env_device_resident_loop_matches_host_loop():
     # the stand-in agent: an occupied bucket for every live environment, -1 for the finished ones; several calls differ
     picks = []
     for k in range(4):
-        b = devenv.policy_random_device(seed=7)
+        b = devenv.policy_random_device(seed=7 + k // 2)   # a pure function of (seed, environment, step count): 0 == 1, 2 == 3
         devenv.sync()
         b = b.cpu().numpy()
         hn = d["has_node"].cpu().numpy()
@@ -136,14 +136,20 @@ def test_env_device_resident_loop_matches_host_loop():
         live = np.flatnonzero(~dn)
         assert all(hn[e, b[e]] == 1 for e in live)
         picks.append(b.copy())
-    if (~dn).any() and (hn[~dn].sum(axis=1) > 3).any():
-        assert any(not np.array_equal(picks[0], p) for p in picks[1:])
+    assert np.array_equal(picks[0], picks[1]) and np.array_equal(picks[2], picks[3])   # no step in between: the same draw
+    many = (~dn) & (hn.sum(axis=1) > 3)
+    assert many.sum() >= 4, "the fixture must leave live environments with several occupied buckets"
+    assert not np.array_equal(picks[0][many], picks[2][many])                           # another seed redraws
 
 
-def test_env_device_loop_as_a_graph_equals_eager():
+@pytest.mark.parametrize("rows", [False, True])
+def test_env_device_loop_as_a_graph_equals_eager(rows, monkeypatch):
     """one step of the device-resident loop (stand-in agent + generate_one_node + observation + outcome) captured as a
     hipGraph and replayed n times == the same n steps enqueued one by one: the loop's step counter lives in HBM, so every
-    replay draws anew"""
+    replay draws anew.  rows: the four-episodes-per-wavefront kernel (AUVP_PRRT_ROWS=1; the default of large batches), whose
+    work counter must restart at every replay (a memset node) -- and eager steps AFTER the replays must still be right"""
+    if rows:
+        monkeypatch.setenv("AUVP_PRRT_ROWS", "1")
     from auv_sim_amd import synth
     from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
     from auv_sim_amd.rrt_env import RRTEnvBatch
@@ -162,9 +168,15 @@ def test_env_device_loop_as_a_graph_equals_eager():
             env.policy_random_device(seed=3)
             env.step_device()
         one_step()  # first-use allocations; also step 0 of both runs
+        if rows:
+            assert env._ctx.prrt_last_kernel() == "prrt_rows_kernel"
         if graph:
             gid = env.capture_step(one_step)
-            env.replay(gid, n_steps - 1)
+            env.replay(gid, n_steps - 1 - 6)
+            for _ in range(3):          # eager steps between and after replays of the same graph
+                one_step()
+            env.replay(gid, 2)
+            one_step()
         else:
             for _ in range(n_steps - 1):
                 one_step()

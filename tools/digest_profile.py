@@ -88,7 +88,11 @@ for key, (needles, units_field) in MEAS.items():
         rec["hbm_bytes_fetch_x2"] = 2 * rd + wr
     try:
         if side is None:
-            j = json.loads(open(os.path.join(src, "pmc@headline@FETCH_SIZE.json")).read().strip().splitlines()[-1])
+            full = os.path.join(src, "pmc@headline@FETCH_SIZE.sides.json")  # the full record (the stdout line is compact)
+            if os.path.exists(full):
+                j = json.load(open(full))
+            else:
+                j = json.loads(open(os.path.join(src, "pmc@headline@FETCH_SIZE.json")).read().strip().splitlines()[-1])
             rec["units"] = j["expansions_per_step"]
             # whole pass (expansion + leaf launch): SURVEY 8(d) B_exp x expansions; per kernel: roofline.algorithmic_bytes_per_launch
             # (expansion kernel) and roofline.leaf_compulsory_bytes
