@@ -18,9 +18,11 @@
 #define AUVP_LN2_64_HI 0x1.62e42fee00000p-7  /* ln2/64, 32 significant bits: N * HI is exact for |N| < 2^21 */
 #define AUVP_LN2_64_LO 0x1.a39ef35793c76p-39
 
-// 2^(j/64) = th + tl
-AUVP_HD void auvp_exp2_j64(int j, double* th, double* tl) {
-  static const double tbl[128] = {
+// 2^(j/64) = tbl[2 j] + tbl[2 j + 1] (hi + lo), 64 entries.  A kernel may keep a copy in LDS and pass that to the *_t
+// functions (pf_kernel.h: the per-lane lookup sits in the middle of a dependent chain, twice per particle and AUV).
+#define AUVP_EXP_TBL_DOUBLES 128
+AUVP_HD const double* auvp_exp_table() {
+  static const double tbl[AUVP_EXP_TBL_DOUBLES] = {
     0x1.0000000000000p+0, 0x0.0p+0,
     0x1.02c9a3e778061p+0, -0x1.19083535b085dp-56,
     0x1.059b0d3158574p+0, 0x1.d73e2a475b465p-55,
@@ -85,8 +87,7 @@ AUVP_HD void auvp_exp2_j64(int j, double* th, double* tl) {
     0x1.efa1bee615a27p+0, 0x1.dc7f486a4b6b0p-54,
     0x1.f50765b6e4540p+0, 0x1.9d3e12dd8a18bp-54,
     0x1.fa7c1819e90d8p+0, 0x1.74853f3a5931ep-55};
-  *th = tbl[2 * j];
-  *tl = tbl[2 * j + 1];
+  return tbl;
 }
 
 AUVP_HD double auvp_bits_to_double(unsigned long long u) {
@@ -95,8 +96,8 @@ AUVP_HD double auvp_bits_to_double(unsigned long long u) {
   return c.d;
 }
 
-// exp(hi + lo), |lo| << |hi|
-AUVP_HD double auvp_exp_hl(double hi, double lo) {
+// exp(hi + lo), |lo| << |hi|; tbl = auvp_exp_table() or a copy of it
+AUVP_HD double auvp_exp_hl_t(double hi, double lo, const double* tbl) {
   if (hi != hi) return hi;
   if (hi > 709.782712893384) return __builtin_inf();
   if (hi < -745.2) return 0.0;
@@ -110,8 +111,7 @@ AUVP_HD double auvp_exp_hl(double hi, double lo) {
   const long long k = (ni - j) / 64;
   const double q = r * r * (0.5 + r * (0x1.5555555555555p-3 + r * (0x1.5555555555555p-5 + r * (0x1.1111111111111p-7 + r * 0x1.6c16c16c16c17p-10))));
   const double p = r + (rt + q);                                // exp(r) - 1
-  double th, tl;
-  auvp_exp2_j64(j, &th, &tl);
+  const double th = tbl[2 * j], tl = tbl[2 * j + 1];
   const double res = th + (tl + th * p);
   if (k >= -1021 && k <= 1023) return res * auvp_bits_to_double((unsigned long long)(k + 1023) << 52);
   if (k > 1023) return res * 0x1p1023 * auvp_bits_to_double((unsigned long long)(k - 1023 + 1023) << 52);
@@ -119,11 +119,13 @@ AUVP_HD double auvp_exp_hl(double hi, double lo) {
   return (res * auvp_bits_to_double((unsigned long long)(k + 1000 + 1023) << 52)) * 0x1p-1000;
 }
 
+AUVP_HD double auvp_exp_hl(double hi, double lo) { return auvp_exp_hl_t(hi, lo, auvp_exp_table()); }
 AUVP_HD double auvp_exp(double x) { return auvp_exp_hl(x, 0.0); }
 
 // math.e ** z  (CPython float pow -> pow(E, z))
-AUVP_HD double auvp_pow_e(double z) {
+AUVP_HD double auvp_pow_e_t(double z, const double* tbl) {
   if (z == 0.0) return 1.0;
-  return auvp_exp_hl(z, z * AUVP_LN_E_M1);
+  return auvp_exp_hl_t(z, z * AUVP_LN_E_M1, tbl);
 }
+AUVP_HD double auvp_pow_e(double z) { return auvp_pow_e_t(z, auvp_exp_table()); }
 #endif  // AUVP_EXP_H

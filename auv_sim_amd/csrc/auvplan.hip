@@ -1033,7 +1033,7 @@ PrrtState* prrt_of(auvp_handle* h) {
 #include "astar_kernel.h"
 #include "astar_host.h"
 #include "sog_kernels.h"
-#include "pf_kernel.h"
+#include "pf_types.h"
 #include "pf_host.h"
 #include "compose_host.h"
 #include "gather_host.h"

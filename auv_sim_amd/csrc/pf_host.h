@@ -3,6 +3,14 @@
 #ifndef AUVP_PF_HOST_H
 #define AUVP_PF_HOST_H
 
+// the kernels live in pf_kernels.hip (a translation unit with its own compiler flags); these are its launchers
+extern "C" {
+int auvpi_pf_threads(void);
+size_t auvpi_pf_lds_bytes(int N);
+hipError_t auvpi_pf_create_launch(const auvp::PfDev* D, hipStream_t stream);
+hipError_t auvpi_pf_step_launch(const auvp::PfDev* D, hipStream_t stream);
+}
+
 namespace {
 
 struct PfState {
@@ -73,16 +81,14 @@ int auvp_pf_create_batch(auvp_handle* h, int32_t F, int32_t N, const double* sha
   if ((rc = upload(h, P.shark0, shark_xy0, (size_t)F * 2))) return rc;
   P.S = 0; P.A = 0;
   auvp::PfDev D = pf_dev(P);
-  const size_t lds = auvp::pf_lds_bytes(N);
-  HIPCHK(h, hipFuncSetAttribute((const void*)auvp::pf_create_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = auvpi_pf_lds_bytes(N);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  hipLaunchKernelGGL(auvp::pf_create_kernel, dim3(F), dim3(PF_T), lds, h->stream, D);
-  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, auvpi_pf_create_launch(&D, h->stream));
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  h->last_ms = ms; h->last_grid = F; h->last_block = PF_T; h->last_lds = (int)lds;
+  h->last_ms = ms; h->last_grid = F; h->last_block = 256; h->last_lds = (int)lds;
   P.ready = true;
   return AUVP_OK;
 }
@@ -160,31 +166,14 @@ int auvp_pf_run(auvp_handle* h, int32_t n_steps, int32_t n_auv, int32_t phases, 
     D.updated = P.updated.as<double>();
     D.choice = P.choice.as<int32_t>();
   }
-  const size_t lds = auvp::pf_lds_bytes(N);
-  // threads per filter, measured on MI355X at N = 1000 (4096 filters x 20 steps).  Round 1: 256 -> 11.6 ms, 1024 -> 14.4 ms
-  // (six barriers per MT19937 regeneration).  Round 4, regeneration without inner barriers: 256 threads (237 registers, one
-  // wavefront per SIMD and workgroup, two workgroups per CU by LDS) 9.2 ms -- one workgroup alone on a CU takes 0.94 of
-  // that: the step is a chain of dependent fp64 latencies, not issue bound (0.40 of the VALU issue slots); 512 threads held to
-  // 128 registers (four wavefronts per SIMD) 7.7 ms; 1024 (one workgroup per CU) 11.5 ms; 384 threads x 3 particles at 168
-  // registers (final kernel): 14.1 ms against 7.1 ms -- six wavefronts do not spread evenly over the four SIMDs
-#ifndef AUVP_PF_THREADS
-#define AUVP_PF_THREADS 512
-#endif
-  constexpr int T = AUVP_PF_THREADS, P1 = (1024 + T - 1) / T, P2 = (2048 + T - 1) / T;
+  const size_t lds = auvpi_pf_lds_bytes(N);
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-  if (N <= 1024) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)auvp::pf_step_kernel<T, P1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((auvp::pf_step_kernel<T, P1>), dim3(F), dim3(T), lds, h->stream, D);
-  } else {
-    HIPCHK(h, hipFuncSetAttribute((const void*)auvp::pf_step_kernel<T, P2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((auvp::pf_step_kernel<T, P2>), dim3(F), dim3(T), lds, h->stream, D);
-  }
-  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, auvpi_pf_step_launch(&D, h->stream));  // (threads per filter: pf_kernels.hip)
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  h->last_ms = ms; h->last_grid = F; h->last_block = AUVP_PF_THREADS; h->last_lds = (int)lds;
+  h->last_ms = ms; h->last_grid = F; h->last_block = auvpi_pf_threads(); h->last_lds = (int)lds;
   return AUVP_OK;
 }
 

@@ -24,30 +24,10 @@
 #ifndef AUVP_PF_KERNEL_H
 #define AUVP_PF_KERNEL_H
 #include "auvp_exp.h"
+#include "auvp_math_late.h"
+#include "pf_types.h"
 
 namespace auvp {
-
-enum { PF_PHASE_UPDATE = 1, PF_PHASE_WEIGHTS = 2, PF_PHASE_MEAN = 4 };
-enum { PF_OK = 0, PF_ERR_ANGLE = 1, PF_ERR_EMPTY = 2 };
-
-struct PfDev {
-  int32_t F, N, A, S, phases, _pad;
-  double* st;              // [F][5][N]  x, y, v, theta, weight per list position
-  int32_t* ent;            // [F][N]     object id of the list position (index drawn by the last correct)
-  int32_t* llen;           // [F]        bound of the object ids (len(list_of_new_particles) of the last correct)
-  uint32_t* mt;            // [F][624]
-  int32_t* mtpos;          // [F]
-  const double* shark0;    // [F][2]     (create)
-  const double* meas;      // [S][F][A][5]
-  const double* shark;     // [S][F][2]
-  double* mean;            // [S][F][2]
-  double* err;             // [S][F]
-  int32_t* out_len;        // [S][F]
-  int32_t* status;         // [F]
-  unsigned long long* ndraw;  // [F]
-  double* updated;         // [S][F][N][5] or null (diagnostic)
-  int32_t* choice;         // [S][F][N] or null (diagnostic)
-};
 
 #define PF_T 256
 #define PF_UPPER 0x80000000u
@@ -146,6 +126,19 @@ __device__ __forceinline__ double pf_block_max(double v, double* red, int tid) {
   return m;
 }
 
+// two maxima at once (the weights of two AUV measurements): same barriers as one
+template <int T>
+__device__ __forceinline__ void pf_block_max2(double& v0, double& v1, double* red, int tid) {
+  v0 = auvp::wave_max_f64(v0);
+  v1 = auvp::wave_max_f64(v1);
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = v0; red[20 + (tid >> 6)] = v1; }
+  __syncthreads();
+  double m0 = red[0], m1 = red[20];
+  for (int w = 1; w < T / 64; w++) { m0 = red[w] > m0 ? red[w] : m0; m1 = red[20 + w] > m1 ? red[20 + w] : m1; }
+  v0 = m0; v1 = m1;
+}
+
 // exclusive scan of one int per thread over the workgroup; *total = sum
 template <int T>
 __device__ __forceinline__ int pf_block_scan(int v, int* red, int tid, int* total) {
@@ -160,12 +153,29 @@ __device__ __forceinline__ int pf_block_scan(int v, int* red, int tid, int* tota
   return base + inc - v;
 }
 
+// weight of one particle for one AUV measurement (:92-116, 285-300): calc_particle_alpha, calc_particle_range, the two
+// Gaussians
+__device__ __forceinline__ double pf_weight(double px, double py, double mx, double my, double mth, double auv_alpha, double auv_range,
+                                            const double* etab, int& status) {
+  double pa = auvp_atan2_late((-my + py), (px + -mx)) - mth;     // calc_particle_alpha
+  if (!pf_angle_wrap(pa)) status = PF_ERR_ANGLE;
+  const double dy = my - py, dx = mx - px;
+  const double pr = auvp_sqrt(dy * dy + dx * dx);                // calc_particle_range
+  double d = pa - auv_alpha;
+  if (!pf_angle_wrap(d)) status = PF_ERR_ANGLE;
+  const double constant = 1.2533141375;
+  const double fa = .001 + (1 / (constant) * (auvp_pow_e_t((-(d * d)) / (0.5), etab)));
+  const double dr = pr - auv_range;
+  const double fw = .001 + (1 / (100 * constant) * (auvp_pow_e_t((-(dr * dr)) / (20000), etab)));
+  return fw * fa;
+}
+
 struct PfLds {
-  uint32_t *mt, *mt2; int* red_i; double* red_d; double *sx, *sy, *sv, *sth, *sw; int* off; uint32_t* wbuf; int* slot;
+  uint32_t *mt, *mt2; int* red_i; double* red_d; double* etab; double *sx, *sy, *sv, *sth, *sw; int* off; uint32_t* wbuf; int* slot;
 };
 __host__ __device__ inline size_t pf_lds_bytes(int N) {
   const size_t n2 = (size_t)(N + 2) & ~(size_t)1;
-  return 2 * 624 * 4 + 32 * 4 + 40 * 8 + 5 * n2 * 8 + n2 * 4 + (size_t)5 * n2 * 4;
+  return 2 * 624 * 4 + 32 * 4 + 40 * 8 + AUVP_EXP_TBL_DOUBLES * 8 + 5 * n2 * 8 + n2 * 4 + (size_t)5 * n2 * 4;
 }
 __device__ __forceinline__ PfLds pf_carve(unsigned char* smem, int N) {
   const size_t n2 = (size_t)(N + 2) & ~(size_t)1;
@@ -174,7 +184,8 @@ __device__ __forceinline__ PfLds pf_carve(unsigned char* smem, int N) {
   L.mt2 = L.mt + 624;
   L.red_i = (int*)(L.mt2 + 624);
   L.red_d = (double*)(L.red_i + 32);  // red_i [0,16): reductions, 16: choice cursor
-  L.sx = L.red_d + 40;                // red_d [0,16): reductions, 16..17: means
+  L.etab = L.red_d + 40;              // red_d [0,16): reductions, 16..17: means; etab: auvp_exp_table() (pf_step_kernel)
+  L.sx = L.etab + AUVP_EXP_TBL_DOUBLES;
   L.sy = L.sx + n2; L.sv = L.sy + n2; L.sth = L.sv + n2; L.sw = L.sth + n2;
   L.off = (int*)(L.sw + n2);
   L.wbuf = (uint32_t*)(L.off + n2);  // 5*n2 words: the RNG window, then the alias slots, then copy -> source particle (off: the drawn indices)
@@ -216,18 +227,21 @@ template <int T, int PPT>
 // per SIMD, one beyond)
 __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_step_kernel(PfDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int f = blockIdx.x, tid = threadIdx.x, N = D.N, A = D.A;
+  const int f = blockIdx.x, tid0 = threadIdx.x, N = D.N, A = D.A;
+  int tid = tid0;
   PfLds L = pf_carve(smem, N);
   PfRng r{L.mt, L.mt2, D.mtpos[f], 0ull};
   double* st = D.st + (size_t)f * 5 * N;
-  for (int i = tid; i < 624; i += T) L.mt[i] = D.mt[(size_t)f * 624 + i];
-  for (int i = tid; i < N; i += T) {
+  _Pragma("unroll 1") for (int i = tid; i < 624; i += T) L.mt[i] = D.mt[(size_t)f * 624 + i];
+  if (tid < AUVP_EXP_TBL_DOUBLES) L.etab[tid] = auvp_exp_table()[tid];  // 1 KB: the exp table's per-lane lookups from LDS
+  _Pragma("unroll 1") for (int i = tid; i < N; i += T) {
     L.sx[i] = st[i]; L.sy[i] = st[N + i]; L.sv[i] = st[2 * N + i]; L.sth[i] = st[3 * N + i]; L.sw[i] = st[4 * N + i];
   }
-  int e[PPT];
-  const int p0 = tid * PPT;
+  // the object id of a list position = the index the last `correct` drew for it: it lives in L.off (the choice array, only
+  // rewritten by the next correct), not in registers across the step loop
+  int p0 = tid * PPT;
 #pragma unroll
-  for (int j = 0; j < PPT; j++) e[j] = (p0 + j < N) ? D.ent[(size_t)f * N + p0 + j] : 0;
+  for (int j = 0; j < PPT; j++) if (p0 + j < N) L.off[p0 + j] = D.ent[(size_t)f * N + p0 + j];
   int llen = D.llen[f];
   int status = D.status[f];
   __syncthreads();
@@ -239,6 +253,10 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
 #endif
 
   for (int s = 0; s < D.S; s++) {
+    // the thread id through an opaque move once per step: every per-thread LDS address is formed from it INSIDE the step --
+    // hoisted out of the step loop (dozens of loop-invariant address registers) they were what the allocator spilled
+    __asm__ volatile("" : "+v"(tid));
+    p0 = tid * PPT;
     if (D.phases & PF_PHASE_UPDATE) {
       // ---- create_and_update: list position p consumes uniforms 2p, 2p+1 of this step
       pf_gen_words<T>(r, L.wbuf, 4 * N, tid);
@@ -250,16 +268,16 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
         if (p < N) { u0[j] = pf_double(L.wbuf[4 * p], L.wbuf[4 * p + 1]); u1[j] = pf_double(L.wbuf[4 * p + 2], L.wbuf[4 * p + 3]); }
       }
       __syncthreads();
-      for (int i = tid; i < llen; i += T) L.slot[i] = 0x7fffffff;
+      _Pragma("unroll 1") for (int i = tid; i < llen; i += T) L.slot[i] = 0x7fffffff;
       __syncthreads();
       // rounds: every pending position offers ((4096 - round) << 12 | position) to its object's slot with atomicMin -- a later
       // round's offers are below every earlier one, so the table is not reset in between; the smallest pending position of an
       // object is applied
       static_assert(T * PPT <= 4096, "positions take 12 bits of a slot");
-      int lead[PPT];
+      int lead[PPT], e[PPT];
       unsigned pending = 0;
 #pragma unroll
-      for (int j = 0; j < PPT; j++) if (p0 + j < N) pending |= 1u << j;
+      for (int j = 0; j < PPT; j++) { e[j] = 0; if (p0 + j < N) { pending |= 1u << j; e[j] = L.off[p0 + j]; } }
       for (int rd = 0;; rd++) {
         const int kb = (4096 - rd) << 12;
 #pragma unroll
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
       __syncthreads();
       if (D.updated) {
         double* u = D.updated + ((size_t)s * D.F + f) * N * 5;
-        for (int i = tid; i < N; i += T) { u[5 * i] = L.sx[i]; u[5 * i + 1] = L.sy[i]; u[5 * i + 2] = L.sv[i]; u[5 * i + 3] = L.sth[i]; u[5 * i + 4] = L.sw[i]; }
+        _Pragma("unroll 1") for (int i = tid; i < N; i += T) { u[5 * i] = L.sx[i]; u[5 * i + 1] = L.sy[i]; u[5 * i + 2] = L.sv[i]; u[5 * i + 3] = L.sth[i]; u[5 * i + 4] = L.sw[i]; }
       }
       // positions are independent copies again after correct; until then the shared object id stays
       PF_STAMP(1)
@@ -309,38 +327,59 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
     if (D.phases & PF_PHASE_WEIGHTS) {
       // ---- update_weights: per AUV measurement, weight of every particle (:285-300)
       // (the per-AUV lists stay in registers: a particle's weight is the sum of its normalised entries in AUV order, :302-305)
+      // One particle at a time through the transcendental chain (atan2, two pow, sqrt): the loop over a thread's positions is
+      // NOT unrolled and the per-AUV weight goes through LDS (wq: the RNG window's space, idle between create_and_update and
+      // correct), so one instance of the chain is live at a time -- unrolled over PPT with the weights in registers the
+      // 128-VGPR budget spilled 132 B per lane (2 GB of scratch write-back per launch, profiles/r4_pf_sog.md).
       double nw[PPT];
 #pragma unroll
       for (int j = 0; j < PPT; j++) nw[j] = 0;
-      for (int a = 0; a < A; a++) {
-        double wv[PPT];
-        const double* m = D.meas + (((size_t)s * D.F + f) * A + a) * 5;
-        const double mx = m[0], my = m[1], mth = m[2], auv_alpha = m[3], auv_range = m[4];
-        double lmax = -__builtin_inf();
-#pragma unroll
+      double* wq = reinterpret_cast<double*>(L.wbuf);
+      const double* mbase = D.meas + (((size_t)s * D.F + f) * A) * 5;
+      int a = 0;
+#ifdef AUVP_PF_AUV_PAIRS
+      // two AUV measurements per trip: two independent chains per particle (the chain's latency, not issue, bounds the step)
+      // and one pair of barriers for both maxima; the sums below still add in AUV order
+      double* wq1 = wq + (((size_t)N + 1) & ~(size_t)1);
+      for (; a + 2 <= A; a += 2) {
+        const double* m = mbase + (size_t)a * 5;
+        const double mx0 = m[0], my0 = m[1], mth0 = m[2], al0 = m[3], rg0 = m[4];
+        const double mx1 = m[5], my1 = m[6], mth1 = m[7], al1 = m[8], rg1 = m[9];
+        double lmax0 = -__builtin_inf(), lmax1 = -__builtin_inf();
+#pragma unroll 1
         for (int j = 0; j < PPT; j++) {
           const int p = p0 + j;
           if (p < N) {
             const double px = L.sx[p], py = L.sy[p];
-            double pa = auvp_atan2((-my + py), (px + -mx)) - mth;     // calc_particle_alpha
-            if (!pf_angle_wrap(pa)) status = PF_ERR_ANGLE;
-            const double dy = my - py, dx = mx - px;
-            const double pr = auvp_sqrt(dy * dy + dx * dx);           // calc_particle_range
-            double d = pa - auv_alpha;
-            if (!pf_angle_wrap(d)) status = PF_ERR_ANGLE;
-            const double constant = 1.2533141375;
-            const double fa = .001 + (1 / (constant) * (auvp_pow_e((-(d * d)) / (0.5))));
-            const double dr = pr - auv_range;
-            const double fw = .001 + (1 / (100 * constant) * (auvp_pow_e((-(dr * dr)) / (20000))));
-            const double w = fw * fa;
-            wv[j] = w;
+            const double w0 = pf_weight(px, py, mx0, my0, mth0, al0, rg0, L.etab, status);
+            const double w1 = pf_weight(px, py, mx1, my1, mth1, al1, rg1, L.etab, status);
+            wq[p] = w0; wq1[p] = w1;
+            lmax0 = w0 > lmax0 ? w0 : lmax0;
+            lmax1 = w1 > lmax1 ? w1 : lmax1;
+          }
+        }
+        pf_block_max2<T>(lmax0, lmax1, L.red_d, tid);
+#pragma unroll
+        for (int j = 0; j < PPT; j++) if (p0 + j < N) { nw[j] += (1 / lmax0) * wq[p0 + j]; nw[j] += (1 / lmax1) * wq1[p0 + j]; }
+      }
+#endif
+      for (; a < A; a++) {
+        const double* m = mbase + (size_t)a * 5;
+        const double mx = m[0], my = m[1], mth = m[2], auv_alpha = m[3], auv_range = m[4];
+        double lmax = -__builtin_inf();
+#pragma unroll 1
+        for (int j = 0; j < PPT; j++) {
+          const int p = p0 + j;
+          if (p < N) {
+            const double w = pf_weight(L.sx[p], L.sy[p], mx, my, mth, auv_alpha, auv_range, L.etab, status);
+            wq[p] = w;   // (read back below by the thread that wrote it: no barrier needed for wq itself)
             lmax = w > lmax ? w : lmax;
           }
         }
         const double den = pf_block_max<T>(lmax, L.red_d, tid);
         // normalize (:133-139) in place
 #pragma unroll
-        for (int j = 0; j < PPT; j++) if (p0 + j < N) nw[j] += (1 / den) * wv[j];
+        for (int j = 0; j < PPT; j++) if (p0 + j < N) nw[j] += (1 / den) * wq[p0 + j];
       }
       PF_STAMP(2)
       double lmax = -__builtin_inf();
@@ -372,7 +411,7 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
       PF_STAMP(3)
       int* cho = L.off;
       if (len == 1) {
-        for (int i = tid; i < N; i += T) cho[i] = 0;  // randint(0, 1): no draw
+        _Pragma("unroll 1") for (int i = tid; i < N; i += T) cho[i] = 0;  // randint(0, 1): no draw
         __syncthreads();
       } else {
         const uint32_t rng = (uint32_t)len - 1u;
@@ -415,22 +454,25 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
       PF_STAMP(4)
       if (D.choice) for (int i = tid; i < N; i += T) D.choice[((size_t)s * D.F + f) * N + i] = cho[i];
       // ---- the new list: position n = copy of the source of list_of_new_particles[cho[n]]
-      double gx[PPT], gy[PPT], gv[PPT], gt[PPT], gw[PPT];
+      // in two halves (x, y / v, theta, weight): fewer doubles live across each barrier (all five spilled four of them)
+      int lo[PPT];
 #pragma unroll
-      for (int j = 0; j < PPT; j++) {
-        const int n = p0 + j;
-        if (n < N) {
-          const int x = cho[n];
-          const int lo = inv[x];
-          gx[j] = L.sx[lo]; gy[j] = L.sy[lo]; gv[j] = L.sv[lo]; gt[j] = L.sth[lo]; gw[j] = L.sw[lo];
-          e[j] = x;
-        }
+      for (int j = 0; j < PPT; j++) lo[j] = (p0 + j < N) ? inv[cho[p0 + j]] : 0;
+      {
+        double gx[PPT], gy[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; j++) if (p0 + j < N) { gx[j] = L.sx[lo[j]]; gy[j] = L.sy[lo[j]]; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PPT; j++) if (p0 + j < N) { L.sx[p0 + j] = gx[j]; L.sy[p0 + j] = gy[j]; }
       }
-      __syncthreads();
+      {
+        double gv[PPT], gt[PPT], gw[PPT];
 #pragma unroll
-      for (int j = 0; j < PPT; j++) {
-        const int n = p0 + j;
-        if (n < N) { L.sx[n] = gx[j]; L.sy[n] = gy[j]; L.sv[n] = gv[j]; L.sth[n] = gt[j]; L.sw[n] = gw[j]; }
+        for (int j = 0; j < PPT; j++) if (p0 + j < N) { gv[j] = L.sv[lo[j]]; gt[j] = L.sth[lo[j]]; gw[j] = L.sw[lo[j]]; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PPT; j++) if (p0 + j < N) { L.sv[p0 + j] = gv[j]; L.sth[p0 + j] = gt[j]; L.sw[p0 + j] = gw[j]; }
       }
       llen = len;
       if (tid == 0) D.out_len[(size_t)s * D.F + f] = len;
@@ -444,6 +486,7 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
         const double* src = tid == 0 ? L.sx : L.sy;
         double sum = 0;
         int i = 0;
+#ifndef AUVP_PF_MEAN_PIPE
         for (; i + 16 <= N; i += 16) {  // 16 LDS reads in flight, then the 16 dependent adds in list order
           double v[16];
 #pragma unroll
@@ -451,6 +494,36 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
 #pragma unroll
           for (int k = 0; k < 16; k++) sum += v[k];
         }
+#else
+        // the MB dependent adds of one block run while the next block's MB LDS reads are in flight (two register blocks)
+#ifndef AUVP_PF_MEAN_BLOCK
+#define AUVP_PF_MEAN_BLOCK 8
+#endif
+        constexpr int MB = AUVP_PF_MEAN_BLOCK;
+        double va[MB], vb[MB];
+        if (N >= MB) {
+#pragma unroll
+          for (int k = 0; k < MB; k++) va[k] = src[k];
+        }
+#pragma unroll 1
+        for (; i + 2 * MB <= N; i += 2 * MB) {
+#pragma unroll
+          for (int k = 0; k < MB; k++) vb[k] = src[i + MB + k];
+#pragma unroll
+          for (int k = 0; k < MB; k++) sum += va[k];
+          if (i + 3 * MB <= N) {
+#pragma unroll
+            for (int k = 0; k < MB; k++) va[k] = src[i + 2 * MB + k];
+          }
+#pragma unroll
+          for (int k = 0; k < MB; k++) sum += vb[k];
+        }
+        if (i + MB <= N) {  // va holds [i, i + MB): loaded up front (i = 0) or by the last trip
+#pragma unroll
+          for (int k = 0; k < MB; k++) sum += va[k];
+          i += MB;
+        }
+#endif
         for (; i < N; i++) sum += src[i];
         L.red_d[16 + (tid >> 6)] = sum / N;
       }
@@ -469,12 +542,12 @@ __global__ __launch_bounds__(T, (T * PPT <= 1280 ? 2 : 1) * T / 256) void pf_ste
   }
 
   // ---- persist
-  for (int i = tid; i < 624; i += T) D.mt[(size_t)f * 624 + i] = r.mt[i];
-  for (int i = tid; i < N; i += T) {
+  _Pragma("unroll 1") for (int i = tid; i < 624; i += T) D.mt[(size_t)f * 624 + i] = r.mt[i];
+  _Pragma("unroll 1") for (int i = tid; i < N; i += T) {
     st[i] = L.sx[i]; st[N + i] = L.sy[i]; st[2 * N + i] = L.sv[i]; st[3 * N + i] = L.sth[i]; st[4 * N + i] = L.sw[i];
   }
 #pragma unroll
-  for (int j = 0; j < PPT; j++) if (p0 + j < N) D.ent[(size_t)f * N + p0 + j] = e[j];
+  for (int j = 0; j < PPT; j++) if (p0 + j < N) D.ent[(size_t)f * N + p0 + j] = L.off[p0 + j];
   if (__syncthreads_or(status != PF_OK) && tid == 0 && D.status[f] == PF_OK) D.status[f] = status != PF_OK ? status : PF_ERR_ANGLE;
   if (tid == 0) { D.mtpos[f] = r.pos; D.llen[f] = llen; D.ndraw[f] += r.drawn; }
 #ifdef AUVP_PF_DIAG

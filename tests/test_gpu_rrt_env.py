@@ -137,9 +137,43 @@ def test_env_device_resident_loop_matches_host_loop():
         assert all(hn[e, b[e]] == 1 for e in live)
         picks.append(b.copy())
     assert np.array_equal(picks[0], picks[1]) and np.array_equal(picks[2], picks[3])   # no step in between: the same draw
+
+
+def test_stand_in_agent_is_a_pure_function_of_seed_environment_and_step_count():
+    """auvp_prrt_policy_random_dev (include/auvplan.h): calls repeated without a step return the same picks, another seed
+    redraws, a step redraws; has_node_dev is not read and may be NULL"""
+    import ctypes as C
+    env = _small_env(E=32, max_nodes=64)
+    env.reset()
+    d = env.device_buffers()
+    for _ in range(12):                                   # grow the trees: several occupied buckets per environment
+        env.policy_random_device(seed=5)
+        env.step_device()
+    env.sync()
+    hn = d["has_node"].cpu().numpy()
+    dn = d["done"].cpu().numpy().astype(bool)
     many = (~dn) & (hn.sum(axis=1) > 3)
-    assert many.sum() >= 4, "the fixture must leave live environments with several occupied buckets"
-    assert not np.array_equal(picks[0][many], picks[2][many])                           # another seed redraws
+    assert many.sum() >= 8, "the fixture must leave live environments with several occupied buckets"
+
+    def pick(seed, null_has_node=False):
+        if null_has_node:
+            env._ctx._chk(env._L.auvp_prrt_policy_random_dev(env._ctx.h, C.c_void_p(0), int(seed), C.c_void_p(d["bucket"].data_ptr())))
+            b = d["bucket"]
+        else:
+            b = env.policy_random_device(seed=seed)
+        env.sync()
+        return b.cpu().numpy().copy()
+    a, a2, a3, b = pick(7), pick(7), pick(7, null_has_node=True), pick(8)
+    assert np.array_equal(a, a2) and np.array_equal(a, a3)
+    assert not np.array_equal(a[many], b[many])
+    live = np.flatnonzero(~dn)
+    assert all(hn[e, a[e]] == 1 for e in live) and (a[dn] == -1).all()
+    env.step_device()                                     # one step: the step count moved, the same seed draws anew
+    env.sync()
+    dn2 = d["done"].cpu().numpy().astype(bool)
+    c = pick(8)
+    still = many & ~dn2
+    assert still.sum() >= 4 and not np.array_equal(b[still], c[still])
 
 
 @pytest.mark.parametrize("rows", [False, True])

@@ -11,10 +11,14 @@ import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
-src = os.path.join(REPO, "auv_sim_amd", "csrc", "auvplan.hip")
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-       "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", src]
-txt = subprocess.run(cmd, capture_output=True, text=True).stderr
+extra = sys.argv[2:]  # extra compiler flags (experiments), e.g. -mllvm -disable-machine-licm
+sys.path.insert(0, REPO)
+import __graft_entry__ as ge  # the product's translation units and flags
+txt = ""
+for unit, unit_flags in ge.UNITS:
+    cmd = [ge.HIPCC] + ge.HIP_FLAGS + unit_flags + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null",
+                                                            os.path.join(ge.CSRC, unit)]
+    txt += subprocess.run(cmd, capture_output=True, text=True).stderr
 demangle = subprocess.run(["c++filt"], input="\n".join(re.findall(r"Function Name: (\S+)", txt)),
                           capture_output=True, text=True).stdout.split("\n")
 blocks = re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
@@ -29,9 +33,10 @@ for b, name in zip(blocks, demangle):
 out = os.path.join(REPO, "profiles", "%s_kernel_resources.md" % tag)
 with open(out, "w") as f:
     f.write("# Kernel resources as the compiler reports them (%s)\n\n" % tag)
-    f.write("`hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Rpass-analysis=kernel-resource-usage` on `auv_sim_amd/csrc/auvplan.hip`\n"
+    f.write("`hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Rpass-analysis=kernel-resource-usage` on the translation units of\n"
+            "`__graft_entry__.UNITS` with their product flags (`pf_kernels.hip`: `-mllvm -disable-machine-licm`)%s\n"
             "(ROCm 7.2).  Occupancy = waves per SIMD the register allocation admits (dynamic LDS can lower it further: see\n"
-            "DESIGN.md per kernel).  Regenerate with `python tools/resource_usage.py <tag>`.\n\n")
+            "DESIGN.md per kernel).  Regenerate with `python tools/resource_usage.py <tag>`.\n\n" % ((", extra flags `%s`" % " ".join(extra)) if extra else ""))
     f.write("| kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | waves/SIMD (registers) | static LDS B |\n|---|---|---|---|---|---|---|\n")
     for r in rows:
         f.write("| `%s` | %s | %s | %s | %s | %s | %s |\n" % r)
