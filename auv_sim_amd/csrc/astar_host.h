@@ -74,7 +74,7 @@ int astar_build_world(auvp_handle* h, AstarState& S) {
   // on the row only, edges ascending, neighbouring intervals touching at most, no degenerate widths (astar_kernel.h)
   int g_ncol = 0, g_nrow = 0;
   std::vector<double> gtab;
-  if (C > 0 && !getenv("AUVP_ASTAR_NO_GRID")) {
+  if (C > 0 && !h->opt_on(OPT_ASTAR_NO_GRID)) {
     int nc = 1;
     while (nc < C && rc[4 * (size_t)nc + 1] == rc[1] && rc[4 * (size_t)nc + 3] == rc[3]) nc++;
     if (C % nc == 0) {
@@ -158,7 +158,7 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
   if (S.world_version != h->world_version && (rc = astar_build_world(h, S))) return rc;
   auvp::AstarParamsDev& P = S.P;
   P.variant = p->variant; P.cap_nodes = p->cap_nodes; P.flags = flags;
-  if (getenv("AUVP_ASTAR_NO_LIST") && atoi(getenv("AUVP_ASTAR_NO_LIST")) != 0) P.flags |= AUVP_KFLAG_ASTAR_NO_LIST;
+  if (h->opt_on(OPT_ASTAR_NO_LIST)) P.flags |= AUVP_KFLAG_ASTAR_NO_LIST;
   P.cap_exp = (flags & AUVP_FLAG_ITER_LOG) ? p->cap_nodes : 0;
   for (int i = 0; i < 4; i++) { P.box[i] = p->box[i]; P.w[i] = p->w[i]; }
   P.velocity = p->velocity;
@@ -207,6 +207,9 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
     HIPCHK(h, S.exp_log.reserve((size_t)E * P.cap_exp * 8 * sizeof(double)));
     B.exp_log = S.exp_log.as<double>();
   }
+  B.pipe_fail = h->pipe_fail_dev;
+  h->pipe_clear();
+  h->pipe_fallback_last = 0;
   const int grid = (E + auvp::ASTAR_WAVES - 1) / auvp::ASTAR_WAVES;
   bool pair = false;
   switch (P.variant) {
@@ -214,11 +217,12 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
     case 1: hipLaunchKernelGGL(auvp::astar_kernel<1>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
     case 2: hipLaunchKernelGGL(auvp::astar_kernel<2>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E); break;
     default: {
-      // latency batches on a product grid: a second wavefront per instance (astar_kernel.h, PAIR); AUVP_ASTAR_PAIR=0 / 1 forces the choice
+      // latency batches on a product grid: a second wavefront per instance (astar_kernel.h, PAIR); option ASTAR_PAIR = 0 / 1
+      // forces the choice.  Not with a visited array the caller carries over (KEEP_VISITED): a batch that had to be repeated on
+      // the one-wavefront kernel (pipeline fallback, below) could not get it back.
       int n_cu = 256;
       (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
-      const char* penv = getenv("AUVP_ASTAR_PAIR");
-      pair = S.W.g_ncol > 0 && (penv ? atoi(penv) != 0 : E <= (size_t)8 * (size_t)(n_cu > 0 ? n_cu : 256));
+      pair = S.W.g_ncol > 0 && !(flags & AUVP_FLAG_KEEP_VISITED) && h->opt_flag(OPT_ASTAR_PAIR, E <= (size_t)8 * (size_t)(n_cu > 0 ? n_cu : 256));
       if (pair) hipLaunchKernelGGL((auvp::astar_kernel<3, true>), dim3(grid), dim3(auvp::ASTAR_WAVES * 128), 0, h->stream, S.W, P, B, (int)E);
       else hipLaunchKernelGGL(auvp::astar_kernel<3>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E);
       break;
@@ -227,6 +231,30 @@ int auvp_astar_batch(auvp_handle* h, int32_t E, const double* starts, const doub
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (pair && h->pipe_failed()) {
+    // the searching wavefront of some instance stopped waiting for its partner (AUVP_ERR_PIPELINE): the batch is searched again
+    // by the one-wavefront kernel, on a fresh epoch of the visited words (same results: tests/test_gpu_astar.py)
+    std::vector<auvp::AstarSummary> sm((size_t)E);
+    HIPCHK(h, hipMemcpy(sm.data(), B.summary, sm.size() * sizeof(auvp::AstarSummary), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (const auvp::AstarSummary& r : sm) n += r.status == AUVP_ERR_PIPELINE ? 1 : 0;
+    h->pipe_clear();
+    if (n > 0 && h->opt_flag(OPT_PIPE_FALLBACK, true)) {
+      h->pipe_fallback_last = n;
+      h->pipe_fallback_total += n;
+      if (S.epoch >= 255u) {
+        HIPCHK(h, hipMemsetAsync(S.cellinfo.p, 0, S.cellinfo.cap, h->stream));
+        S.epoch = 0;
+      }
+      S.epoch++;
+      P.epoch = S.epoch;
+      pair = false;
+      hipLaunchKernelGGL(auvp::astar_kernel<3>, dim3(grid), dim3(auvp::ASTAR_WAVES * 64), 0, h->stream, S.W, P, B, (int)E);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipEventRecord(h->ev1, h->stream));  // (the time the caller waited: both searches)
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+  }
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;

@@ -107,6 +107,7 @@ struct AstarBuffers {
   int32_t* hab_left;     // [E][H]
   double* exp_log;       // optional [E][cap_exp][8]
   AstarSummary* summary; // [E]
+  int32_t* pipe_fail;    // host-mapped word, set to 1 by an instance that ends with AUVP_ST_PIPELINE (null: not reported)
 };
 
 __device__ __forceinline__ double astar_sqdist(double ax, double ay, double bx, double by) {
@@ -156,7 +157,6 @@ struct AstarPairBox {
   double len_[8], pr[8], tn[8];
   int ts_[8], tb[8], key[8];
 };
-constexpr int ASTAR_SPIN_LIMIT = 1 << 24;
 
 // one instantiation per variant (VARIANT = AstarParamsDev::variant): the other variants' state and branches are gone
 template <int VARIANT, bool PAIR = false>
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
           const int sm = lds_peek(&box->seq_m);
           if (lds_peek(&box->stop)) { stop = true; break; }
           if (uni(sm) == e + 1) break;
-          if (++spins > ASTAR_SPIN_LIMIT) { stop = true; break; }
+          if (++spins > pipe_spin_limit()) { stop = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
         if (stop) break;
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         {
           int spins = 0;
           while (uni(lds_peek(&box->seq_x)) != n_exp) {
-            if (++spins > ASTAR_SPIN_LIMIT) { status = -9; break; }
+            if (++spins > pipe_spin_limit()) { status = AUVP_ST_PIPELINE; break; }
             __builtin_amdgcn_s_sleep(1);
           }
           if (status) break;
@@ -778,6 +778,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
   for (int i = lane; i < n_hopen; i += 64) B.hab_left[(size_t)ep * (H > 0 ? H : 1) + i] = hopen[i];
   if (lane == 0) {
     AstarSummary& s = B.summary[ep];
+    pipe_report(B.pipe_fail, status);
     s.status = status; s.found = found >= 0 ? 1 : 0; s.n_nodes = n_nodes; s.n_expansions = n_exp; s.n_children = n_children;
     int L = 0;
     for (int m = found; m >= 0; m = (int)(__double_as_longlong(rec[2 * (size_t)m + 1].w) & 0xffffffffll)) L++;

@@ -159,6 +159,7 @@ struct RrtBuffers {
   // their ancestors), path points of those nodes, path elements re-summed in the reference's order, leaves re-summed --
   // the units of the leaf pass's compulsory-traffic figure (bench.py)
   unsigned long long* leaf_stats;
+  int32_t* pipe_fail;  // host-mapped word, set to 1 by an episode that ends with AUVP_ST_PIPELINE (null: not reported)
 };
 
 }  // namespace auvp

@@ -28,10 +28,45 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 // + `s_waitcnt vmcnt(0) lgkmcnt(0)` per poll -- every look at a flag also waits for the wavefront's outstanding global loads
 // and stores.  With the explicit LDS pointer they are ds_read / ds_write, which wait on the LDS counter alone.
 #define AUVP_LDS_PTR(T, p) ((volatile __attribute__((address_space(3))) T*)(p))
+// a speculative pipeline gave up (a bounded wait ran out: status AUVP_ST_PIPELINE): tell the host through its mapped flag, so
+// that it re-runs the batch on the one-wavefront kernel (auvplan.hip: pipeline fallback) -- the status alone would need a
+// read-back of every summary after every launch
+#define AUVP_ST_GENERATOR (-7)
+#define AUVP_ST_PIPELINE (-9)
+__device__ __forceinline__ void pipe_report(int32_t* flag, int status) {
+  if (status == AUVP_ST_PIPELINE && flag) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// polls before a bounded wait of a speculative pipeline gives up (a protocol bug or a descheduled wavefront must not hang
+// the GPU): ~seconds.  -DAUVP_PIPE_DIAG builds (libauvplan_diag.so, tests only) take the limit and a delay injection from a
+// device table the host fills at auvp_create from AUVP_DIAG_SPIN / AUVP_DIAG_JITTER:
+//   [0] spin limit (0: the default)   [1] jitter mode: 0 off, 1 wavefronts with wave % [2] == [3], 2 wavefronts with wave / [2] == [3]
+//   [4] longest delay in units of s_sleep 1 (~64 clocks)   [5] seed
+// pipe_jitter() runs before every hand-over word (lds_poke / lds_poke64): a pseudo-random delay of 0 .. [4] units on the chosen
+// stage's wavefronts -- it moves the relative speed of the stages around, which is what the redo paths depend on.
+#define AUVP_PIPE_SPIN_DEFAULT (1 << 24)
+#ifdef AUVP_PIPE_DIAG
+__device__ int auvp_diag_cfg[8];
+__device__ __forceinline__ int pipe_spin_limit() { const int v = auvp_diag_cfg[0]; return v > 0 ? v : AUVP_PIPE_SPIN_DEFAULT; }
+__device__ __forceinline__ void pipe_jitter() {
+  const int mode = auvp_diag_cfg[1];
+  if (!mode) return;
+  const int wave = (int)(threadIdx.x >> 6), mod = auvp_diag_cfg[2] > 0 ? auvp_diag_cfg[2] : 1;
+  if ((mode == 1 ? wave % mod : wave / mod) != auvp_diag_cfg[3]) return;
+  uint32_t x = (uint32_t)__builtin_amdgcn_s_memtime() * 2654435761u ^ ((uint32_t)auvp_diag_cfg[5] + blockIdx.x * 0x9e3779b9u + (uint32_t)wave * 0x85ebca6bu);
+  x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+  const int n = (int)(x % (uint32_t)(auvp_diag_cfg[4] + 1));
+  for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(1);
+}
+#else
+__device__ __forceinline__ constexpr int pipe_spin_limit() { return AUVP_PIPE_SPIN_DEFAULT; }
+__device__ __forceinline__ void pipe_jitter() {}
+#endif
+
 __device__ __forceinline__ int lds_peek(const int* p) { return *AUVP_LDS_PTR(const int, p); }
-__device__ __forceinline__ void lds_poke(int* p, int v) { *AUVP_LDS_PTR(int, p) = v; }
+__device__ __forceinline__ void lds_poke(int* p, int v) { pipe_jitter(); *AUVP_LDS_PTR(int, p) = v; }
 __device__ __forceinline__ unsigned long long lds_peek64(const unsigned long long* p) { return *AUVP_LDS_PTR(const unsigned long long, p); }
-__device__ __forceinline__ void lds_poke64(unsigned long long* p, unsigned long long v) { *AUVP_LDS_PTR(unsigned long long, p) = v; }
+__device__ __forceinline__ void lds_poke64(unsigned long long* p, unsigned long long v) { pipe_jitter(); *AUVP_LDS_PTR(unsigned long long, p) = v; }
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   long long b = __double_as_longlong(v);

@@ -44,7 +44,26 @@ struct DevBuf {
 
 }  // namespace
 
+// Tuning / diagnostic options of a handle (auvp_set_option, include/auvplan.h).  Every kernel choice the host makes has a
+// measured default ("auto": the option is unset); an option forces it.  The environment variable AUVP_<NAME> gives an
+// option its initial value ONCE, when the handle is created -- no launch path reads the environment.
+enum AuvpOpt {
+  OPT_ROWS, OPT_DUO, OPT_TRIO, OPT_QUAD, OPT_TIGHT_CULL, OPT_NN_EXACT, OPT_LEAF_SWEEP_ALL, OPT_NO_HABITAT_GRID, OPT_RG_MAX_ENTRIES,
+  OPT_NO_GRID_INDEX, OPT_PRRT_LAT, OPT_PRRT_PIPE, OPT_PRRT_OBST_LDS, OPT_PRRT_NEXT_LDS, OPT_PRRT_ROWS, OPT_ASTAR_NO_GRID,
+  OPT_ASTAR_NO_LIST, OPT_ASTAR_PAIR, OPT_SOG_TILE, OPT_PIPE_FALLBACK, OPT_COUNT
+};
+static const char* const AUVP_OPT_NAMES[OPT_COUNT] = {
+  "ROWS", "DUO", "TRIO", "QUAD", "TIGHT_CULL", "NN_EXACT", "LEAF_SWEEP_ALL", "NO_HABITAT_GRID", "RG_MAX_ENTRIES",
+  "NO_GRID_INDEX", "PRRT_LAT", "PRRT_PIPE", "PRRT_OBST_LDS", "PRRT_NEXT_LDS", "PRRT_ROWS", "ASTAR_NO_GRID",
+  "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK"};
+
 struct auvp_handle {
+  bool opt_has[OPT_COUNT] = {};
+  long long opt_val[OPT_COUNT] = {};
+  // option K as a yes / no choice: its value when set, `dflt` (the measured heuristic) otherwise
+  bool opt_flag(int k, bool dflt) const { return opt_has[k] ? opt_val[k] != 0 : dflt; }
+  bool opt_on(int k) const { return opt_has[k] && opt_val[k] != 0; }
+  long long opt_num(int k, long long dflt) const { return opt_has[k] ? opt_val[k] : dflt; }
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
@@ -79,6 +98,16 @@ struct auvp_handle {
   void (*pf_free)(void*) = nullptr;
   void* comm = nullptr;  // RCCL communicator state (gather_host.h)
   void (*comm_free)(void*) = nullptr;
+  // Pipeline fallback.  The latency kernels (rrt_trio / rrt_duo, prrt_pipe, the paired astar_kernel) are speculative
+  // pipelines of several wavefronts per episode whose waits are bounded; an episode whose wait runs out ends with
+  // AUVP_ERR_PIPELINE and sets this host-mapped word.  The host then repeats the work on the one-wavefront kernel (same
+  // results by construction: tests/test_gpu_duo_kernel.py etc.) -- a caller never sees the status.  Counters: episodes redone.
+  int32_t* pipe_fail_host = nullptr;
+  int32_t* pipe_fail_dev = nullptr;
+  int pipe_fallback_last = 0;
+  long long pipe_fallback_total = 0;
+  bool pipe_failed() const { return pipe_fail_host && __atomic_load_n(pipe_fail_host, __ATOMIC_ACQUIRE) != 0; }
+  void pipe_clear() { if (pipe_fail_host) __atomic_store_n(pipe_fail_host, 0, __ATOMIC_RELEASE); }
 };
 
 namespace {
@@ -149,7 +178,7 @@ int build_habitat_grid(auvp_handle* h, const double* habitats, int H) {
   WorldDev& W = h->W;
   W.hg_n = 0; W._pad_hg = 0; W.hg_x0 = W.hg_y0 = W.hg_inv_w = W.hg_inv_h = 0.0;
   W.hg_mask = nullptr;
-  if (H <= 0 || H > 64 || getenv("AUVP_NO_HABITAT_GRID")) return AUVP_OK;
+  if (H <= 0 || H > 64 || h->opt_on(OPT_NO_HABITAT_GRID)) return AUVP_OK;
   const int G = 32;
   double x0 = INFINITY, y0 = INFINITY, x1 = -INFINITY, y1 = -INFINITY;
   std::vector<double> rr(H);
@@ -208,7 +237,60 @@ int auvp_create(int device, auvp_handle** out) {
     delete h;
     return AUVP_ERR_HIP;
   }
+  // options: initial values from AUVP_<NAME>, read here and nowhere else
+  for (int k = 0; k < OPT_COUNT; k++) {
+    const std::string name = std::string("AUVP_") + AUVP_OPT_NAMES[k];
+    if (const char* e = getenv(name.c_str())) { h->opt_has[k] = true; h->opt_val[k] = atoll(e); }
+  }
+  if (hipHostMalloc(reinterpret_cast<void**>(&h->pipe_fail_host), 64, hipHostMallocMapped) == hipSuccess) {
+    h->pipe_fail_host[0] = 0;
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->pipe_fail_dev), h->pipe_fail_host, 0) != hipSuccess) h->pipe_fail_dev = nullptr;
+  } else {
+    h->pipe_fail_host = nullptr;
+    (void)hipGetLastError();
+  }
+#ifdef AUVP_PIPE_DIAG
+  {
+    // diagnostic build only (libauvplan_diag.so): spin limit and delay injection of the speculative pipelines (auvp_wave.h)
+    int cfg[8] = {0, 0, 1, 0, 0, 0, 0, 0};
+    if (const char* e = getenv("AUVP_DIAG_SPIN")) cfg[0] = atoi(e);
+    if (const char* e = getenv("AUVP_DIAG_JITTER")) (void)sscanf(e, "%d,%d,%d,%d,%d", &cfg[1], &cfg[2], &cfg[3], &cfg[4], &cfg[5]);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(auvp_diag_cfg), cfg, sizeof cfg) != hipSuccess) { auvp_destroy(h); return AUVP_ERR_HIP; }
+  }
+#endif
   *out = h;
+  return AUVP_OK;
+}
+
+int auvp_set_option(auvp_handle* h, const char* name, int64_t value) {
+  if (!h || !name) return AUVP_ERR_ARG;
+  for (int k = 0; k < OPT_COUNT; k++)
+    if (!strcmp(name, AUVP_OPT_NAMES[k])) { h->opt_has[k] = true; h->opt_val[k] = value; return AUVP_OK; }
+  return fail(h, AUVP_ERR_ARG, "unknown option %s", name);
+}
+
+int auvp_unset_option(auvp_handle* h, const char* name) {
+  if (!h || !name) return AUVP_ERR_ARG;
+  for (int k = 0; k < OPT_COUNT; k++)
+    if (!strcmp(name, AUVP_OPT_NAMES[k])) { h->opt_has[k] = false; h->opt_val[k] = 0; return AUVP_OK; }
+  return fail(h, AUVP_ERR_ARG, "unknown option %s", name);
+}
+
+int auvp_get_option(auvp_handle* h, const char* name, int32_t* is_set, int64_t* value) {
+  if (!h || !name) return AUVP_ERR_ARG;
+  for (int k = 0; k < OPT_COUNT; k++)
+    if (!strcmp(name, AUVP_OPT_NAMES[k])) {
+      if (is_set) *is_set = h->opt_has[k] ? 1 : 0;
+      if (value) *value = h->opt_val[k];
+      return AUVP_OK;
+    }
+  return fail(h, AUVP_ERR_ARG, "unknown option %s", name);
+}
+
+int auvp_pipeline_fallbacks(auvp_handle* h, int32_t* last, int64_t* total) {
+  if (!h) return AUVP_ERR_ARG;
+  if (last) *last = h->pipe_fallback_last;
+  if (total) *total = h->pipe_fallback_total;
   return AUVP_OK;
 }
 
@@ -224,6 +306,7 @@ void auvp_destroy(auvp_handle* h) {
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->pipe_fail_host) (void)hipHostFree(h->pipe_fail_host);
   delete h;
 }
 
@@ -334,7 +417,7 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
     int64_t total = 0, run = 0;
     for (size_t r = 0; r < R; r++) { run += cnt[r]; total += run; }
     int64_t budget = 32ll << 20;
-    if (const char* e = getenv("AUVP_RG_MAX_ENTRIES")) budget = atoll(e);
+    budget = h->opt_num(OPT_RG_MAX_ENTRIES, budget);
     if (total <= budget && R + 1 < (size_t)INT32_MAX) {
       rg_enabled = 1;
       roff.assign(R + 1, 0);
@@ -374,7 +457,7 @@ int auvp_world_set(auvp_handle* h, const double* obstacles, int32_t O, const dou
       for (int r = 1; r < nr && ok; r++) ok = sgy0[r] >= sgy0[r - 1] && sgy1[r] >= sgy1[r - 1];
       for (int c = 0; c < nc && ok; c++) ok = std::isfinite(sgx0[c]) && std::isfinite(sgx1[c]);
       for (int r = 0; r < nr && ok; r++) ok = std::isfinite(sgy0[r]) && std::isfinite(sgy1[r]);
-      if (ok && !getenv("AUVP_NO_GRID_INDEX")) { sg_ncol = nc; sg_nrow = nr; }
+      if (ok && !h->opt_on(OPT_NO_GRID_INDEX)) { sg_ncol = nc; sg_nrow = nr; }
     }
   }
   double prob_absmax = 0.0;
@@ -656,6 +739,7 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   B.phase_clocks = nullptr;
   HIPCHK(h, h->d_leaf_stats.reserve(4 * sizeof(unsigned long long)));
   B.leaf_stats = h->d_leaf_stats.as<unsigned long long>();
+  B.pipe_fail = h->pipe_fail_dev;
   if (flags & AUVP_FLAG_PHASE_CLOCKS) {
     HIPCHK(h, h->d_phase.reserve((size_t)E * 5 * sizeof(unsigned long long)));
     HIPCHK(h, hipMemsetAsync(h->d_phase.p, 0, (size_t)E * 5 * sizeof(unsigned long long), h->stream));
@@ -688,10 +772,10 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   return AUVP_OK;
 }
 
-int auvp_rrt_run(auvp_handle* h) {
-  if (!h) return AUVP_ERR_ARG;
-  if (!h->prepared) return fail(h, AUVP_ERR_STATE, "auvp_rrt_prepare not called");
-  HIPCHK(h, hipSetDevice(h->device));
+}  // extern "C"
+
+// one pass over the prepared batch: the expansion launch + the leaf pass.  one_wave_only: never a speculative pipeline
+static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
   const RrtParamsDev& P = h->P;
   const RrtBuffers& B = h->B;
   const int E = h->E;
@@ -704,9 +788,8 @@ int auvp_rrt_run(auvp_handle* h) {
   {
     const double reach = 0.25 * P.freq * P.dist_to_end;
     const double lam = h->obst_area > 0.0 ? 4.0 * reach * reach * (double)O_ / h->obst_area : (O_ > 0 ? 1e9 : 0.0);
-    const char* tenv = getenv("AUVP_TIGHT_CULL");
-    if (tenv ? atoi(tenv) != 0 : lam > 0.5) PR.flags |= AUVP_KFLAG_TIGHT_CULL;
-    if (const char* ne = getenv("AUVP_NN_EXACT")) if (atoi(ne) != 0) PR.flags |= AUVP_KFLAG_NN_EXACT;
+    if (h->opt_flag(OPT_TIGHT_CULL, lam > 0.5)) PR.flags |= AUVP_KFLAG_TIGHT_CULL;
+    if (h->opt_on(OPT_NN_EXACT)) PR.flags |= AUVP_KFLAG_NN_EXACT;
   }
   const int jslots = (O_ <= 64 ? 1 : (O_ <= 128 ? 2 : (O_ <= 256 ? 4 : (O_ <= 512 ? 8 : 16)))) * 64;
   int n_cu_ = 256;
@@ -741,25 +824,22 @@ int auvp_rrt_run(auvp_handle* h) {
   // ... and where it pays: a batch the one-episode kernel can keep resident in one go (6 waves per SIMD = 24 episodes per
   // CU) runs faster there -- the rows kernel would leave the SIMDs with one or two waves.  Measured on MI355X, M
   // expansions/s one-episode vs rows: 4 096 episodes 616 vs 507, 6 144 episodes 704 vs 645, 8 192 episodes 699 vs 849,
-  // 10 240 episodes 737 vs 877.  AUVP_ROWS=1 / 0 force it on (limits permitting) / off.
-  const char* rows_env = getenv("AUVP_ROWS");
+  // 10 240 episodes 737 vs 877.  Option ROWS = 1 / 0 forces it on (limits permitting) / off.
   const bool rows_ok = P.mode == 0 && !iter_log && nfreq <= RW_MAX_FREQ && O_ <= RW_MAX_OBST && P.max_iter < 65534 &&
                        rp.total <= 160 * 1024;
-  const bool use_rows = rows_ok && (rows_env ? atoi(rows_env) != 0 : E > 24 * n_cu_);
+  const bool use_rows = rows_ok && h->opt_flag(OPT_ROWS, E > 24 * n_cu_);
   int grid_used = grid, block_used = xw * 64, lds_used = (int)lds;
   // latency runs (at most four episodes per CU: one episode, config 2's 1 024 replicas): two wavefronts per episode
-  // (rrt_duo_kernel.h).  AUVP_DUO=1 / 0 force it on (limits permitting) / off.
-  const char* duo_env = getenv("AUVP_DUO");
+  // (rrt_duo_kernel.h).  Option DUO = 1 / 0 forces it on (limits permitting) / off.
   const bool duo_ok = P.mode == 0 && !diag && nfreq <= DUO_MAX_FREQ && nfreq >= 1 && O_ <= 256 && h->max_pts <= 64;
   // Measured (tools/duo_probe.py, M expansions/s one vs two wavefronts per episode): 1 episode 0.25 vs 0.32, 256: 62 vs 80,
   // 1 024: 227 vs 271 (config 2's replicas, 64 obstacles: 241 vs 283), 2 048: 409 vs 435, 4 096: 621 vs 485
-  const bool use_duo = duo_ok && !use_rows && (duo_env ? atoi(duo_env) != 0 : E <= 8 * n_cu_);
+  const bool use_duo = duo_ok && !use_rows && !one_wave_only && h->opt_flag(OPT_DUO, E <= 8 * n_cu_);
   // ... and three (rrt_trio_kernel.h: stream, geometry, tree -- a pipeline over the iterations) for at most four episodes per
   // CU.  Measured (tools/duo_probe.py, M expansions/s, one / two / three wavefronts per episode): 1 episode 0.25 / 0.32 / 0.40,
   // 256: 61 / 80 / 95, 1 024: 226 / 271 / 303 (config 2's replicas: 239 / 282 / 309), 2 048: 406 / 434 / 304.
-  // AUVP_TRIO=1 / 0 force it on (limits permitting) / off; an explicit AUVP_DUO=1 takes precedence.
-  const char* trio_env = getenv("AUVP_TRIO");
-  const bool use_trio = duo_ok && !use_rows && (trio_env ? atoi(trio_env) != 0 : (E <= TRIO_EP * n_cu_ && !(duo_env && atoi(duo_env) != 0)));
+  // Option TRIO = 1 / 0 forces it on (limits permitting) / off; an explicit DUO = 1 takes precedence.
+  const bool use_trio = duo_ok && !use_rows && !one_wave_only && h->opt_flag(OPT_TRIO, E <= TRIO_EP * n_cu_ && !h->opt_on(OPT_DUO));
   h->last_rrt_kernel = use_rows ? "rrt_rows_kernel" : (use_trio ? "rrt_trio_kernel" : (use_duo ? "rrt_duo_kernel" : "rrt_explore_kernel"));
   if (use_trio) {
     int eps_wg = (E + n_cu_ - 1) / n_cu_;
@@ -768,9 +848,8 @@ int auvp_rrt_run(auvp_handle* h) {
     const int dl = trio_lds_bytes(P.K, jd * 64, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), eps_wg);
     if (dl > 160 * 1024) return fail(h, AUVP_ERR_ARG, "LDS need %d B > 160 KiB (K=%d)", dl, P.K);
     // the parent lookup as a fourth wavefront per episode (rrt_trio_kernel<J, 4>) where every episode has a CU to itself: one
-    // episode 2.52 -> 2.49 us per expansion, 256 episodes 95 -> 100 M/s (1 024: 303 -> 262 M/s, so not there).  AUVP_QUAD=1 / 0
-    const char* quad_env = getenv("AUVP_QUAD");
-    const bool quad = quad_env ? atoi(quad_env) != 0 : E <= n_cu_;
+    // episode 2.52 -> 2.49 us per expansion, 256 episodes 95 -> 100 M/s (1 024: 303 -> 262 M/s, so not there).  Option QUAD
+    const bool quad = h->opt_flag(OPT_QUAD, E <= n_cu_);
     grid_used = (E + eps_wg - 1) / eps_wg; block_used = eps_wg * (quad ? 256 : 192); lds_used = dl;
     if (quad) h->last_rrt_kernel = "rrt_trio_kernel<4 wavefronts>";
     auto launch_trio = [&](auto kern) -> hipError_t {
@@ -836,8 +915,8 @@ int auvp_rrt_run(auvp_handle* h) {
     // dynamic LDS of the leaf pass: the separable-grid edge tables + one "ancestor of a qualifying leaf" bit per node
     // and episode (trees too large for that are swept whole)
     const int gl = rrt_leaf_grid_lds_bytes(h->W.sg_enabled, h->W.sg_ncol, h->W.sg_nrow);
-    // (AUVP_LEAF_SWEEP_ALL=1: no pruning, every node visited -- what trees of more than 131 072 nodes get; for tests)
-    const int bm_words = getenv("AUVP_LEAF_SWEEP_ALL") ? 0 : rrt_leaf_mark_words(B.cap_nodes);
+    // (option LEAF_SWEEP_ALL: no pruning, every node visited -- what trees of more than 131 072 nodes get; for tests)
+    const int bm_words = h->opt_on(OPT_LEAF_SWEEP_ALL) ? 0 : rrt_leaf_mark_words(B.cap_nodes);
     const int dyn = gl + RRT_LEAF_WAVES * bm_words * 4;
     HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_leaf_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
     hipLaunchKernelGGL(rrt_leaf_kernel, dim3((E + RRT_LEAF_WAVES - 1) / RRT_LEAF_WAVES), dim3(RRT_LEAF_WAVES * 64), dyn, h->stream,
@@ -857,6 +936,39 @@ int auvp_rrt_run(auvp_handle* h) {
   h->last_grid = grid_used; h->last_block = block_used; h->last_lds = lds_used;
   h->have_batch = true;
   return AUVP_OK;
+}
+
+// AUVP_ERR_PIPELINE episodes of the pass that just ran (its mapped flag is set): counted from the summaries
+static int rrt_count_pipeline_failures(auvp_handle* h, int* n) {
+  std::vector<RrtSummary> s((size_t)h->E);
+  HIPCHK(h, hipMemcpy(s.data(), h->B.summary, s.size() * sizeof(RrtSummary), hipMemcpyDeviceToHost));
+  *n = 0;
+  for (const RrtSummary& r : s) *n += r.status == AUVP_ERR_PIPELINE ? 1 : 0;
+  return AUVP_OK;
+}
+
+extern "C" {
+
+int auvp_rrt_run(auvp_handle* h) {
+  if (!h) return AUVP_ERR_ARG;
+  if (!h->prepared) return fail(h, AUVP_ERR_STATE, "auvp_rrt_prepare not called");
+  HIPCHK(h, hipSetDevice(h->device));
+  h->pipe_clear();
+  h->pipe_fallback_last = 0;
+  int rc = rrt_run_pass(h, false);
+  if (rc != AUVP_OK || !h->pipe_failed()) return rc;
+  // a speculative pipeline gave up on some episode: the batch starts from its prepared state in every pass, so the whole
+  // pass is repeated on the one-wavefront kernel (option PIPE_FALLBACK = 0: leave the status in the summaries instead)
+  int n = 0;
+  if ((rc = rrt_count_pipeline_failures(h, &n))) return rc;
+  h->pipe_clear();
+  if (n == 0 || !h->opt_flag(OPT_PIPE_FALLBACK, true)) return AUVP_OK;
+  h->pipe_fallback_last = n;
+  h->pipe_fallback_total += n;
+  const double first_ms = h->last_ms;
+  rc = rrt_run_pass(h, true);
+  h->last_ms += first_ms;  // (the time the caller waited)
+  return rc;
 }
 
 int auvp_rrt_summaries(auvp_handle* h, auvp_rrt_summary* out) {
@@ -1016,7 +1128,7 @@ int auvp_last_launch(auvp_handle* h, int32_t* grid, int32_t* block, int32_t* lds
 #include "probe_kernels.h"
 #include "planner_rrt_kernel.h"
 #include "planner_rows_kernel.h"
-#include "planner_duo_kernel.h"
+#include "planner_goal_arc.h"
 #include "planner_pipe_kernel.h"
 #include "planner_rrt_host.h"
 

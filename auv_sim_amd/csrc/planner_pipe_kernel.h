@@ -23,17 +23,19 @@
 // Why H may run three inserts ahead: an insert changes what H looked at only if it went into the bucket the packet chose AND
 // `_randbelow(len(bucket))` now comes out differently (members are kept in creation order, a new one goes to the end: the same
 // index is the same node unless the size's bit length changed or a thrown-away try is now below the size), or it occupied a new
-// bucket AND `_randbelow(n_occ)` now comes out differently (planner_duo_kernel.h); M keeps the buckets of its last eight inserts
+// bucket AND `_randbelow(n_occ)` now comes out differently (n_occ's bit length changed, or a thrown-away try is now below n_occ); M keeps the buckets of its last eight inserts
 // and checks every insert the packet's snapshot did not know.  On a conflict M starts a new epoch: H rewinds the
 // generator to the first word of that step (the ring keeps 1 248 words: every word since the oldest unfinished step's start
 // stays available) and the stages start over from there.
 //
 // Bit-identical to prrt_kernel: trees, bucket lists, counters, paths, generator state and position
 // (tests/test_gpu_planner_duo.py, tests/experiments/soak_planner_duo.py).
-// Limits (the host falls back to prrt_kernel): as planner_duo_kernel.h.
+// Limits (the host falls back to prrt_kernel): plan mode (not the one-step mode of the environment), no step log, freq <= 30,
+// <= 256 obstacles, at most four episodes per CU.  An episode whose bounded wait runs out ends with AUVP_ST_PIPELINE and is
+// redone by prrt_kernel (planner_rrt_host.h: pipeline fallback).
 #ifndef AUVP_PLANNER_PIPE_KERNEL_H
 #define AUVP_PLANNER_PIPE_KERNEL_H
-#include "planner_duo_kernel.h"
+#include "planner_goal_arc.h"
 #include "rrt_trio_kernel.h"
 
 namespace auvp {
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
             continue;
           }
           if (k < P.max_step && k < cv.m_done + PPIPE_LEAD) break;
-          if (++spins > DUO_SPIN_LIMIT) { give_up(); goto h_end; }
+          if (++spins > pipe_spin_limit()) { give_up(); goto h_end; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
           if (cv.stop || cv.abort) goto s_end;
           if (cv.epoch != epoch) { epoch = cv.epoch; k = cv.restart_k; continue; }
           if (tg == duo_tag(epoch, k)) break;
-          if (++spins > DUO_SPIN_LIMIT) { give_up(); goto s_end; }
+          if (++spins > pipe_spin_limit()) { give_up(); goto s_end; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
           if (cv.stop || cv.abort) goto g_end;
           if (cv.epoch != epoch) { epoch = cv.epoch; k = cv.restart_k; continue; }
           if (tg == duo_tag(epoch, k)) break;
-          if (++spins > DUO_SPIN_LIMIT) { give_up(); goto g_end; }
+          if (++spins > pipe_spin_limit()) { give_up(); goto g_end; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -785,8 +787,8 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           if (lane == 0) duo_poke(&ctl->epoch, my_epoch);
         }
-        if (uni(duo_peek(&ctl->abort))) { status = -9; break; }
-        if (++spins > DUO_SPIN_LIMIT) { give_up(); status = -9; break; }
+        if (uni(duo_peek(&ctl->abort))) { status = AUVP_ST_PIPELINE; break; }
+        if (++spins > pipe_spin_limit()) { give_up(); status = AUVP_ST_PIPELINE; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -899,12 +901,13 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
   {
     int spins = 0;
     while (!uni(duo_peek(&ctl->h_done)) || !uni(duo_peek(&ctl->s_done)) || !uni(duo_peek(&ctl->g_done))) {
-      if (++spins > DUO_SPIN_LIMIT) { status = -9; break; }
+      if (++spins > pipe_spin_limit()) { status = AUVP_ST_PIPELINE; break; }
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
   if (lane == 0) {
+    pipe_report(B.pipe_fail, status);
     sum.status = status; sum.n_nodes = n_nodes; sum.n_points = n_points; sum.n_occ = n_occ; sum.steps = step;
     sum.done = done; sum.last_accepted = last_accepted; sum.last_new_node = last_new;
     sum.rng_after = ctl->final_after; sum.n_draw32 = ctl->final_drawn;

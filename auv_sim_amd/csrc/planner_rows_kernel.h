@@ -122,7 +122,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           last_accepted = 0; last_new = -1; prev_n_arc = PRW_NO_ARC; stepped = false;
           // whole 16-word blocks are regenerated in place (rrt_rows_kernel.h): the frontier must sit on a block boundary,
           // which every state this kernel or the host's seeding writes does
-          if (((rng.pslot + rng.avail) & 15u) != 0u) status = -7;
+          if (((rng.pslot + rng.avail) & 15u) != 0u) status = AUVP_ST_GENERATOR;
           live = true;
         }
         wave_sync();

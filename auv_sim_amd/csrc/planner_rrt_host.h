@@ -22,6 +22,7 @@ struct PrrtState {
   // work counter of the four-episodes-per-wavefront kernel (planner_rows_kernel.h).  It is never reset between launches: a
   // launch hands out ids counter - work_base, and every one of its rows ends with exactly one pull that finds no episode, so
   // the next launch's base is known on the host (no fill launch per plan / step)
+  DevBuf snap_sum, snap_rng, snap_mt, redo_mask, redo_count;  // the pipeline fallback's snapshot of a launch's episodes
   DevBuf work;
   int work_base = 0;
   bool work_memset = false;  // set by the first launch under stream capture: the counter is zeroed by a memset node per launch
@@ -40,15 +41,15 @@ struct PrrtState {
 PrrtState* prrt_of(auvp_handle* h);
 
 // `sync`: wait for the launch and record its HIP-event time (the device-resident loop passes false: it only enqueues)
-int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
+int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true, bool one_wave_only = false) {
   S.P.step_mode = step_mode;
+  if (!one_wave_only) { h->pipe_clear(); h->pipe_fallback_last = 0; }
   const int nfreq = (int)std::floor(S.P.freq);
   // latency run (at most two waves per SIMD on this GPU) or throughput run: register budget and steer differ (planner_rrt_kernel.h)
   int n_cu_l = 256;
   (void)hipDeviceGetAttribute(&n_cu_l, hipDeviceAttributeMultiprocessorCount, h->device);
   if (n_cu_l <= 0) n_cu_l = 256;
-  const char* lenv = getenv("AUVP_PRRT_LAT");
-  const bool lat = lenv ? atoi(lenv) != 0 : S.E <= 8 * n_cu_l;
+  const bool lat = h->opt_flag(OPT_PRRT_LAT, S.E <= 8 * n_cu_l);
   // latency runs: workgroups small enough that every CU gets one (512 episodes: 256 workgroups of two waves)
   int wg_waves = auvp::RRT_WAVES;
   if (lat) { wg_waves = (S.E + n_cu_l - 1) / n_cu_l; wg_waves = wg_waves < 1 ? 1 : (wg_waves > auvp::RRT_WAVES ? auvp::RRT_WAVES : wg_waves); }
@@ -68,11 +69,10 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
   size_t lds_used = lds;
   S.last_kernel = "prrt_kernel";
   // plan-mode latency runs of at most four episodes per CU: a pipeline of four wavefronts per episode (planner_pipe_kernel.h).
-  // AUVP_PRRT_DUO=0 / 1 forces the choice where the kernels' limits allow it; AUVP_PRRT_PIPE=0: the helper + main + goal-arc
-  // form of planner_duo_kernel.h, with AUVP_PRRT_TRIO=0 helper + main only
-  const char* denv = getenv("AUVP_PRRT_DUO");
-  const bool use_duo = !S.use_rows && step_mode == 0 && lat && !(S.P.flags & AUVP_FLAG_ITER_LOG) && nfreq <= auvp::DUO_MAX_FREQ && O <= 256 &&
-                       S.B.max_pts <= auvp::DUO_CS + 2 && (denv ? atoi(denv) != 0 : S.E <= 4 * n_cu_l);
+  // Option PRRT_PIPE = 0 / 1 forces the choice where the kernel's limits allow it.  Only where this call waits for the launch:
+  // the pipeline is speculative and an episode it gives up on is redone on prrt_kernel below (pipeline fallback).
+  const bool use_pipe = sync && !one_wave_only && !S.use_rows && step_mode == 0 && lat && !(S.P.flags & AUVP_FLAG_ITER_LOG) &&
+                        nfreq <= auvp::DUO_MAX_FREQ && O <= 256 && S.B.max_pts <= auvp::DUO_CS + 2 && h->opt_flag(OPT_PRRT_PIPE, S.E <= 4 * n_cu_l);
   if (S.use_rows) {
     // persistent rows (four episodes per wavefront) fed from a device counter: as many workgroups as fit the chip at
     // three per CU (one wave per SIMD each), fewer when the batch is smaller
@@ -82,11 +82,10 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     block_used = auvp::PRW_WAVES * 64;
     const int occ_bytes = auvp::prrt_rows_occ_bytes(S.P.n_buckets, S.P.max_step);
     lds_used = (size_t)per_wg * (auvp::PRW_LDS_PER_EP + occ_bytes);
-    // the obstacle slot tables as an LDS tile where three workgroups per CU still fit beside it (AUVP_PRRT_OBST_LDS=0 / 1 overrides)
-    const char* oenv = getenv("AUVP_PRRT_OBST_LDS");
+    // the obstacle slot tables as an LDS tile where three workgroups per CU still fit beside it (option PRRT_OBST_LDS overrides)
     // (LDS is handed out in 1 280-byte granules on this GPU: three workgroups of 53 760 B fit a CU, three of 54 272 B do not)
     auto granules = [](size_t b) { return (b + 1279) / 1280 * 1280; };
-    const bool obst_lds = oenv ? atoi(oenv) != 0 : 3 * granules(lds_used + auvp::PRW_OBST_TILE) <= (size_t)160 * 1024;
+    const bool obst_lds = h->opt_flag(OPT_PRRT_OBST_LDS, 3 * granules(lds_used + auvp::PRW_OBST_TILE) <= (size_t)160 * 1024);
     if (obst_lds) lds_used += auvp::PRW_OBST_TILE;
     // The ids a launch hands out are counter - work_base.  Eager launches carry the base as an argument (no memset per
     // launch).  A launch recorded into a hipGraph would freeze that argument while the counter keeps advancing on every
@@ -115,18 +114,27 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
       // every episode once + one empty pull per row; a failed launch pulled nothing, a memset-fronted one restarts at 0
       if (le == hipSuccess && !S.work_memset) S.work_base += S.E + grid_used * per_wg;
     }
-  } else if (use_duo && (getenv("AUVP_PRRT_PIPE") ? atoi(getenv("AUVP_PRRT_PIPE")) != 0 : true)) {
+  } else if (use_pipe) {
     // four wavefronts per episode, feed-forward (planner_pipe_kernel.h)
     S.last_kernel = "prrt_pipe_kernel";
     int eps_wg = (S.E + n_cu_l - 1) / n_cu_l;
     eps_wg = eps_wg < 1 ? 1 : (eps_wg > auvp::PPIPE_EP ? auvp::PPIPE_EP : eps_wg);
     grid_used = (S.E + eps_wg - 1) / eps_wg;
     block_used = eps_wg * 256;
-    // the member lists' next links in LDS where they fit beside the slots (AUVP_PRRT_NEXT_LDS=0 / 1 overrides)
-    const char* nenv = getenv("AUVP_PRRT_NEXT_LDS");
+    // the member lists' next links in LDS where they fit beside the slots (option PRRT_NEXT_LDS = 0 keeps them in memory)
     int next_lds = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, S.B.cap_nodes) <= (size_t)150 * 1024 ? 1 : 0;
-    if (nenv) next_lds = next_lds && atoi(nenv) != 0;
+    next_lds = next_lds && h->opt_flag(OPT_PRRT_NEXT_LDS, true);
     lds_used = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, next_lds ? S.B.cap_nodes : 0);
+    // what the fallback needs to take an episode back to where this launch found it: its record, generator and position
+    le = S.snap_sum.reserve((size_t)S.E * sizeof(auvp::PrrtSummary));
+    if (le == hipSuccess) le = S.snap_rng.reserve((size_t)S.E * 4 * sizeof(int32_t));
+    if (le == hipSuccess) le = S.snap_mt.reserve((size_t)S.E * 624 * sizeof(uint32_t));
+    if (le == hipSuccess) le = S.redo_mask.reserve((size_t)S.E);
+    HIPCHK(h, le);
+    hipLaunchKernelGGL(auvp::prrt_snapshot_kernel, dim3(S.E), dim3(256), 0, h->stream, S.B, S.snap_sum.as<auvp::PrrtSummary>(),
+                       S.snap_rng.as<int32_t>(), S.snap_mt.as<uint32_t>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));  // (the launch's own time starts after the snapshot)
     auto launch_pipe = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
       if (e != hipSuccess) return e;
@@ -136,30 +144,6 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
     if (O <= 64) le = launch_pipe(auvp::prrt_pipe_kernel<1>);
     else if (O <= 128) le = launch_pipe(auvp::prrt_pipe_kernel<2>);
     else le = launch_pipe(auvp::prrt_pipe_kernel<4>);
-  } else if (use_duo) {
-    const char* tenv = getenv("AUVP_PRRT_TRIO");
-    const bool trio = tenv ? atoi(tenv) != 0 : true;
-    S.last_kernel = trio ? "prrt_duo_kernel<3 wavefronts>" : "prrt_duo_kernel";
-    int eps_wg = (S.E + n_cu_l - 1) / n_cu_l;
-    eps_wg = eps_wg < 1 ? 1 : (eps_wg > auvp::PDUO_EP ? auvp::PDUO_EP : eps_wg);
-    grid_used = (S.E + eps_wg - 1) / eps_wg;
-    block_used = eps_wg * (trio ? 192 : 128);
-    lds_used = (size_t)eps_wg * auvp::pduo_per_episode_bytes(S.B.max_pts);
-    auto launch_duo = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E);
-      return hipGetLastError();
-    };
-    if (trio) {
-      if (O <= 64) le = launch_duo(auvp::prrt_duo_kernel<1, 3>);
-      else if (O <= 128) le = launch_duo(auvp::prrt_duo_kernel<2, 3>);
-      else le = launch_duo(auvp::prrt_duo_kernel<4, 3>);
-    } else {
-      if (O <= 64) le = launch_duo(auvp::prrt_duo_kernel<1, 2>);
-      else if (O <= 128) le = launch_duo(auvp::prrt_duo_kernel<2, 2>);
-      else le = launch_duo(auvp::prrt_duo_kernel<4, 2>);
-    }
   } else if (lat) {
     if (O <= 64) le = launch(auvp::prrt_kernel<1, true>);
     else if (O <= 128) le = launch(auvp::prrt_kernel<2, true>);
@@ -181,6 +165,31 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true) {
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
+  if (use_pipe && h->pipe_failed()) {
+    // some episode's pipeline gave up (AUVP_ERR_PIPELINE): those episodes go back to where this launch found them (record,
+    // generator, bucket table; the tree is append-only) and are planned by the one-wavefront kernel -- the others, finished, are
+    // not touched (redo_mask).  Option PIPE_FALLBACK = 0 leaves the status in the summaries instead.
+    h->pipe_clear();
+    if (h->opt_flag(OPT_PIPE_FALLBACK, true)) {
+      HIPCHK(h, S.redo_count.reserve(sizeof(int32_t)));
+      HIPCHK(h, hipMemsetAsync(S.redo_count.p, 0, sizeof(int32_t), h->stream));
+      hipLaunchKernelGGL(auvp::prrt_undo_kernel, dim3((S.E + 63) / 64), dim3(64), 0, h->stream, S.P, S.B, S.E, S.snap_sum.as<auvp::PrrtSummary>(),
+                         S.snap_rng.as<int32_t>(), S.snap_mt.as<uint32_t>(), S.redo_mask.as<uint8_t>(), S.redo_count.as<int32_t>());
+      HIPCHK(h, hipGetLastError());
+      int32_t n = 0;
+      HIPCHK(h, hipMemcpyAsync(&n, S.redo_count.p, sizeof n, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      if (n > 0) {
+        h->pipe_fallback_last += n;
+        h->pipe_fallback_total += n;
+        S.B.redo_mask = S.redo_mask.as<uint8_t>();
+        const int rc = prrt_launch(h, S, step_mode, true, true);
+        S.B.redo_mask = nullptr;
+        h->last_ms += ms;  // (the time the caller waited)
+        if (rc != AUVP_OK) return rc;
+      }
+    }
+  }
   return AUVP_OK;
 }
 
@@ -240,6 +249,7 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
   B.st_log = nullptr;
   B.env_flags = 0; B._pad_env = 0; B.env_done = nullptr; B.env_reward = nullptr; B.env_done_out = nullptr;
   B.env_bucket_out = nullptr; B.env_agent_seed = 0ull; B.env_err = nullptr;
+  B.pipe_fail = h->pipe_fail_dev; B.redo_mask = nullptr;
   B.env_obs_grid = nullptr; B.env_obs_has = nullptr; B.env_obs_num = nullptr;
   if (flags & AUVP_FLAG_ITER_LOG) {
     HIPCHK(h, S.st_log.reserve((size_t)E * p->max_step * 8 * sizeof(int32_t)));
@@ -248,15 +258,13 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
   }
   {
     // throughput batches (more than eight episodes per CU) of the environment's planner shape run four episodes per
-    // wavefront (planner_rows_kernel.h); AUVP_PRRT_ROWS=0 / 1 forces the choice where the kernel's limits allow it
+    // wavefront (planner_rows_kernel.h); option PRRT_ROWS = 0 / 1 forces the choice where the kernel's limits allow it
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
     if (n_cu <= 0) n_cu = 256;
     const bool rows_ok = nfreq <= auvp::PRW_MAX_FREQ && h->W.n_obstacles <= auvp::RW_MAX_OBST && !(flags & AUVP_FLAG_ITER_LOG);
-    const char* renv = getenv("AUVP_PRRT_ROWS");
-    const char* lenv = getenv("AUVP_PRRT_LAT");
-    const bool lat = lenv ? atoi(lenv) != 0 : E <= 8 * n_cu;
-    S.use_rows = rows_ok && (renv ? atoi(renv) != 0 : !lat);
+    const bool lat = h->opt_flag(OPT_PRRT_LAT, E <= 8 * n_cu);
+    S.use_rows = rows_ok && h->opt_flag(OPT_PRRT_ROWS, !lat);
   }
   return AUVP_OK;
 }

@@ -76,6 +76,8 @@ struct PrrtBuffers {
   int32_t* env_bucket_out;    // [E] PRRT_ENV_AGENT: the bucket the agent picked (-1: finished environment)
   unsigned long long env_agent_seed;
   int32_t* env_err;           // [2] {status, environment} of the first episode that failed on the device (0: none)
+  int32_t* pipe_fail;         // host-mapped word, set to 1 by an episode that ends with AUVP_ST_PIPELINE (null: not reported)
+  const uint8_t* redo_mask;   // [E] or null: only episodes whose byte is non-zero are touched (the pipeline fallback's re-run)
   // PRRT_ENV_DELTA: the caller's observation arrays (rrt_env.py:250-295) hold the previous step's observation and this
   // launch updates the entries of the ONE bucket per environment whose node_array grew (a step adds at most one node):
   // rrt_grid[e][b][3] = has_node... -- one launch per environment step instead of a rewrite of all E x n_buckets entries
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
   const int lane = lane_id();
   const int ep = (int)blockIdx.x * (int)(blockDim.x >> 6) + wave;  // (RRT_WAVES episodes per workgroup; fewer for small batches)
   if (ep >= n_episodes) return;
+  if (B.redo_mask && !uni((int)B.redo_mask[ep])) return;  // the pipeline fallback's re-run: the other episodes are not touched
   const int nfreq = (int)P.freq;
   const int C = nfreq < 1 ? 1 : (nfreq > 63 ? 63 : nfreq);
   const int per_wave = prrt_lds_per_wave(B.max_pts, nfreq, LAT);
@@ -789,6 +792,45 @@ __global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, co
     pos++;
     m = r.y;
   }
+}
+
+// ---- pipeline fallback (planner_rrt_host.h): prrt_pipe_kernel is speculative; an episode it gives up on (AUVP_ST_PIPELINE)
+// is taken back to where the launch found it and planned again by prrt_kernel.
+// Before the launch: the episode's record, generator words and generator position (one workgroup per episode).
+__global__ __launch_bounds__(256) void prrt_snapshot_kernel(PrrtBuffers B, PrrtSummary* __restrict__ snap_sum, int32_t* __restrict__ snap_rng,
+                                                             uint32_t* __restrict__ snap_mt) {
+  const size_t e = blockIdx.x;
+  const int t = threadIdx.x;
+  const int32_t* ss = reinterpret_cast<const int32_t*>(B.summary + e);
+  int32_t* sd = reinterpret_cast<int32_t*>(snap_sum + e);
+  if (t < (int)(sizeof(PrrtSummary) / 4)) sd[t] = ss[t];
+  if (t < 4) snap_rng[4 * e + t] = B.rng_state[4 * e + t];
+  for (int i = t; i < 624; i += 256) snap_mt[e * 624 + i] = B.mt[e * 624 + i];
+}
+// After it: one thread per episode.  The tree is append-only (nodes and points past the old counts are ignored); the bucket
+// table is not: every insert of the failed launch is taken out again, newest first (a node's `next` is the member that headed
+// its bucket before it), then record, generator and position return to the snapshot.  redo_mask[e] = 1 for these episodes.
+__global__ __launch_bounds__(64) void prrt_undo_kernel(PrrtParamsDev P, PrrtBuffers B, int n_episodes, const PrrtSummary* __restrict__ snap_sum,
+                                                        const int32_t* __restrict__ snap_rng, const uint32_t* __restrict__ snap_mt,
+                                                        uint8_t* __restrict__ redo_mask, int32_t* __restrict__ redo_count) {
+  const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e >= n_episodes) return;
+  PrrtSummary& cur = B.summary[e];
+  if (cur.status != AUVP_ST_PIPELINE) { redo_mask[e] = 0; return; }
+  redo_mask[e] = 1;
+  atomicAdd(redo_count, 1);
+  const PrrtSummary old = snap_sum[e];
+  const PrrtNode* nodes = B.nodes + (size_t)e * B.cap_nodes;
+  int2* buckets = B.buckets + (size_t)e * P.n_buckets;
+  for (int me = cur.n_nodes - 1; me >= old.n_nodes; me--) {
+    const int bk = nodes[me].bucket;
+    if (bk < 0) continue;
+    const int c = prrt_bucket_count(buckets[bk], B.bucket_epoch);
+    buckets[bk] = prrt_bucket_word(c > 0 ? c - 1 : 0, nodes[me].next, B.bucket_epoch);
+  }
+  cur = old;
+  for (int k = 0; k < 4; k++) B.rng_state[4 * (size_t)e + k] = snap_rng[4 * (size_t)e + k];
+  for (int i = 0; i < 624; i++) B.mt[(size_t)e * 624 + i] = snap_mt[(size_t)e * 624 + i];
 }
 
 // Planner_RRT.__init__ (:34-75): mps_list = [start]; add_node_to_grid(start).  One thread per episode.

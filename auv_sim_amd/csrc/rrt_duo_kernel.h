@@ -29,7 +29,6 @@ constexpr int DUO_MAX_FREQ = 30;
 constexpr int DUO_CS = 32;        // sub-arc slots of a steer (freq <= 30: lanes 0..29, lane 30 = the entry angle)
 constexpr int DUO_EP = 4;         // episodes per workgroup at most (eight wavefronts)
 constexpr int DUO_WIN = 160;      // window entries: up to 62 selection draws + 1 + 3 x 30, rounded up
-constexpr int DUO_SPIN_LIMIT = 1 << 24;  // polls before a wait gives up (a protocol bug must not hang the GPU)
 
 struct DuoPacket {  // LDS: what one iteration needs of the random stream
   // {redo epoch << 32 | iteration + 1}: written LAST, as one 64-bit word; main accepts a packet only under the tag it expects,
@@ -223,7 +222,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
             break;
           }
           if (i < P.max_iter && uni(duo_peek(&ctl->valid_seq)) >= i) break;
-          if (++spins > DUO_SPIN_LIMIT) { give_up(); goto helper_end; }
+          if (++spins > pipe_spin_limit()) { give_up(); goto helper_end; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
           int spins = 0;
           while (uni(duo_peek(&ctl->done_seq)) < i) {
             if (uni(duo_peek(&ctl->abort)) || uni(duo_peek(&ctl->stop))) return -1;
-            if (++spins > DUO_SPIN_LIMIT) { give_up(); return -1; }
+            if (++spins > pipe_spin_limit()) { give_up(); return -1; }
             __builtin_amdgcn_s_sleep(1);
           }
           synced = true;
@@ -418,8 +417,8 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
           my_epoch++;
           if (lane == 0) duo_poke(&ctl->redo_epoch, my_epoch);
         }
-        if (uni(duo_peek(&ctl->abort))) { status = -9; break; }
-        if (++spins > DUO_SPIN_LIMIT) { give_up(); status = -9; break; }
+        if (uni(duo_peek(&ctl->abort))) { status = AUVP_ST_PIPELINE; break; }
+        if (++spins > pipe_spin_limit()) { give_up(); status = AUVP_ST_PIPELINE; break; }
         __builtin_amdgcn_s_sleep(1);
       }
     }
@@ -600,7 +599,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
   {
     int spins = 0;
     while (!uni(duo_peek(&ctl->helper_done))) {
-      if (++spins > DUO_SPIN_LIMIT) { status = -9; break; }
+      if (++spins > pipe_spin_limit()) { status = AUVP_ST_PIPELINE; break; }
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -608,6 +607,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
   for (int i = lane; i < K + 1; i += 64) B.bin_count[(size_t)ep * (K + 1) + i] = bin_count[i];
   if (lane == 0) {
     RrtSummary& s = B.summary[ep];
+    pipe_report(B.pipe_fail, status);
     s.status = status; s.n_nodes = n_nodes; s.n_points = n_points; s.n_leaves = 0;
     s.best_leaf = -1; s.best_path_len = 0; s.iters_run = it; s.n_candidates = n_cand;
     s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
           done = cv.done_seq;
           snap_ver = cv.ver;
           if (k < P.max_iter && done >= k - (TRIO_RING - 1)) break;
-          if (++spins > DUO_SPIN_LIMIT) { give_up(); goto h_end; }
+          if (++spins > pipe_spin_limit()) { give_up(); goto h_end; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
             if (uni(duo_peek(&ctl->abort)) || uni(duo_peek(&ctl->stop))) return -1;
             if (uni(duo_peek(&ctl->epoch)) != epoch) return 2;  // a new epoch: back to the top
             if (uni(duo_peek(&ctl->done_seq)) >= k) break;
-            if (++spins > DUO_SPIN_LIMIT) { give_up(); return -1; }
+            if (++spins > pipe_spin_limit()) { give_up(); return -1; }
             __builtin_amdgcn_s_sleep(1);
           }
           synced = true;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
             continue;
           }
           if (k < P.max_iter && tg == duo_tag(epoch, k)) break;
-          if (++spins > DUO_SPIN_LIMIT) { give_up(); goto l_end; }
+          if (++spins > pipe_spin_limit()) { give_up(); goto l_end; }
           __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
             continue;
           }
           if (k < P.max_iter && tg == duo_tag(epoch, k)) break;
-          if (++spins > DUO_SPIN_LIMIT) { give_up(); goto m_end; }
+          if (++spins > pipe_spin_limit()) { give_up(); goto m_end; }
           __builtin_amdgcn_s_sleep(1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -651,8 +651,8 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
         int spins = 0;
         for (;;) {
           if (duo_peek64(&g->tag) == duo_tag(epoch, it)) break;
-          if (uni(duo_peek(&ctl->abort))) { status = -9; break; }
-          if (++spins > DUO_SPIN_LIMIT) { give_up(); status = -9; break; }
+          if (uni(duo_peek(&ctl->abort))) { status = AUVP_ST_PIPELINE; break; }
+          if (++spins > pipe_spin_limit()) { give_up(); status = AUVP_ST_PIPELINE; break; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
   {
     int spins = 0;
     while (!uni(duo_peek(&ctl->h_done)) || !uni(duo_peek(&ctl->m_done)) || !uni(duo_peek(&ctl->l_done))) {
-      if (++spins > DUO_SPIN_LIMIT) { status = -9; break; }
+      if (++spins > pipe_spin_limit()) { status = AUVP_ST_PIPELINE; break; }
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -791,6 +791,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
   for (int i = lane; i < K + 1; i += 64) B.bin_count[(size_t)ep * (K + 1) + i] = bin_count[i];
   if (lane == 0) {
     RrtSummary& s = B.summary[ep];
+    pipe_report(B.pipe_fail, status);
     s.status = status; s.n_nodes = n_nodes; s.n_points = n_points; s.n_leaves = 0;
     s.best_leaf = -1; s.best_path_len = 0; s.iters_run = it; s.n_candidates = n_cand;
     s.best_cost[0] = __builtin_inf(); s.best_cost[1] = 0.0; s.best_cost[2] = 0.0; s.best_cost[3] = 0.0;

@@ -416,9 +416,8 @@ extern "C" int auvp_sog_convert(auvp_handle* h, const double* cells, int32_t C, 
   if (n_pts) hipLaunchKernelGGL(auvp::sog_count_kernel, dim3((n_pts + 255) / 256), dim3(256), 0, h->stream, D);
   hipLaunchKernelGGL(auvp::sog_occ_kernel, dim3((unsigned)((tsg + 255) / 256)), dim3(256), 0, h->stream, D);
   // the LDS-tiled sums where a tile with its halo fits (count <= 24: 150 KB), with the radius as a compile-time constant up to
-  // eight cells; AUVP_SOG_TILE=0 forces the per-cell sweep of L2, =2 the tiled kernel with the radius at run time
-  const char* tenv = getenv("AUVP_SOG_TILE");
-  const int tmode = tenv ? atoi(tenv) : 1;
+  // eight cells; option SOG_TILE = 0 forces the per-cell sweep of L2, 2 the tiled kernel with the radius at run time
+  const int tmode = (int)h->opt_num(OPT_SOG_TILE, 1);
   const size_t tile_lds = auvp::sog_tile_bytes(D.count);
   const bool tiled = D.count > 0 && tile_lds <= (size_t)150 * 1024 && tmode != 0;
   const dim3 tgrid((cols + SOG_TW - 1) / SOG_TW, (rows + SOG_TH - 1) / SOG_TH, T);

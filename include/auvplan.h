@@ -28,7 +28,14 @@ enum {
   AUVP_ERR_HIP = -3,
   AUVP_ERR_STATE = -4,
   AUVP_ERR_KEY = -5, /* time-bin key outside 1..K: KeyError at rrt_dubins.py:124 */
-  AUVP_ERR_COMM = -6 /* RCCL missing or a collective failed (auvp_comm_*, auvp_gather*) */
+  AUVP_ERR_COMM = -6, /* RCCL missing or a collective failed (auvp_comm_*, auvp_gather*) */
+  /* per-episode statuses a kernel can leave in a summary record (never returned by an entry point): */
+  AUVP_ERR_GENERATOR = -7, /* an episode's stored MT19937 block phase does not fit the kernel that picked it up (a batch was
+                            * moved between the one-episode and the four-episodes-per-wavefront planner kernels) */
+  AUVP_ERR_PIPELINE = -9   /* a bounded wait of a multi-wavefront (speculative) latency kernel ran out.  The reference cannot
+                            * fail there (rrt_dubins.py:116-151, gym_rrt/envs/rrt_dubins.py:205-248): the host repeats the
+                            * affected work on the one-wavefront kernel inside the same call and counts it
+                            * (auvp_pipeline_fallbacks); the status stays visible only with option PIPE_FALLBACK = 0 */
 };
 
 enum { AUVP_MODE_TIMEBIN = 0, AUVP_MODE_PLANTIME = 1, AUVP_MODE_NN = 2 };
@@ -39,6 +46,17 @@ const char* auvp_version(void);
  * usable -- there is no CPU fallback */
 int auvp_create(int device, auvp_handle** out);
 void auvp_destroy(auvp_handle* h);
+/* Tuning / diagnostic options of a handle.  Every kernel choice the host makes (how many wavefronts per episode, LDS tiles,
+ * culls) has a measured default; an option forces it: `name` without the AUVP_ prefix, e.g. "ROWS", "DUO", "TRIO", "QUAD",
+ * "PRRT_ROWS", "PRRT_PIPE", "PRRT_LAT", "ASTAR_PAIR", "SOG_TILE", "TIGHT_CULL", "NN_EXACT", "PIPE_FALLBACK" (the full list:
+ * INTEGRATION.md).  The environment variable AUVP_<NAME> gives an option its initial value when the handle is created; no
+ * other call reads the environment.  auvp_unset_option returns the choice to the default.  Unknown name: AUVP_ERR_ARG. */
+int auvp_set_option(auvp_handle* h, const char* name, int64_t value);
+int auvp_unset_option(auvp_handle* h, const char* name);
+int auvp_get_option(auvp_handle* h, const char* name, int32_t* is_set, int64_t* value);
+/* episodes / instances the last planning call (*last) and all calls so far (*total) repeated on the one-wavefront kernel
+ * because a speculative latency kernel ended them with AUVP_ERR_PIPELINE (0 in normal operation) */
+int auvp_pipeline_fallbacks(auvp_handle* h, int32_t* last, int64_t* total);
 const char* auvp_last_error(auvp_handle* h);
 
 /* World model shared by every episode of a batch.

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the tests steer kernel choices through AUVP_<NAME> in os.environ on live contexts: auv_sim_amd/_lib.py pushes the environment
+# into the handle's options before every call when this is set (the library itself reads the environment once, at auvp_create)
+os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

@@ -2,8 +2,11 @@
 """Randomised sweep of the helper-wavefront kernels (rrt_duo_kernel, rrt_trio_kernel) against rrt_explore_kernel: random
 worlds, planner parameters, batch sizes and budgets, every summary field and a sample of trees bit for bit.  The speculative
 stages (redo / new epoch, the start-of-episode phase where most bins are empty) depend on timing between wavefronts, so the
-sweep repeats every case.  usage: python tests/experiments/soak_duo.py <cases> <seed>"""
+sweep repeats every case.  With a diagnostic build (AUVPLAN_LIBRARY=auv_sim_amd/libauvplan_diag.so) AUVP_DIAG_JITTER delays
+one stage's hand-overs and AUVP_DIAG_SPIN makes the bounded waits run out: the episodes the pipeline fallback redid are counted
+in the last line.  usage: python tests/experiments/soak_duo.py <cases> <seed>"""
 import os
+os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np
@@ -16,6 +19,7 @@ rng = np.random.default_rng(seed)
 ctx = _lib.Context(0)
 os.environ["AUVP_ROWS"] = "0"
 bad = 0
+fallbacks = 0
 for c in range(n_cases):
     n_obst = int(rng.choice([8, 64, 128, 256]))
     world = synth.make_world(seed=int(rng.integers(1, 10_000)), n_obstacles=n_obst)
@@ -35,7 +39,10 @@ for c in range(n_cases):
         os.environ["AUVP_QUAD"] = "1" if kern == "quad" else "0"
         for _ in range(rep):
             s = ctx.rrt_explore_batch(init, seeds, n_iter, **kw).copy()
-            assert ctx.last_rrt_kernel().startswith("rrt_%s_kernel" % ("trio" if kern == "quad" else kern)), ctx.last_rrt_kernel()
+            redone = ctx.pipeline_fallbacks()[0]
+            fallbacks += redone
+            want = "rrt_explore_kernel" if redone else "rrt_%s_kernel" % ("trio" if kern == "quad" else kern)
+            assert ctx.last_rrt_kernel().startswith(want), (ctx.last_rrt_kernel(), want)
             trees = [ctx.tree(e, s[e]) for e in range(min(E, 3))]
             if ref is None:
                 ref = (s, trees)
@@ -45,5 +52,5 @@ for c in range(n_cases):
             if not ok:
                 bad += 1
                 print("MISMATCH case %d %s: O=%d E=%d iters=%d %s" % (c, kern, n_obst, E, n_iter, kw))
-print("%d cases, %d mismatches" % (n_cases, bad))
+print("%d cases, %d mismatches, %d episodes redone by the pipeline fallback" % (n_cases, bad, fallbacks))
 sys.exit(1 if bad else 0)

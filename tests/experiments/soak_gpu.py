@@ -5,6 +5,7 @@ kernel, the one-episode kernel and the CPU checker (RRT.exploring, time-bin samp
 and plan-time sampling), the astar_fixLenSOG / astar_fixLen searches and Planner_RRT.planning (latency, throughput and
 four-episodes-per-wavefront kernels) with the checker.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
 import os
+os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import random
 import sys
 

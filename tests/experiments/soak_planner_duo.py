@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
-"""Randomised sweep of prrt_duo_kernel (two and three wavefronts per Planner_RRT episode) against prrt_kernel: random worlds,
+"""Randomised sweep of prrt_pipe_kernel (four wavefronts per Planner_RRT episode) against prrt_kernel: random worlds,
 goals near and far (so that plannings end at every stage: the take-back of a step's insert when the arc of the step before is
 free depends on timing between the wavefronts), planner parameters and budgets; every summary field, trees, bucket lists and
 paths bit for bit, and the planning continued by generate_one_node steps.  Every case is repeated.
+With a diagnostic build (AUVPLAN_LIBRARY=auv_sim_amd/libauvplan_diag.so) AUVP_DIAG_JITTER delays one stage's hand-overs and
+AUVP_DIAG_SPIN makes the bounded waits run out: the episodes redone by the pipeline fallback are counted in the last line.
 usage: python tests/experiments/soak_planner_duo.py <cases> <seed>"""
 import os
+os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np
@@ -18,6 +21,7 @@ rng = np.random.default_rng(seed)
 ctx = _lib.Context(0)
 os.environ["AUVP_PRRT_ROWS"] = "0"
 bad = 0
+FALLBACKS = [0]
 for c in range(n_cases):
     n_obst = int(rng.choice([8, 64, 128, 256]))
     w = synth.make_rect_world(seed=int(rng.integers(1, 10_000)), n_obstacles=n_obst)
@@ -33,15 +37,15 @@ for c in range(n_cases):
     goals[near] = starts[near, :2] + rng.uniform(-25, 25, (int(near.sum()), 2))
     seeds = rng.integers(0, 2 ** 40, E).astype(np.uint64)
     ref = None
-    for waves, rep in ((0, 1), (2, 2), (3, 3), (4, 3)):
-        os.environ["AUVP_PRRT_DUO"] = "1" if waves else "0"
-        os.environ["AUVP_PRRT_TRIO"] = "1" if waves == 3 else "0"
+    for waves, rep in ((0, 1), (4, 4)):
         os.environ["AUVP_PRRT_PIPE"] = "1" if waves == 4 else "0"
         for _ in range(rep):
             pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, **kw)
             s = pb.plan().copy()
-            want = {0: "prrt_kernel", 2: "prrt_duo_kernel", 3: "prrt_duo_kernel<3 wavefronts>", 4: "prrt_pipe_kernel"}[waves]
-            assert ctx.prrt_last_kernel() == want, ctx.prrt_last_kernel()
+            want = {0: "prrt_kernel", 4: "prrt_pipe_kernel"}[waves]
+            # (a batch the pipeline's limits exclude, or whose failed episodes were redone, reports prrt_kernel)
+            assert ctx.prrt_last_kernel() in (want, "prrt_kernel"), ctx.prrt_last_kernel()
+            FALLBACKS[0] += ctx.pipeline_fallbacks()[0]
             sample = sorted(set(rng.integers(0, E, 4).tolist())) if ref is None else ref[3]
             trees = [pb.tree(e, s[e]) for e in sample]
             grids = [pb.grid(e) for e in sample]
@@ -65,5 +69,5 @@ for c in range(n_cases):
                 print("MISMATCH case %d waves %d E=%d max_step=%d obst=%d %s: %s" % (c, waves, E, max_step, n_obst, kw, diff[:8]))
     if c % 10 == 9:
         print("  %d cases, %d mismatches (last: E=%d max_step=%d done %d)" % (c + 1, bad, E, max_step, int(ref[0]["done"].sum())), flush=True)
-print("planner soak: %d cases, %d mismatches" % (n_cases, bad))
+print("planner soak: %d cases, %d mismatches, %d episodes redone by the pipeline fallback" % (n_cases, bad, FALLBACKS[0]))
 sys.exit(1 if bad else 0)

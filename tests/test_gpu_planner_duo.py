@@ -1,6 +1,7 @@
-"""prrt_duo_kernel (two wavefronts per Planner_RRT episode: a helper produces the draws, the node pick and the steer's random
-half one step ahead, planner_duo_kernel.h) against prrt_kernel and the checker: bit-identical trees, bucket lists, counters,
-generator state / position and paths -- and the planning can be continued by generate_one_node steps of the other kernel."""
+"""prrt_pipe_kernel (four wavefronts per Planner_RRT episode, a speculative pipeline over the steps: planner_pipe_kernel.h)
+against prrt_kernel and the checker: bit-identical trees, bucket lists, counters, generator state / position and paths -- and
+the planning can be continued by generate_one_node steps of the other kernel.  (Rounds 3-4 also had a two / three-wavefront
+prrt_duo_kernel here; removed in round 5.)"""
 import ctypes as C
 
 import numpy as np
@@ -22,20 +23,19 @@ def _fields_equal(a, b):
 
 
 def _plan(ctx, w, starts, goals, seeds, max_step, duo, monkeypatch, **kw):
-    """duo: 0 = prrt_kernel, 2 / 3 = prrt_duo_kernel with two / three wavefronts per episode, 4 = prrt_pipe_kernel"""
+    """duo: 0 = prrt_kernel, 4 = prrt_pipe_kernel"""
     from auv_sim_amd._prrt_lib import PlannerBatch
     monkeypatch.setenv("AUVP_PRRT_ROWS", "0")
-    monkeypatch.setenv("AUVP_PRRT_DUO", "1" if duo else "0")
-    monkeypatch.setenv("AUVP_PRRT_TRIO", "1" if duo == 3 else "0")
     monkeypatch.setenv("AUVP_PRRT_PIPE", "1" if duo == 4 else "0")
     pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, **kw)
     s = pb.plan().copy()
     ctx.L.auvp_prrt_last_kernel.restype = C.c_char_p
-    assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == {0: "prrt_kernel", 2: "prrt_duo_kernel", 3: "prrt_duo_kernel<3 wavefronts>", 4: "prrt_pipe_kernel"}[duo]
+    assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == {0: "prrt_kernel", 4: "prrt_pipe_kernel"}[duo]
+    assert ctx.pipeline_fallbacks()[0] == 0
     return pb, s
 
 
-@pytest.mark.parametrize("waves", [2, 3, 4])
+@pytest.mark.parametrize("waves", [4])
 @pytest.mark.parametrize("n_ep,freq,max_step,n_obst,subs", [(37, 10, 400, 256, 2), (64, 15, 250, 64, 1), (5, 3, 300, 256, 4), (1, 10, 2000, 256, 1),
                                                            (130, 30, 150, 128, 2), (9, 10, 1, 64, 1)])
 def test_duo_equals_one_wavefront_per_episode(ctx, orc, n_ep, freq, max_step, n_obst, subs, waves, monkeypatch):
@@ -94,8 +94,6 @@ def test_pipeline_continues_a_tree_with_and_without_the_link_mirror(ctx, next_ld
     res = []
     for pipe in (0, 1):
         monkeypatch.setenv("AUVP_PRRT_ROWS", "0")
-        monkeypatch.setenv("AUVP_PRRT_DUO", str(pipe))
-        monkeypatch.setenv("AUVP_PRRT_TRIO", "0")
         monkeypatch.setenv("AUVP_PRRT_PIPE", str(pipe))
         monkeypatch.setenv("AUVP_PRRT_NEXT_LDS", next_lds)
         pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, freq=10, cell=5, subs=2)

@@ -28,7 +28,7 @@ def test_helper_wavefront_kernels_random_cases():
 
 
 def test_planner_helper_wavefronts_random_cases():
-    """prrt_duo_kernel with two and three wavefronts per Planner_RRT episode against prrt_kernel: random worlds, goals near and
+    """prrt_pipe_kernel (four wavefronts per Planner_RRT episode) against prrt_kernel: random worlds, goals near and
     far (plannings that end while the next step is already inserted), parameters and budgets, every case repeated"""
     r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "experiments", "soak_planner_duo.py"), "40", "5"],
                        cwd=REPO, capture_output=True, text=True, timeout=900)
@@ -51,3 +51,46 @@ def test_shark_grid_random_cases():
                        cwd=REPO, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+# ---- the speculative pipelines under a diagnostic build (libauvplan_diag.so = -DAUVP_PIPE_DIAG, built by __graft_entry__.build):
+# delay injection on one stage at a time, and bounded waits that run out
+DIAG = os.path.join(REPO, "auv_sim_amd", "libauvplan_diag.so")
+# (script, cases, seed, {stage name: "mode,mod,residue"}): which wavefronts of a workgroup belong to the stage
+#   rrt_duo: wave & 1 (0 main, 1 helper); rrt_trio <J, 3>: wave % 3 (0 M geometry, 1 H stream, 2 T tree) -- the <J, 4> form of the
+#   same sweep has wave % 4, so `1,3,r` lands on varying roles there: all the better; prrt_pipe: wave & 3 (0 M, 1 H, 2 S, 3 G)
+STAGES = {"soak_duo.py": {"main_or_M": "1,3,0", "H": "1,3,1", "T": "1,3,2", "helper": "1,2,1"},
+          "soak_planner_duo.py": {"M": "1,4,0", "H": "1,4,1", "S": "1,4,2", "G": "1,4,3"}}
+
+
+def _diag_run(script, cases, seed, jitter=None, spin=None):
+    assert os.path.exists(DIAG), "libauvplan_diag.so is built by __graft_entry__.build()"
+    env = dict(os.environ, AUVPLAN_LIBRARY=DIAG)
+    env.pop("AUVP_DIAG_JITTER", None)
+    env.pop("AUVP_DIAG_SPIN", None)
+    if jitter:
+        env["AUVP_DIAG_JITTER"] = jitter
+    if spin:
+        env["AUVP_DIAG_SPIN"] = str(spin)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "experiments", script), str(cases), str(seed)],
+                       cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert " 0 mismatches" in last, last
+    return int(last.split("mismatches,")[1].split()[0])   # episodes redone by the pipeline fallback
+
+
+@pytest.mark.parametrize("script,stage", [(s, k) for s in STAGES for k in STAGES[s]])
+def test_pipelines_under_delay_injection(script, stage):
+    """a pseudo-random delay of 0 .. 32 x s_sleep 1 (~0 .. 2 000 clocks) before every hand-over word of ONE stage: the rare
+    orderings (a stage stalled across an epoch change, a ring wrap during a rewind) must give the one-wavefront kernel's trees"""
+    redone = _diag_run(script, 12, 21, jitter="%s,32,7" % STAGES[script][stage])
+    assert redone == 0   # (the default spin limit: a delayed stage is waited for, not given up on)
+
+
+@pytest.mark.parametrize("script,spin", [("soak_duo.py", 300), ("soak_planner_duo.py", 200)])
+def test_a_wait_that_runs_out_is_redone_on_the_one_wavefront_kernel(script, spin):
+    """bounded waits of a few hundred polls (AUVP_DIAG_SPIN) + a delayed stage: episodes end with AUVP_ERR_PIPELINE inside the
+    launch and the host redoes them on the one-wavefront kernel in the same call -- same trees, bucket lists, generator state"""
+    redone = _diag_run(script, 12, 4, jitter="%s,64,3" % list(STAGES[script].values())[1], spin=spin)
+    assert redone > 0

@@ -3,6 +3,7 @@
 AUVP_ROWS=1: four), on the headline world: where the host's choice between them (auvplan.hip: rows above 24 episodes per CU)
 sits.  Run on a GPU box: python tools/batch_size_probe.py [iters]"""
 import os
+os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 """Latency runs with one (rrt_explore_kernel), two (rrt_duo_kernel) and three (rrt_trio_kernel) wavefronts per episode: one
 episode, 64 / 256 / 1 024 episodes of the headline world, and config 2's 1 024 replicas (64 obstacles).  Run on a GPU box."""
 import os
+os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 """Config 4 (512 Planner_RRT.planning(2000) episodes) with one / two / three wavefronts per episode.  With a diagnostic build
 (AUVPLAN_LIBRARY=<lib built with -DAUVP_DUO_DIAG>) also the shader clocks per step each wavefront spends at work."""
 import os
+os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np

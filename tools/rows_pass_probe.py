@@ -10,6 +10,7 @@ Prints one JSON line per freq: rrt_rows_kernel ms on the headline batch (12 288 
 nodes and path points per episode (the trees are the same for every padding)."""
 import json
 import os
+os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np
