@@ -88,9 +88,9 @@ def test_pipelines_under_delay_injection(script, stage):
     assert redone == 0   # (the default spin limit: a delayed stage is waited for, not given up on)
 
 
-@pytest.mark.parametrize("script,spin", [("soak_duo.py", 300), ("soak_planner_duo.py", 200)])
+@pytest.mark.parametrize("script,spin", [("soak_duo.py", 6), ("soak_planner_duo.py", 6)])
 def test_a_wait_that_runs_out_is_redone_on_the_one_wavefront_kernel(script, spin):
-    """bounded waits of a few hundred polls (AUVP_DIAG_SPIN) + a delayed stage: episodes end with AUVP_ERR_PIPELINE inside the
+    """bounded waits of six polls (AUVP_DIAG_SPIN: a poll is ~100 clocks, a stage thousands) + a delayed stage: episodes end with AUVP_ERR_PIPELINE inside the
     launch and the host redoes them on the one-wavefront kernel in the same call -- same trees, bucket lists, generator state"""
     redone = _diag_run(script, 12, 4, jitter="%s,64,3" % list(STAGES[script].values())[1], spin=spin)
     assert redone > 0
