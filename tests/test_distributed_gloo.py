@@ -1,4 +1,5 @@
-"""The N>1 path on CPU: world_size-2 gloo run of the shard + gather logic bench.py uses."""
+"""The N>1 path on CPU: gloo runs of the shard + gather logic bench.py uses, at world size 2 and at the target's world size 8
+(eight processes: uneven and empty shards, config 4's 512 episodes, config 5's 12 500 episodes per rank as lengths)."""
 import os
 import socket
 
@@ -100,18 +101,28 @@ def test_shard_range_partitions_everything():
 import pytest
 
 
-@pytest.mark.parametrize("E_total", [11, 12, 1])  # uneven split, even split, one rank with nothing
-def test_two_rank_gather_gloo(E_total):
+def _run_ranks(target, world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, E_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)], sorted(res)
+
+
+@pytest.mark.parametrize("E_total", [11, 12, 1])  # uneven split, even split, one rank with nothing
+def test_two_rank_gather_gloo(E_total):
+    _run_ranks(_worker, 2, E_total)
+
+
+@pytest.mark.parametrize("E_total", [512, 9, 1])  # config 4 (64 per rank), one rank with two, seven ranks with nothing
+def test_eight_rank_gather_gloo(E_total):
+    """the target's world size: every rank rebuilds the whole result in global episode order (== the one-rank order)"""
+    _run_ranks(_worker, 8, E_total)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -244,16 +255,45 @@ def _rccl_python_worker(rank, world, port, E_total, q):
 
 @pytest.mark.parametrize("E_total", [9, 8, 1])  # uneven, even, one rank with an empty shard
 def test_rccl_gather_python_two_ranks(E_total):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_rccl_python_worker, args=(r, 2, port, E_total, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    _run_ranks(_rccl_python_worker, 2, E_total)
+
+
+@pytest.mark.parametrize("E_total", [512, 13, 3])  # config 4; uneven; five ranks with an empty shard
+def test_rccl_gather_python_eight_ranks(E_total):
+    """RcclGather's Python at world size 8 (the C-ABI stand-in broadcasts from every root in turn, like the library's grouped
+    ncclBroadcast): counts, buffer sizing, slicing, order"""
+    _run_ranks(_rccl_python_worker, 8, E_total)
+
+
+def _lengths_worker(rank, world, port, per_rank, q):
+    """config 5's shape as LENGTHS only: 12 500 episodes per rank, variable path lengths, payload of one float per point"""
+    import sys
+    sys.path.insert(0, REPO)
+    from auv_sim_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = D.TorchGather()
+    E_total = per_rank * world
+    lo, hi = D.shard_range(E_total, rank, world)
+    ok = (hi - lo) == per_rank
+    e = torch.arange(lo, hi, dtype=torch.int64)
+    lens = (e * 7919) % 5                          # 0..4 points, a function of the global episode id
+    paths = torch.repeat_interleave(e.to(torch.float64), lens).reshape(-1, 1)
+    all_len, all_paths = G.gather_paths(paths, lens)
+    for r in range(world):
+        rlo, rhi = D.shard_range(E_total, r, world)
+        ee = torch.arange(rlo, rhi, dtype=torch.int64)
+        want_len = (ee * 7919) % 5
+        ok &= bool((all_len[r].cpu() == want_len).all())
+        ok &= bool((all_paths[r].cpu().reshape(-1) == torch.repeat_interleave(ee.to(torch.float64), want_len)).all())
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gather_of_config5_sized_shards():
+    _run_ranks(_lengths_worker, 8, 12500)
 
 
 def test_rccl_unloadable_is_an_error_code_not_a_crash():

@@ -72,3 +72,14 @@ def test_two_ranks_on_one_gpu_shard_the_batch_and_report_per_rank():
         assert isinstance(rf[k], float) and rf[k] > 0, k
     assert rf["frac"] <= 1.0 and rf["leaf_frac"] <= 1.0
     assert 1000.0 < rf["hbm_measured_GBps"] < 8000.0  # a measured HBM read rate, below the datasheet peak
+
+
+def test_eight_ranks_on_one_gpu_spawn_shard_and_gather():
+    """the target's world size through bench.py's own spawn path: eight fresh ranks share GPU 0 (gloo transport), eight episodes
+    each; the gathered result covers the 64 global episode ids and equals one rank running all 64"""
+    eight = _bench(8, 8, extra=["--no-extra"], one_gpu=True)
+    assert eight["n_gpus"] == 8 and eight["config"]["parallelism"] == "episodes sharded x8" and eight["_line"]["n_gpus"] == 8
+    assert len(eight["kernel_ms_per_rank"]) == 8 and len(eight["gather_ms_per_rank"]) == 8
+    one = _bench(1, 64, extra=["--no-extra"])
+    assert eight["expansions_per_step"] == one["expansions_per_step"] == 64 * 300
+    assert eight["accepted_nodes_per_step"] == one["accepted_nodes_per_step"] > 0
