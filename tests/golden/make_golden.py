@@ -20,6 +20,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE  # where the fixtures are written: this directory, or a scratch directory in --check mode
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get("AUVP_REFERENCE", "/root/reference")
 sys.path.insert(0, REPO)
@@ -92,7 +93,7 @@ def sha(*arrays):
 
 
 def save_npz(name, **arrs):
-    path = os.path.join(HERE, name)
+    path = os.path.join(OUT, name)
     np.savez_compressed(path, **arrs)
     print("wrote", path, os.path.getsize(path), "bytes")
 
@@ -129,7 +130,7 @@ def g7():
         "atan2_x_1": [math.atan2(x, 1.0) for x in xs],
         "pow2": [x ** 2 for x in xs],
     }
-    with open(os.path.join(HERE, "g7_random_kat.json"), "w") as f:
+    with open(os.path.join(OUT, "g7_random_kat.json"), "w") as f:
         json.dump(out, f, indent=0)
     print("wrote g7_random_kat.json")
 
@@ -197,7 +198,7 @@ def g5():
            "penta": [[0, 0], [180, -20], [240, 90], [120, 200], [-30, 120]],
            "cases": [{"pts": p, "obs": o, "free": r} for p, o, r in cases],
            "penta_cases": [{"pts": p, "obs": o, "free": r} for p, o, r in pcases]}
-    with open(os.path.join(HERE, "g5_collision.json"), "w") as f:
+    with open(os.path.join(OUT, "g5_collision.json"), "w") as f:
         json.dump(out, f)
     print("wrote g5_collision.json", sum(c[2] for c in cases), "free of", len(cases),
           "| penta", sum(c[2] for c in pcases), "of", len(pcases))
@@ -245,7 +246,7 @@ def g4():
             "n_bins": T, "pts": pts, "bin_lo": lo, "bin_hi": hi, "total": total, "weights": weights,
             "out": [float(res[0])] + [float(c) for c in res[1]],
         })
-    with open(os.path.join(HERE, "g4_cost.json"), "w") as f:
+    with open(os.path.join(OUT, "g4_cost.json"), "w") as f:
         json.dump({"cases": cases}, f)
     print("wrote g4_cost.json")
 
@@ -368,6 +369,12 @@ def g3():
         ("g3_tb_dense", 13, dict(seed=4, n_obstacles=64, obst_radius=(4.0, 9.0)), 600, "timebin",
          {"freq": 12}),
         ("g3_tb_o256_i10000", 7, dict(seed=2, n_obstacles=256), 10000, "timebin", {"keep_points": False}),
+        # edge cases (commit e55714b; their specs were missing from this list until round 5): a horizon that is not a multiple
+        # of the bin interval, so that inserts beyond it reset the overflow bin (rrt_dubins.py:148-151); more sub-arcs per
+        # steer than a wavefront has lanes (freq 100 / 70); a world without obstacles and habitats, nearest-neighbour sampling
+        ("g3_tb_binreset", 21, dict(seed=5, n_obstacles=40, n_bins=3), 900, "timebin", {"max_traj_time": 122.0, "shark_interval": 30}),
+        ("g3_tb_freq100", 22, dict(seed=6, n_obstacles=64), 300, "timebin", {"freq": 100, "max_traj_time": 300.0}),
+        ("g3_nn_freq70_noobs", 23, dict(seed=7, n_obstacles=0, n_habitats=0), 300, "nn", {"freq": 70, "max_traj_time": 200.0}),
         # the bench world itself (bench.py: 256 obstacles, 200x200 cells of 10 m = 40 000 cells, 10 bins) with a short
         # horizon so the reference's linear cell scan (path_planning/cost.py:181-184, ~20 000 dict entries per path
         # point) finishes: pins the device's cell index at the headline size against the reference.  The 4.5 MB of
@@ -1047,7 +1054,7 @@ def g12():
                 outs.append(float(c))
             points.append({"world_seed": 300 + k, "n_habitats": len(habitats), "cell": 10.0 if k % 2 else 20.0, "n_bins": T,
                            "bin": k % T, "pts": pts[:40], "weights": w3, "out": outs})
-    with open(os.path.join(HERE, "g12_cost_twins.json"), "w") as f:
+    with open(os.path.join(OUT, "g12_cost_twins.json"), "w") as f:
         json.dump({"twin": twin, "edges": edges, "points": points}, f)
     print("wrote g12_cost_twins.json", len(twin), len(edges), len(points))
 
@@ -1213,7 +1220,7 @@ def g14():
             case["correction_zero_raises"] = type(e).__name__
         out["cases"].append(case)
         print("g14", name, "grid", rows, "x", cols, "cells", len(cells), {k: v for k, v in case.items() if k.endswith("raises")})
-    with open(os.path.join(HERE, "g14_shark_update.json"), "w") as f:
+    with open(os.path.join(OUT, "g14_shark_update.json"), "w") as f:
         json.dump(out, f)
 
 
@@ -1232,7 +1239,7 @@ def g15():
             self.bounds = (float(i), 0.5 * i, float(i) + 1.0, 0.5 * i + 1.0)
     cell_list = [Cell(i) for i in range(1200)]
     src = os.path.join(REF, "path_planning", "shark_data")
-    dst = os.path.join(HERE, "shark_data")
+    dst = os.path.join(OUT, "shark_data")
     os.makedirs(dst, exist_ok=True)
     out = {}
     for name in sorted(os.listdir(src)):
@@ -1252,13 +1259,83 @@ def g15():
             out["%s_%s_first_cell" % (stem, twin)] = np.array(list(g[keys[0]].keys())[0])
             out["%s_%s_last_cell" % (stem, twin)] = np.array(list(g[keys[-1]].keys())[-1])
             print("g15", stem, twin, "bins", len(keys), "cells per bin", sorted(set(lens)), "sum", float(vals.sum()))
-    np.savez_compressed(os.path.join(HERE, "g15_shark_grid_csv.npz"), **out)
+    np.savez_compressed(os.path.join(OUT, "g15_shark_grid_csv.npz"), **out)
 
 
 ALL = {"g15": g15, "g7": g7, "g5": g5, "g4": g4, "g3": g3, "g2": g2, "g1": g1, "g6": g6, "g6b": g6b, "g8": g8, "g9": g9,
        "g10": g10, "g11": g11, "g12": g12, "g13": g13, "g14": g14}
 
+# the fast subset `--check` regenerates by default (seconds of reference Python each); AUVP_G3_ONLY narrows g3
+FAST = ("g7", "g5", "g4", "g1", "g12", "g14", "g15")
+FAST_G3 = "g3_tb_o64_i500,g3_nn_o64_i500,g3_pt_o64_i500,g3_tb_binreset,g3_tb_freq100,g3_nn_freq70_noobs,g3_tb_short_traj,g3_tb_dense"
+
+
+def _same(a, b):
+    if isinstance(a, dict) and isinstance(b, dict):
+        return a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, (list, tuple)) and isinstance(b, (list, tuple)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, float) and isinstance(b, float):
+        return a == b or (a != a and b != b)
+    return a == b
+
+
+def compare_dirs(new_dir, old_dir):
+    """every file the generators wrote into new_dir against the committed fixture of the same name: every array of an .npz
+    (dtype, shape, values; NaNs equal), every value of a .json, the bytes of a .csv.gz's content.  Returns the differences."""
+    import gzip
+    bad = []
+    n_files = 0
+    for root, _, files in os.walk(new_dir):
+        for f in sorted(files):
+            new = os.path.join(root, f)
+            old = os.path.join(old_dir, os.path.relpath(new, new_dir))
+            n_files += 1
+            if not os.path.exists(old):
+                bad.append("%s: no committed fixture" % f)
+            elif f.endswith(".npz"):
+                a, b = np.load(new, allow_pickle=False), np.load(old, allow_pickle=False)
+                if sorted(a.files) != sorted(b.files):
+                    bad.append("%s: arrays %s" % (f, sorted(set(a.files) ^ set(b.files))))
+                    continue
+                for k in a.files:
+                    x, y = a[k], b[k]
+                    if x.dtype != y.dtype or x.shape != y.shape or not np.array_equal(x, y, equal_nan=x.dtype.kind == "f"):
+                        bad.append("%s[%s]" % (f, k))
+            elif f.endswith(".json"):
+                if not _same(json.load(open(new)), json.load(open(old))):
+                    bad.append(f)
+            elif f.endswith(".gz"):
+                if gzip.open(new).read() != gzip.open(old).read():
+                    bad.append(f)
+    return n_files, bad
+
+
+def check(which):
+    """--check: run the generators into a scratch directory and compare with the committed fixtures (nothing is overwritten)"""
+    import tempfile
+    global OUT
+    fast = not which
+    which = which or list(FAST) + ["g3"]
+    if fast and "AUVP_G3_ONLY" not in os.environ:
+        os.environ["AUVP_G3_ONLY"] = FAST_G3
+    with tempfile.TemporaryDirectory(prefix="auvp_golden_") as tmp:
+        OUT = tmp
+        try:
+            for w in which:
+                ALL[w]()
+        finally:
+            OUT = HERE
+        n, bad = compare_dirs(tmp, HERE)
+    print("golden check: %d regenerated files, %d differences%s" % (n, len(bad), (": " + ", ".join(bad[:12])) if bad else ""))
+    return n, bad
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or list(ALL)
+    args = sys.argv[1:]
+    if args and args[0] == "--check":
+        # python tests/golden/make_golden.py --check [g1 g3 ...]   (no names: the fast subset; exit status 1 on a difference)
+        sys.exit(1 if check(args[1:])[1] else 0)
+    which = args or list(ALL)
     for w in which:
         ALL[w]()
