@@ -403,6 +403,9 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       }
     }
     const int cur = uni(bi);
+    // open nodes are left but none could be chosen: every remaining f is a nan (non-finite weights or grid values -- outside
+    // the reference's domain; in the scan a nan also marks a closed node).  An error status, never an index out of bounds.
+    if (cur == 0x7fffffff) { status = -1; break; }
     if (list_ok) {  // the last entry takes the place of the popped one (the order of the list does not matter)
       const int pp = uni(bpos);
       if (lane == 0 && pp != n_list - 1) { of_l[pp] = of_l[n_list - 1]; oi_l[pp] = oi_l[n_list - 1]; }

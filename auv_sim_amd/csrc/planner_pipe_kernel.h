@@ -905,6 +905,9 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // a stage that gave up (abort) may have posted its final words before this wavefront had finished: the episode's stream
+    // position is then not to be trusted even though every step went through -- it is redone like any other failed episode
+    if (status == 0 && uni(duo_peek(&ctl->abort))) status = AUVP_ST_PIPELINE;
   }
   if (lane == 0) {
     pipe_report(B.pipe_fail, status);

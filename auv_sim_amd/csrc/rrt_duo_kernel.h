@@ -603,6 +603,9 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
       __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // a stage that gave up (abort) may have posted its final words before this wavefront had finished: the episode's stream
+    // position is then not to be trusted even though every step went through -- it is redone like any other failed episode
+    if (status == 0 && uni(duo_peek(&ctl->abort))) status = AUVP_ST_PIPELINE;
   }
   for (int i = lane; i < K + 1; i += 64) B.bin_count[(size_t)ep * (K + 1) + i] = bin_count[i];
   if (lane == 0) {

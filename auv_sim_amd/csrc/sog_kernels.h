@@ -356,12 +356,34 @@ extern "C" int auvp_sog_convert(auvp_handle* h, const double* cells, int32_t C, 
     const double span = hi - lo, yspan = yhi - ylo;
     if (span > 0 && std::isfinite(wmin)) NBX = (int)std::min(1024.0, std::max(1.0, std::ceil(span / wmin)));
     if (yspan > 0 && std::isfinite(hmin)) NBY = (int)std::min(1024.0, std::max(1.0, std::ceil(yspan / hmin)));
-    X0 = lo; inv_w = span > 0 ? (double)NBX / span : 0.0;
-    Y0 = ylo; inv_h = yspan > 0 ? (double)NBY / yspan : 0.0;
     auto bucket = [](double v, double v0, double inv, int nb) {
       const int b = (int)std::floor((v - v0) * inv);
       return std::max(0, std::min(nb - 1, b));
     };
+    // The bucket size comes from the SMALLEST cell, and a cell is entered into every bucket it overlaps: a list of mixed sizes
+    // (one large cell beside many small ones, thin slivers) would make the table and its items O(C x NBX x NBY).  Bounded:
+    // the table to max(4 096, 8 C) buckets, the items to 16 C + 4 096 -- the index is halved in both directions until it fits
+    // (a coarser index lists more candidate cells per point, in the same order: same result).
+    X0 = lo; Y0 = ylo;
+    for (;;) {
+      inv_w = span > 0 ? (double)NBX / span : 0.0;
+      inv_h = yspan > 0 ? (double)NBY / yspan : 0.0;
+      if (NBX == 1 && NBY == 1) break;
+      bool fits = (size_t)NBX * NBY <= std::max<size_t>(4096, 8 * (size_t)C);
+      if (fits) {
+        const size_t budget = 16 * (size_t)C + 4096;
+        size_t items = 0;
+        for (int c = 0; c < C && items <= budget; c++) {
+          const size_t nx = (size_t)(bucket(cells[4 * c + 2], X0, inv_w, NBX) - bucket(cells[4 * c], X0, inv_w, NBX) + 1);
+          const size_t ny = (size_t)(bucket(cells[4 * c + 3], Y0, inv_h, NBY) - bucket(cells[4 * c + 1], Y0, inv_h, NBY) + 1);
+          items += nx * ny;
+        }
+        fits = items <= budget;
+      }
+      if (fits) break;
+      NBX = std::max(1, NBX / 2);
+      NBY = std::max(1, NBY / 2);
+    }
     // the device computes the same floor((v - v0) * inv), clamped: a monotone map, so every coordinate inside a cell lands in
     // a bucket between those of the cell's two ends
     std::vector<int32_t> cnt((size_t)NBX * NBY + 1, 0);
