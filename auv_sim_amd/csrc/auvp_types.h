@@ -160,7 +160,6 @@ struct RrtBuffers {
   // the units of the leaf pass's compulsory-traffic figure (bench.py)
   unsigned long long* leaf_stats;
   int32_t* pipe_fail;  // host-mapped word, set to 1 by an episode that ends with AUVP_ST_PIPELINE (null: not reported)
-  uint32_t* mt_ring;   // [E][624] working copy of the generator state for rrt_rows_kernel<true> (ring in global memory)
 };
 
 }  // namespace auvp

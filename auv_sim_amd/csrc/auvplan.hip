@@ -50,12 +50,12 @@ struct DevBuf {
 enum AuvpOpt {
   OPT_ROWS, OPT_DUO, OPT_TRIO, OPT_QUAD, OPT_TIGHT_CULL, OPT_NN_EXACT, OPT_LEAF_SWEEP_ALL, OPT_NO_HABITAT_GRID, OPT_RG_MAX_ENTRIES,
   OPT_NO_GRID_INDEX, OPT_PRRT_LAT, OPT_PRRT_PIPE, OPT_PRRT_OBST_LDS, OPT_PRRT_NEXT_LDS, OPT_PRRT_ROWS, OPT_ASTAR_NO_GRID,
-  OPT_ASTAR_NO_LIST, OPT_ASTAR_PAIR, OPT_SOG_TILE, OPT_PIPE_FALLBACK, OPT_ROWS_RING, OPT_COUNT
+  OPT_ASTAR_NO_LIST, OPT_ASTAR_PAIR, OPT_SOG_TILE, OPT_PIPE_FALLBACK, OPT_COUNT
 };
 static const char* const AUVP_OPT_NAMES[OPT_COUNT] = {
   "ROWS", "DUO", "TRIO", "QUAD", "TIGHT_CULL", "NN_EXACT", "LEAF_SWEEP_ALL", "NO_HABITAT_GRID", "RG_MAX_ENTRIES",
   "NO_GRID_INDEX", "PRRT_LAT", "PRRT_PIPE", "PRRT_OBST_LDS", "PRRT_NEXT_LDS", "PRRT_ROWS", "ASTAR_NO_GRID",
-  "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "ROWS_RING"};
+  "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK"};
 
 struct auvp_handle {
   bool opt_has[OPT_COUNT] = {};
@@ -83,7 +83,7 @@ struct auvp_handle {
   RrtBuffers B{};
   int max_pts = 0;
   DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_seeds, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_phase, d_leaf_stats, d_mt_ring, d_node_c, d_node_q, d_node_xy, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+      d_leaf_c, d_leaf_i, d_phase, d_leaf_stats, d_node_c, d_node_q, d_node_xy, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
@@ -885,32 +885,10 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
     const RowsLdsPlan rq = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), wg_waves);
     const int per_wg = wg_waves * RW_ROWS;
     grid_used = (E + per_wg - 1) / per_wg; block_used = wg_waves * 64; lds_used = rq.total;
-    // Batches that can give every CU more than 48 episodes run the form with the generator's state in global memory (a ring per
-    // episode + a 256-word LDS window: rrt_rows_kernel<true>): 16 waves = 64 episodes per workgroup, four wavefronts per SIMD
-    // instead of three.  Option ROWS_RING = 1 / 0 forces the choice.  (profiles/r5_rows_fourth_wave.md)
-    const bool ring = h->opt_flag(OPT_ROWS_RING, E > RW_WAVES * RW_ROWS * n_cu);
-    if (ring) {
-      wg_waves = (E + RW_ROWS * n_cu - 1) / (RW_ROWS * n_cu);
-      wg_waves = wg_waves < 1 ? 1 : (wg_waves > 16 ? 16 : wg_waves);
-      const RowsLdsPlan rr = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), wg_waves, true);
-      const RowsLdsPlan rmax = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), 16, true);
-      const int pw = wg_waves * RW_ROWS;
-      grid_used = (E + pw - 1) / pw; block_used = wg_waves * 64; lds_used = rr.total;
-      h->last_rrt_kernel = "rrt_rows_kernel<ring>";
-      le = h->d_mt_ring.reserve((size_t)E * 624 * sizeof(uint32_t));
-      RrtBuffers BR = B;
-      BR.mt_ring = h->d_mt_ring.as<uint32_t>();
-      if (le == hipSuccess) le = hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_rows_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, rmax.total);
-      if (le == hipSuccess) {
-        hipLaunchKernelGGL(rrt_rows_kernel<true>, dim3(grid_used), dim3(block_used), rr.total, h->stream, h->W, PR, BR, (int)E);
-        le = hipGetLastError();
-      }
-    } else {
-      le = hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_rows_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, rp.total);
-      if (le == hipSuccess) {
-        hipLaunchKernelGGL(rrt_rows_kernel<false>, dim3(grid_used), dim3(block_used), rq.total, h->stream, h->W, PR, B, (int)E);
-        le = hipGetLastError();
-      }
+    le = hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, rp.total);
+    if (le == hipSuccess) {
+      hipLaunchKernelGGL(rrt_rows_kernel, dim3(grid_used), dim3(block_used), rq.total, h->stream, h->W, PR, B, (int)E);
+      le = hipGetLastError();
     }
   } else {
   // compile-time specialisation: obstacles per lane (J), parent-sampling mode, diagnostics on/off

@@ -23,10 +23,7 @@
 
 namespace auvp {
 
-#ifndef AUVP_RW_WAVES
-#define AUVP_RW_WAVES 12
-#endif
-constexpr int RW_WAVES = AUVP_RW_WAVES;  // most waves per workgroup (48 episodes: one workgroup fills a CU's LDS); small batches use fewer
+constexpr int RW_WAVES = 12;  // most waves per workgroup (48 episodes: one workgroup fills a CU's LDS); small batches use fewer
 constexpr int RW_ROWS = 4;    // episodes per wave
 constexpr int RW_C = 15;      // sub-arcs per steer pass (lane 15 of the row: pass-entry angle)
 constexpr int RW_MAX_FREQ = 2 * RW_C;
@@ -37,15 +34,15 @@ struct RowsLdsPlan {
   int tables, mt, scratch, bins, per_ep, obst, total;
 };
 
-__host__ __device__ inline RowsLdsPlan rrt_rows_lds_plan(int K, int n_obst_slots, int tables_bytes, int waves = RW_WAVES, bool ring = false) {
+__host__ __device__ inline RowsLdsPlan rrt_rows_lds_plan(int K, int n_obst_slots, int tables_bytes, int waves = RW_WAVES) {
   RowsLdsPlan p;
   p.tables = (tables_bytes + 15) & ~15;
-  p.mt = ring ? 256 * 4 : 624 * 4;  // the generator's state, or (ring) the window of its 256 most recent words
+  p.mt = 624 * 4;
   const int win = RW_WIN * 8, inc = 4 * 18 * 8;
   p.scratch = ((win > inc ? win : inc) + 15) & ~15;
   p.bins = (((K + 2) * 2) + 15) & ~15;
   p.per_ep = p.mt + p.scratch + p.bins;
-  p.obst = n_obst_slots * (8 + 8 + 4) + (ring ? 16 * 32 : 0);  // x, y f64; cull radius f32; (ring) the 16 slot boxes
+  p.obst = n_obst_slots * (8 + 8 + 4);  // x, y f64; cull radius f32
   p.total = p.tables + waves * RW_ROWS * p.per_ep + p.obst;
   return p;
 }
@@ -146,163 +143,7 @@ __device__ __forceinline__ void rows_advance(RowRng& r, bool on, uint32_t nwords
   }
 }
 
-// ---- the same stream with its state OUT of LDS (rrt_rows_kernel<true>: 16 waves = 64 episodes per CU) --------------------
-// MT19937 in absolute stream terms is x[w] = x[w-227] ^ twist(x[w-624], x[w-623]).  The 624-word state of an episode is a
-// ring in global memory (RrtBuffers::mt_ring: word w at slot w mod 624): generating word w reads slots w mod 624 and
-// (w+1) mod 624 -- written 624 / 623 words ago, one coalesced 64-byte read per 16-word block and row -- and overwrites the
-// first.  The most recent 256 words live in an LDS window (word w at index w & 255, 1 KB per episode instead of 2.5): it
-// serves x[w-227] and every consumer (rows_random_at), so the only global traffic is one read and one write stream, 8 bytes
-// per generated word.  Invariants: avail (generated, not consumed) stays below 225, so a round's 32 new words overwrite
-// only consumed ones; reads of a round come before its writes.  The words of the state the episode starts with are
-// "generated" by copying (copy_left counts them): block 0 of the stream IS the state.
-struct RingRowRng {
-  uint32_t* s;     // LDS window [256]
-  uint32_t* ring;  // RrtBuffers::mt_ring (uniform); the episode's ring [624] starts at ring + 624 ep, formed where it is used
-  int ep;
-  uint32_t gslot, cl, avail, copy_left;  // slot of the next word to generate; window index of the next word to consume
-  unsigned long long drawn;
-};
-constexpr uint32_t RW_RING_WIN = 256;
-
-__device__ __forceinline__ void rows_ensure(RingRowRng& r, bool want, uint32_t need, int rl) {
-  for (;;) {
-    const bool go = want && r.avail < need;
-    if (!__any(go)) break;
-    const uint32_t wl0 = (r.cl + r.avail) & (RW_RING_WIN - 1u);  // window index of the first new word (a multiple of 16)
-    int e_ = r.ep;
-    __asm__ volatile("" : "+v"(e_));
-    uint32_t* g = r.ring + (size_t)e_ * 624;
-    uint32_t v2[2], kk[2], wl[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      uint32_t fh = r.gslot + 16u * (uint32_t)h;
-      fh = fh >= 624u ? fh - 624u : fh;
-      const uint32_t k = fh + (uint32_t)rl;
-      const uint32_t k1 = (k == 623u) ? 0u : k + 1u;
-      uint32_t a = 0u, b = 0u;
-      if (go) { a = g[k]; b = g[k1]; }
-      wl[h] = (wl0 + 16u * (uint32_t)h + (uint32_t)rl) & (RW_RING_WIN - 1u);
-      const uint32_t c = r.s[(wl[h] + (RW_RING_WIN - 227u)) & (RW_RING_WIN - 1u)];  // x[w-227]: 227 words back in the window
-      const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
-      const bool copy = r.copy_left > 16u * (uint32_t)h;  // (copy_left is a multiple of 16)
-      v2[h] = copy ? a : (c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u));
-      kk[h] = k;
-    }
-    wave_sync();  // every lane's window reads are issued before any lane's write
-    if (go) {
-      r.s[wl[0]] = v2[0]; r.s[wl[1]] = v2[1];
-      if (r.copy_left == 0u) g[kk[0]] = v2[0];
-      if (r.copy_left <= 16u) g[kk[1]] = v2[1];
-    }
-    wave_sync();
-    if (go) {
-      uint32_t gs = r.gslot + 32u;
-      r.gslot = gs >= 624u ? gs - 624u : gs;
-      r.avail += 32u;
-      r.copy_left = r.copy_left > 32u ? r.copy_left - 32u : 0u;
-    }
-  }
-}
-// Once per iteration: every row that asks is brought to `target` words ahead of its consumer (enough for a whole iteration:
-// the selection's 32 + two passes' windows), so that the rows_ensure calls inside the iteration find nothing to do.  The
-// global accesses of a top-up are batched: the reads of round k + 1 are in flight while round k is computed, and the new
-// words go to the ring in a second sweep out of the LDS window -- in rows_ensure every round's reads queue behind the previous
-// round's writes (memory operations complete in order), two round trips per 32 words on the iteration's critical path.
-__device__ __forceinline__ void rows_topup(RingRowRng& r, bool want, uint32_t target, int rl) {
-  int e_ = r.ep;
-  __asm__ volatile("" : "+v"(e_));
-  uint32_t* g = r.ring + (size_t)e_ * 624;
-  const bool any_go = __any(want && r.avail < target);
-  if (!any_go) return;
-  const uint32_t gslot0 = r.gslot, avail0 = r.avail, copy0 = r.copy_left;
-  auto slot_of = [&](uint32_t gs, int h, uint32_t& k, uint32_t& k1) {
-    uint32_t fh = gs + 16u * (uint32_t)h;
-    fh = fh >= 624u ? fh - 624u : fh;
-    k = fh + (uint32_t)rl;
-    k1 = (k == 623u) ? 0u : k + 1u;
-  };
-  uint32_t a[2] = {0u, 0u}, b[2] = {0u, 0u};
-  bool go = want && r.avail < target;
-  if (go) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) { uint32_t k, k1; slot_of(r.gslot, h, k, k1); a[h] = g[k]; b[h] = g[k1]; }
-  }
-  for (;;) {
-    if (!__any(go)) break;
-    // the next round's reads first (their slots were written 560+ words ago: nothing of this top-up is in them)
-    uint32_t gs_n = r.gslot + 32u;
-    gs_n = gs_n >= 624u ? gs_n - 624u : gs_n;
-    const bool go_n = go && r.avail + 32u < target;
-    uint32_t an[2] = {0u, 0u}, bn[2] = {0u, 0u};
-    if (go_n) {
-#pragma unroll
-      for (int h = 0; h < 2; h++) { uint32_t k, k1; slot_of(gs_n, h, k, k1); an[h] = g[k]; bn[h] = g[k1]; }
-    }
-    const uint32_t wl0 = (r.cl + r.avail) & (RW_RING_WIN - 1u);
-    uint32_t v2[2], wl[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      wl[h] = (wl0 + 16u * (uint32_t)h + (uint32_t)rl) & (RW_RING_WIN - 1u);
-      const uint32_t c = r.s[(wl[h] + (RW_RING_WIN - 227u)) & (RW_RING_WIN - 1u)];
-      const uint32_t y = (a[h] & 0x80000000u) | (b[h] & 0x7fffffffu);
-      const bool copy = r.copy_left > 16u * (uint32_t)h;
-      v2[h] = copy ? a[h] : (c ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u));
-    }
-    wave_sync();
-    if (go) {
-      r.s[wl[0]] = v2[0]; r.s[wl[1]] = v2[1];
-      r.gslot = gs_n;
-      r.avail += 32u;
-      r.copy_left = r.copy_left > 32u ? r.copy_left - 32u : 0u;
-    }
-    wave_sync();
-    a[0] = an[0]; a[1] = an[1]; b[0] = bn[0]; b[1] = bn[1];
-    go = go_n;
-  }
-  // second sweep: the words generated above, out of the window into the ring (copied words are in the ring already)
-  {
-    uint32_t gs = gslot0, done = 0u, cp = copy0;
-    const uint32_t made = r.avail - avail0;  // a multiple of 32, row-uniform
-    const uint32_t wbase = (r.cl + avail0) & (RW_RING_WIN - 1u);
-    for (;;) {
-      const bool more = want && done < made;
-      if (!__any(more)) break;
-      if (more) {
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          uint32_t k, k1;
-          slot_of(gs, h, k, k1);
-          const uint32_t v = r.s[(wbase + done + 16u * (uint32_t)h + (uint32_t)rl) & (RW_RING_WIN - 1u)];
-          if (cp <= 16u * (uint32_t)h) g[k] = v;
-        }
-        gs += 32u;
-        gs = gs >= 624u ? gs - 624u : gs;
-        done += 32u;
-        cp = cp > 32u ? cp - 32u : 0u;
-      }
-    }
-  }
-}
-__device__ __forceinline__ void rows_topup(RowRng&, bool, uint32_t, int) {}  // (state in LDS: rows_ensure is cheap enough)
-
-__device__ __forceinline__ double rows_random_at(const RingRowRng& r, uint32_t j) {
-  const uint32_t k = (r.cl + 2u * j) & (RW_RING_WIN - 1u);  // (even: the pair never straddles the window's end)
-  const uint2 w = *reinterpret_cast<const uint2*>(r.s + k);
-  const uint32_t a = mt_temper(w.x) >> 5, b = mt_temper(w.y) >> 6;
-  return py_random_from(a, b);
-}
-__device__ __forceinline__ void rows_advance(RingRowRng& r, bool on, uint32_t nwords) {
-  if (on) {
-    r.cl = (r.cl + nwords) & (RW_RING_WIN - 1u);
-    r.avail -= nwords;
-    r.drawn += nwords;
-  }
-}
-
-// RING = false: generator state in LDS, 12 waves = 48 episodes per workgroup (three wavefronts per SIMD).
-// RING = true:  generator state in global memory + a 256-word LDS window, 16 waves = 64 episodes (four per SIMD).
-template <bool RING>
-__global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
+__global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const RrtTables S = rrt_tables_view(smem, W.n_habitats, W.n_poly);
   const int wave = (int)(threadIdx.x >> 6);
@@ -310,15 +151,12 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
   const int row = lane >> 4, rl = lane & 15, rowbase = lane & 48;
   const int K = P.K;
   const int wg_waves = (int)(blockDim.x >> 6);
-  const RowsLdsPlan plan = rrt_rows_lds_plan(K, RW_MAX_OBST, rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins), wg_waves, RING);
+  const RowsLdsPlan plan = rrt_rows_lds_plan(K, RW_MAX_OBST, rrt_tables_bytes(W.n_habitats, W.n_poly, W.n_bins), wg_waves);
   unsigned char* ebase = smem + plan.tables + (size_t)(wave * RW_ROWS + row) * plan.per_ep;
   uint32_t* mt = reinterpret_cast<uint32_t*>(ebase);
   double* win = reinterpret_cast<double*>(ebase + plan.mt);  // [RW_WIN] tempered random() values of a pass
   double* inc = win;                                         // [4][18] running sums (aliases the window once it is dead)
   uint16_t* bin_count = reinterpret_cast<uint16_t*>(ebase + plan.mt + plan.scratch);
-  // row-uniform counters that are touched once per iteration at most live in the episode's LDS block, not in registers
-  // (entries 16, 17 of the last running-sum row: beyond the window, padding of the sums)
-  int* ectr = reinterpret_cast<int*>(inc + 70);
 
   rrt_tables_stage(S, W);
   if (threadIdx.x == 0) *S.params = P;
@@ -327,9 +165,7 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
   double* oly = olx + RW_MAX_OBST;
   float* olr = reinterpret_cast<float*>(oly + RW_MAX_OBST);
   // the spatially sorted tile (WorldDev::os_*): slot s = obstacles 16 s .. 16 s + 15
-  const double4* slot_box = reinterpret_cast<const double4*>(olr + RW_MAX_OBST);  // (ring) [16] x0, y0, x1, y1 per slot
   for (int i = threadIdx.x; i < RW_MAX_OBST; i += blockDim.x) { olx[i] = W.os_x[i]; oly[i] = W.os_y[i]; olr[i] = W.os_r[i]; }
-  if (RING && threadIdx.x < 16) const_cast<double4*>(slot_box)[threadIdx.x] = reinterpret_cast<const double4*>(W.os_box)[threadIdx.x];
   __syncthreads();
 
   const int ep = ((int)blockIdx.x * wg_waves + wave) * RW_ROWS + row;
@@ -339,45 +175,23 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
 
   // ---- per-episode views ----
   const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
-  // The per-episode array bases are formed where they are used, from the episode id through an opaque move: as loop
-  // invariants they are ~18 vector registers held across the whole iteration (a row's episode is not wave-uniform), the
-  // difference between a kernel that fits four wavefronts per SIMD and one that spills (profiles/r5_rows_fourth_wave.md)
-  auto eps_now = [&]() { int e = eps; __asm__ volatile("" : "+v"(e)); return (size_t)e; };
-#define nodeF (B.node_f + eps_now() * capn * 8)
-#define nodeI (reinterpret_cast<int4*>(B.node_i) + eps_now() * capn)
-#define nodeQ (B.node_q + eps_now() * capn)
-#define ptF (B.points + eps_now() * capp * 6)
-#define bins bin_lists(B, eps_now(), K)
-  if (rl < 4) ectr[rl] = 0;
+  double* nodeF = B.node_f + (size_t)eps * capn * 8;
+  int4* nodeI = reinterpret_cast<int4*>(B.node_i) + (size_t)eps * capn;
+  uint8_t* nodeQ = B.node_q + (size_t)eps * capn;
+  double* ptF = B.points + (size_t)eps * capp * 6;
+  const BinLists bins = bin_lists(B, (size_t)eps, K);
+  int next_chunk = 0;
   const double* init = B.init + (size_t)eps * 6;
 
-  std::conditional_t<RING, RingRowRng, RowRng> rng;
+  RowRng rng;
   rng.s = mt;
+  for (int i = rl; i < 624; i += 16) mt[i] = B.mt[(size_t)eps * 624 + i];
   {
     int idx = B.mt_index ? B.mt_index[eps] : 624;
     idx = idx < 0 ? 0 : (idx > 624 ? 624 : idx);
-    if constexpr (RING) {
-      // the ring starts as a copy of the state handed in (B.mt is not written: a prepared batch can be run again); the frontier
-      // starts at the consumer's position rounded up to a block, the window holds the 256 words before it
-      rng.ring = B.mt_ring;
-      rng.ep = eps;
-      for (int i = rl; i < 624; i += 16) B.mt_ring[(size_t)eps * 624 + i] = B.mt[(size_t)eps * 624 + i];
-      const int g0 = (idx + 15) & ~15;  // <= 624
-      for (int i = rl; i < 256; i += 16) {
-        const int w = g0 - 256 + i;  // word index; lands at window index w & 255
-        if (w >= 0) mt[w & 255] = B.mt[(size_t)eps * 624 + w];
-      }
-      rng.gslot = g0 == 624 ? 0u : (uint32_t)g0;
-      rng.cl = (uint32_t)idx & 255u;
-      rng.avail = (uint32_t)(g0 - idx);
-      rng.copy_left = (uint32_t)(624 - g0);
-      rng.drawn = 0ull;
-    } else {
-      for (int i = rl; i < 624; i += 16) mt[i] = B.mt[(size_t)eps * 624 + i];
-      rng.pslot = idx == 624 ? 0u : (uint32_t)idx;
-      rng.avail = (uint32_t)(624 - idx);
-      rng.drawn = 0ull;
-    }
+    rng.pslot = idx == 624 ? 0u : (uint32_t)idx;
+    rng.avail = (uint32_t)(624 - idx);
+    rng.drawn = 0ull;
   }
   for (int i = rl; i < K + 2; i += 16) bin_count[i] = 0;
   wave_sync();
@@ -389,18 +203,13 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
     bin_count[K >= 1 ? 1 : 0] = 1;
   }
   wave_sync();
-  int n_nodes = 1, n_points = 0, status = 0;
+  int n_nodes = 1, n_points = 0, status = 0, n_cand = 0, iters_run = 0;
   // lane rl keeps the bounding box of obstacle slot rl: one compare round tells which slots a steer can touch
-  // lane rl looks at the bounding box of obstacle slot rl: (ring) read from an LDS copy where it is used -- eight registers
-  // less; the 48-episode form has no LDS left for the copy and keeps the box in registers
-  double4 sbox_reg = make_double4(0.0, 0.0, 0.0, 0.0);
-  if (!RING) sbox_reg = reinterpret_cast<const double4*>(W.os_box)[rl];
-#define sbox (RING ? slot_box[rl] : sbox_reg)
+  const double4 sbox = reinterpret_cast<const double4*>(W.os_box)[rl];
   const int nv_poly = W.n_poly;
 
   for (int it = 0; it < P.max_iter; it++) {
     if (!__any(live)) break;
-    rows_topup(rng, live, 192u, rl);  // (ring) one batched generation per iteration; avail stays below 224
     // ------------------------------------------------------------ parent selection (:121-127)
     // lane rl of a row tries draw rl: ran_bin = int(uniform(1, K+1)) until that bin is non-empty; the first success in
     // stream order wins, a key beyond K before it is a KeyError.  14 tries per round leave room for the two draws
@@ -420,7 +229,7 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
         const uint32_t okm = row_ballot(cj != 0, rowbase), badm = row_ballot(badkey, rowbase);
         const int f_ok = okm ? (__ffs((int)okm) - 1) : 16, f_bad = badm ? (__ffs((int)badm) - 1) : 16;
         if (search) {
-          if (f_bad < f_ok) { status = -5; live = false; ectr[2] = it; search = false; }
+          if (f_bad < f_ok) { status = -5; live = false; iters_run = it; search = false; }
           else if (f_ok < 16) { fo = f_ok; search = false; }
         }
         const bool again = search;
@@ -579,7 +388,7 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
       const bool app = taken && (mv >= Q.min_dist);
       const uint32_t amask = row_ballot(app, rowbase);
       const int napp = __popc(amask);
-      if (on && (n_points + cnt + napp > capp)) { status = -2; live = false; ectr[2] = it; }
+      if (on && (n_points + cnt + napp > capp)) { status = -2; live = false; iters_run = it; }
       const bool wr = app && live;
       if (wr) {
         const int rank = __popc(amask & ((1u << rl) - 1u));
@@ -654,7 +463,7 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
         const bool cand = hs_ && (TIGHT ? !(auvp_fabs(oxj - tcx) > thx + orj || auvp_fabs(oyj - tcy) > thy + orj)
                                         : !(auvp_fabs(oxj - px0) > hx + orj || auvp_fabs(oyj - py0) > hx + orj));
         uint32_t cm = row_ballot(cand, rowbase);
-        if (cm != 0u && rl == 0) ectr[1] += __popc(cm);
+        n_cand += __popc(cm);
         while (__any(cm != 0u)) {
           const bool has = cm != 0u;
           const int cl = has ? (__ffs((int)cm) - 1) : 0;
@@ -699,7 +508,7 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
     const bool bad = row_ballot(hit || outside, rowbase) != 0u;
     const bool ok = live && !bad;
     // ------------------------------------------------------------ accept (:144-151)
-    if (ok && n_nodes >= capn) { status = -2; live = false; ectr[2] = it; }
+    if (ok && n_nodes >= capn) { status = -2; live = false; iters_run = it; }
     const bool acc_ = ok && live;
     const int me = n_nodes;
     if (acc_) {
@@ -715,10 +524,8 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
       if (!over || fi <= (double)K) {
         const int bi = (int)fi;
         const int c = over ? 0 : (int)bin_count[bi];  // an overflowing regular key is reset first (:149-151)
-        int next_chunk = ectr[0];
         int32_t* slot = (c >= bcap || c >= 65535) ? nullptr : bin_slot_for_append(bins, bi, c, next_chunk, rl == 0);
-        if (rl == 0) ectr[0] = next_chunk;
-        if (!slot) { status = -2; live = false; ectr[2] = it; stored = false; }
+        if (!slot) { status = -2; live = false; iters_run = it; stored = false; }
         else if (rl == 0) { *slot = me; bin_count[bi] = (uint16_t)(c + 1); }
       }
       if (stored) {
@@ -739,9 +546,7 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
 
   // ---- epilogue ----
   const bool valid = ep < n_episodes;
-  wave_sync();
-  const int iters_run = live ? P.max_iter : ectr[2];
-  const int n_cand = ectr[1];
+  if (live) iters_run = P.max_iter;
   const unsigned long long drawn = rng.drawn;
   rows_ensure(rng, valid, 2u, rl);
   const double after = rows_random_at(rng, 0u);
@@ -756,12 +561,6 @@ __global__ __launch_bounds__((RING ? 16 : RW_WAVES) * 64, 1) void rrt_rows_kerne
       s.rng_after = after; s.leaf_elems = 0; s.n_draw32 = drawn; s.nn_scanned = 0ull;
     }
   }
-#undef nodeF
-#undef nodeI
-#undef nodeQ
-#undef ptF
-#undef bins
-#undef sbox
 }
 
 }  // namespace auvp

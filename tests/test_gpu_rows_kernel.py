@@ -76,27 +76,15 @@ def test_rows_kernel_equals_one_episode_kernel_and_checker(ctx, orc, name, monke
     init[:, 2] = np.linspace(-3.0, 3.0, E)
     seeds = np.arange(4000, 4000 + E, dtype=np.uint64)
     out = {}
-    # "ring": rrt_rows_kernel<true> -- the generator's state in a global-memory ring + a 256-word LDS window (what batches of
-    # more than 48 episodes per CU get); "1": rrt_rows_kernel<false>, the state in LDS; "0": one episode per wavefront
-    for rows in ("ring", "1", "0"):
-        monkeypatch.setenv("AUVP_ROWS", "0" if rows == "0" else "1")
-        monkeypatch.setenv("AUVP_ROWS_RING", "1" if rows == "ring" else "0")
+    for rows in ("1", "0"):
+        monkeypatch.setenv("AUVP_ROWS", rows)
         summ = ctx.rrt_explore_batch(init, seeds, n_iter, **kw).copy()
-        assert ctx.last_launch_parts()[2] == (1 if rows == "0" else 4)
-        if rows != "0":
-            assert ctx.last_rrt_kernel() == {"ring": "rrt_rows_kernel<ring>", "1": "rrt_rows_kernel"}[rows]
+        assert ctx.last_launch_parts()[2] == (4 if rows == "1" else 1)
         trees = [ctx.tree(e, summ[e]) for e in range(E)]
         paths = ctx.paths(summ)
         out[rows] = (summ, trees, paths)
-    sr, tr, pr = out["ring"]
     sa, ta, pa = out["1"]
     sb, tb, pb = out["0"]
-    for f in sa.dtype.names:   # the two forms of the four-episode kernel: every field, failed episodes included
-        assert np.array_equal(sr[f], sa[f]), ("ring", f)
-    for e in range(E):
-        for k in ("nodes", "parent", "pt_off", "pt_cnt", "points"):
-            assert np.array_equal(tr[e][k], ta[e][k]), ("ring", e, k)
-        assert np.array_equal(pr[e], pa[e])
     failed = sa["status"] < 0
     for f in sa.dtype.names:
         # an episode that stopped with a capacity error reports where it stopped; the position of its random stream at
@@ -142,12 +130,10 @@ def test_rows_kernel_continues_a_global_random_state(ctx, orc, monkeypatch):
     init = np.zeros((1, 6))
     init[0, 0], init[0, 1] = world["start"]
     res = {}
-    for rows in ("ring", "1", "0"):
-        monkeypatch.setenv("AUVP_ROWS", "0" if rows == "0" else "1")
-        monkeypatch.setenv("AUVP_ROWS_RING", "1" if rows == "ring" else "0")
+    for rows in ("1", "0"):
+        monkeypatch.setenv("AUVP_ROWS", rows)
         res[rows] = ctx.rrt_explore_batch(init, (words, idx), 700).copy()
     for f in res["1"].dtype.names:
-        assert np.array_equal(res["ring"][f], res["1"][f]), f
         if f != "n_candidates":  # (cull diagnostic: depends on the kernel's cull box, see above)
             assert np.array_equal(res["1"][f], res["0"][f]), f
     n = int(res["1"][0]["n_draw32"])
