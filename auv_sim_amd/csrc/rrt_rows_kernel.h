@@ -84,6 +84,84 @@ __device__ __forceinline__ double row_prev_f64(double v, double first) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// theta += phi, left to right, for the four rows of a wavefront at once: every lane ends with
+// (((theta0 + phi_0) + phi_1) + ... + phi_rl), phi_j = the value lane j of its row wrote to `row_phi[j]`.  Lane s adds
+// phi_0 .. phi_s itself, the values broadcast out of LDS, under an exec mask that drops lanes rl < j at step j: ONE vector
+// instruction per step (the DPP row-shift chain this replaces cost five: two v_mov_dpp + the add + the merge of the first
+// lane).  The masks are constants -- lanes with (lane & 15) >= j -- and only shrink, so the LDS reads issued under them still
+// reach every lane that will use them; four reads stay in flight.  Requires all 64 lanes enabled at the call (the kernels
+// call it from wave-uniform control flow only) and restores that.
+__device__ __forceinline__ double rows_theta_chain(double theta0, const double* row_phi) {
+  double th = theta0, t0, t1, t2, t3;
+  const uint32_t a = (uint32_t)(size_t)((const __attribute__((address_space(3))) double*)row_phi);
+  __asm__ volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "ds_read_b64 %[t0], %[a] offset:0\n\t"
+      "ds_read_b64 %[t1], %[a] offset:8\n\t"
+      "ds_read_b64 %[t2], %[a] offset:16\n\t"
+      "ds_read_b64 %[t3], %[a] offset:24\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_add_f64 %[th], %[th], %[t0]\n\t"
+      "ds_read_b64 %[t0], %[a] offset:32\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xfffefffe\n\ts_mov_b32 exec_hi, 0xfffefffe\n\t"
+      "v_add_f64 %[th], %[th], %[t1]\n\t"
+      "ds_read_b64 %[t1], %[a] offset:40\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xfffcfffc\n\ts_mov_b32 exec_hi, 0xfffcfffc\n\t"
+      "v_add_f64 %[th], %[th], %[t2]\n\t"
+      "ds_read_b64 %[t2], %[a] offset:48\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xfff8fff8\n\ts_mov_b32 exec_hi, 0xfff8fff8\n\t"
+      "v_add_f64 %[th], %[th], %[t3]\n\t"
+      "ds_read_b64 %[t3], %[a] offset:56\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xfff0fff0\n\ts_mov_b32 exec_hi, 0xfff0fff0\n\t"
+      "v_add_f64 %[th], %[th], %[t0]\n\t"
+      "ds_read_b64 %[t0], %[a] offset:64\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xffe0ffe0\n\ts_mov_b32 exec_hi, 0xffe0ffe0\n\t"
+      "v_add_f64 %[th], %[th], %[t1]\n\t"
+      "ds_read_b64 %[t1], %[a] offset:72\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xffc0ffc0\n\ts_mov_b32 exec_hi, 0xffc0ffc0\n\t"
+      "v_add_f64 %[th], %[th], %[t2]\n\t"
+      "ds_read_b64 %[t2], %[a] offset:80\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xff80ff80\n\ts_mov_b32 exec_hi, 0xff80ff80\n\t"
+      "v_add_f64 %[th], %[th], %[t3]\n\t"
+      "ds_read_b64 %[t3], %[a] offset:88\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xff00ff00\n\ts_mov_b32 exec_hi, 0xff00ff00\n\t"
+      "v_add_f64 %[th], %[th], %[t0]\n\t"
+      "ds_read_b64 %[t0], %[a] offset:96\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xfe00fe00\n\ts_mov_b32 exec_hi, 0xfe00fe00\n\t"
+      "v_add_f64 %[th], %[th], %[t1]\n\t"
+      "ds_read_b64 %[t1], %[a] offset:104\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xfc00fc00\n\ts_mov_b32 exec_hi, 0xfc00fc00\n\t"
+      "v_add_f64 %[th], %[th], %[t2]\n\t"
+      "ds_read_b64 %[t2], %[a] offset:112\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "s_mov_b32 exec_lo, 0xf800f800\n\ts_mov_b32 exec_hi, 0xf800f800\n\t"
+      "v_add_f64 %[th], %[th], %[t3]\n\t"
+      "s_waitcnt lgkmcnt(2)\n\t"
+      "s_mov_b32 exec_lo, 0xf000f000\n\ts_mov_b32 exec_hi, 0xf000f000\n\t"
+      "v_add_f64 %[th], %[th], %[t0]\n\t"
+      "s_waitcnt lgkmcnt(1)\n\t"
+      "s_mov_b32 exec_lo, 0xe000e000\n\ts_mov_b32 exec_hi, 0xe000e000\n\t"
+      "v_add_f64 %[th], %[th], %[t1]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "s_mov_b32 exec_lo, 0xc000c000\n\ts_mov_b32 exec_hi, 0xc000c000\n\t"
+      "v_add_f64 %[th], %[th], %[t2]\n\t"
+      "s_mov_b64 exec, -1"
+      : [th] "+v"(th), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+      : [a] "v"(a)
+      : "memory");
+  return th;
+}
+
 // Per-row view of the MT19937 stream (state in the episode's LDS block, refilled in place like WaveRng, 16 words per
 // round and row).  pslot / avail / drawn are row-uniform.
 struct RowRng {
@@ -339,17 +417,10 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       }
       wave_sync();  // the window is dead: its LDS becomes the running-sum scratch
       // theta += phi, left to right: lane s ends with (((theta0 + phi_0) + phi_1) + ... + phi_s); untaken and idle lanes add
-      // an exact 0.0.  One DPP row shift per step; lane s is final after s + 1 steps.
-      double th = phi;
-      {
-        int nmax = 0;  // longest pass among the rows (wave-uniform loop bound)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int nr = __builtin_amdgcn_readlane(n, 16 * r);
-          nmax = nr > nmax ? nr : nmax;
-        }
-        for (int s = 0; s < nmax; s++) th = row_prev_f64(th, cth) + phi;
-      }
+      // an exact 0.0 (rows_theta_chain: the phis go through the row's LDS scratch)
+      inc[rl] = phi;
+      wave_sync();
+      const double th = rows_theta_chain(cth, inc);
       const double myth = (rl == 15) ? cth : th;  // lane 15: the pass-entry angle
       double sn, cs;
       auvp_sincos(myth, &sn, &cs);
