@@ -128,6 +128,34 @@ def pmc_valu_issue(meas, kernel=None):
         return None
 
 
+def pmc_latency(meas, kernel_prefix, units_now):
+    """counters of a LATENCY measurement (a few dependent chains: one episode, 1 024 replicas) from the committed PMC passes:
+    vector / scalar instructions per expansion, the share of the resident wavefronts' cycles spent waiting, HBM bytes per
+    launch.  {} when the committed passes do not hold that kernel."""
+    pj = _pmc()
+    try:
+        m = pj["measurements"][meas]
+        kn = [k for k in m["kernels"] if k.startswith(kernel_prefix)]
+        if not kn:
+            return {}
+        k = m["kernels"][kn[0]]
+        c = k["per_launch"]
+        u0 = float(m.get("units") or 0.0)
+        sc = units_now / u0 if (u0 > 0 and units_now) else 1.0
+        out = {"pmc_kernel": kn[0], "valu_per_expansion": k.get("sq_insts_valu_per_unit"), "salu_per_expansion": k.get("sq_insts_salu_per_unit"),
+               "wait_any_share": k.get("wait_any_share"), "valu_active_share": k.get("valu_active_share")}
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f, w = 1024.0 * float(c["FETCH_SIZE"]), 1024.0 * float(c["WRITE_SIZE"])
+            out["traffic"], out["traffic_raw"] = (2.0 * f + w) * sc, (f + w) * sc
+        out["traffic_source"] = "profiles/%s pmc@%s" % (pj.get("tag", "?"), meas)
+        return {k2: v for k2, v in out.items() if v is not None}
+    except Exception:
+        return {}
+
+
+SHADER_GHZ = 2.4  # MI355X_MICROARCH.md: engine clock the latency figures are quoted in
+
+
 def pmc_kernel_traffic(meas, kernel, units_now):
     """(2 x FETCH_SIZE + WRITE_SIZE, FETCH_SIZE + WRITE_SIZE) of ONE kernel of a profiled measurement, bytes per launch"""
     pj = _pmc()
@@ -569,8 +597,17 @@ def bench_single_episode(ctx, world, args, reps=3):
         if i:
             ms.append(ctx.last_kernel_ms())
     k_ms = float(np.mean(ms))
-    return {"metric": "single-episode latency (seed 7)", "kernel": ctx.last_rrt_kernel(), "kernel_ms": k_ms, "iters": int(summ[0]["iters_run"]),
-            "expansions_per_s": float(summ[0]["iters_run"]) / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / float(summ[0]["iters_run"])}
+    iters = float(summ[0]["iters_run"])
+    exp_ms = ctx.last_launch_parts()[0]
+    kname = ctx.last_rrt_kernel()
+    # a latency measurement: ONE dependent chain (3-4 wavefronts of one CU) -- no throughput roof applies; what is reported is
+    # the chain's length in shader clocks per iteration, with the counters of the committed pass beside it
+    roof = dict({"bound": "latency", "kernel": kname, "kernel_ms": exp_ms, "clocks_per_iteration": exp_ms * 1e-3 * SHADER_GHZ * 1e9 / iters,
+                 "achieved": rrt_expand_bytes(summ) / (exp_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": rrt_expand_bytes(summ) / (exp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None},
+                **pmc_latency("single_episode", kname.split("<")[0], iters))
+    return {"metric": "single-episode latency (seed 7)", "kernel": kname, "kernel_ms": k_ms, "iters": int(iters),
+            "expansions_per_s": iters / (k_ms * 1e-3), "us_per_expansion": 1e3 * k_ms / iters, "roofline": roof}
 
 
 def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0, mode=None, kw=None, meas="-"):
@@ -594,7 +631,7 @@ def _rrt_batch(ctx, world, n_ep, args, reps=2, cpu_seconds=0.0, mode=None, kw=No
     k_ms = float(np.mean(ms))
     iters = float(summ["iters_run"].sum())
     out = {"value": iters / (k_ms * 1e-3), "unit": "expansions/s", "episodes": n_ep, "kernel_ms": k_ms, "mode": mode,
-           "kernel": ctx.last_rrt_kernel(),
+           "kernel": ctx.last_rrt_kernel(), "iters_per_launch": iters,
            "accept_rate": float((summ["n_nodes"] - 1).sum()) / iters,
            "cull_candidates_per_expansion": float(summ["n_candidates"].sum()) / iters,
            "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
@@ -629,6 +666,12 @@ def bench_rrt_replicas(ctx, args, n_ep=1024):
     as the chip has SIMDs -- rrt_duo_kernel, two wavefronts per episode (one per SIMD and a helper beside it)."""
     out = _rrt_batch(ctx, bench_world(64, args.grid), n_ep, args)
     out["metric"] = "RRT.exploring expansions/s, %d replicas, 64 obstacles, %dx%d cells" % (n_ep, args.grid, args.grid)
+    if "roofline" in out:
+        # one latency chain per SIMD: the chain's length per iteration is the figure; counters of the committed pass beside it
+        r = out["roofline"]
+        r["bound"] = "latency"
+        r["clocks_per_iteration"] = r["kernel_ms"] * 1e-3 * SHADER_GHZ * 1e9 / (out["iters_per_launch"] / n_ep)
+        r.update(pmc_latency("rrt_1024_replicas", out["kernel"].split("<")[0], out["iters_per_launch"]))
     return out
 
 

@@ -45,6 +45,8 @@ MEAS = {
     "rrt_nn": (RRT, "iters_per_launch"),
     "rrt_nn_long_horizon": (RRT, "iters_per_launch"),
     "config5": (("prrt_kernel", "prrt_rows_kernel"), "planner_steps_per_tracking_step"),
+    "single_episode": (("rrt_trio_kernel", "rrt_duo_kernel", "rrt_explore_kernel", "rrt_leaf_kernel"), "iters"),
+    "rrt_1024_replicas": (("rrt_trio_kernel", "rrt_duo_kernel", "rrt_explore_kernel", "rrt_rows_kernel", "rrt_leaf_kernel"), "iters_per_launch"),
     "particle_filter": (("pf_step_kernel",), None),
     "shark_grid": (("sog_count_kernel", "sog_occ_kernel", "sog_grid_kernel", "sog_grid_tile_kernel", "sog_grid_tile_c_kernel"), None),
 }
@@ -118,6 +120,13 @@ for key, (needles, units_field) in MEAS.items():
             kr["valu_exec_mask_occupancy"] = km["SQ_THREAD_CYCLES_VALU"] / (km["SQ_ACTIVE_INST_VALU"] * 64.0)
         if "SQ_INSTS_VALU" in km and rec.get("units"):
             kr["sq_insts_valu_per_unit"] = km["SQ_INSTS_VALU"] / rec["units"]
+        if "SQ_INSTS_SALU" in km and rec.get("units"):
+            kr["sq_insts_salu_per_unit"] = km["SQ_INSTS_SALU"] / rec["units"]
+        if km.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_WAIT_ANY" in km:
+            # share of the resident wavefronts' cycles spent waiting (any reason): latency kernels sit here
+            kr["wait_any_share"] = km["SQ_WAIT_ANY"] / km["SQ_WAVE_CYCLES"]
+        if km.get("SQ_WAVE_CYCLES", 0) > 0 and "SQ_ACTIVE_INST_VALU" in km:
+            kr["valu_active_share"] = km["SQ_ACTIVE_INST_VALU"] / km["SQ_WAVE_CYCLES"]
     out["measurements"][key] = rec
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 json.dump(out, open(os.path.join(REPO, "profiles", "pmc_latest.json"), "w"), indent=1)

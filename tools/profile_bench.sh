@@ -8,7 +8,7 @@
 #   trace_<side>, pmc@<side>@<C>   the same for one side measurement (bench.py --only <side>); default sides below
 set -u
 TAG=${1:-r3}; shift || true
-SIDES="astar planner_rrt rrt_nn rrt_nn_long_horizon config5"
+SIDES="astar planner_rrt rrt_nn rrt_nn_long_horizon config5 single_episode rrt_1024_replicas particle_filter shark_grid"
 HEADLINE=1
 while [ $# -gt 0 ]; do
   case "$1" in
