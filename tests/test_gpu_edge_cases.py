@@ -254,3 +254,29 @@ def test_exploring_table_sizes(ctx, orc, H, V, T):
             assert np.array_equal(t["parent"], r["parent"]) and np.array_equal(t["nodes"], r["nodes"])
             if r["status"] == 0:
                 assert np.array_equal(np.array(s["best_cost"]), r["best_cost"])
+
+
+def test_options_are_per_handle_and_read_the_environment_once(monkeypatch):
+    """auvp_set_option / auvp_get_option / auvp_unset_option (include/auvplan.h): unset = the measured default; AUVP_<NAME> in the
+    environment is an option's INITIAL value, read by auvp_create and by nothing else; options of one handle do not leak into
+    another; an unknown name is AUVP_ERR_ARG"""
+    import ctypes as C
+    from auv_sim_amd import _lib
+    raw = getattr(_lib.load(), "_lib", _lib.load())   # (the suite's environment-sync proxy is bypassed: the plain library)
+    monkeypatch.setenv("AUVP_ROWS", "1")
+    monkeypatch.delenv("AUVP_TRIO", raising=False)
+    a = _lib.Context(0)
+    monkeypatch.setenv("AUVP_ROWS", "0")        # after auvp_create: not seen by `a`
+    b = _lib.Context(0)
+
+    def get(ctx, name):
+        s, v = C.c_int32(-1), C.c_int64(-1)
+        assert raw.auvp_get_option(ctx.h, name.encode(), C.byref(s), C.byref(v)) == 0
+        return (s.value, v.value)
+    assert get(a, "ROWS") == (1, 1) and get(b, "ROWS") == (1, 0) and get(a, "TRIO")[0] == 0
+    assert raw.auvp_set_option(a.h, b"TRIO", 1) == 0 and get(a, "TRIO") == (1, 1) and get(b, "TRIO")[0] == 0
+    assert raw.auvp_unset_option(a.h, b"TRIO") == 0 and get(a, "TRIO")[0] == 0
+    assert raw.auvp_set_option(a.h, b"NO_SUCH_OPTION", 1) == -1 and b"unknown option" in raw.auvp_last_error(a.h)
+    assert a.pipeline_fallbacks() == (0, 0)
+    a.close()
+    b.close()
