@@ -156,6 +156,21 @@ def pmc_latency(meas, kernel_prefix, units_now):
 SHADER_GHZ = 2.4  # MI355X_MICROARCH.md: engine clock the latency figures are quoted in
 
 
+def pmc_valu_issue_est(kernel, units_now, kernel_ms):
+    """vector-issue fraction of a launch that has no counter pass of its own, from the instructions per work unit the same
+    kernel showed in ANY committed pass (a property of the kernel and the workload's shape) and this launch's time:
+    valu_per_unit x units x 4 cycles / (1 024 SIMDs x time x SHADER_GHZ).  None when no committed pass ran that kernel."""
+    pj = _pmc()
+    try:
+        for m in pj["measurements"].values():
+            k = m["kernels"].get(kernel)
+            if k and k.get("sq_insts_valu_per_unit"):
+                return 4.0 * float(k["sq_insts_valu_per_unit"]) * units_now / (N_SIMD * kernel_ms * 1e-3 * SHADER_GHZ * 1e9)
+    except Exception:
+        pass
+    return None
+
+
 def pmc_kernel_traffic(meas, kernel, units_now):
     """(2 x FETCH_SIZE + WRITE_SIZE, FETCH_SIZE + WRITE_SIZE) of ONE kernel of a profiled measurement, bytes per launch"""
     pj = _pmc()
@@ -565,6 +580,8 @@ def rrt_pass_rooflines(ctx, summ, meas, exp_ms, leaf_ms, kname, compact=False, *
     tx2, traw = pmc_kernel_traffic(meas, kname, iters) if comparable else (None, None)
     lx2, lraw = pmc_kernel_traffic(meas, "rrt_leaf_kernel", iters) if comparable else (None, None)
     vi = pmc_valu_issue(meas, kname) if comparable else None
+    if vi is None:  # (a side batch of a kernel that has a pass elsewhere: its instructions per expansion over this launch's time)
+        vi = pmc_valu_issue_est(kname, iters, exp_ms)
     lvi = pmc_valu_issue(meas, "rrt_leaf_kernel") if comparable else None
     leaf_ach = a_leaf / (leaf_ms * 1e-3) / 1e9 if leaf_ms > 0 else 0.0
     pass_ach = a_8d / ((exp_ms + leaf_ms) * 1e-3) / 1e9
@@ -669,9 +686,14 @@ def bench_rrt_replicas(ctx, args, n_ep=1024):
     if "roofline" in out:
         # one latency chain per SIMD: the chain's length per iteration is the figure; counters of the committed pass beside it
         r = out["roofline"]
-        r["bound"] = "latency"
         r["clocks_per_iteration"] = r["kernel_ms"] * 1e-3 * SHADER_GHZ * 1e9 / (out["iters_per_launch"] / n_ep)
         r.update(pmc_latency("rrt_1024_replicas", out["kernel"].split("<")[0], out["iters_per_launch"]))
+        vi = pmc_valu_issue("rrt_1024_replicas", r.get("pmc_kernel")) if r.get("pmc_kernel") else None
+        if vi is not None:
+            r["valu_issue_frac"] = vi
+        # three wavefronts per episode, one episode per SIMD: every SIMD runs one chain; whichever of chain latency and vector
+        # issue is the larger share names the bound
+        r["bound"] = "valu_issue" if (vi is not None and vi >= 0.5) else "latency"
     return out
 
 
