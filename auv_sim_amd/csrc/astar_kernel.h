@@ -137,7 +137,7 @@ __device__ __forceinline__ bool astar_point_free(const AstarWorldDev& W, double 
     double dx = px - W.ox[i], dy = py - W.oy[i];
     hit = hit | (dx * dx + dy * dy <= W.ot[i]);
   }
-  return !__any(hit);
+  return !wave_any(hit);
 }
 
 constexpr int ASTAR_WAVES = 4;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       const double sq_ = astar_sqdist(cxp, cyp, qx, qy);
       const bool lattice = sq_ == 100.0 || sq_ == 200.0;
       double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
-      if (!__all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
+      if (!wave_all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
       const double len_ = clen + root_;
       const double dist_left = auvp_fabs(limit - len_);
       const int ts_ = (int)(P.velocity == 1.0 ? len_ : len_ / P.velocity);
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         if (have) { a = colj ? gx0[idx] : gy0[idx]; b = colj ? gx1[idx] : gy1[idx]; }
         const bool okx = (gc == 0 || xl < qx) && (gc == W.g_ncol || !(xh < qx));
         const bool oky = (gr == 0 || yl < qy) && (gr == W.g_nrow || !(yh < qy));
-        if (__any(!okx || !oky)) {
+        if (wave_any(!okx || !oky)) {
           // ---- a guess was off: the walk, and the rows / columns around the true bounds
           if (!okx) gc = astar_lower_bound(gx1, W.g_ncol, qx, gc);
           if (!oky) gr = astar_lower_bound(gy1, W.g_nrow, qy, gr);
@@ -318,21 +318,21 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
           const double dd = auvp_fabs(a - b);
           m = auvp_fabs(v - a) <= dd && auvp_fabs(v - b) <= dd;
         }
-        const unsigned long long bm = __ballot(m);
+        const unsigned long long bm = wave_ballot(m);
         const unsigned g8 = (unsigned)((bm >> (k8 * 8)) & 0xffull);
         const unsigned cm3 = g8 & 7u, rm3 = (g8 >> 3) & 7u;
         if (cm3 && rm3) key = (gr - 1 + (__ffs((int)rm3) - 1)) * W.g_ncol + (gc - 1 + (__ffs((int)cm3) - 1));
         // the first time bin that holds the time stamp (:520-527): bins 0..7 from the read above, further ones eight at a time
         {
-          const unsigned long long tm = __ballot(s8 < T && tsd <= bb.y && tsd >= bb.x);
+          const unsigned long long tm = wave_ballot(s8 < T && tsd <= bb.y && tsd >= bb.x);
           const unsigned t8 = (unsigned)((tm >> (k8 * 8)) & 0xffull);
           if (t8) tb = __ffs((int)t8) - 1;
         }
-        for (int t0 = 8; t0 < T && !__all(tb >= 0); t0 += 8) {
+        for (int t0 = 8; t0 < T && !wave_all(tb >= 0); t0 += 8) {
           const int t = t0 + s8;
           bool mt = false;
           if (t < T) { const double2 b2 = *reinterpret_cast<const double2*>(&s_bins[t][0]); mt = tsd <= b2.y && tsd >= b2.x; }
-          const unsigned long long tm = __ballot(mt);
+          const unsigned long long tm = wave_ballot(mt);
           const unsigned t8 = (unsigned)((tm >> (k8 * 8)) & 0xffull);
           if (tb < 0 && t8) tb = t0 + (__ffs((int)t8) - 1);
         }
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     {
       const bool have = bi != 0x7fffffff;
       const double fmin = wave_min_f64_dpp(have ? bf : __builtin_inf());
-      const unsigned long long eq = __ballot(have && bf == fmin);
+      const unsigned long long eq = wave_ballot(have && bf == fmin);
       if (__popcll(eq) == 1) {
         const int l = __ffsll((long long)eq) - 1;
         bi = __builtin_amdgcn_readlane(bi, l);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       };
       if (poly_lds) fan(&s_poly[0][0]);
       else fan(W.poly);
-      unsigned long long bm = __ballot(any_tri);
+      unsigned long long bm = wave_ballot(any_tri);
       inb = ((bm >> (k8 * 8)) & 0xffull) != 0;
     }
     bool hit = false;
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       if (obs_lds) circles(s_obs[0], s_obs[1], s_obs[2]);
       else circles(W.ox, W.oy, W.ot);
     }
-    const unsigned long long hm = __ballot(hit);
-    const unsigned long long im = __ballot(inb && s8 == 0);
+    const unsigned long long hm = wave_ballot(hit);
+    const unsigned long long im = wave_ballot(inb && s8 == 0);
     int childmask = 0;  // bit k: neighbour k becomes a child
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
             const double ddx = qx - s_hab[hb][0], ddy = qy - s_hab[hb][1];
             cov = ddx * ddx + ddy * ddy <= s_hab[hb][2];
           }
-          const unsigned long long bm = __ballot(cov);
+          const unsigned long long bm = wave_ballot(cov);
           cmine |= ((bm >> (8 * (lane & 7))) & 0xffull) << h0;
         }
         if (lane < 8 && ((childmask >> lane) & 1)) covm_v = cmine;
@@ -563,14 +563,14 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       const double sq_ = astar_sqdist(cxp, cyp, px, py);
       const bool lattice = sq_ == 100.0 || sq_ == 200.0;
       double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
-      if (!__all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
+      if (!wave_all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
       const double len_ = clen + root_;
       // visited bitmap (:414-416), numpy index semantics (negative wraps)
       int xi = (int)(px + 500), yi = (int)(py + 200);
       if (xi < 0) xi += P.vx;
       if (yi < 0) yi += P.vy;
       const bool oob = mine && (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy);
-      if (__any(oob)) { status = -1; break; }
+      if (wave_any(oob)) { status = -1; break; }
       const size_t vi = (size_t)xi * P.vy + yi;
       const uint32_t ciw = mine ? ciw_early : 0u;  // (requested before the bounds test; same index)
       const bool was = (ciw & 0xff000000u) == ep_tag && (ciw & 0x10000u);
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         put_node(c, px, py, g_, h_, f_, g_, len_, cur, 0, open_);
         if (!was) cellinfo[vi] = ep_tag | 0x10000u;
       }
-      const unsigned long long om = __ballot(mine && open_);
+      const unsigned long long om = wave_ballot(mine && open_);
       const int opened = __popcll(om);
       if (list_ok) {
         if (n_list + opened > ASTAR_OPEN_CAP) list_ok = false;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         put_node(c, px, py, g_, h_, f_, g_, len_, cur, ts_, open_);
         if (!was || need_key) cellinfo[vi] = ep_tag | 0x10000u | (uint32_t)(key + 1);  // visited from now on, key kept
       }
-      const unsigned long long om = __ballot(mine && open_);
+      const unsigned long long om = wave_ballot(mine && open_);
       const int opened = __popcll(om);
       if (list_ok) {
         if (n_list + opened > ASTAR_OPEN_CAP) list_ok = false;
@@ -648,12 +648,12 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         int xi = (int)(px + 500), yi = (int)(py + 200);
         if (xi < 0) xi += P.vx;
         if (yi < 0) yi += P.vy;
-        if (__any(mine && (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy))) { status = -1; break; }
+        if (wave_any(mine && (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy))) { status = -1; break; }
         const size_t vi = (size_t)xi * P.vy + yi;
         const bool ci_live = (ciw & 0xff000000u) == ep_tag;
         const int key = mine ? key_x : 0;
         const bool bad = mine && (tb < 0 || key < 0 || ntop > C);
-        if (__any(bad)) { status = -1; break; }
+        if (wave_any(bad)) { status = -1; break; }
         const int was = (mine && ci_live && (ciw & 0x10000u)) ? 1 : 0;
         finish_children(kk, mine, px, py, len_, dist_left, ts_, vi, key, false, mine ? pr_x : 0.0, mine ? tn_x : 0.0, was);
       } else {
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         };
         if (grid_lds) lookup(s_grid, s_grid + W.g_ncol, s_grid + 2 * W.g_ncol, s_grid + 2 * W.g_ncol + W.g_nrow);
         else lookup(W.gx0, W.gx1, W.gy0, W.gy1);
-        const unsigned long long bm = __ballot(m);
+        const unsigned long long bm = wave_ballot(m);
         const unsigned g8 = (unsigned)((bm >> (k8 * 8)) & 0xffull);
         const unsigned cm3 = g8 & 7u, rm3 = (g8 >> 3) & 7u;
         if (cm3 && rm3) key_grid = (gr - 1 + (__ffs((int)rm3) - 1)) * W.g_ncol + (gc - 1 + (__ffs((int)cm3) - 1));
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       const double sq_ = astar_sqdist(cxp, cyp, px, py);
       const bool lattice = sq_ == 100.0 || sq_ == 200.0;
       double root_ = sq_ == 100.0 ? 10.0 : 0x1.c48c6001f0acp+3;
-      if (!__all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
+      if (!wave_all(lattice)) root_ = lattice ? root_ : auvp_sqrt(sq_);
       const double len_ = clen + root_;
       const double dist_left = auvp_fabs(limit - len_);
       const int ts_ = (int)(P.velocity == 1.0 ? len_ : len_ / P.velocity);  // x / 1.0 is x: no division on the chain
@@ -706,10 +706,10 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
           const int t = t0 + s8;
           bool m = false;
           if (t < T) { const double2 bb = *reinterpret_cast<const double2*>(&s_bins[t][0]); m = tsn <= bb.y && tsn >= bb.x; }
-          const unsigned long long bm = __ballot(m);
+          const unsigned long long bm = wave_ballot(m);
           const unsigned mine8 = (unsigned)((bm >> (8 * (lane & 7))) & 0xffull);  // lane kk < 8: its own child's slices
           if (tb < 0 && mine8) tb = t0 + (__ffs((int)mine8) - 1);
-          if (__all(tb >= 0 || lane >= 8)) break;
+          if (wave_all(tb >= 0 || lane >= 8)) break;
         }
       }
       const int ntop = (int)dist_left;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
       if (xi < 0) xi += P.vx;
       if (yi < 0) yi += P.vy;
       const bool oob = mine && (xi < 0 || xi >= P.vx || yi < 0 || yi >= P.vy);
-      if (__any(oob)) { status = -1; break; }
+      if (wave_any(oob)) { status = -1; break; }
       const size_t vi = (size_t)xi * P.vy + yi;
       // the cell of a lattice point is looked up once per search: within one instance the visited-bitmap index
       // identifies the point (points are 10 apart), so the key is kept next to it
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     // get_cell_prob (:485-514) for ALL children of this expansion in one sweep over the cells: a lane loads one
     // cell per pass and tests it against the (uniform) positions of the eight neighbours, so the sweep costs
     // ceil(C / 64) independent loads instead of that many dependent round trips per child
-      if (__any(need_key)) {
+      if (wave_any(need_key)) {
         int keys[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
       double cpx[8], cpy[8];
 #pragma unroll
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
         for (int k = 0; k < 8; k++) {
           const bool m = in && (auvp_fabs(cpx[k] - r.x) <= ddx && auvp_fabs(cpx[k] - r.z) <= ddx) &&
                          (auvp_fabs(cpy[k] - r.y) <= ddy && auvp_fabs(cpy[k] - r.w) <= ddy);
-          const unsigned long long mm = __ballot(m);
+          const unsigned long long mm = wave_ballot(m);
           if (keys[k] < 0 && mm) keys[k] = c0 + (__ffsll((long long)mm) - 1);
         }
       }
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(ASTAR_WAVES * 64 * (PAIR ? 2 : 1)) void astar_kerne
     }
       if (need_key) key = s_keys[wave][kk];
       const bool bad = mine && (tb < 0 || key < 0 || ntop > C);
-      if (__any(bad)) { status = -1; break; }
+      if (wave_any(bad)) { status = -1; break; }
       double pr = 0.0, tn = 0.0;
       int was = 0;
       if (mine) { pr = W.prob[(size_t)tb * C + key]; tn = W.topn[(size_t)tb * (C + 1) + ntop]; was = (ci_live && (ciw & 0x10000u)) ? 1 : 0; }
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(64) void astar_path_kernel(AstarWorldDev W, AstarPa
           double d = auvp_sqrt(astar_sqdist(W.hab[4 * h], W.hab[4 * h + 1], bx, by));
           inside = inside | (d <= W.hab[4 * h + 2]);
         }
-        if (!__any(inside)) keepm[curp >> 6] &= ~(1ull << (curp & 63));
+        if (!wave_any(inside)) keepm[curp >> 6] &= ~(1ull << (curp & 63));
         index += 1; curp = index;
       } else {
         check = curp; index += 1; curp = index;

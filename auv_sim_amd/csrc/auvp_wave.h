@@ -28,6 +28,14 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 // + `s_waitcnt vmcnt(0) lgkmcnt(0)` per poll -- every look at a flag also waits for the wavefront's outstanding global loads
 // and stores.  With the explicit LDS pointer they are ds_read / ds_write, which wait on the LDS counter alone.
 #define AUVP_LDS_PTR(T, p) ((volatile __attribute__((address_space(3))) T*)(p))
+// Wavefront votes on a BOOLEAN: HIP's __any / __all / __ballot take an int, so a predicate is first turned into 0 / 1 in a
+// vector register and then compared with zero again -- two vector instructions per vote on kernels that are bound by
+// vector issue and vote dozens of times per iteration.  The builtin takes the i1 as it is: the vote is the compare itself
+// (and an s_and with exec).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
 // a speculative pipeline gave up (a bounded wait ran out: status AUVP_ST_PIPELINE): tell the host through its mapped flag, so
 // that it re-runs the batch on the one-wavefront kernel (auvplan.hip: pipeline fallback) -- the status alone would need a
 // read-back of every summary after every launch

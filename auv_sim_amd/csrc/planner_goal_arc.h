@@ -57,7 +57,7 @@ __device__ __forceinline__ bool prrt_goal_arc(const PrrtParamsDev& P, const doub
                 const bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
                 outside = !(wx && wy);
               }
-              if (__any(outside)) { free_ = false; break; }
+              if (wave_any(outside)) { free_ = false; break; }
               const double rad = auvp_fabs(radius), dth = auvp_fabs(ang_vel) * (double)(nv - 1);
               double bx0, by0, bx1, by1;
               if (dth < AUVP_PI) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ bool prrt_goal_arc(const PrrtParamsDev& P, const doub
 #pragma unroll
               for (int j = 0; j < J; j++) {
                 const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
-                unsigned long long cm = __ballot(cand);
+                unsigned long long cm = wave_ballot(cand);
                 while (cm) {
                   const int l = __ffsll((long long)cm) - 1;
                   cm &= cm - 1ull;
@@ -86,7 +86,7 @@ __device__ __forceinline__ bool prrt_goal_arc(const PrrtParamsDev& P, const doub
                   hitl |= (lane < nv) && (ex * ex + ey * ey <= otl);
                 }
               }
-              if (__any(hitl)) free_ = false;
+              if (wave_any(hitl)) free_ = false;
             }
             if (free_) {
               is_free = true;

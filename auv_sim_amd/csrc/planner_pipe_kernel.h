@@ -120,7 +120,7 @@ __device__ __forceinline__ uint32_t ppipe_randbelow(RingRng& r, uint32_t n, int&
     if (r.avail < 8u && !more()) { ok = false; return 0u; }
     uint32_t v = 0xffffffffu;
     if (lane < 8) v = ring_word(r, (uint32_t)lane) >> (32 - k);
-    const unsigned long long okm = __ballot(lane < 8 && v < n);
+    const unsigned long long okm = wave_ballot(lane < 8 && v < n);
     const int f = okm ? (__ffsll((long long)okm) - 1) : 8;
     if (RMIN) {
       // tries in front of the success (all eight when there is none) were >= n: their minimum over lanes 0..7 on the DPP path
@@ -195,7 +195,7 @@ __device__ __forceinline__ bool prrt_goal_arc_eval(const PrrtParamsDev& P, const
             const bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
             outside = !(wx && wy);
           }
-          if (__any(outside)) { free_ = false; break; }
+          if (wave_any(outside)) { free_ = false; break; }
           // prrt_hits: a conservative box of this piece of the arc picks the candidate obstacles
           const double rad = auvp_fabs(radius), dth = auvp_fabs(ang_vel) * (double)(nv - 1);
           double bx0, by0, bx1, by1;
@@ -216,7 +216,7 @@ __device__ __forceinline__ bool prrt_goal_arc_eval(const PrrtParamsDev& P, const
 #pragma unroll
           for (int j = 0; j < J; j++) {
             const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
-            unsigned long long cm = __ballot(cand);
+            unsigned long long cm = wave_ballot(cand);
             while (cm) {
               const int l = __ffsll((long long)cm) - 1;
               cm &= cm - 1ull;
@@ -225,7 +225,7 @@ __device__ __forceinline__ bool prrt_goal_arc_eval(const PrrtParamsDev& P, const
               hitl |= (lane < nv) && (ex * ex + ey * ey <= otl);
             }
           }
-          if (__any(hitl)) free_ = false;
+          if (wave_any(hitl)) free_ = false;
         }
         if (free_) {
           is_free = true;
@@ -430,11 +430,11 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
                   for (int c = 0; c < 4; c++) {
                     if (pv < 0) {
                       const bool is = v[c] == b;
-                      const unsigned long long bal = __ballot(is);
+                      const unsigned long long bal = wave_ballot(is);
                       const int cc = __popcll(bal);
                       if (seen + cc > rsel) {
                         const int want = rsel - seen;
-                        const unsigned long long sel = __ballot(is && (int)__popcll(bal & ((1ull << lane) - 1ull)) == want);
+                        const unsigned long long sel = wave_ballot(is && (int)__popcll(bal & ((1ull << lane) - 1ull)) == want);
                         pv = base + 64 * c + (__ffsll((long long)sel) - 1);
                       }
                       seen += cc;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
                       phi = (s1 + s2) / (2 * radius);
                     }
                   }
-                  tmask = __ballot(taken);
+                  tmask = wave_ballot(taken);
                   ring_advance(rng, (uint32_t)(4 * n));
                   if (lane < DUO_CS) { q->radius[lane] = radius; q->phi[lane] = phi; }
                   if (lane == 0) { q->px = p0; q->py = p1; q->pth = p2; q->ptt = p3; }
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
             const bool wy = (y >= P.rect[1]) && (y <= P.rect[3]);
             outside = outside | !(wx && wy);
           }
-          ok = (!prrt_hits<J>(ox, oy, ot, orr, spts, P_n, bbx0, bby0, bbx1, bby1) && !__any(outside)) ? 1 : 0;
+          ok = (!prrt_hits<J>(ox, oy, ot, orr, spts, P_n, bbx0, bby0, bbx1, bby1) && !wave_any(outside)) ? 1 : 0;
         }
       }
       if (lane == 0) {
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
             // inserts into the chosen bucket since the snapshot: its members are kept in creation order and a new one goes to the
             // end, so `_randbelow(len)` (:223) picks the same node unless the size's bit length changed or a try the packet threw
             // away (>= the old size) is below the new size -- the rule of the bucket choice, one level down
-            const int added = __popcll(__ballot(lane < PPIPE_HIST && newest >= pv && newest >= 0 && hist == qb));
+            const int added = __popcll(wave_ballot(lane < PPIPE_HIST && newest >= pv && newest >= 0 && hist == qb));
             const int c0 = uni(q->cnt_b), c2 = c0 + added;
             // (a bucket word read AFTER one of those inserts may be ahead of the records it points to: nothing is published between a
             // record and its bucket word -- such a packet is redone)
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
           ie |= sub >= P.S;
           bk = (row * P.cols + col) * P.S + sub;
         }
-        if (__any(ie)) { status = -1; break; }
+        if (wave_any(ie)) { status = -1; break; }
         bk = uni(bk);
       }
       me = n_nodes;

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
 
   for (;;) {
     // ---------------------------------------------------------------- rows without an episode take the next one
-    if (__any(!live && more)) {
+    if (wave_any(!live && more)) {
       const bool need = !live && more;
       int e = 0;
       if (need && rl == 0) e = atomicAdd(work_counter, 1) - work_base;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         }
       }
       const bool load = need && more && !skip;
-      if (__any(load)) {
+      if (wave_any(load)) {
         wave_sync();
         if (load) {
           const uint32_t* src = B.mt + (size_t)ep * 624;
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         wave_sync();
       }
     }
-    if (!__any(live)) {
-      if (__any(more)) continue;  // (every row drew an episode the step skips: draw again)
+    if (!wave_any(live)) {
+      if (wave_any(more)) continue;  // (every row drew an episode the step skips: draw again)
       break;
     }
     // per-episode array bases are formed where they are used, from the episode id alone (an opaque copy keeps the compiler
@@ -159,12 +159,12 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         if (fin) res = got;
         rows_advance(rng, search, fin ? (uint32_t)(f + 1) : 8u);
         search = search && !fin;
-        if (!__any(search)) break;
+        if (!wave_any(search)) break;
       }
       return res;
     };
 
-    if (__any(act)) {
+    if (wave_any(act)) {
       // ---------------------------------------------------------------- bucket + node choice (:186, :214-223)
       int b = 0;
       if (P.step_mode) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       int par = act ? head_b : 0;
       {
         int hops = act ? cnt_b - 1 - (int)rsel : 0;
-        while (__any(hops > 0)) {
+        while (wave_any(hops > 0)) {
           if (hops > 0) { par = nodes[par].next; hops--; }
         }
       }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         // angle_wrap (:425-433): add -+2 pi until inside [-pi, pi] (at most once for |phi| <= pi)
         for (int guard = 0; guard < 64; guard++) {
           const bool hi = a > AUVP_PI, lo = a < -AUVP_PI;
-          if (!__any(taken && (hi || lo))) break;
+          if (!wave_any(taken && (hi || lo))) break;
           a = hi ? a + (-2 * AUVP_PI) : (lo ? a + (2 * AUVP_PI) : a);
         }
         th = taken ? a : prev;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         const bool slot_hit = on && !(sbox.z < mnx - ts || sbox.x > mxx + ts || sbox.w < mny - ts || sbox.y > mxy + ts);
         uint32_t sm = row_ballot(slot_hit, rowbase);
         bool hit = false;
-        while (__any(sm != 0u)) {
+        while (wave_any(sm != 0u)) {
           const bool hs_ = sm != 0u;
           const int j0 = hs_ ? 16 * (__ffs((int)sm) - 1) : 0;
           sm &= sm - 1u;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           const double orj = (double)(OBST_LDS ? tl_r[oi] : W.os_r[oi]), otj = W.os_t[oi];
           const bool cand = hs_ && !(auvp_fabs(oxj - tcx) > thx + orj || auvp_fabs(oyj - tcy) > thy + orj);
           uint32_t cm = row_ballot(cand, rowbase);
-          while (__any(cm != 0u)) {
+          while (wave_any(cm != 0u)) {
             const bool has = cm != 0u;
             const int cl = has ? (__ffs((int)cm) - 1) : 0;
             cm &= cm - 1u;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       }
       int n_arc = act ? prev_n_arc : -1;
       bool free_ = false;
-      if (__any(eval)) {
+      if (wave_any(eval)) {
         n_arc = eval ? -1 : n_arc;
         const double2 goal = *reinterpret_cast<const double2*>(B.goal + 2 * (size_t)(ep < 0 ? 0 : ep));
         const double gx = goal.x, gy = goal.y;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         double diffg = theta - th0;
         for (int guard = 0; guard < 64; guard++) {  // angle_wrap
           const bool hi = diffg > AUVP_PI, lo = diffg < -AUVP_PI;
-          if (!__any(eval && (hi || lo))) break;
+          if (!wave_any(eval && (hi || lo))) break;
           diffg = hi ? diffg + (-2 * AUVP_PI) : (lo ? diffg + (2 * AUVP_PI) : diffg);
         }
         bool go = eval && !(auvp_fabs(diffg) > AUVP_PI / 2);
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         double phi2 = dphi;
         for (int guard = 0; guard < 64; guard++) {
           const bool hi = phi2 > AUVP_PI, lo = phi2 < -AUVP_PI;
-          if (!__any(go && (hi || lo))) break;
+          if (!wave_any(go && (hi || lo))) break;
           phi2 = hi ? phi2 + (-2 * AUVP_PI) : (lo ? phi2 + (2 * AUVP_PI) : phi2);
         }
         phi2 = 2 * phi2;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         // sin / cos of th0: an accepted node's angle went through the steer's sincos already; only an arc from an older
         // node (this step's was rejected and no arc has been evaluated yet) needs its own
         double s0 = fin_sn, c0 = fin_cs;
-        if (__any(eval && !ok)) {
+        if (wave_any(eval && !ok)) {
           double s1, c1;
           auvp_sincos(th0, &s1, &c1);
           if (!ok) { s0 = s1; c0 = c1; }
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         // sample the arc 16 points per row and pass; a row stops at its first pass that is not free
         bool sampling = go;
         free_ = go;
-        for (int i0 = 0; __any(sampling && i0 < n_arc); i0 += 16) {
+        for (int i0 = 0; wave_any(sampling && i0 < n_arc); i0 += 16) {
           const bool on = sampling && i0 < n_arc;
           const int nv = on ? ((n_arc - i0) < 16 ? (n_arc - i0) : 16) : 0;
           const int i = i0 + rl;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           const bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
           const bool outside = row_ballot(pv && !(wx && wy), rowbase) != 0u;
           bool hitp = false;
-          if (__any(on && !outside)) hitp = obstacle_hit(on && !outside, pv, ax, ay);
+          if (wave_any(on && !outside)) hitp = obstacle_hit(on && !outside, pv, ax, ay);
           if (on && (outside || hitp)) { free_ = false; sampling = false; }
         }
         if (free_) {
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           int L = 1 + n_arc;
           int m = lastn;
           bool walking = true;
-          while (__any(walking)) {
+          while (wave_any(walking)) {
             if (walking) {
               const int4 r = *reinterpret_cast<const int4*>(&nodes[m].step);
               if (r.y < 0) walking = false;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
 
     // ---------------------------------------------------------------- rows whose episode is finished store it
     const bool fin = live && (status != 0 || done || (P.step_mode ? stepped : step >= P.max_step));
-    if (__any(fin)) {
+    if (wave_any(fin)) {
       const unsigned long long drawn = rng.drawn;
       wave_sync();
       if (fin) {

@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t rng_randbelow(WaveRng& r, uint32_t n) {
     rng_ensure(r, 8u);
     uint32_t v = 0xffffffffu;
     if (lane < 8) v = rng_word(r, (uint32_t)lane) >> (32 - k);
-    unsigned long long okm = __ballot(lane < 8 && v < n);
+    unsigned long long okm = wave_ballot(lane < 8 && v < n);
     if (okm) {
       int f = __ffsll((long long)okm) - 1;
       uint32_t res = (uint32_t)__builtin_amdgcn_readlane((int)v, f);
@@ -186,7 +186,7 @@ __device__ __forceinline__ bool prrt_hits(const double (&ox)[J], const double (&
   for (int j = 0; j < J; j++) {
     const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
     // lanes = path points: each candidate is broadcast and tested against every point at once
-    unsigned long long cm = __ballot(cand);
+    unsigned long long cm = wave_ballot(cand);
     while (cm) {
       const int c = __ffsll((long long)cm) - 1;
       cm &= cm - 1ull;
@@ -198,7 +198,7 @@ __device__ __forceinline__ bool prrt_hits(const double (&ox)[J], const double (&
       }
     }
   }
-  return __any(hit != 0);
+  return wave_any(hit != 0);
 }
 
 // Two register budgets per J: batches that fill the chip run five waves per SIMD (96 VGPRs, a few spilled; six or eight
@@ -332,11 +332,11 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
       for (int k = 0; k < 4; k++) {
         if (par < 0) {
           const bool is = v[k] == b;
-          const unsigned long long bal = __ballot(is);
+          const unsigned long long bal = wave_ballot(is);
           const int c = __popcll(bal);
           if (seen + c > rsel) {
             const int want = rsel - seen;
-            const unsigned long long sel = __ballot(is && (int)__popcll(bal & ((1ull << lane) - 1ull)) == want);
+            const unsigned long long sel = wave_ballot(is && (int)__popcll(bal & ((1ull << lane) - 1ull)) == want);
             par = base + 64 * k + (__ffsll((long long)sel) - 1);
           }
           seen += c;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
             phi = (s1 + s2) / (2 * radius);
           }
         }
-        const unsigned long long tmask = __ballot(taken);
+        const unsigned long long tmask = wave_ballot(taken);
         // theta = angle_wrap(theta + phi) for the taken sub-arcs only, left to right: a uniform loop over the sub-arcs (phi of
         // lane s read across the wave); lane s keeps the angle after its step, idle lanes the chunk-entry angle
         double th = cth, myth = cth;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
             phi = (s1 + s2) / (2 * radius);
           }
         }
-        const unsigned long long tmask = __ballot(taken);
+        const unsigned long long tmask = wave_ballot(taken);
         wave_sync();
         if (lane <= C) phi_l[lane] = phi;
         wave_sync();
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
         outside = outside | !(wx && wy);
       }
       const double bx0 = bbx0, by0 = bby0, bx1 = bbx1, by1 = bby1;
-      ok = !prrt_hits<J>(ox, oy, ot, orr, pts, P_n, bx0, by0, bx1, by1) && !__any(outside);
+      ok = !prrt_hits<J>(ox, oy, ot, orr, pts, P_n, bx0, by0, bx1, by1) && !wave_any(outside);
     }
     int me = -1;
     if (ok) {
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
         idx_err |= sub >= P.S;
         bk = (row * P.cols + col) * P.S + sub;
       }
-      if (__any(idx_err)) { status = -1; break; }
+      if (wave_any(idx_err)) { status = -1; break; }
       bk = uni(bk);
       int2 bwn = make_int2(0, 0);
       if (bk >= 0) bwn = buckets[bk];
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
                 bool wy = (ay >= P.rect[1]) && (ay <= P.rect[3]);
                 outside = !(wx && wy);
               }
-              if (__any(outside)) { free_ = false; break; }
+              if (wave_any(outside)) { free_ = false; break; }
               // Here the lanes hold the POINTS (up to 64 of them), so the roles are swapped with respect to
               // prrt_hits: a conservative box of this piece of the arc picks the candidate obstacles (lanes =
               // obstacles, one ballot per slot), and each candidate is broadcast and tested against all points
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
 #pragma unroll
               for (int j = 0; j < J; j++) {
                 const bool cand = !(auvp_fabs(ox[j] - cxm) > hx + orr[j] || auvp_fabs(oy[j] - cym) > hy + orr[j]);
-                unsigned long long cm = __ballot(cand);
+                unsigned long long cm = wave_ballot(cand);
                 while (cm) {
                   const int l = __ffsll((long long)cm) - 1;
                   cm &= cm - 1ull;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
                   hitl |= (lane < nv) && (ex * ex + ey * ey <= otl);
                 }
               }
-              if (__any(hitl)) free_ = false;
+              if (wave_any(hitl)) free_ = false;
             }
             arc_free = free_ ? 1 : 0;
             if (free_) {

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64) void collision_probe_kernel(WorldDev W, int n_p
     }
   }
   const bool outside = any_point_outside(poly, W.n_poly, reinterpret_cast<const double(*)[2]>(pts + 2 * (size_t)b), e - b);
-  bool ok = !__any(hit) && !outside;
+  bool ok = !wave_any(hit) && !outside;
   if (lane == 0) out[p] = ok ? 1 : 0;
 }
 

@@ -273,12 +273,12 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
         const bool cand = lane < 60;
         const bool badkey = cand && rbj > K;
         const int cj = (cand && !badkey) ? bin_count[rbj] : 0;
-        const unsigned long long okm = __ballot(cj != 0), badm = __ballot(badkey);
+        const unsigned long long okm = wave_ballot(cj != 0), badm = wave_ballot(badkey);
         const int fo = okm ? (__ffsll((long long)okm) - 1) : 64, fb = badm ? (__ffsll((long long)badm) - 1) : 64;
         // candidates in front of the decision that were found empty: what an append could have changed
         const int first = fo < fb ? fo : fb;
         const unsigned long long before = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
-        if ((__ballot(cand && !badkey && cj == 0) & before) != 0ull) rejects = 1;
+        if ((wave_ballot(cand && !badkey && cj == 0) & before) != 0ull) rejects = 1;
         if (fb < fo) { status = -5; break; }
         if (fo < 64) {
           f = fo;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
               const double diff = py_uniform(-Q.diff_max, Q.diff_max, uw[jj + 1]);
               fl = auvp_fabs(dist) > auvp_fabs(diff);
             }
-            msk[t] = __ballot(fl);
+            msk[t] = wave_ballot(fl);
           }
         }
         const bool active = lane < n;
@@ -337,11 +337,11 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
         }
         for (;;) {
           const bool tk = active && ((win >> cbelow) & 1ull);
-          tmask = __ballot(tk);
+          tmask = wave_ballot(tk);
           const int cnew = __popcll(tmask & ((1ull << lane) - 1ull));
           const bool changed = active && (cnew != cbelow);
           cbelow = cnew;
-          if (!__any(changed)) break;
+          if (!wave_any(changed)) break;
         }
         const int mypos = 2 * lane + cbelow;
         const int used = 2 * n + __popcll(tmask);
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
       double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
       if (active) { mx = inc[lane]; my = inc[DUO_CS + lane]; mt_ = inc[2 * DUO_CS + lane]; ml = inc[3 * DUO_CS + lane]; }
       const bool app = taken && (mv >= Q.min_dist);
-      const unsigned long long amask = __ballot(app);
+      const unsigned long long amask = wave_ballot(app);
       const int napp = __popcll(amask);
       if (n_points + napp > capp || napp + 1 > max_pts) cap_err = true;
       if (!cap_err) {
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
     for (int j = 0; j < J; j++) {
       const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = (double)olr[j * 64 + lane];
       const bool cand = !(auvp_fabs(oxj - cxm) > hx + orj || auvp_fabs(oyj - cym) > hy + orj);
-      unsigned long long cm = __ballot(cand);
+      unsigned long long cm = wave_ballot(cand);
       n_cand += __popcll(cm);
       while (cm) {
         const int idx = uni(j * 64 + (__ffsll((long long)cm) - 1));
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
     }
     const double* sb = S.world->safe_box;
     const bool box_inside = W.has_safe_box && bx0 > sb[0] && by0 > sb[1] && bx1 < sb[2] && by1 < sb[3];
-    const bool ok = !__any(hit != 0) && (box_inside || !any_point_outside(S.poly, W.n_poly, pts, P_n));
+    const bool ok = !wave_any(hit != 0) && (box_inside || !any_point_outside(S.poly, W.n_poly, pts, P_n));
     if (ok) {
       if (n_nodes >= capn) { status = -2; break; }
       // ---------------------------------------------------------------- accept (:144-151)

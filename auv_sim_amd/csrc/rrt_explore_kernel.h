@@ -133,7 +133,7 @@ __device__ __forceinline__ bool any_point_outside(const double (*poly)[2], int n
       const double x = pts[p][0], y = pts[p][1];
       if ((yi > y) != (yj > y)) cross = x < (xj - xi) * (y - yi) / (yj - yi) + xi;
     }
-    const unsigned long long cm = __ballot(cross);
+    const unsigned long long cm = wave_ballot(cross);
     // lanes 0..per-1 each judge one point of this pass
     const int q = p0 + lane;
     if (lane < per && q < n_pts) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ bool any_point_outside(const double (*poly)[2], int n
       outside = outside | ((__popcll(grp) & 1) == 0);
     }
   }
-  return __any(outside);
+  return wave_any(outside);
 }
 
 // cost.py:181-184 first-match cell scan through the x-bucket index; returns cell id or -1
@@ -330,14 +330,14 @@ __device__ __forceinline__ void cost_element(const WorldDev& W, const RrtTables&
 __device__ __forceinline__ void cost_accumulate(int n_valid, double tv, int hab, double* term, CostAcc& acc) {
   const int lane = lane_id();
   term[lane] = tv;
-  unsigned long long hm = __ballot(hab >= 0);
+  unsigned long long hm = wave_ballot(hab >= 0);
   acc.hits += __popcll(hm);
   unsigned long long vis = acc.visited;
   while (hm) {  // at most H distinct habitats; usually one or two per pass
     int l = __ffsll((long long)hm) - 1;
     int h = __builtin_amdgcn_readlane(hab, l);
     vis |= (1ull << h);
-    hm &= ~__ballot(hab == h);
+    hm &= ~wave_ballot(hab == h);
   }
   acc.visited = vis;
   wave_sync();
@@ -478,10 +478,10 @@ __device__ __forceinline__ int nn_closest(const double2* __restrict__ xy, int n_
   const double band = gmin + gmin * 0x1p-49;
   const bool suspect = (bd > gmin && bd <= band) || (sd > gmin && sd <= band);
   int cand = 0x7fffffff;
-  const bool exact = __any(suspect) || force_exact;
+  const bool exact = wave_any(suspect) || force_exact;
   if (slow) *slow = exact ? 1 : 0;
   if (!exact) {
-    const unsigned long long em = __ballot(bd == gmin);
+    const unsigned long long em = wave_ballot(bd == gmin);
     if (__popcll(em) == 1) return uni(__builtin_amdgcn_readlane(bt, __ffsll((long long)em) - 1) + (__ffsll((long long)em) - 1));
     cand = (bd == gmin) ? bt + lane : 0x7fffffff;
   } else {
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
         const bool cand = lane < 60;  // leave room for the two draws that follow the successful one
         const bool badkey = cand && rbj > K;
         const int cj = (cand && !badkey) ? bin_count[rbj] : 0;
-        const unsigned long long okm = __ballot(cj != 0), badm = __ballot(badkey);
+        const unsigned long long okm = wave_ballot(cj != 0), badm = wave_ballot(badkey);
         const int fo = okm ? (__ffsll((long long)okm) - 1) : 64, fb = badm ? (__ffsll((long long)badm) - 1) : 64;
         if (fb < fo) { status = -5; break; }
         if (fo < 64) {
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
             double diff = py_uniform(-Q.diff_max, Q.diff_max, uw[jj + 1]);
             f = auvp_fabs(dist) > auvp_fabs(diff);
           }
-          msk[t] = __ballot(f);
+          msk[t] = wave_ballot(f);
         }
       }
       // Where does sub-arc s start?  pos_s = 2s + (#taken among sub-arcs < s).  Fixed point of
@@ -747,11 +747,11 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
       }
       for (;;) {
         bool tk = active && ((win >> cbelow) & 1ull);
-        tmask = __ballot(tk);
+        tmask = wave_ballot(tk);
         int cnew = __popcll(tmask & ((1ull << lane) - 1ull));
         bool changed = active && (cnew != cbelow);
         cbelow = cnew;
-        if (!__any(changed)) break;
+        if (!wave_any(changed)) break;
       }
       const int mypos = 2 * lane + cbelow;
       const int used = 2 * n + __popcll(tmask);
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
       double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
       if (active) { mx = inc[lane]; my = inc[CS + lane]; mt_ = inc[2 * CS + lane]; ml = inc[3 * CS + lane]; }
       const bool app = taken && (mv >= Q.min_dist);
-      const unsigned long long amask = __ballot(app);
+      const unsigned long long amask = wave_ballot(app);
       const int napp = __popcll(amask);
       if (n_points + cnt + napp > capp || cnt + napp + 1 > max_pts) { cap_err = true; break; }
       if (app) {
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
     for (int j = 0; j < J; j++) {
       const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = (double)olr[j * 64 + lane];
       const bool cand = !(auvp_fabs(oxj - cxm) > hx + orj || auvp_fabs(oyj - cym) > hy + orj);
-      unsigned long long cm = __ballot(cand);
+      unsigned long long cm = wave_ballot(cand);
       n_cand += __popcll(cm);
       while (cm) {
         const int idx = uni(j * 64 + (__ffsll((long long)cm) - 1));
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
     // every point is strictly inside it and the crossing test would say so too; skip it then
     const double* sb = S.world->safe_box;  // the LDS copy: four doubles less held in scalar registers
     const bool box_inside = W.has_safe_box && bx0 > sb[0] && by0 > sb[1] && bx1 < sb[2] && by1 < sb[3];
-    const bool ok = !__any(hit != 0) && (box_inside || !any_point_outside(S.poly, W.n_poly, pts, P_n));
+    const bool ok = !wave_any(hit != 0) && (box_inside || !any_point_outside(S.poly, W.n_poly, pts, P_n));
     if (log_it && lane == 0) {
       B.it_parent[logb + it] = par;
       B.it_accepted[logb + it] = ok ? 1 : 0;
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
         const bool push = need && !pushed && par >= 0;
         if (push) { atomicOr(&mark[par >> 5], 1u << (par & 31)); pushed = true; }
         // another round only if some lane just marked a parent inside this block
-        if (!__any(push && par >= n0)) break;
+        if (!wave_any(push && par >= n0)) break;
         wave_sync();
       }
       if (need) atomicOr(&mark[m >> 5], 1u << (m & 31));
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     while (qn < 64 && scan < n_nodes) {
       const int mm = scan + lane;
       const bool f = mm < n_nodes && (!mark || ((mark[mm >> 5] >> (mm & 31)) & 1u));
-      const unsigned long long fm = __ballot(f);
+      const unsigned long long fm = wave_ballot(f);
       if (f) c_ids[qn + __popcll(fm & ((1ull << lane) - 1ull))] = mm;
       qn += __popcll(fm);
       scan += 64;
@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     wave_sync();
     // parents inside this pass: a lane is ready once its parent's entry is final (a parent always has the smaller
     // index, so the lowest pending lane is ready in every round); all ready lanes add their parent's sums at once
-    unsigned long long pending = __ballot(live && r.y >= first_id);
+    unsigned long long pending = wave_ballot(live && r.y >= first_id);
     while (pending) {
       const int p = c_par[lane];
       const bool mine = (pending >> lane) & 1ull;
@@ -1250,7 +1250,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
       wave_sync();
       if (ready) { c_S[lane] = aS + c_S[lane]; c_hits[lane] += aH; c_elems[lane] += aE; c_vis[lane] |= aV; }
       wave_sync();
-      pending &= ~__ballot(ready);
+      pending &= ~wave_ballot(ready);
     }
     const double S = c_S[lane];
     const int hits = c_hits[lane], elems = c_elems[lane];
@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
         if (!(err == err) || !(tot == tot)) { lo = -__builtin_inf(); hi = __builtin_inf(); }  // nan: decide exactly
       }
     }
-    const unsigned long long qm = __ballot(q);
+    const unsigned long long qm = wave_ballot(q);
     if (qm != 0ull) {
     n_leaves += __popcll(qm);
     // exclusive prefix minimum of hi over the lanes (creation order), seeded with the earlier passes
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
     before = before < min_hi ? before : min_hi;
     leaf_elems += q ? (long long)elems : 0ll;  // (per lane; summed over the wavefront once, where the record is written)
     const bool cand = q && (log_leaf || lo < before);
-    unsigned long long cm = __ballot(cand);
+    unsigned long long cm = wave_ballot(cand);
     min_hi = readlane_f64(pm, 63) < min_hi ? readlane_f64(pm, 63) : min_hi;
     while (cm) {
       const int l = __ffsll((long long)cm) - 1;

@@ -49,7 +49,7 @@ __host__ __device__ inline RowsLdsPlan rrt_rows_lds_plan(int K, int n_obst_slots
 
 // ---- row helpers (16 lanes = one episode) ----
 __device__ __forceinline__ uint32_t row_ballot(bool pred, int rowbase) {
-  return (uint32_t)((__ballot(pred) >> rowbase) & 0xffffull);
+  return (uint32_t)((wave_ballot(pred) >> rowbase) & 0xffffull);
 }
 __device__ __forceinline__ int row_read(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 __device__ __forceinline__ double row_read_f64(double v, int src_lane) {
@@ -174,9 +174,12 @@ struct RowRng {
 // pslot + avail is kept a multiple of 16 (624 = 39 x 16; it starts at 624 = 0): whole 16-word blocks are regenerated, so
 // a block never wraps and lane rl's word is block + rl.
 __device__ __forceinline__ void rows_ensure(RowRng& r, bool want, uint32_t need, int rl) {
+  // (a row that does not ask needs 0 words: the loop's vote is then the ballot of ONE compare, `avail < need` -- a vote on
+  // `want && ...` costs two more vector instructions, a 0 / 1 and its compare with zero)
+  const uint32_t need_w = want ? need : 0u;
   for (;;) {
-    const bool go = want && r.avail < need;
-    if (!__any(go)) break;
+    const bool go = r.avail < need_w;
+    if (__builtin_amdgcn_uicmp(r.avail, need_w, 36 /* unsigned < */) == 0ull) break;
     // up to 32 words per row and round, two per lane (words 227 apart are independent, so any 32 consecutive are)
     uint32_t n = (624u - r.avail) & ~15u;
     n = n < 32u ? n : 32u;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   const int ep = ((int)blockIdx.x * wg_waves + wave) * RW_ROWS + row;
   bool live = ep < n_episodes;  // row-uniform; a row that fails keeps running as a no-op until the wave is done
   const int eps = live ? ep : 0;
-  if (!__any(live)) return;
+  if (!wave_any(live)) return;
 
   // ---- per-episode views ----
   const int capn = B.cap_nodes, capp = B.cap_points, bcap = B.bin_cap;
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
   const int nv_poly = W.n_poly;
 
   for (int it = 0; it < P.max_iter; it++) {
-    if (!__any(live)) break;
+    if (!wave_any(live)) break;
     // ------------------------------------------------------------ parent selection (:121-127)
     // lane rl of a row tries draw rl: ran_bin = int(uniform(1, K+1)) until that bin is non-empty; the first success in
     // stream order wins, a key beyond K before it is a KeyError.  14 tries per round leave room for the two draws
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
         // rows that just finished pick up the winner's values (rows still searching read garbage they overwrite later)
         const int rb_n = row_read(rbj, src), cnt_n = row_read(cj, src);
         if (!again && live && cnt == 0) { rb = rb_n; cnt = cnt_n; }
-        if (!__any(again)) break;
+        if (!wave_any(again)) break;
       }
       const double u1 = row_read_f64(u, rowbase + fo + 1), u2 = row_read_f64(u, rowbase + fo + 2);
       if (live) {
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
     for (int pass = 0; pass < 2; pass++) {
       const int c0 = pass * RW_C;
       const bool on = live && c0 < n_total;  // rows with sub-arcs left
-      if (!__any(on)) break;
+      if (!wave_any(on)) break;
       const int n = on ? ((n_total - c0) < RW_C ? (n_total - c0) : RW_C) : 0;
       const int nwin = 3 * n;
 #ifdef AUVP_ROWS_PAD
@@ -380,28 +383,31 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
       unsigned long long tpred = 0ull;
 #pragma unroll
       for (int t = 0; t < 3; t++) {
+        // every lane compares (entries past the window are whatever the scratch holds: never a trap, masked below); the
+        // predicate is the AND of two single-compare ballots, taken in scalar registers (nwin = 0 for rows that are not `on`)
         const int j = rl + 16 * t;
-        bool f = false;
-        if (on && j + 1 < nwin) {
-          const double dist = py_uniform(0.0, Q.dist_to_end, win[j]);
-          const double diff = py_uniform(-Q.diff_max, Q.diff_max, win[j + 1]);
-          f = auvp_fabs(dist) > auvp_fabs(diff);
-        }
-        tpred |= (unsigned long long)row_ballot(f, rowbase) << (16 * t);
+        const double dist = py_uniform(0.0, Q.dist_to_end, win[j]);
+        const double diff = py_uniform(-Q.diff_max, Q.diff_max, win[j + 1]);
+        const unsigned long long fb = __builtin_amdgcn_fcmp(auvp_fabs(dist), auvp_fabs(diff), 2 /* ordered > */) &
+                                      __builtin_amdgcn_uicmp((unsigned)(j + 1), (unsigned)nwin, 36 /* unsigned < */);
+        tpred |= ((fb >> rowbase) & 0xffffull) << (16 * t);
       }
       // where does sub-arc s start?  pos_s = 2s + (#taken among sub-arcs < s): fixed point of
       //   taken_s = T[2s + c_s],  c_s = popcount(taken below s),  started from "everything taken"
+      // (the votes are ballots of ONE compare each -- `__builtin_amdgcn_uicmp` -- with the lanes that do not take part made
+      // neutral through their data: a vote on `active && x` costs two more vector instructions, a 0 / 1 and its compare)
       const bool active = rl < n;
-      int cbelow = rl;
+      const uint32_t mywin = active ? (uint32_t)(tpred >> (2 * rl)) : 0u;  // bits 0 .. rl are looked at (cbelow <= rl <= 14)
+      const uint32_t below_me = active ? ((1u << rl) - 1u) : 0u;
+      int cbelow = active ? rl : 0;
       uint32_t tmask;
-      const unsigned long long mywin = tpred >> (2 * rl);
       for (;;) {
-        const bool tk = active && ((mywin >> cbelow) & 1ull);
-        tmask = row_ballot(tk, rowbase);
-        const int cnew = __popc(tmask & ((1u << rl) - 1u));
-        const bool changed = active && (cnew != cbelow);
+        const unsigned long long tb = __builtin_amdgcn_uicmp((mywin >> cbelow) & 1u, 0u, 33 /* != */);
+        tmask = (uint32_t)((tb >> rowbase) & 0xffffull);
+        const int cnew = __popc(tmask & below_me);
+        const unsigned long long chg = __builtin_amdgcn_uicmp((unsigned)cnew, (unsigned)cbelow, 33 /* != */);
         cbelow = cnew;
-        if (!__any(changed)) break;
+        if (chg == 0ull) break;
       }
       const int mypos = 2 * rl + cbelow;
       const int used = 2 * n + __popc(tmask);
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
         sm = row_ballot(tight, rowbase);
         ex0 = mnx; ey0 = mny; ex1 = mxx; ey1 = mxy;
       }
-      while (__any(sm != 0u)) {  // slots some row has to look into (none at all for most steers of a sparse world)
+      while (wave_any(sm != 0u)) {  // slots some row has to look into (none at all for most steers of a sparse world)
         const bool hs_ = sm != 0u;
         const int j0 = hs_ ? 16 * (__ffs((int)sm) - 1) : 0;
         sm &= sm - 1u;
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
                                         : !(auvp_fabs(oxj - px0) > hx + orj || auvp_fabs(oyj - py0) > hx + orj));
         uint32_t cm = row_ballot(cand, rowbase);
         n_cand += __popc(cm);
-        while (__any(cm != 0u)) {
+        while (wave_any(cm != 0u)) {
           const bool has = cm != 0u;
           const int cl = has ? (__ffs((int)cm) - 1) : 0;
           cm &= cm - 1u;
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, 
     const double* sb = S.world->safe_box;
     const bool box_inside = W.has_safe_box && ex0 > sb[0] && ey0 > sb[1] && ex1 < sb[2] && ey1 < sb[3];
     bool outside = false;
-    if (__any(live && !box_inside)) {
+    if (wave_any(live && !box_inside)) {
       // lane = path point (two passes' points + the parent's end on lane 15); edges of the polygon one at a time
       auto crossing_outside = [&](double x, double y) {
         if (nv_poly <= 0) return true;

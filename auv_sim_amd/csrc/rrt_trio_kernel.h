@@ -345,11 +345,11 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
         const bool cand = lane < 60;
         const bool badkey = cand && rbj > K;
         const int cj = (cand && !badkey) ? bin_count[rbj] : 0;
-        const unsigned long long okm = __ballot(cj != 0), badm = __ballot(badkey);
+        const unsigned long long okm = wave_ballot(cj != 0), badm = wave_ballot(badkey);
         const int fo = okm ? (__ffsll((long long)okm) - 1) : 64, fb = badm ? (__ffsll((long long)badm) - 1) : 64;
         const int first = fo < fb ? fo : fb;
         const unsigned long long before = first >= 64 ? ~0ull : ((1ull << first) - 1ull);
-        if ((__ballot(cand && !badkey && cj == 0) & before) != 0ull) rejects = 1;
+        if ((wave_ballot(cand && !badkey && cj == 0) & before) != 0ull) rejects = 1;
         if (fb < fo) { status = -5; break; }
         if (fo < 64) {
           f = fo;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
               const double diff = py_uniform(-Q.diff_max, Q.diff_max, uw[jj + 1]);
               fl = auvp_fabs(dist) > auvp_fabs(diff);
             }
-            msk[t] = __ballot(fl);
+            msk[t] = wave_ballot(fl);
           }
         }
         // the parent's record is requested here, between the predicate and the fixed point: its id (requested before the window)
@@ -417,11 +417,11 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
         }
         for (;;) {
           const bool tk = active && ((win >> cbelow) & 1ull);
-          tmask = __ballot(tk);
+          tmask = wave_ballot(tk);
           const int cnew = __popcll(tmask & ((1ull << lane) - 1ull));
           const bool changed = active && (cnew != cbelow);
           cbelow = cnew;
-          if (!__any(changed)) break;
+          if (!wave_any(changed)) break;
         }
         const int mypos = 2 * lane + cbelow;
         const int used = 2 * n + __popcll(tmask);
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
         double mx = 0.0, my = 0.0, mt_ = 0.0, ml = 0.0;
         if (active) { mx = inc[lane]; my = inc[DUO_CS + lane]; mt_ = inc[2 * DUO_CS + lane]; ml = inc[3 * DUO_CS + lane]; }
         const bool app = taken && (mv >= Q.min_dist);
-        const unsigned long long amask = __ballot(app);
+        const unsigned long long amask = wave_ballot(app);
         cnt = __popcll(amask);
         if (app) {
           const int rank = __popcll(amask & ((1ull << lane) - 1ull));
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
       for (int j = 0; j < J; j++) {
         const double oxj = olx[j * 64 + lane], oyj = oly[j * 64 + lane], orj = (double)olr[j * 64 + lane];
         const bool cand = !(auvp_fabs(oxj - cxm) > hx + orj || auvp_fabs(oyj - cym) > hy + orj);
-        unsigned long long cm = __ballot(cand);
+        unsigned long long cm = wave_ballot(cand);
         n_cand += __popcll(cm);
         while (cm) {
           const int idx = uni(j * 64 + (__ffsll((long long)cm) - 1));
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
       }
       const double* sb = S.world->safe_box;
       const bool box_inside = W.has_safe_box && bx0 > sb[0] && by0 > sb[1] && bx1 < sb[2] && by1 < sb[3];
-      rejected = __any(hit != 0);
+      rejected = wave_any(hit != 0);
       if (!rejected && !box_inside) {
         if (pv0) { pts[lane][0] = q0.x; pts[lane][1] = q0.y; }
         wave_sync();

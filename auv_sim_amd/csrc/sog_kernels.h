@@ -47,11 +47,11 @@ __global__ __launch_bounds__(256) void sog_count_kernel(SogDev D) {
   // keys -- one atomic per key and wavefront instead of one per point on the same address
   {
     const int key = b * D.n_sharks + s, lane = threadIdx.x & 63;
-    unsigned long long todo = __ballot(1);
+    unsigned long long todo = wave_ballot(1);
     while (todo) {
       const int leader = __ffsll(todo) - 1;
       const int k0 = __shfl(key, leader);
-      const unsigned long long same = __ballot(key == k0) & todo;
+      const unsigned long long same = wave_ballot(key == k0) & todo;
       if (lane == leader) atomicAdd(&D.npts[k0], __popcll(same));
       todo &= ~same;
       if (key == k0) break;
