@@ -237,8 +237,10 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         double a = prev + phi;
         // angle_wrap (:425-433): add -+2 pi until inside [-pi, pi] (at most once for |phi| <= pi)
         for (int guard = 0; guard < 64; guard++) {
+          // (the vote is the ballot of ONE compare, |a| > pi, over all lanes: a lane that is not taken holds an angle that is
+          // wrapped already, and its `a` is not used)
+          if (__builtin_amdgcn_fcmp(auvp_fabs(a), AUVP_PI, 2 /* ordered > */) == 0ull) break;
           const bool hi = a > AUVP_PI, lo = a < -AUVP_PI;
-          if (!wave_any(taken && (hi || lo))) break;
           a = hi ? a + (-2 * AUVP_PI) : (lo ? a + (2 * AUVP_PI) : a);
         }
         th = taken ? a : prev;
@@ -410,9 +412,9 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         const double gx = goal.x, gy = goal.y;
         const double theta = auvp_atan2_late(gy - ly, gx - lx);
         double diffg = theta - th0;
-        for (int guard = 0; guard < 64; guard++) {  // angle_wrap
+        for (int guard = 0; guard < 64; guard++) {  // angle_wrap (all lanes: rows that do not evaluate hold angles in range)
+          if (__builtin_amdgcn_fcmp(auvp_fabs(diffg), AUVP_PI, 2 /* ordered > */) == 0ull) break;
           const bool hi = diffg > AUVP_PI, lo = diffg < -AUVP_PI;
-          if (!wave_any(eval && (hi || lo))) break;
           diffg = hi ? diffg + (-2 * AUVP_PI) : (lo ? diffg + (2 * AUVP_PI) : diffg);
         }
         bool go = eval && !(auvp_fabs(diffg) > AUVP_PI / 2);
@@ -421,8 +423,8 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         go = go && (dphi != 0);
         double phi2 = dphi;
         for (int guard = 0; guard < 64; guard++) {
+          if (__builtin_amdgcn_fcmp(auvp_fabs(phi2), AUVP_PI, 2 /* ordered > */) == 0ull) break;
           const bool hi = phi2 > AUVP_PI, lo = phi2 < -AUVP_PI;
-          if (!wave_any(go && (hi || lo))) break;
           phi2 = hi ? phi2 + (-2 * AUVP_PI) : (lo ? phi2 + (2 * AUVP_PI) : phi2);
         }
         phi2 = 2 * phi2;
