@@ -335,13 +335,19 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
           const unsigned long long lo = sh < 64 ? msk[0] : msk[1], hi = sh < 64 ? msk[1] : 0ull;
           win = (lo >> s6) | ((hi << 1) << (63 - s6));
         }
-        for (;;) {
-          const bool tk = active && ((win >> cbelow) & 1ull);
-          tmask = wave_ballot(tk);
-          const int cnew = __popcll(tmask & ((1ull << lane) - 1ull));
-          const bool changed = active && (cnew != cbelow);
-          cbelow = cnew;
-          if (!wave_any(changed)) break;
+        // (votes as ballots of ONE compare each, the lanes that take no part made neutral through their data: a vote on
+        // `active && x` costs two more vector instructions on this chain -- a 0 / 1 and its compare with zero)
+        {
+          const uint32_t win32 = active ? (uint32_t)win : 0u;  // bits 0 .. lane are looked at (cbelow <= lane <= 29)
+          const uint32_t below_me = active ? ((1u << lane) - 1u) : 0u;
+          cbelow = active ? lane : 0;
+          for (;;) {
+            tmask = __builtin_amdgcn_uicmp((win32 >> cbelow) & 1u, 0u, 33 /* != */);
+            const int cnew = __popc((uint32_t)tmask & below_me);
+            const unsigned long long chg = __builtin_amdgcn_uicmp((unsigned)cnew, (unsigned)cbelow, 33 /* != */);
+            cbelow = cnew;
+            if (chg == 0ull) break;
+          }
         }
         const int mypos = 2 * lane + cbelow;
         const int used = 2 * n + __popcll(tmask);

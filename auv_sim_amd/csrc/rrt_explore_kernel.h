@@ -745,13 +745,19 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
         const int s6 = sh & 63;
         win = (lo >> s6) | ((hi << 1) << (63 - s6));
       }
-      for (;;) {
-        bool tk = active && ((win >> cbelow) & 1ull);
-        tmask = wave_ballot(tk);
-        int cnew = __popcll(tmask & ((1ull << lane) - 1ull));
-        bool changed = active && (cnew != cbelow);
-        cbelow = cnew;
-        if (!wave_any(changed)) break;
+      // (votes as ballots of ONE compare each, the lanes that take no part made neutral through their data: a vote on
+      // `active && x` costs two more vector instructions on this chain -- a 0 / 1 and its compare with zero)
+      {
+        const unsigned long long win_a = active ? win : 0ull;  // bits 0 .. lane are looked at (a chunk has up to 63 sub-arcs)
+        const unsigned long long below_me = active ? ((1ull << lane) - 1ull) : 0ull;
+        cbelow = active ? lane : 0;
+        for (;;) {
+          tmask = __builtin_amdgcn_uicmp((uint32_t)(win_a >> cbelow) & 1u, 0u, 33 /* != */);
+          const int cnew = __popcll(tmask & below_me);
+          const unsigned long long chg = __builtin_amdgcn_uicmp((unsigned)cnew, (unsigned)cbelow, 33 /* != */);
+          cbelow = cnew;
+          if (chg == 0ull) break;
+        }
       }
       const int mypos = 2 * lane + cbelow;
       const int used = 2 * n + __popcll(tmask);
