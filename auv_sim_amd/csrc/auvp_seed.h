@@ -57,7 +57,7 @@ __device__ __forceinline__ void mt_seed_by_array_column(unsigned long long seed,
 // random.seed(seeds[e]) for every generator of a batch, 64 per workgroup (2 us per generator on a host core: 1.0 of the 1.4 ms
 // a 512-episode Planner_RRT batch took to create, 25 ms of a 12 288-episode RRT.exploring batch).  rng_state (optional):
 // the planner's {slot, available, drawn lo, drawn hi} words, zeroed -- a freshly seeded generator has generated nothing yet.
-__global__ __launch_bounds__(64) void mt_seed_kernel(const unsigned long long* __restrict__ seeds, uint32_t* __restrict__ mt,
+static __global__ __launch_bounds__(64) void mt_seed_kernel(const unsigned long long* __restrict__ seeds, uint32_t* __restrict__ mt,
                                                      int32_t* __restrict__ rng_state, int n) {
   extern __shared__ __align__(16) unsigned char seed_smem[];
   uint32_t* mtl = reinterpret_cast<uint32_t*>(seed_smem);

@@ -24,6 +24,10 @@
 
 using namespace auvp;
 
+// rrt_rows_kernel lives in rows_kernels.hip (a translation unit with its own compiler flags); this is its launcher
+extern "C" hipError_t auvpi_rrt_rows_launch(const auvp::WorldDev* W, const auvp::RrtParamsDev* P, const auvp::RrtBuffers* B, int n_episodes,
+                                            int grid, int block, int lds_max, int lds, hipStream_t stream);
+
 static_assert(sizeof(auvp_rrt_summary) == sizeof(RrtSummary), "summary layout");
 
 namespace {
@@ -885,11 +889,7 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
     const RowsLdsPlan rq = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), wg_waves);
     const int per_wg = wg_waves * RW_ROWS;
     grid_used = (E + per_wg - 1) / per_wg; block_used = wg_waves * 64; lds_used = rq.total;
-    le = hipFuncSetAttribute(reinterpret_cast<const void*>(rrt_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, rp.total);
-    if (le == hipSuccess) {
-      hipLaunchKernelGGL(rrt_rows_kernel, dim3(grid_used), dim3(block_used), rq.total, h->stream, h->W, PR, B, (int)E);
-      le = hipGetLastError();
-    }
+    le = auvpi_rrt_rows_launch(&h->W, &PR, &B, (int)E, grid_used, block_used, rp.total, rq.total, h->stream);  // (rows_kernels.hip)
   } else {
   // compile-time specialisation: obstacles per lane (J), parent-sampling mode, diagnostics on/off
   const int jsel = O <= 64 ? 0 : (O <= 128 ? 1 : (O <= 256 ? 2 : (O <= 512 ? 3 : 4)));

@@ -40,6 +40,12 @@ struct PrrtState {
 
 PrrtState* prrt_of(auvp_handle* h);
 
+}  // namespace
+extern "C" hipError_t auvpi_prrt_rows_launch(int obst_lds, const auvp::WorldDev* W, const auvp::PrrtParamsDev* P, const auvp::PrrtBuffers* B,
+                                             int n_episodes, int* work_counter, int work_base, int occ_bytes, int grid, int block, int lds,
+                                             hipStream_t stream);
+namespace {
+
 // `sync`: wait for the launch and record its HIP-event time (the device-resident loop passes false: it only enqueues)
 int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true, bool one_wave_only = false) {
   S.P.step_mode = step_mode;
@@ -103,14 +109,10 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true, b
       le = hipMemsetAsync(S.work.p, 0, sizeof(int), h->stream);
       S.work_base = 0;
     } else le = hipSuccess;
-    auto launch_rows = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, S.work.as<int>(), S.work_base, occ_bytes);
-      return hipGetLastError();
-    };
     if (le == hipSuccess) {
-      le = obst_lds ? launch_rows(auvp::prrt_rows_kernel<true>) : launch_rows(auvp::prrt_rows_kernel<false>);
+      // (the kernel lives in prrt_rows_kernels.hip: a translation unit with its own compiler flags)
+      le = auvpi_prrt_rows_launch(obst_lds ? 1 : 0, &h->W, &S.P, &S.B, S.E, S.work.as<int>(), S.work_base, occ_bytes, grid_used, block_used,
+                                  (int)lds_used, h->stream);
       // every episode once + one empty pull per row; a failed launch pulled nothing, a memset-fronted one restarts at 0
       if (le == hipSuccess && !S.work_memset) S.work_base += S.E + grid_used * per_wg;
     }

@@ -743,7 +743,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
 
 // generate_final_course(final_node) (:317-327) in the order planning() returns it: final node, arc
 // points last to first, then every ancestor segment down to the start.  Element = x,y,theta,traj_t,length.
-__global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, const int64_t* __restrict__ offsets,
+static __global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, const int64_t* __restrict__ offsets,
                                                                double* __restrict__ out, int n_episodes) {
   const int ep = blockIdx.x;
   if (ep >= n_episodes) return;
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(64) void prrt_final_course_kernel(PrrtBuffers B, co
 // ---- pipeline fallback (planner_rrt_host.h): prrt_pipe_kernel is speculative; an episode it gives up on (AUVP_ST_PIPELINE)
 // is taken back to where the launch found it and planned again by prrt_kernel.
 // Before the launch: the episode's record, generator words and generator position (one workgroup per episode).
-__global__ __launch_bounds__(256) void prrt_snapshot_kernel(PrrtBuffers B, PrrtSummary* __restrict__ snap_sum, int32_t* __restrict__ snap_rng,
+static __global__ __launch_bounds__(256) void prrt_snapshot_kernel(PrrtBuffers B, PrrtSummary* __restrict__ snap_sum, int32_t* __restrict__ snap_rng,
                                                              uint32_t* __restrict__ snap_mt) {
   const size_t e = blockIdx.x;
   const int t = threadIdx.x;
@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256) void prrt_snapshot_kernel(PrrtBuffers B, PrrtS
 // After it: one thread per episode.  The tree is append-only (nodes and points past the old counts are ignored); the bucket
 // table is not: every insert of the failed launch is taken out again, newest first (a node's `next` is the member that headed
 // its bucket before it), then record, generator and position return to the snapshot.  redo_mask[e] = 1 for these episodes.
-__global__ __launch_bounds__(64) void prrt_undo_kernel(PrrtParamsDev P, PrrtBuffers B, int n_episodes, const PrrtSummary* __restrict__ snap_sum,
+static __global__ __launch_bounds__(64) void prrt_undo_kernel(PrrtParamsDev P, PrrtBuffers B, int n_episodes, const PrrtSummary* __restrict__ snap_sum,
                                                         const int32_t* __restrict__ snap_rng, const uint32_t* __restrict__ snap_mt,
                                                         uint8_t* __restrict__ redo_mask, int32_t* __restrict__ redo_count) {
   const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -834,7 +834,7 @@ __global__ __launch_bounds__(64) void prrt_undo_kernel(PrrtParamsDev P, PrrtBuff
 }
 
 // Planner_RRT.__init__ (:34-75): mps_list = [start]; add_node_to_grid(start).  One thread per episode.
-__global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuffers B, int n_episodes, uint8_t* __restrict__ env_done,
+static __global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, PrrtBuffers B, int n_episodes, uint8_t* __restrict__ env_done,
                                                         int32_t* __restrict__ env_err) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e == 0 && env_err) { env_err[0] = 0; env_err[1] = 0; }
@@ -914,7 +914,7 @@ __device__ inline void mt_seed_by_array(unsigned long long seed, uint32_t* mt) {
 // made the round-2 kernel 0.3 ms for 12 500 episodes).  Layout mtl[word * 65 + thread]: conflict-free both for the
 // per-thread recurrence (bank = word + thread) and for the coalesced write-out (one episode's 624 words by 64 lanes).
 constexpr int PRRT_SEED_LDS = MT_SEED_LDS;
-__global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, PrrtGoalMap M, const double* __restrict__ pf_state,
+static __global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, PrrtGoalMap M, const double* __restrict__ pf_state,
                                                                  int n_episodes) {
   extern __shared__ __align__(16) unsigned char seed_smem[];
   uint32_t* mtl = reinterpret_cast<uint32_t*>(seed_smem);
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(64) void prrt_from_particles_kernel(PrrtBuffers B, 
 // RRTEnv's per-step observation arrays (gym_rrt/envs/rrt_env.py:250-295), elementwise over
 // (episode, bucket): [cell.x, cell.y, subsection.theta, len(node_array)], has_node, node counts.
 // The reference rebuilds these three O(#buckets) Python lists after every node.
-__global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, PrrtBuffers B, const double* __restrict__ thetas,
+static __global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, PrrtBuffers B, const double* __restrict__ thetas,
                                                                int n_episodes, double* __restrict__ rrt_grid,
                                                                long long* __restrict__ has_node, long long* __restrict__ num_nodes) {
   const long long total = (long long)n_episodes * P.n_buckets;
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256) void prrt_observation_kernel(PrrtParamsDev P, 
 // The step's outcome and the stand-in agent live inside prrt_kernel's step mode (PrrtBuffers::env_*).  The kernels below
 // serve the launches that cannot carry them: the four-episodes-per-wavefront kernel (batches of more than eight
 // environments per CU) and callers that want the agent as a launch of its own.
-__global__ __launch_bounds__(256) void prrt_env_outcome_kernel(PrrtBuffers B, int n_episodes, const int32_t* __restrict__ bucket_ids) {
+static __global__ __launch_bounds__(256) void prrt_env_outcome_kernel(PrrtBuffers B, int n_episodes, const int32_t* __restrict__ bucket_ids) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_episodes) return;
   const bool was = B.env_done[e] != 0;
@@ -982,7 +982,7 @@ __global__ __launch_bounds__(256) void prrt_env_outcome_kernel(PrrtBuffers B, in
   prrt_env_outcome(B, e, was, skipped, s.status, s.done, s.last_accepted);
 }
 
-__global__ __launch_bounds__(256) void prrt_policy_random_kernel(PrrtBuffers B, int n_episodes, unsigned long long seed,
+static __global__ __launch_bounds__(256) void prrt_policy_random_kernel(PrrtBuffers B, int n_episodes, unsigned long long seed,
                                                                  int32_t* __restrict__ bucket_out) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n_episodes) return;

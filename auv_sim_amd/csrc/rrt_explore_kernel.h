@@ -1014,7 +1014,7 @@ __host__ __device__ inline int rrt_leaf_mark_words(int cap_nodes) {
   return w <= 4096 ? w : 0;
 }
 
-__global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes,
+static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes,
                                                                       int mark_words) {
   __shared__ __align__(16) unsigned char tables[RRT_WORLD_BYTES + RRT_MAX_HAB * 32 + RRT_MAX_POLY * 16 + RRT_MAX_BINS * 16];
   __shared__ double w_term[RRT_LEAF_WAVES][64];
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev 
 }
 
 // generate_final_course (:321-331) of the best leaf, written root -> leaf (exploring reverses it, :174)
-__global__ __launch_bounds__(64) void rrt_final_course_kernel(RrtBuffers B, const int64_t* __restrict__ offsets,
+static __global__ __launch_bounds__(64) void rrt_final_course_kernel(RrtBuffers B, const int64_t* __restrict__ offsets,
                                                               double* __restrict__ out, int n_episodes) {
   const int ep = blockIdx.x;
   if (ep >= n_episodes) return;

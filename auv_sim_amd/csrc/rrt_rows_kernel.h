@@ -224,7 +224,9 @@ __device__ __forceinline__ void rows_advance(RowRng& r, bool on, uint32_t nwords
   }
 }
 
-__global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
+// (internal linkage: the kernel is compiled -- and launched -- by rows_kernels.hip, a translation unit with its own scheduler
+// strategy; other units that include this header for the row helpers drop their unused copy)
+static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes) {
   extern __shared__ __align__(16) unsigned char smem[];
   const RrtTables S = rrt_tables_view(smem, W.n_habitats, W.n_poly);
   const int wave = (int)(threadIdx.x >> 6);
