@@ -14,11 +14,24 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 extra = sys.argv[2:]  # extra compiler flags (experiments), e.g. -mllvm -disable-machine-licm
 sys.path.insert(0, REPO)
 import __graft_entry__ as ge  # the product's translation units and flags
+# a unit other than auvplan.hip LAUNCHES only the kernels named here (the shared headers' other kernels are compiled into it as
+# unused internal-linkage copies: not listed); auvplan.hip launches everything else
+OWN = {"pf_kernels.hip": ("pf_",), "rows_kernels.hip": ("rrt_rows_kernel",), "prrt_rows_kernels.hip": ("prrt_rows_kernel",)}
+elsewhere = tuple(n for v in OWN.values() for n in v)
 txt = ""
 for unit, unit_flags in ge.UNITS:
     cmd = [ge.HIPCC] + ge.HIP_FLAGS + unit_flags + extra + ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null",
                                                             os.path.join(ge.CSRC, unit)]
-    txt += subprocess.run(cmd, capture_output=True, text=True).stderr
+    err = subprocess.run(cmd, capture_output=True, text=True).stderr
+    for blk in re.split(r"(?=[^\n]*remark: [^\n]*Function Name: )", err):
+        m = re.search(r"Function Name: (\S+)", blk)
+        if not m:
+            continue
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout
+        short_name = re.sub(r"\(.*", "", name).replace("auvp::", "").replace("void ", "").strip()
+        mine = short_name.startswith(OWN[unit]) if unit in OWN else not short_name.startswith(elsewhere)
+        if mine:
+            txt += blk
 demangle = subprocess.run(["c++filt"], input="\n".join(re.findall(r"Function Name: (\S+)", txt)),
                           capture_output=True, text=True).stdout.split("\n")
 blocks = re.split(r"remark: [^\n]*Function Name: ", txt)[1:]
