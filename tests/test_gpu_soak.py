@@ -94,3 +94,38 @@ def test_a_wait_that_runs_out_is_redone_on_the_one_wavefront_kernel(script, spin
     launch and the host redoes them on the one-wavefront kernel in the same call -- same trees, bucket lists, generator state"""
     redone = _diag_run(script, 12, 4, jitter="%s,64,3" % list(STAGES[script].values())[1], spin=spin)
     assert redone > 0
+
+
+def test_pipe_fallback_off_leaves_the_declared_status_in_the_summaries():
+    """option PIPE_FALLBACK = 0 (include/auvplan.h): an episode whose bounded wait ran out keeps AUVP_ERR_PIPELINE (-9) in its
+    summary record and nothing is redone; with the default the same launch returns complete trees and counts the episodes"""
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from auv_sim_amd import _lib, synth
+ctx = _lib.Context(0)
+w = synth.make_world(seed=1, n_obstacles=64)
+ctx.set_world(w["obstacles"], w["habitats"], w["polygon"], w["bins"], w["cells"], w["prob"])
+E = 8
+init = np.zeros((E, 6)); init[:, 0], init[:, 1] = w["start"]
+seeds = np.arange(E, dtype=np.uint64) + 3
+ctx.set_option("ROWS", 0); ctx.set_option("TRIO", 1)
+ctx.set_option("PIPE_FALLBACK", 0)
+s0 = ctx.rrt_explore_batch(init, seeds, 400).copy()
+f0 = ctx.pipeline_fallbacks()
+ctx.set_option("PIPE_FALLBACK", None)
+s1 = ctx.rrt_explore_batch(init, seeds, 400).copy()
+f1 = ctx.pipeline_fallbacks()
+ctx.set_option("TRIO", 0); ctx.set_option("DUO", 0)
+s2 = ctx.rrt_explore_batch(init, seeds, 400).copy()
+print(int((s0["status"] == -9).sum()), f0[0], int((s1["status"] < 0).sum()), f1[0], ctx.last_rrt_kernel(),
+      all(np.array_equal(s1[k], s2[k]) for k in s1.dtype.names if k != "n_candidates"))
+''' % REPO
+    env = dict(os.environ, AUVPLAN_LIBRARY=DIAG, AUVP_DIAG_SPIN="6", AUVP_DIAG_JITTER="1,3,1,32,5")
+    env.pop("AUVP_TEST_ENV_OPTIONS", None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    n9, redone0, nbad1, redone1, kern, same = r.stdout.strip().splitlines()[-1].split()
+    assert int(n9) > 0 and int(redone0) == 0          # the status is visible, nothing was redone
+    assert int(nbad1) == 0 and int(redone1) == int(n9) > 0   # the default redoes exactly those episodes ...
+    assert same == "True"                              # ... and returns the one-wavefront kernel's results
