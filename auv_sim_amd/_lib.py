@@ -108,6 +108,7 @@ def load():
     L.auvp_check_collision_batch.argtypes = [vp, C.c_int32, _ip, _dp, _bp]
     L.auvp_cost_paths.argtypes = [vp, C.c_int32, _ip, _dp, _ip, _ip, _dp, _dp, _dp]
     L.auvp_sincos_dev.argtypes = [vp, C.c_int32, _dp, _dp, _dp]
+    L.auvp_math_dev.argtypes = [vp, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp]
     L.auvp_nn_closest_batch.argtypes = [vp, C.c_int32, _dp, C.c_int32, _dp, C.c_int32, _ip, _ip]
     L.auvp_random_stream_dev.argtypes = [vp, C.c_uint64, C.c_int32, _dp]
     L.auvp_rrt_phase_clocks.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -397,6 +398,16 @@ class Context:
         s, c = np.zeros_like(x), np.zeros_like(x)
         self._chk(self.L.auvp_sincos_dev(self.h, len(x), _p(x), _p(s), _p(c)))
         return s, c
+
+    MATH_OPS = {"sincos": 0, "atan2": 1, "pow_e": 2, "div_plain": 3, "sqrt_plain": 4, "hypot": 5, "div": 6, "sqrt": 7}
+
+    def math(self, op, a, b=None):
+        """auvp_math_dev: one portable elementary function on the device (bit-exactness probe)"""
+        a = _f64(a).ravel()
+        b = np.zeros_like(a) if b is None else _f64(b).ravel()
+        o0, o1 = np.zeros_like(a), np.zeros_like(a)
+        self._chk(self.L.auvp_math_dev(self.h, self.MATH_OPS[op], len(a), _p(a), _p(b), _p(o0), _p(o1)))
+        return (o0, o1) if op == "sincos" else o0
 
     def random_stream(self, seed, n):
         out = np.zeros(n)

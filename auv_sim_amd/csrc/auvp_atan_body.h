@@ -39,16 +39,16 @@ AUVP_HD double AUVP_ATAN_FN(double x) {
   else if (ax < 1.1875) { id = 1; num = ax - 1.0; den = ax + 1.0; hi = AUVP_ATAN_K(AUVP_ATAN_HI1); lo = AUVP_ATAN_K(AUVP_ATAN_LO1); }
   else if (ax < 2.4375) { id = 2; num = ax - 1.5; den = 1.0 + 1.5 * ax; hi = AUVP_ATAN_K(AUVP_ATAN_HI2); lo = AUVP_ATAN_K(AUVP_ATAN_LO2); }
   else { id = 3; num = -1.0; den = ax; hi = AUVP_ATAN_K(AUVP_ATAN_HI3); lo = AUVP_ATAN_K(AUVP_ATAN_LO3); }
-  if (id >= 0) ax = num / den;
+  if (id >= 0) ax = auvp_div_plain(num, den);  // den in [1, 2^66), |num| <= den: never near the ends of the exponent range
   double z = ax * ax;
   double w = z * z;
-  double s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
-  double s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+  double s1 = z * auvp_fma(w, auvp_fma(w, auvp_fma(w, auvp_fma(w, auvp_fma(w, a10, a8), a6), a4), a2), a0);
+  double s2 = w * auvp_fma(w, auvp_fma(w, auvp_fma(w, auvp_fma(w, a9, a7), a5), a3), a1);
   if (id < 0) {
-    double r = ax - ax * (s1 + s2);
+    double r = auvp_fma(-ax, s1 + s2, ax);
     return neg ? -r : r;
   }
-  double r = hi - ((ax * (s1 + s2) - lo) - ax);
+  double r = hi - (auvp_fma(ax, s1 + s2, -lo) - ax);
   return neg ? -r : r;
 }
 

@@ -109,10 +109,11 @@ AUVP_HD double auvp_exp_hl_t(double hi, double lo, const double* tbl) {
   const long long ni = (long long)n;
   const int j = (int)(ni & 63);
   const long long k = (ni - j) / 64;
-  const double q = r * r * (0.5 + r * (0x1.5555555555555p-3 + r * (0x1.5555555555555p-5 + r * (0x1.1111111111111p-7 + r * 0x1.6c16c16c16c17p-10))));
+  const double q = r * r * auvp_fma(r, auvp_fma(r, auvp_fma(r, auvp_fma(r, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7), 0x1.5555555555555p-5),
+                                                 0x1.5555555555555p-3), 0.5);
   const double p = r + (rt + q);                                // exp(r) - 1
   const double th = tbl[2 * j], tl = tbl[2 * j + 1];
-  const double res = th + (tl + th * p);
+  const double res = th + auvp_fma(th, p, tl);
   if (k >= -1021 && k <= 1023) return res * auvp_bits_to_double((unsigned long long)(k + 1023) << 52);
   if (k > 1023) return res * 0x1p1023 * auvp_bits_to_double((unsigned long long)(k - 1023 + 1023) << 52);
   // subnormal range: two exact-power steps (the second one rounds)

@@ -20,11 +20,61 @@
 #define AUVP_HD static inline
 #endif
 
+// AUVP_K(c): how a polynomial / reduction constant reaches its use.  Plain: the literal.  A translation unit compiled with
+// -DAUVP_MATH_SGPR_CONSTS (device pass only) forms it in a scalar register pair right where it is used -- two s_mov_b32 inside a
+// volatile asm, which nothing hoists: the VOP3 forms of the fp64 instructions take no 64-bit literal, and a kernel whose
+// scalar registers are full otherwise keeps the ~16 constants of a sin / cos in VECTOR registers for the whole loop and copies
+// each one (v_mov_b64) in front of the v_fmac that consumes it.  Same doubles either way.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(AUVP_MATH_SGPR_CONSTS)
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ double auvp_sgpr_f64() {
+  unsigned a, b;
+  __asm__ volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(a), "=s"(b) : "i"(LO), "i"(HI));
+  return __builtin_bit_cast(double, ((unsigned long long)b << 32) | (unsigned long long)a);
+}
+#define AUVP_K_BITS(c) __builtin_bit_cast(unsigned long long, (double)(c))
+#define AUVP_K(c) auvp_sgpr_f64<(unsigned)(AUVP_K_BITS(c) & 0xffffffffull), (unsigned)(AUVP_K_BITS(c) >> 32)>()
+#else
+#define AUVP_K(c) (c)
+#endif
+
 AUVP_HD double auvp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 AUVP_HD double auvp_sqrt(double a) { return __builtin_sqrt(a); }
 AUVP_HD double auvp_fabs(double a) { return __builtin_fabs(a); }
 AUVP_HD double auvp_rint(double a) { return __builtin_rint(a); }
 AUVP_HD double auvp_floor(double a) { return __builtin_floor(a); }
+
+// a / b and sqrt(x) for operands of UNEXCEPTIONAL magnitude -- the steer's quotients and chord lengths (rrt_dubins.py:268-281):
+// |a|, |b|, |a / b| within 2^+-500 (a may be +0), b != 0; x = 0 or within 2^+-500.  Host: the IEEE operation.  Device: the
+// same correctly rounded result from the core of the compiler's own expansion -- reciprocal (square root) estimate, two
+// Newton steps, one residual correction -- without the steps that only serve exponents near the ends of the range
+// (v_div_scale x 2 + v_div_fixup: 8 instead of 11 vector instructions; the input scaling of sqrt: 13 instead of 19).  With a
+// zero divisor the reference raises ZeroDivisionError (a 2^-53 draw); host and device both return a non-finite value then.
+AUVP_HD double auvp_div_plain(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(b);
+  r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-b, r, 1.0), r);
+  const double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+#else
+  return a / b;
+#endif
+}
+AUVP_HD double auvp_sqrt_plain(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return x == 0.0 ? x : g;
+#else
+  return __builtin_sqrt(x);
+#endif
+}
 
 // pi/2 = PIO2_HI + PIO2_LO + PIO2_LO2 (each the nearest double to the running remainder)
 #define AUVP_PIO2_HI 0x1.921fb54442d18p+0
@@ -38,42 +88,53 @@ AUVP_HD double auvp_floor(double a) { return __builtin_floor(a); }
 // product is split exactly with a second fma, so r+t carries ~100 bits of the reduced argument
 // for |x| up to ~1e9.  Beyond that accuracy degrades gracefully (still deterministic).
 AUVP_HD int auvp_rem_pio2(double x, double* r, double* t) {
-  double n = auvp_rint(x * AUVP_INV_PIO2);
-  double hi = auvp_fma(-n, AUVP_PIO2_HI, x);
-  double p = n * AUVP_PIO2_LO;
-  double pe = auvp_fma(n, AUVP_PIO2_LO, -p);  // exact error of p
+  const double pio2_lo = AUVP_K(AUVP_PIO2_LO);
+  double n = auvp_rint(x * AUVP_K(AUVP_INV_PIO2));
+  double hi = auvp_fma(-n, AUVP_K(AUVP_PIO2_HI), x);
+  double p = n * pio2_lo;
+  double pe = auvp_fma(n, pio2_lo, -p);  // exact error of p
   double rr = hi - p;
   double tt = (hi - rr) - p;                  // rounding error of the subtraction
   tt = tt - pe;
-  tt = auvp_fma(-n, AUVP_PIO2_LO2, tt);
+  tt = auvp_fma(-n, AUVP_K(AUVP_PIO2_LO2), tt);
   *r = rr;
   *t = tt;
-  // n is integral and |n| < 2^53: take it modulo 4 without leaving fp64
-  double q = n - 4.0 * auvp_floor(n * 0.25);
-  return (int)q;
+  // n is integral: n mod 4 = the two low mantissa bits of n + 1.5 * 2^52 (exact for |n| < 2^51, i.e. |x| < 3.5e15; beyond
+  // that still deterministic, the same bits on host and device)
+  union { double d; unsigned long long u; } m;
+  m.d = n + AUVP_K(0x1.8p52);
+  return (int)(m.u & 3ull);
 }
 
 // sin(x + y) for |x| <= ~pi/4 with tail y
 AUVP_HD double auvp_ksin(double x, double y) {
-  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+#define AUVP_S1 -1.66666666666666324348e-01
+#define AUVP_S2 8.33333333332248946124e-03
+#define AUVP_S3 -1.98412698298579493134e-04
+#define AUVP_S4 2.75573137070700676789e-06
+#define AUVP_S5 -2.50507602534068634195e-08
+#define AUVP_S6 1.58969099521155010221e-10
   double z = x * x;
   double v = z * x;
-  double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
-  return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+  double r = auvp_fma(z, auvp_fma(z, auvp_fma(z, auvp_fma(z, AUVP_K(AUVP_S6), AUVP_K(AUVP_S5)), AUVP_K(AUVP_S4)), AUVP_K(AUVP_S3)),
+                      AUVP_K(AUVP_S2));
+  return x - auvp_fma(-v, AUVP_K(AUVP_S1), auvp_fma(z, auvp_fma(-v, r, 0.5 * y), -y));
 }
 
 // cos(x + y) for |x| <= ~pi/4 with tail y
 AUVP_HD double auvp_kcos(double x, double y) {
-  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+#define AUVP_C1 4.16666666666666019037e-02
+#define AUVP_C2 -1.38888888888741095749e-03
+#define AUVP_C3 2.48015872894767294178e-05
+#define AUVP_C4 -2.75573143513906633035e-07
+#define AUVP_C5 2.08757232129817482790e-09
+#define AUVP_C6 -1.13596475577881948265e-11
   double z = x * x;
-  double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  double r = z * auvp_fma(z, auvp_fma(z, auvp_fma(z, auvp_fma(z, auvp_fma(z, AUVP_K(AUVP_C6), AUVP_K(AUVP_C5)), AUVP_K(AUVP_C4)),
+                                              AUVP_K(AUVP_C3)), AUVP_K(AUVP_C2)), AUVP_K(AUVP_C1));
   double hz = 0.5 * z;
   double w = 1.0 - hz;
-  return w + (((1.0 - w) - hz) + (z * r - x * y));
+  return w + (((1.0 - w) - hz) + auvp_fma(z, r, -(x * y)));
 }
 
 AUVP_HD void auvp_sincos(double x, double* s, double* c) {

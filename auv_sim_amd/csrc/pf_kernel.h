@@ -160,13 +160,13 @@ __device__ __forceinline__ double pf_weight(double px, double py, double mx, dou
   double pa = auvp_atan2_late((-my + py), (px + -mx)) - mth;     // calc_particle_alpha
   if (!pf_angle_wrap(pa)) status = PF_ERR_ANGLE;
   const double dy = my - py, dx = mx - px;
-  const double pr = auvp_sqrt(dy * dy + dx * dx);                // calc_particle_range
+  const double pr = auvp_sqrt_plain(dy * dy + dx * dx);          // calc_particle_range (0 or >= the squared spacing of the coordinates)
   double d = pa - auv_alpha;
   if (!pf_angle_wrap(d)) status = PF_ERR_ANGLE;
   const double constant = 1.2533141375;
   const double fa = .001 + (1 / (constant) * (auvp_pow_e_t((-(d * d)) / (0.5), etab)));
   const double dr = pr - auv_range;
-  const double fw = .001 + (1 / (100 * constant) * (auvp_pow_e_t((-(dr * dr)) / (20000), etab)));
+  const double fw = .001 + (1 / (100 * constant) * (auvp_pow_e_t(-auvp_div_plain(dr * dr, 20000), etab)));  // (-(x)) / c == -(x / c)
   return fw * fa;
 }
 

@@ -465,8 +465,8 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
                     taken = auvp_fabs(dist) > auvp_fabs(diff);
                     if (taken) {
                       const double s1 = dist + diff, s2 = dist - diff;
-                      radius = (s1 + s2) / (-s1 + s2);
-                      phi = (s1 + s2) / (2 * radius);
+                      radius = auvp_div_plain(s1 + s2, -s1 + s2);
+                      phi = auvp_div_plain(s1 + s2, 2 * radius);
                     }
                   }
                   tmask = wave_ballot(taken);
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
             if (taken) {
               dx = radius * (sn - so);
               dy = radius * (-cs + co);
-              dt = auvp_sqrt(dx * dx + dy * dy) / 1;
+              dt = auvp_sqrt_plain(dx * dx + dy * dy) / 1;
             }
           }
           double mx = 0.0, my = 0.0, mt_ = 0.0;

@@ -217,8 +217,8 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         taken = auvp_fabs(dist) > auvp_fabs(diff);
         if (taken) {
           const double s1 = dist + diff, s2 = dist - diff;
-          radius = (s1 + s2) / (-s1 + s2);
-          phi = (s1 + s2) / (2 * radius);
+          radius = auvp_div_plain(s1 + s2, -s1 + s2);
+          phi = auvp_div_plain(s1 + s2, 2 * radius);
         }
       }
       rows_advance(rng, act, (uint32_t)(4 * n));
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
         if (taken) {
           dx = radius * (sn - so);
           dy = radius * (-cs + co);
-          dt = auvp_sqrt(dx * dx + dy * dy) / 1;
+          dt = auvp_sqrt_plain(dx * dx + dy * dy) / 1;
         }
       }
       // x += dx; y += dy; t += dt, left to right (untaken sub-arcs add an exact 0.0): the same kind of chain

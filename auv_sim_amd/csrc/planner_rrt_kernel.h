@@ -384,8 +384,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
           taken = auvp_fabs(dist) > auvp_fabs(diff);
           if (taken) {
             double s1 = dist + diff, s2 = dist - diff;
-            radius = (s1 + s2) / (-s1 + s2);
-            phi = (s1 + s2) / (2 * radius);
+            radius = auvp_div_plain(s1 + s2, -s1 + s2);
+            phi = auvp_div_plain(s1 + s2, 2 * radius);
           }
         }
         const unsigned long long tmask = wave_ballot(taken);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
           if (taken) {
             dx = radius * (sn - so);
             dy = radius * (-cs + co);
-            dt = auvp_sqrt(dx * dx + dy * dy) / 1;
+            dt = auvp_sqrt_plain(dx * dx + dy * dy) / 1;
           }
         }
         // x += dx; y += dy; t += dt, left to right (untaken sub-arcs add an exact 0.0): the same uniform loop
@@ -452,8 +452,8 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
           taken = auvp_fabs(dist) > auvp_fabs(diff);
           if (taken) {
             double s1 = dist + diff, s2 = dist - diff;
-            radius = (s1 + s2) / (-s1 + s2);
-            phi = (s1 + s2) / (2 * radius);
+            radius = auvp_div_plain(s1 + s2, -s1 + s2);
+            phi = auvp_div_plain(s1 + s2, 2 * radius);
           }
         }
         const unsigned long long tmask = wave_ballot(taken);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
           double so = sc[2 * prev], co = sc[2 * prev + 1];
           dx = radius * (sn - so);
           dy = radius * (-cs + co);
-          dt = auvp_sqrt(dx * dx + dy * dy) / 1;
+          dt = auvp_sqrt_plain(dx * dx + dy * dy) / 1;
         }
         if (active) { inc[3 * lane] = dx; inc[3 * lane + 1] = dy; inc[3 * lane + 2] = dt; }
         wave_sync();

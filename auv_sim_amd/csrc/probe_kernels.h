@@ -4,6 +4,7 @@
 // vectors on its own.  Included at the end of auvplan.hip (same translation unit).
 #ifndef AUVP_PROBE_KERNELS_H
 #define AUVP_PROBE_KERNELS_H
+#include "auvp_exp.h"
 
 namespace auvp {
 
@@ -110,6 +111,28 @@ __global__ __launch_bounds__(256) void hbm_copy_probe_kernel(const uint4* __rest
 __global__ void sincos_probe_kernel(int n, const double* __restrict__ x, double* __restrict__ s, double* __restrict__ c) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) auvp_sincos(x[i], &s[i], &c[i]);
+}
+
+// one portable function per op (auvp_math_dev): 0 sin / cos, 1 atan2(a, b), 2 pow(e, a), 3 auvp_div_plain(a, b),
+// 4 auvp_sqrt_plain(a), 5 hypot(a, b), 6 a / b, 7 sqrt(a)
+__global__ void math_probe_kernel(int op, int n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ o0,
+                                  double* __restrict__ o1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = a[i], y = b[i];
+  double r0 = 0.0, r1 = 0.0;
+  switch (op) {
+    case 0: auvp_sincos(x, &r0, &r1); break;
+    case 1: r0 = auvp_atan2(x, y); break;
+    case 2: r0 = auvp_pow_e(x); break;
+    case 3: r0 = auvp_div_plain(x, y); break;
+    case 4: r0 = auvp_sqrt_plain(x); break;
+    case 5: r0 = auvp_hypot(x, y); break;
+    case 6: r0 = x / y; break;
+    default: r0 = auvp_sqrt(x); break;
+  }
+  o0[i] = r0;
+  o1[i] = r1;
 }
 
 __global__ __launch_bounds__(64) void random_probe_kernel(const uint32_t* __restrict__ mt, int n, double* __restrict__ out) {
@@ -271,6 +294,24 @@ int auvp_sincos_dev(auvp_handle* h, int32_t n, const double* x, double* s, doubl
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(s, h->d_tmp1.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipMemcpyAsync(c, h->d_tmp2.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return AUVP_OK;
+}
+
+int auvp_math_dev(auvp_handle* h, int32_t op, int32_t n, const double* a, const double* b, double* out0, double* out1) {
+  if (!h || n < 0 || op < 0 || op > 7 || !a || !b || !out0 || !out1) return AUVP_ERR_ARG;
+  if (n == 0) return AUVP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  int rc;
+  if ((rc = upload(h, h->d_tmp0, a, (size_t)n))) return rc;
+  if ((rc = upload(h, h->d_tmp1, b, (size_t)n))) return rc;
+  HIPCHK(h, h->d_tmp2.reserve((size_t)2 * n * sizeof(double)));
+  double* o = h->d_tmp2.as<double>();
+  hipLaunchKernelGGL(math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (int)op, (int)n, h->d_tmp0.as<double>(),
+                     h->d_tmp1.as<double>(), o, o + n);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out0, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(out1, o + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return AUVP_OK;
 }

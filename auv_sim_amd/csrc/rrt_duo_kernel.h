@@ -357,8 +357,8 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
           const double dist = py_uniform(0.0, Q.dist_to_end, uw[mypos]);
           const double diff = py_uniform(-Q.diff_max, Q.diff_max, uw[mypos + 1]);
           const double s1 = dist + diff, s2 = dist - diff;
-          radius = (s1 + s2) / (-s1 + s2);
-          phi = (s1 + s2) / (2 * radius);
+          radius = auvp_div_plain(s1 + s2, -s1 + s2);
+          phi = auvp_div_plain(s1 + s2, 2 * radius);
           vt = py_uniform(0.0, 2 * Q.v, uw[mypos + 2]);
         }
         // the parent's record (main wrote it at least one finished iteration ago -- or the packet is redone)
@@ -477,8 +477,8 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
         const double so = sc[2 * prev], co = sc[2 * prev + 1];
         dx = radius * (sn - so);
         dy = radius * (-cs + co);
-        mv = auvp_sqrt(dx * dx + dy * dy);
-        dt = mv / vt;
+        mv = auvp_sqrt_plain(dx * dx + dy * dy);
+        dt = auvp_div_plain(mv, vt);
       }
       if (lane < DUO_CS) { inc[lane] = dx; inc[DUO_CS + lane] = dy; inc[2 * DUO_CS + lane] = dt; inc[3 * DUO_CS + lane] = mv; }
       wave_sync();

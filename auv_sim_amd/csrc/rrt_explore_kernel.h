@@ -767,8 +767,8 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
         double dist = py_uniform(0.0, Q.dist_to_end, uw[mypos]);
         double diff = py_uniform(-Q.diff_max, Q.diff_max, uw[mypos + 1]);
         double s1 = dist + diff, s2 = dist - diff;
-        radius = (s1 + s2) / (-s1 + s2);
-        phi = (s1 + s2) / (2 * radius);
+        radius = auvp_div_plain(s1 + s2, -s1 + s2);
+        phi = auvp_div_plain(s1 + s2, 2 * radius);
         vt = py_uniform(0.0, 2 * Q.v, uw[mypos + 2]);
       }
       wave_sync();  // the window is dead: its LDS becomes the steer scratch
@@ -800,8 +800,8 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
         double so = sc[2 * prev], co = sc[2 * prev + 1];
         dx = radius * (sn - so);
         dy = radius * (-cs + co);
-        mv = auvp_sqrt(dx * dx + dy * dy);
-        dt = mv / vt;
+        mv = auvp_sqrt_plain(dx * dx + dy * dy);
+        dt = auvp_div_plain(mv, vt);
       }
       if (active) { inc[lane] = dx; inc[CS + lane] = dy; inc[2 * CS + lane] = dt; inc[3 * CS + lane] = mv; }
       else if (lane < CS) { inc[lane] = 0.0; inc[CS + lane] = 0.0; inc[2 * CS + lane] = 0.0; inc[3 * CS + lane] = 0.0; }

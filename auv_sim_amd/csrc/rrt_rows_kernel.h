@@ -419,8 +419,8 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
         const double dist = py_uniform(0.0, Q.dist_to_end, win[mypos]);
         const double diff = py_uniform(-Q.diff_max, Q.diff_max, win[mypos + 1]);
         const double s1 = dist + diff, s2 = dist - diff;
-        radius = (s1 + s2) / (-s1 + s2);
-        phi = (s1 + s2) / (2 * radius);
+        radius = auvp_div_plain(s1 + s2, -s1 + s2);
+        phi = auvp_div_plain(s1 + s2, 2 * radius);
         vt = py_uniform(0.0, 2 * Q.v, win[mypos + 2]);
       }
       wave_sync();  // the window is dead: its LDS becomes the running-sum scratch
@@ -440,8 +440,8 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
         if (taken) {
           dx = radius * (sn - so);
           dy = radius * (-cs + co);
-          mv = auvp_sqrt(dx * dx + dy * dy);
-          dt = mv / vt;
+          mv = auvp_sqrt_plain(dx * dx + dy * dy);
+          dt = auvp_div_plain(mv, vt);
         }
       }
       // x += dx; y += dy; t += dt; length += movement: four serial chains per row, lanes 0..3, 18-double rows in LDS

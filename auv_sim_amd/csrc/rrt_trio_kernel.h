@@ -559,8 +559,8 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
           const double dist = py_uniform(0.0, Q.dist_to_end, q->ud[lane]);
           const double diff = py_uniform(-Q.diff_max, Q.diff_max, q->uf[lane]);
           const double s1 = dist + diff, s2 = dist - diff;
-          radius = (s1 + s2) / (-s1 + s2);
-          phi = (s1 + s2) / (2 * radius);
+          radius = auvp_div_plain(s1 + s2, -s1 + s2);
+          phi = auvp_div_plain(s1 + s2, 2 * radius);
           vt = py_uniform(0.0, 2 * Q.v, q->uv[lane]);
         }
         if (lane < DUO_CS) phi_l[lane] = phi;
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(TRIO_EP * 64 * NW, 1) void rrt_trio_kernel(WorldDev
           const double so = sc[2 * prev], co = sc[2 * prev + 1];
           dx = radius * (sn - so);
           dy = radius * (-cs + co);
-          mv = auvp_sqrt(dx * dx + dy * dy);
-          dt = mv / vt;
+          mv = auvp_sqrt_plain(dx * dx + dy * dy);
+          dt = auvp_div_plain(mv, vt);
         }
         if (lane < DUO_CS) { inc[lane] = dx; inc[DUO_CS + lane] = dy; inc[2 * DUO_CS + lane] = dt; inc[3 * DUO_CS + lane] = mv; }
         wave_sync();

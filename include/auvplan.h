@@ -361,6 +361,12 @@ int auvp_nn_closest_batch(auvp_handle* h, int32_t n_nodes, const double* xy, int
 int auvp_hbm_probe(auvp_handle* h, uint64_t bytes, int32_t reps, double* read_GBps, double* copy_GBps);
 /* portable sin/cos evaluated on the device (bit-exactness probe for auvp_math.h) */
 int auvp_sincos_dev(auvp_handle* h, int32_t n, const double* x, double* s, double* c);
+/* one portable elementary function of auv_sim_amd/csrc/auvp_math.h / auvp_exp.h evaluated on the device over n operand pairs
+ * (bit-exactness probe: the tests compare with the host build of the same header and with the IEEE operation).  op: 0 sin -> out0,
+ * cos -> out1 of a (math.sin / math.cos, path_planning/rrt_dubins.py:275-276); 1 atan2(a, b) (gym_rrt/envs/rrt_dubins.py:387);
+ * 2 math.e ** a (particleFilter.py:103-116); 3 the steer's short division a / b and 4 its square root (rrt_dubins.py:268-281;
+ * operands of unexceptional magnitude: auvp_div_plain / auvp_sqrt_plain); 5 hypot(a, b); 6 a / b and 7 sqrt(a) as compiled. */
+int auvp_math_dev(auvp_handle* h, int32_t op, int32_t n, const double* a, const double* b, double* out0, double* out1);
 /* CPython random() stream of `seed` generated by the wave-level device MT19937 */
 int auvp_random_stream_dev(auvp_handle* h, uint64_t seed, int32_t n, double* out);
 

@@ -49,6 +49,52 @@ def test_device_sincos_bit_exact(ctx, orc):
     assert np.max(np.abs(c[m] - np.cos(x[m])) / np.spacing(np.abs(np.cos(x[m])) + 1e-300)) <= 1.0
 
 
+def test_device_math_bit_exact(ctx, orc):
+    """auvp_math_dev: the device build of auvp_math.h / auvp_exp.h against the host build of the same headers (the portable
+    checker library) and, for the short division / square root of the steer (auvp_div_plain / auvp_sqrt_plain:
+    rrt_dubins.py:268-281), against the IEEE operation on operands across the magnitudes a steer can produce"""
+    rng = np.random.default_rng(11)
+    n = 400000
+    # the steer's quotients: 2 dist / (-2 diff), 2 dist / (2 radius), movement / velocity -- and generic pairs over 2^+-200
+    dist, diff = rng.uniform(0, 2, n), rng.uniform(-0.5, 0.5, n)
+    diff[:48] = 2.0 ** -np.arange(1, 49) * 0.25
+    diff[48:96] = -(2.0 ** -np.arange(1, 49)) * 0.25
+    s1, s2 = dist + diff, dist - diff
+    ok = (-s1 + s2) != 0.0  # (a zero divisor is the reference's ZeroDivisionError: not a value to compare)
+    dist, diff, s1, s2 = dist[ok], diff[ok], s1[ok], s2[ok]
+    n = len(dist)
+    radius = (s1 + s2) / (-s1 + s2)
+    mv, vt = rng.uniform(0, 2, n), rng.uniform(0, 4, n) + 2.0 ** -53
+    mv[:1000] = 0.0
+    ga = rng.uniform(1, 2, n) * 2.0 ** rng.integers(-200, 200, n) * rng.choice([-1.0, 1.0], n)
+    gb = rng.uniform(1, 2, n) * 2.0 ** rng.integers(-200, 200, n) * rng.choice([-1.0, 1.0], n)
+    for a, b in ((s1 + s2, -s1 + s2), (s1 + s2, 2 * radius), (mv, vt), (ga, gb)):
+        with np.errstate(all="ignore"):
+            want = a / b
+        got = ctx.math("div_plain", a, b)
+        bad = np.flatnonzero(got != want)
+        assert len(bad) == 0, (len(bad), a[bad[:4]], b[bad[:4]], got[bad[:4]], want[bad[:4]])
+        assert np.array_equal(ctx.math("div", a, b), want)
+    x = np.concatenate([rng.uniform(0, 8, n), rng.uniform(1, 2, n) * 2.0 ** rng.integers(-400, 400, n), np.zeros(8),
+                        rng.uniform(0, 1, 1000) ** 8 * 1e-30])
+    assert np.array_equal(ctx.math("sqrt_plain", x), np.sqrt(x))
+    assert np.array_equal(ctx.math("sqrt", x), np.sqrt(x))
+    assert not np.signbit(ctx.math("sqrt_plain", np.zeros(4))).any()
+    # the elementary functions: device == host build of the same header, bit for bit
+    L = orc.lib("portable")
+    m = 20000
+    ya, xa = rng.uniform(-300, 300, m), rng.uniform(-300, 300, m)
+    ya[:200] = rng.uniform(-1e-9, 1e-9, 200); xa[200:400] = rng.uniform(-1e-9, 1e-9, 200); ya[400:420] = 0.0; xa[420:440] = 0.0
+    assert np.array_equal(ctx.math("atan2", ya, xa), np.array([L.orc_atan2(float(p), float(q)) for p, q in zip(ya, xa)]))
+    assert np.array_equal(ctx.math("hypot", ya, xa), np.array([L.orc_hypot(float(p), float(q)) for p, q in zip(ya, xa)]))
+    from oracle import orc_pf
+    z = np.concatenate([rng.uniform(-60, 5, m), -rng.uniform(0, 1, 2000) ** 4 * 700, np.array([0.0, -0.0, 1.0, -745.0, 709.0])])
+    assert np.array_equal(ctx.math("pow_e", z), orc_pf.pow_e(z, "portable"))
+    xs = rng.uniform(-60, 60, m)
+    s, c = ctx.math("sincos", xs)
+    assert np.array_equal(s, np.array([L.orc_sin(float(v)) for v in xs])) and np.array_equal(c, np.array([L.orc_cos(float(v)) for v in xs]))
+
+
 def test_collision_golden(ctx):
     g = json.load(open(os.path.join(GOLDEN, "g5_collision.json")))
     for poly, cases in ((g["rect"], g["cases"]), (g["penta"], g["penta_cases"])):
