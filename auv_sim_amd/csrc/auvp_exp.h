@@ -106,18 +106,17 @@ AUVP_HD double auvp_exp_hl_t(double hi, double lo, const double* tbl) {
   const double rl = auvp_fma(-n, AUVP_LN2_64_LO, lo);
   const double r = r0 + rl;
   const double rt = (r0 - r) + rl;                              // r + rt = r0 + rl to ~2^-106
-  const long long ni = (long long)n;
-  const int j = (int)(ni & 63);
-  const long long k = (ni - j) / 64;
+  const int ni = (int)n;                                        // |n| <= 745.2 * 64 / ln 2 < 2^17
+  const int j = ni & 63;
+  const int k = ni >> 6;                                        // (ni - j) / 64: arithmetic shift of a two's-complement int
   const double q = r * r * auvp_fma(r, auvp_fma(r, auvp_fma(r, auvp_fma(r, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7), 0x1.5555555555555p-5),
                                                  0x1.5555555555555p-3), 0.5);
   const double p = r + (rt + q);                                // exp(r) - 1
   const double th = tbl[2 * j], tl = tbl[2 * j + 1];
   const double res = th + auvp_fma(th, p, tl);
-  if (k >= -1021 && k <= 1023) return res * auvp_bits_to_double((unsigned long long)(k + 1023) << 52);
-  if (k > 1023) return res * 0x1p1023 * auvp_bits_to_double((unsigned long long)(k - 1023 + 1023) << 52);
-  // subnormal range: two exact-power steps (the second one rounds)
-  return (res * auvp_bits_to_double((unsigned long long)(k + 1000 + 1023) << 52)) * 0x1p-1000;
+  // res * 2^k: exact in the normal range, ONE rounding in the subnormal range (k < -1021), finite for k = 1024 when res < 1 --
+  // what the two-step products of powers of two did; ldexp is one instruction on the device
+  return __builtin_ldexp(res, k);
 }
 
 AUVP_HD double auvp_exp_hl(double hi, double lo) { return auvp_exp_hl_t(hi, lo, auvp_exp_table()); }
@@ -125,8 +124,7 @@ AUVP_HD double auvp_exp(double x) { return auvp_exp_hl(x, 0.0); }
 
 // math.e ** z  (CPython float pow -> pow(E, z))
 AUVP_HD double auvp_pow_e_t(double z, const double* tbl) {
-  if (z == 0.0) return 1.0;
-  return auvp_exp_hl_t(z, z * AUVP_LN_E_M1, tbl);
+  return auvp_exp_hl_t(z, z * AUVP_LN_E_M1, tbl);  // (z = +-0: n = 0, r = 0, the table's first entry: exactly 1.0)
 }
 AUVP_HD double auvp_pow_e(double z) { return auvp_pow_e_t(z, auvp_exp_table()); }
 #endif  // AUVP_EXP_H
