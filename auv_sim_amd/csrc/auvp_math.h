@@ -20,11 +20,14 @@
 #define AUVP_HD static inline
 #endif
 
-// AUVP_K(c): how a polynomial / reduction constant reaches its use.  Plain: the literal.  A translation unit compiled with
+// AUVP_K(c): how a reduction constant reaches its use.  Plain: the literal.  A translation unit compiled with
 // -DAUVP_MATH_SGPR_CONSTS (device pass only) forms it in a scalar register pair right where it is used -- two s_mov_b32 inside a
 // volatile asm, which nothing hoists: the VOP3 forms of the fp64 instructions take no 64-bit literal, and a kernel whose
-// scalar registers are full otherwise keeps the ~16 constants of a sin / cos in VECTOR registers for the whole loop and copies
-// each one (v_mov_b64) in front of the v_fmac that consumes it.  Same doubles either way.
+// scalar registers are full otherwise keeps the constants of a sin / cos in VECTOR registers for the whole loop.
+// AUVP_FMA_K(a, b, c) = fma(a, b, c) with a CONSTANT addend -- a Horner step.  The compiler selects the two-address
+// v_fmac_f64 for it and therefore first copies the constant into the destination (v_mov_b64, or two v_mov_b32 out of scalar
+// registers): two to three vector instructions per step.  The SGPR-constant build spells the step as two s_mov_b32 into a fixed
+// scalar pair + ONE v_fma_f64 that reads it.  Same doubles either way.
 #if defined(__HIP_DEVICE_COMPILE__) && defined(AUVP_MATH_SGPR_CONSTS)
 template <unsigned LO, unsigned HI>
 __device__ __forceinline__ double auvp_sgpr_f64() {
@@ -32,10 +35,18 @@ __device__ __forceinline__ double auvp_sgpr_f64() {
   __asm__ volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(a), "=s"(b) : "i"(LO), "i"(HI));
   return __builtin_bit_cast(double, ((unsigned long long)b << 32) | (unsigned long long)a);
 }
+template <unsigned LO, unsigned HI>
+__device__ __forceinline__ double auvp_fma_sgpr_k(double a, double b) {
+  double d;
+  __asm__("s_mov_b32 s96, %3\n\ts_mov_b32 s97, %4\n\tv_fma_f64 %0, %1, %2, s[96:97]" : "=v"(d) : "v"(a), "v"(b), "i"(LO), "i"(HI) : "s96", "s97");
+  return d;
+}
 #define AUVP_K_BITS(c) __builtin_bit_cast(unsigned long long, (double)(c))
 #define AUVP_K(c) auvp_sgpr_f64<(unsigned)(AUVP_K_BITS(c) & 0xffffffffull), (unsigned)(AUVP_K_BITS(c) >> 32)>()
+#define AUVP_FMA_K(a, b, c) auvp_fma_sgpr_k<(unsigned)(AUVP_K_BITS(c) & 0xffffffffull), (unsigned)(AUVP_K_BITS(c) >> 32)>(a, b)
 #else
 #define AUVP_K(c) (c)
+#define AUVP_FMA_K(a, b, c) __builtin_fma(a, b, c)
 #endif
 
 AUVP_HD double auvp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -116,8 +127,7 @@ AUVP_HD double auvp_ksin(double x, double y) {
 #define AUVP_S6 1.58969099521155010221e-10
   double z = x * x;
   double v = z * x;
-  double r = auvp_fma(z, auvp_fma(z, auvp_fma(z, auvp_fma(z, AUVP_K(AUVP_S6), AUVP_K(AUVP_S5)), AUVP_K(AUVP_S4)), AUVP_K(AUVP_S3)),
-                      AUVP_K(AUVP_S2));
+  double r = AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_K(AUVP_S6), AUVP_S5), AUVP_S4), AUVP_S3), AUVP_S2);
   return x - auvp_fma(-v, AUVP_K(AUVP_S1), auvp_fma(z, auvp_fma(-v, r, 0.5 * y), -y));
 }
 
@@ -130,8 +140,8 @@ AUVP_HD double auvp_kcos(double x, double y) {
 #define AUVP_C5 2.08757232129817482790e-09
 #define AUVP_C6 -1.13596475577881948265e-11
   double z = x * x;
-  double r = z * auvp_fma(z, auvp_fma(z, auvp_fma(z, auvp_fma(z, auvp_fma(z, AUVP_K(AUVP_C6), AUVP_K(AUVP_C5)), AUVP_K(AUVP_C4)),
-                                              AUVP_K(AUVP_C3)), AUVP_K(AUVP_C2)), AUVP_K(AUVP_C1));
+  double r = z * AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_K(AUVP_C6), AUVP_C5), AUVP_C4), AUVP_C3), AUVP_C2),
+                            AUVP_C1);
   double hz = 0.5 * z;
   double w = 1.0 - hz;
   return w + (((1.0 - w) - hz) + auvp_fma(z, r, -(x * y)));
