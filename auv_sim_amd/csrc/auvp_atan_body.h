@@ -15,12 +15,17 @@ AUVP_HD double AUVP_ATAN_FN(double x) {
 #define AUVP_ATAN_LO2 1.39033110312309984516e-17
 #define AUVP_ATAN_LO3 6.12323399573676603587e-17
   const double hi3 = AUVP_ATAN_HI3, lo3 = AUVP_ATAN_LO3;
-  const double a0 = 3.33333333333329318027e-01, a1 = -1.99999999998764832476e-01,
-               a2 = 1.42857142725034663711e-01, a3 = -1.11111104054623557880e-01,
-               a4 = 9.09088713343650656196e-02, a5 = -7.69187620504482999495e-02,
-               a6 = 6.66107313738753120669e-02, a7 = -5.83357013379057348645e-02,
-               a8 = 4.97687799461593236017e-02, a9 = -3.65315727442169155270e-02,
-               a10 = 1.62858201153657823623e-02;
+#define AUVP_AT0 3.33333333333329318027e-01
+#define AUVP_AT1 -1.99999999998764832476e-01
+#define AUVP_AT2 1.42857142725034663711e-01
+#define AUVP_AT3 -1.11111104054623557880e-01
+#define AUVP_AT4 9.09088713343650656196e-02
+#define AUVP_AT5 -7.69187620504482999495e-02
+#define AUVP_AT6 6.66107313738753120669e-02
+#define AUVP_AT7 -5.83357013379057348645e-02
+#define AUVP_AT8 4.97687799461593236017e-02
+#define AUVP_AT9 -3.65315727442169155270e-02
+#define AUVP_AT10 1.62858201153657823623e-02
   const int neg = x < 0.0;
   double ax = auvp_fabs(x);
   if (x != x) return x;
@@ -42,8 +47,8 @@ AUVP_HD double AUVP_ATAN_FN(double x) {
   if (id >= 0) ax = auvp_div_plain(num, den);  // den in [1, 2^66), |num| <= den: never near the ends of the exponent range
   double z = ax * ax;
   double w = z * z;
-  double s1 = z * auvp_fma(w, auvp_fma(w, auvp_fma(w, auvp_fma(w, auvp_fma(w, a10, a8), a6), a4), a2), a0);
-  double s2 = w * auvp_fma(w, auvp_fma(w, auvp_fma(w, auvp_fma(w, a9, a7), a5), a3), a1);
+  double s1 = z * AUVP_FMA_K(w, AUVP_FMA_K(w, AUVP_FMA_K(w, AUVP_FMA_K(w, AUVP_FMA_K(w, AUVP_K(AUVP_AT10), AUVP_AT8), AUVP_AT6), AUVP_AT4), AUVP_AT2), AUVP_AT0);
+  double s2 = w * AUVP_FMA_K(w, AUVP_FMA_K(w, AUVP_FMA_K(w, AUVP_FMA_K(w, AUVP_K(AUVP_AT9), AUVP_AT7), AUVP_AT5), AUVP_AT3), AUVP_AT1);
   if (id < 0) {
     double r = auvp_fma(-ax, s1 + s2, ax);
     return neg ? -r : r;

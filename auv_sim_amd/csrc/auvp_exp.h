@@ -109,8 +109,8 @@ AUVP_HD double auvp_exp_hl_t(double hi, double lo, const double* tbl) {
   const int ni = (int)n;                                        // |n| <= 745.2 * 64 / ln 2 < 2^17
   const int j = ni & 63;
   const int k = ni >> 6;                                        // (ni - j) / 64: arithmetic shift of a two's-complement int
-  const double q = r * r * auvp_fma(r, auvp_fma(r, auvp_fma(r, auvp_fma(r, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7), 0x1.5555555555555p-5),
-                                                 0x1.5555555555555p-3), 0.5);
+  const double q = r * r * AUVP_FMA_K(r, AUVP_FMA_K(r, AUVP_FMA_K(r, AUVP_FMA_K(r, AUVP_K(0x1.6c16c16c16c17p-10), 0x1.1111111111111p-7), 0x1.5555555555555p-5),
+                                                     0x1.5555555555555p-3), 0.5);
   const double p = r + (rt + q);                                // exp(r) - 1
   const double th = tbl[2 * j], tl = tbl[2 * j + 1];
   const double res = th + auvp_fma(th, p, tl);
