@@ -1412,11 +1412,15 @@ def main():
                 v = out.get(name)
                 if isinstance(v, dict):
                     out["roofline"][key] = v.get("us_per_expansion" if name == "single_episode" else "value")
-    if rank == 0:
-        emit(out)
     if world_size > 1:
+        # the process group goes first: whatever the communicator prints when it is torn down comes BEFORE the result line, and
+        # the other ranks are past their last collective when rank 0 prints
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world_size > 1:
+            time.sleep(0.5)  # (after the timed region and every collective: lets the other ranks' exit output drain first)
+        emit(out)
 
 
 if __name__ == "__main__":
