@@ -1022,7 +1022,7 @@ static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(Wo
   __shared__ int32_t w_hits[RRT_LEAF_WAVES][64], w_elems[RRT_LEAF_WAVES][64], w_par[RRT_LEAF_WAVES][64], w_off[RRT_LEAF_WAVES][64];
   __shared__ int32_t w_cpos[RRT_LEAF_WAVES][64], w_ids[RRT_LEAF_WAVES][128];
   __shared__ unsigned long long w_vis[RRT_LEAF_WAVES][64];
-  __shared__ uint8_t w_owner[RRT_LEAF_WAVES][2048];  // owner lane of every point of the pass in flight
+  __shared__ __align__(16) uint8_t w_owner[RRT_LEAF_WAVES][2048];  // owner lane of every point of the pass in flight (re-summation: 256 doubles)
   extern __shared__ __align__(16) unsigned char leaf_dyn[];
   const RrtTables St = rrt_tables_view(tables, W.n_habitats, W.n_poly);
   const int wave = uni((int)(threadIdx.x >> 6));
@@ -1093,11 +1093,18 @@ static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(Wo
   if (mark) {
     for (int i = lane; i < mark_words; i += 64) mark[i] = 0u;
     wave_sync();
-    for (int n0 = ((n_nodes - 1) >> 6) << 6; n0 >= 0; n0 -= 64) {
+    // (the parent link and the leaf flag of the NEXT block are requested before this block's rounds: every block was a full
+    // memory round trip on its own -- ~150 of them per episode, one after the other)
+    const int n_top = ((n_nodes - 1) >> 6) << 6;
+    int par_nx = (n_top + lane < n_nodes) ? nodeI[n_top + lane].y : -1;
+    uint8_t q_nx = (n_top + lane < n_nodes) ? nodeQ[n_top + lane] : (uint8_t)0;
+    for (int n0 = n_top; n0 >= 0; n0 -= 64) {
       const int m = n0 + lane;
       const bool live = m < n_nodes;
-      const int par = live ? nodeI[m].y : -1;
-      bool need = live && m >= 1 && nodeQ[m] != 0;
+      const int par = par_nx;
+      const uint8_t q_me = q_nx;
+      if (n0 >= 64) { par_nx = nodeI[m - 64].y; q_nx = nodeQ[m - 64]; }  // (blocks below the top one are full)
+      bool need = live && m >= 1 && q_me != 0;
       bool pushed = false;
       for (;;) {
         need = need || (live && ((mark[m >> 5] >> (m & 31)) & 1u));
@@ -1316,32 +1323,64 @@ static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(Wo
       const double lo_l = readlane_f64(lo, l);
       if (!log_leaf && !(lo_l < best_tot)) continue;  // an exact total found meanwhile already rules it out
       // ---- the reference's ordered sum: [leaf] + reversed(leaf.path[1:]) + [parent] + reversed(parent.path[1:]) ... root
+      // In chunks of up to 64 chain nodes: (A) the parent links are walked on their own -- a chain of dependent reads,
+      // nothing else waits on it -- and leave one descriptor per node in LDS (arrays of the pass that are dead by now);
+      // (B) the chunk's elements -- a node's own term, then its points last to first -- are evaluated lane = element, every
+      // lane busy, into an LDS buffer in the reference's order, RS_CAP at a time; (C) the buffer is summed left to right, one
+      // rounded add per element.  The same terms in the same order as a walk that evaluates node after node.  (Built and
+      // dropped: skip links -- every node record carrying its depth and its nearest ancestor at a depth that is a multiple of
+      // 8, so that a chunk costs 8 + 8 dependent reads instead of 64 -- bit-identical and no faster: profiles/r5_leaf_pass.md.)
+      constexpr int RS_CAP = 256;  // elements per window: the owner table's 2 048 bytes as doubles
+      double* rs_buf = reinterpret_cast<double*>(c_owner);
+      int32_t *d_off = c_off, *d_w = c_cpos, *d_pos = c_par;
+      double* d_tv = term;
       double c2num = 0.0;
       int mm = leaf;
-      int4 rr = nodeI[mm];
-      double tvn = nodeF[(size_t)mm * 8 + 6];
-      for (;;) {
-        // the parent's record is requested while this node's points are evaluated (the walk is a chain of dependent reads)
-        int4 rr_up = make_int4(0, -1, 0, 0);
-        double tvn_up = 0.0;
-        if (rr.y >= 0) { rr_up = nodeI[rr.y]; tvn_up = nodeF[(size_t)rr.y * 8 + 6]; }
-        c2num = c2num + tvn;  // the node's own state comes before the points that led to it
-        if (rr.y < 0) break;  // the root has no path of its own
-        for (int k0 = 0; k0 < rr.w; k0 += 64) {
-          const int nv = (rr.w - k0) < 64 ? (rr.w - k0) : 64;
-          double tvp = 0.0;
-          int habp = -1;
-          if (lane < nv) {  // last point first; the term is evaluated again from the record
-            const double* rec = ptF + ((size_t)rr.z + (size_t)(rr.w - 1 - (k0 + lane))) * 3;
-            const double2 xy = *reinterpret_cast<const double2*>(rec);
-            cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, rec[2], tvp, habp, true, grid_lds);
+      while (mm >= 0) {
+        // (A) descriptors
+        int nh = 0, cnt = 0;
+        while (nh < 64 && mm >= 0) {
+          const int4 rr = nodeI[mm];
+          const double tvn = nodeF[(size_t)mm * 8 + 6];
+          const int par_m = uni(rr.y);
+          const int w = par_m >= 0 ? uni(rr.w) : 0;  // the root has no path of its own
+          if (lane == 0) { d_off[nh] = rr.z; d_w[nh] = w; d_pos[nh] = cnt; d_tv[nh] = tvn; }
+          cnt += 1 + w; nh++;
+          mm = par_m;
+        }
+        wave_sync();
+        for (int e0 = 0; e0 < cnt; e0 += RS_CAP) {
+          const int ne = (cnt - e0) < RS_CAP ? (cnt - e0) : RS_CAP;
+          // (B) the window's elements, 64 per round
+          for (int s0 = 0; s0 < ne; s0 += 64) {
+            const int sl = e0 + s0 + lane;
+            if (s0 + lane < ne) {
+              int h = 0;
+#pragma unroll
+              for (int st = 32; st >= 1; st >>= 1)
+                if (h + st < nh && d_pos[h + st] <= sl) h += st;
+              const int k = sl - d_pos[h];
+              double tv_e = 0.0;
+              if (k == 0) tv_e = d_tv[h];  // the node's own state comes before the points that led to it
+              else {                        // point w - k: last point first; the term is evaluated again from the record
+                const double* rec = ptF + ((size_t)d_off[h] + (size_t)(d_w[h] - k)) * 3;
+                const double2 xy = *reinterpret_cast<const double2*>(rec);
+                int habp = -1;
+                cost_element(W, St, 0, W.n_bins, P.w[2], xy.x, xy.y, rec[2], tv_e, habp, true, grid_lds);
+              }
+              rs_buf[s0 + lane] = tv_e;
+            }
           }
           wave_sync();
-          term[lane] = tvp;
+          // (C) one rounded add per element, in order
+          int i = 0;
+          for (; i + 4 <= ne; i += 4) {
+            const double2 a = *reinterpret_cast<const double2*>(rs_buf + i), b = *reinterpret_cast<const double2*>(rs_buf + i + 2);
+            c2num = c2num + a.x; c2num = c2num + a.y; c2num = c2num + b.x; c2num = c2num + b.y;
+          }
+          for (; i < ne; i++) c2num = c2num + rs_buf[i];
           wave_sync();
-          for (int i = 0; i < nv; i++) c2num = c2num + term[i];
         }
-        mm = rr.y; rr = rr_up; tvn = tvn_up;
       }
       const int lhits = __builtin_amdgcn_readlane(hits, l), lelems = __builtin_amdgcn_readlane(elems, l);
       st_resummed = uni(st_resummed + lelems); st_releaves = uni(st_releaves + 1);
