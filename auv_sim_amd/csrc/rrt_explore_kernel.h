@@ -1182,8 +1182,11 @@ static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(Wo
       }
       const int pidx = q.v ? c_off[q.o] + (j - c_cpos[q.o]) : 0;
       const double* rec = ptF + (size_t)pidx * 3;
-      q.xy = *reinterpret_cast<const double2*>(rec);
-      q.t = rec[2];
+      // (read once: non-temporal, so that the stream of point records does not push the probability table out of L2 -- 1-3 %)
+      typedef double nt_f64x2 __attribute__((ext_vector_type(2)));
+      const nt_f64x2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f64x2*>(rec));
+      q.xy = make_double2(v.x, v.y);
+      q.t = __builtin_nontemporal_load(rec + 2);
       return q;
     };
     Slot sa = fetch(lane), sb = fetch(64 + lane);
