@@ -474,15 +474,11 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
         const size_t gi = (size_t)(n_points + cnt + rank);  // speculative: committed only if the node is accepted
         double* ra = ptF + gi * 3;                       // x, y, traj_t: what the leaf pass reads
         double* rb = ptF + (size_t)capp * 3 + gi * 3;    // theta, v, length
-#ifdef AUVP_ROWS_NT
+        // (92 GB per launch that this kernel never reads back: non-temporal stores, -0.3 %)
         typedef double nt_f64x2 __attribute__((ext_vector_type(2)));
         nt_f64x2 va, vb; va.x = mx; va.y = my; vb.x = myth; vb.y = vt;
         __builtin_nontemporal_store(va, reinterpret_cast<nt_f64x2*>(ra)); __builtin_nontemporal_store(mt_, ra + 2);
         __builtin_nontemporal_store(vb, reinterpret_cast<nt_f64x2*>(rb)); __builtin_nontemporal_store(ml, rb + 2);
-#else
-        *reinterpret_cast<double2*>(ra) = make_double2(mx, my); ra[2] = mt_;
-        *reinterpret_cast<double2*>(rb) = make_double2(myth, vt); rb[2] = ml;
-#endif
       }
       ptx[pass] = mx; pty[pass] = my; ptv[pass] = wr;
       {
