@@ -28,8 +28,8 @@ AUVP_HD double AUVP_ATAN_FN(double x) {
 #define AUVP_AT10 1.62858201153657823623e-02
   const int neg = x < 0.0;
   double ax = auvp_fabs(x);
-  if (x != x) return x;
-  if (ax >= 0x1p66) {  // |x| >= 2^66: pi/2
+  if (!(ax < 0x1p66)) {  // one test for the two rare cases: nan, |x| >= 2^66 (pi/2)
+    if (x != x) return x;
     double r = hi3 + lo3;
     return neg ? -r : r;
   }
@@ -73,28 +73,29 @@ AUVP_HD double AUVP_ATAN_FN(double x) {
 // `abs(diff) > pi/2` test and one floor(length/exp_rate).
 AUVP_HD double AUVP_ATAN2_FN(double y, double x) {
   const double pi = AUVP_PI, pi_lo = 1.2246467991473531772E-16, pio2 = AUVP_PIO2_HI;
-  if (x != x || y != y) return x + y;
-  if (y == 0.0) {
-    // atan2(+-0, +x) = +-0 ; atan2(+-0, -x) = +-pi
-    int xneg = (x < 0.0) || (x == 0.0 && __builtin_signbit(x));
-    if (!xneg) return y;
-    return __builtin_signbit(y) ? -pi : pi;
-  }
-  if (x == 0.0) return y < 0.0 ? -pio2 : pio2;
-  double ax = auvp_fabs(x), ay = auvp_fabs(y);
+  const double ax = auvp_fabs(x), ay = auvp_fabs(y);
   double z;
-  if (ax == __builtin_inf() || ay == __builtin_inf()) {
-    if (ax == ay) z = 0.5 * pio2;            // pi/4
-    else if (ay == __builtin_inf()) z = pio2;
-    else z = 0.0;
-  } else {
+  if (ax > 0.0 && ay > 0.0 && ax < __builtin_inf() && ay < __builtin_inf()) {
+    // the regular case first (finite, non-zero operands: one test instead of a chain of five)
     double q = ay / ax;
     if (q >= 0x1p64) z = pio2 + 0.5 * pi_lo;
     else if (x < 0.0 && q < 0x1p-64) z = 0.0;
     else z = AUVP_ATAN_FN(q);
+  } else {
+    if (x != x || y != y) return x + y;
+    if (y == 0.0) {
+      // atan2(+-0, +x) = +-0 ; atan2(+-0, -x) = +-pi
+      int xneg = (x < 0.0) || (x == 0.0 && __builtin_signbit(x));
+      if (!xneg) return y;
+      return __builtin_signbit(y) ? -pi : pi;
+    }
+    if (x == 0.0) return y < 0.0 ? -pio2 : pio2;
+    // an infinite operand
+    if (ax == ay) z = 0.5 * pio2;            // pi/4
+    else if (ay == __builtin_inf()) z = pio2;
+    else z = 0.0;
   }
   if (x > 0.0) return y < 0.0 ? -z : z;
   double r = pi - (z - pi_lo);
   return y < 0.0 ? -r : r;
 }
-

@@ -98,9 +98,10 @@ AUVP_HD double auvp_bits_to_double(unsigned long long u) {
 
 // exp(hi + lo), |lo| << |hi|; tbl = auvp_exp_table() or a copy of it
 AUVP_HD double auvp_exp_hl_t(double hi, double lo, const double* tbl) {
-  if (hi != hi) return hi;
-  if (hi > 709.782712893384) return __builtin_inf();
-  if (hi < -745.2) return 0.0;
+  if (!(hi >= -745.2 && hi <= 709.782712893384)) {  // one test for the three rare cases
+    if (hi != hi) return hi;
+    return hi > 0.0 ? __builtin_inf() : 0.0;
+  }
   const double n = auvp_rint(hi * AUVP_INV_LN2_64);
   const double r0 = auvp_fma(-n, AUVP_LN2_64_HI, hi);          // exact
   const double rl = auvp_fma(-n, AUVP_LN2_64_LO, lo);
