@@ -185,12 +185,12 @@ AUVP_HD double auvp_cos(double x) {
 AUVP_HD double auvp_hypot(double x, double y) {
   double ax = auvp_fabs(x), ay = auvp_fabs(y);
   if (ax < ay) { double t = ax; ax = ay; ay = t; }
-  if (ay == 0.0) return ax;
-  double h = auvp_sqrt(auvp_fma(ax, ax, ay * ay));
+  if (ax == 0.0) return ax;  // (both zero: nothing to divide by; a zero smaller operand falls out of the formula: h = ax, r = 0)
+  double h = auvp_sqrt_plain(auvp_fma(ax, ax, ay * ay));
   double h2 = h * h;
   double ax2 = ax * ax;
   double r = auvp_fma(-ay, ay, h2 - ax2) + auvp_fma(h, h, -h2) - auvp_fma(ax, ax, -ax2);
-  return h - r / (2.0 * h);
+  return h - auvp_div_plain(r, 2.0 * h);
 }
 
 #endif  // AUVP_MATH_H
