@@ -60,3 +60,37 @@ def test_pow_e_half_ulp_and_equal_to_libm(orc):
     assert (got == libm).mean() > 0.98
     big = np.abs(libm) > 1e-300
     assert (np.abs(got - libm)[big] <= np.spacing(np.abs(libm))[big]).all()
+
+
+def test_atan2_special_cases_and_accuracy(orc):
+    """atan2 of auvp_atan_body.h (regular case behind one test, the rare cases in a side branch): every special operand
+    combination like math.atan2 (signed zeros, infinities, nan), <= 1.2 ulp vs mpmath elsewhere"""
+    import itertools
+    import mpmath as mp
+    mp.mp.prec = 200
+    L = orc.lib("portable")
+    inf, nan = float("inf"), float("nan")
+    vals = [0.0, -0.0, 1.0, -1.0, inf, -inf, nan, 1e-300, -1e-300, 1e300, -1e300, 2.5, -3.75, 5e-324]
+    for y, x in itertools.product(vals, vals):
+        a, b = L.orc_atan2(y, x), math.atan2(y, x)
+        if b != b:
+            assert a != a, (y, x, a)
+        elif x == 0.0 or y == 0.0 or abs(x) == inf or abs(y) == inf:  # the special operands: exactly libm's value and sign
+            assert a == b and math.copysign(1.0, a) == math.copysign(1.0, b), (y, x, a, b)
+        else:
+            assert abs(a - b) <= 2 * math.ulp(b), (y, x, a, b)
+    rng = np.random.default_rng(4)
+    worst = 0.0
+    for y, x in zip(rng.uniform(-300, 300, 3000), rng.uniform(-300, 300, 3000)):
+        worst = max(worst, _ulp_err(L.orc_atan2(float(y), float(x)), mp.atan2(mp.mpf(float(y)), mp.mpf(float(x))), mp))
+    assert worst <= 1.2, worst
+
+
+def test_hypot_equals_libm(orc):
+    """Borges' fused hypot with the short square root / division: equal to glibc's on every sampled input, zero operands included"""
+    L = orc.lib("portable")
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(-300, 300, 20000), np.zeros(100), rng.uniform(-1e-9, 1e-9, 500), np.zeros(3)])
+    ys = np.concatenate([rng.uniform(-300, 300, 20000), rng.uniform(-5, 5, 100), np.zeros(500), np.array([0.0, -0.0, 2.0])])
+    got = np.array([L.orc_hypot(float(x), float(y)) for x, y in zip(xs, ys)])
+    assert np.array_equal(got, np.array([math.hypot(float(x), float(y)) for x, y in zip(xs, ys)]))  # (CPython -> glibc, like the reference)
