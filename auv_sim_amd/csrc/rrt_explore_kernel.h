@@ -1004,6 +1004,12 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
 // The order in which the LDS atomics add a node's terms is not defined; S only steers which leaves are re-summed, every
 // reported number comes from the exact integers and the ordered re-summation.
 constexpr int RRT_LEAF_WAVES = 4;  // episodes per workgroup of the leaf pass (they share the world tables in LDS)
+#ifndef AUVP_LEAF_NPL
+#define AUVP_LEAF_NPL 2
+#endif
+#ifndef AUVP_LEAF_WPE
+#define AUVP_LEAF_WPE 4
+#endif
 __host__ __device__ inline int rrt_leaf_grid_lds_bytes(int sg_enabled, int ncol, int nrow) {
   const long long b = 16LL * ((long long)ncol + nrow);
   return (sg_enabled && b <= 48 * 1024) ? (int)b : 0;  // bigger grids are looked up in the global copy
@@ -1014,7 +1020,7 @@ __host__ __device__ inline int rrt_leaf_mark_words(int cap_nodes) {
   return w <= 4096 ? w : 0;
 }
 
-static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes,
+static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) __attribute__((amdgpu_waves_per_eu(AUVP_LEAF_WPE, AUVP_LEAF_WPE))) void rrt_leaf_kernel(WorldDev W, RrtParamsDev P, RrtBuffers B, int n_episodes,
                                                                       int mark_words) {
   __shared__ __align__(16) unsigned char tables[RRT_WORLD_BYTES + RRT_MAX_HAB * 32 + RRT_MAX_POLY * 16 + RRT_MAX_BINS * 16];
   __shared__ double w_term[RRT_LEAF_WAVES][64];
@@ -1189,34 +1195,45 @@ static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) void rrt_leaf_kernel(Wo
       q.t = __builtin_nontemporal_load(rec + 2);
       return q;
     };
-    Slot sa = fetch(lane), sb = fetch(64 + lane);
-    for (int j0 = 0; j0 < n_slots; j0 += 128) {
-      const Slot ca = sa, cb = sb;
-      if (j0 + 128 < n_slots) { sa = fetch(j0 + 128 + lane); sb = fetch(j0 + 192 + lane); }
-      double tva = 0.0, tvb = 0.0;
-      int haba = -1, habb = -1;
+    constexpr int NPL = AUVP_LEAF_NPL;  // points per lane and round
+    Slot sn[NPL];
+#pragma unroll
+    for (int u = 0; u < NPL; u++) sn[u] = fetch(u * 64 + lane);
+    for (int j0 = 0; j0 < n_slots; j0 += 64 * NPL) {
+      Slot c[NPL];
+#pragma unroll
+      for (int u = 0; u < NPL; u++) c[u] = sn[u];
+      if (j0 + 64 * NPL < n_slots) {
+#pragma unroll
+        for (int u = 0; u < NPL; u++) sn[u] = fetch(j0 + 64 * NPL + u * 64 + lane);
+      }
+      double tv[NPL];
+      int hb[NPL];
       {
-        // both elements' index arithmetic first, then their four dependent global reads (prob, habitat mask) back to back
-        CostPre qa, qb;
-        qa.tb = -1; qa.c = -1; qa.midx = -1; qb = qa;
-        if (ca.v) qa = cost_pre(W, St, 0, W.n_bins, ca.xy.x, ca.xy.y, ca.t, grid_lds);
-        if (cb.v) qb = cost_pre(W, St, 0, W.n_bins, cb.xy.x, cb.xy.y, cb.t, grid_lds);
-        double pra = 0.0, prb = 0.0;
-        unsigned long long mka = 0ull, mkb = 0ull;
-        if (qa.c >= 0) pra = W.prob[(size_t)qa.tb * W.n_cells + qa.c];
-        if (qb.c >= 0) prb = W.prob[(size_t)qb.tb * W.n_cells + qb.c];
-        if (qa.midx >= 0) mka = W.hg_mask[qa.midx];
-        if (qb.midx >= 0) mkb = W.hg_mask[qb.midx];
-        cost_post(W, St, P.w[2], ca.xy.x, ca.xy.y, qa, pra, mka, tva, haba);
-        cost_post(W, St, P.w[2], cb.xy.x, cb.xy.y, qb, prb, mkb, tvb, habb);
+        // every element's index arithmetic first, then their dependent global reads (prob, habitat mask) back to back
+        CostPre q[NPL];
+        double pr[NPL];
+        unsigned long long mk[NPL];
+#pragma unroll
+        for (int u = 0; u < NPL; u++) {
+          q[u].tb = -1; q[u].c = -1; q[u].midx = -1;
+          if (c[u].v) q[u] = cost_pre(W, St, 0, W.n_bins, c[u].xy.x, c[u].xy.y, c[u].t, grid_lds);
+        }
+#pragma unroll
+        for (int u = 0; u < NPL; u++) {
+          pr[u] = 0.0; mk[u] = 0ull;
+          if (q[u].c >= 0) pr[u] = W.prob[(size_t)q[u].tb * W.n_cells + q[u].c];
+          if (q[u].midx >= 0) mk[u] = W.hg_mask[q[u].midx];
+        }
+#pragma unroll
+        for (int u = 0; u < NPL; u++) cost_post(W, St, P.w[2], c[u].xy.x, c[u].xy.y, q[u], pr[u], mk[u], tv[u], hb[u]);
       }
-      if (ca.v) {
-        if (tva != 0.0) atomicAdd(&c_S[ca.o], tva);
-        if (haba >= 0) { atomicAdd(&c_hits[ca.o], 1); atomicOr(&c_vis[ca.o], 1ull << haba); }
-      }
-      if (cb.v) {
-        if (tvb != 0.0) atomicAdd(&c_S[cb.o], tvb);
-        if (habb >= 0) { atomicAdd(&c_hits[cb.o], 1); atomicOr(&c_vis[cb.o], 1ull << habb); }
+#pragma unroll
+      for (int u = 0; u < NPL; u++) {
+        if (c[u].v) {
+          if (tv[u] != 0.0) atomicAdd(&c_S[c[u].o], tv[u]);
+          if (hb[u] >= 0) { atomicAdd(&c_hits[c[u].o], 1); atomicOr(&c_vis[c[u].o], 1ull << hb[u]); }
+        }
       }
     }
     wave_sync();
