@@ -304,7 +304,9 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
       double u = 0.0;
       for (;;) {
         rows_ensure(rng, search, 32u, rl);
-        if (search) u = rows_random_at(rng, (uint32_t)rl);
+        // (the round's sixteen draws also go to the window area, free at this point: they ARE window entries 0 .. 15 of the
+        // first pass -- stream entry e at win[e] -- and the two draws after the winner's are read from there)
+        if (search) { u = rows_random_at(rng, (uint32_t)rl); win[rl] = u; }
         const int rbj = (int)py_uniform(1.0, (double)(K + 1), u);
         const bool cand = search && rl < 14;
         const bool badkey = cand && rbj > K;
@@ -323,7 +325,8 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
         if (!again && live && cnt == 0) { rb = rb_n; cnt = cnt_n; }
         if (!wave_any(again)) break;
       }
-      const double u1 = row_read_f64(u, rowbase + fo + 1), u2 = row_read_f64(u, rowbase + fo + 2);
+      wave_sync();
+      const double u1 = win[fo + 1], u2 = win[fo + 2];
       if (live) {
         const int ri = (int)py_uniform(0.0, (double)cnt, u1);
         par = bin_member(bins, rb, ri);
@@ -346,7 +349,17 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
     // is still on its way from memory
     const bool on0 = live && 0 < n_total;
     const int n0_ = on0 ? (n_total < RW_C ? n_total : RW_C) : 0;
-    make_window(on0, 3 * n0_, base);
+    {
+      // first pass: window entry j = stream entry base + j = win[base + j]; entries below 16 are there already
+      const int e_end = base + 3 * n0_;
+      rows_ensure(rng, on0, (uint32_t)(2 * e_end), rl);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const int e = 16 + rl + 16 * t;
+        if (on0 && e < e_end) win[e] = rows_random_at(rng, (uint32_t)e);
+      }
+      wave_sync();
+    }
     double cx = 0.0, cy = 0.0, cth = 0.0, ctt = 0.0, clen = 0.0;
     if (live) {
       const double2 a = *reinterpret_cast<const double2*>(nodeF + (size_t)par * 8);
@@ -381,6 +394,7 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
 #endif
       const int b0 = first_pass ? base : 0;  // later passes start at the (advanced) head of the stream
       if (pass != 0) make_window(on, nwin, b0);
+      const double* wp = win + (pass == 0 ? base : 0);  // window entry j of this pass
       // "taken" predicate for every possible start offset, 48 bits per row
       unsigned long long tpred = 0ull;
 #pragma unroll
@@ -388,8 +402,8 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
         // every lane compares (entries past the window are whatever the scratch holds: never a trap, masked below); the
         // predicate is the AND of two single-compare ballots, taken in scalar registers (nwin = 0 for rows that are not `on`)
         const int j = rl + 16 * t;
-        const double dist = py_uniform(0.0, Q.dist_to_end, win[j]);
-        const double diff = py_uniform(-Q.diff_max, Q.diff_max, win[j + 1]);
+        const double dist = py_uniform(0.0, Q.dist_to_end, wp[j]);
+        const double diff = py_uniform(-Q.diff_max, Q.diff_max, wp[j + 1]);
         const unsigned long long fb = __builtin_amdgcn_fcmp(auvp_fabs(dist), auvp_fabs(diff), 2 /* ordered > */) &
                                       __builtin_amdgcn_uicmp((unsigned)(j + 1), (unsigned)nwin, 36 /* unsigned < */);
         tpred |= ((fb >> rowbase) & 0xffffull) << (16 * t);
@@ -416,12 +430,12 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
       const bool taken = (tmask >> rl) & 1u;
       double radius = 0.0, phi = 0.0, vt = 1.0;
       if (taken) {
-        const double dist = py_uniform(0.0, Q.dist_to_end, win[mypos]);
-        const double diff = py_uniform(-Q.diff_max, Q.diff_max, win[mypos + 1]);
+        const double dist = py_uniform(0.0, Q.dist_to_end, wp[mypos]);
+        const double diff = py_uniform(-Q.diff_max, Q.diff_max, wp[mypos + 1]);
         const double s1 = dist + diff, s2 = dist - diff;
         radius = auvp_div_plain(s1 + s2, -s1 + s2);
         phi = auvp_div_plain(s1 + s2, 2 * radius);
-        vt = py_uniform(0.0, 2 * Q.v, win[mypos + 2]);
+        vt = py_uniform(0.0, 2 * Q.v, wp[mypos + 2]);
       }
       wave_sync();  // the window is dead: its LDS becomes the running-sum scratch
       // theta += phi, left to right: lane s ends with (((theta0 + phi_0) + phi_1) + ... + phi_s); untaken and idle lanes add
