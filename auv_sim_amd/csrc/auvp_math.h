@@ -20,15 +20,16 @@
 #define AUVP_HD static inline
 #endif
 
-// AUVP_K(c): how a reduction constant reaches its use.  Plain: the literal.  A translation unit compiled with
-// -DAUVP_MATH_SGPR_CONSTS (device pass only) forms it in a scalar register pair right where it is used -- two s_mov_b32 inside a
-// volatile asm, which nothing hoists: the VOP3 forms of the fp64 instructions take no 64-bit literal, and a kernel whose
-// scalar registers are full otherwise keeps the constants of a sin / cos in VECTOR registers for the whole loop.
-// AUVP_FMA_K(a, b, c) = fma(a, b, c) with a CONSTANT addend -- a Horner step.  The compiler selects the two-address
-// v_fmac_f64 for it and therefore first copies the constant into the destination (v_mov_b64, or two v_mov_b32 out of scalar
-// registers): two to three vector instructions per step.  The SGPR-constant build spells the step as two s_mov_b32 into a fixed
-// scalar pair + ONE v_fma_f64 that reads it.  Same doubles either way.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(AUVP_MATH_SGPR_CONSTS)
+// AUVP_K(c): how a reduction constant reaches its use; AUVP_FMA_K(a, b, c) = fma(a, b, c) with a CONSTANT addend -- a Horner
+// step.  Plain: the literal / __builtin_fma.  The compiler selects the two-address v_fmac_f64 for such a step and therefore
+// first copies the constant into the destination (v_mov_b64, or two v_mov_b32 out of scalar registers), and a kernel whose
+// scalar registers are full keeps the ~16 constants of a sin / cos in VECTOR registers for the whole loop.  The `_sk`
+// instantiation of the sin / cos family (auvp_sincos_sk: device code only, below) forms a constant in a scalar register pair
+// right where it is used -- two s_mov_b32 inside an asm, which nothing hoists -- and spells a Horner step as those two moves into
+// a FIXED scalar pair + ONE v_fma_f64 that reads it.  Same doubles either way.  Measured (profiles/r5_valu_issue.md, DESIGN.md
+// section 0): worth 1-2.5 % in the RRT.exploring kernels (vector-issue bound), -2..-5 % in the planner and particle-filter
+// kernels (short of SCALAR issue: a scalar move costs a wavefront as much as an fp64 instruction there) -- hence two names.
+#if defined(__HIP_DEVICE_COMPILE__)
 template <unsigned LO, unsigned HI>
 __device__ __forceinline__ double auvp_sgpr_f64() {
   unsigned a, b;
@@ -42,12 +43,9 @@ __device__ __forceinline__ double auvp_fma_sgpr_k(double a, double b) {
   return d;
 }
 #define AUVP_K_BITS(c) __builtin_bit_cast(unsigned long long, (double)(c))
-#define AUVP_K(c) auvp_sgpr_f64<(unsigned)(AUVP_K_BITS(c) & 0xffffffffull), (unsigned)(AUVP_K_BITS(c) >> 32)>()
-#define AUVP_FMA_K(a, b, c) auvp_fma_sgpr_k<(unsigned)(AUVP_K_BITS(c) & 0xffffffffull), (unsigned)(AUVP_K_BITS(c) >> 32)>(a, b)
-#else
+#endif
 #define AUVP_K(c) (c)
 #define AUVP_FMA_K(a, b, c) __builtin_fma(a, b, c)
-#endif
 
 AUVP_HD double auvp_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 AUVP_HD double auvp_sqrt(double a) { return __builtin_sqrt(a); }
@@ -94,81 +92,27 @@ AUVP_HD double auvp_sqrt_plain(double x) {
 #define AUVP_INV_PIO2 0x1.45f306dc9c883p-1
 #define AUVP_PI 0x1.921fb54442d18p+1
 
-// x = n*(pi/2) + (r + t), |r+t| <= ~pi/4; returns n mod 4 in [0,3].
-// hi = x - n*PIO2_HI is exact (single fma rounding of a value that fits 53 bits); the PIO2_LO
-// product is split exactly with a second fma, so r+t carries ~100 bits of the reduced argument
-// for |x| up to ~1e9.  Beyond that accuracy degrades gracefully (still deterministic).
-AUVP_HD int auvp_rem_pio2(double x, double* r, double* t) {
-  const double pio2_lo = AUVP_K(AUVP_PIO2_LO);
-  double n = auvp_rint(x * AUVP_K(AUVP_INV_PIO2));
-  double hi = auvp_fma(-n, AUVP_K(AUVP_PIO2_HI), x);
-  double p = n * pio2_lo;
-  double pe = auvp_fma(n, pio2_lo, -p);  // exact error of p
-  double rr = hi - p;
-  double tt = (hi - rr) - p;                  // rounding error of the subtraction
-  tt = tt - pe;
-  tt = auvp_fma(-n, AUVP_K(AUVP_PIO2_LO2), tt);
-  *r = rr;
-  *t = tt;
-  // n is integral: n mod 4 = the two low mantissa bits of n + 1.5 * 2^52 (exact for |n| < 2^51, i.e. |x| < 3.5e15; beyond
-  // that still deterministic, the same bits on host and device)
-  union { double d; unsigned long long u; } m;
-  m.d = n + AUVP_K(0x1.8p52);
-  return (int)(m.u & 3ull);
-}
-
-// sin(x + y) for |x| <= ~pi/4 with tail y
-AUVP_HD double auvp_ksin(double x, double y) {
-#define AUVP_S1 -1.66666666666666324348e-01
-#define AUVP_S2 8.33333333332248946124e-03
-#define AUVP_S3 -1.98412698298579493134e-04
-#define AUVP_S4 2.75573137070700676789e-06
-#define AUVP_S5 -2.50507602534068634195e-08
-#define AUVP_S6 1.58969099521155010221e-10
-  double z = x * x;
-  double v = z * x;
-  double r = AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_K(AUVP_S6), AUVP_S5), AUVP_S4), AUVP_S3), AUVP_S2);
-  return x - auvp_fma(-v, AUVP_K(AUVP_S1), auvp_fma(z, auvp_fma(-v, r, 0.5 * y), -y));
-}
-
-// cos(x + y) for |x| <= ~pi/4 with tail y
-AUVP_HD double auvp_kcos(double x, double y) {
-#define AUVP_C1 4.16666666666666019037e-02
-#define AUVP_C2 -1.38888888888741095749e-03
-#define AUVP_C3 2.48015872894767294178e-05
-#define AUVP_C4 -2.75573143513906633035e-07
-#define AUVP_C5 2.08757232129817482790e-09
-#define AUVP_C6 -1.13596475577881948265e-11
-  double z = x * x;
-  double r = z * AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_FMA_K(z, AUVP_K(AUVP_C6), AUVP_C5), AUVP_C4), AUVP_C3), AUVP_C2),
-                            AUVP_C1);
-  double hz = 0.5 * z;
-  double w = 1.0 - hz;
-  return w + (((1.0 - w) - hz) + auvp_fma(z, r, -(x * y)));
-}
-
-AUVP_HD void auvp_sincos(double x, double* s, double* c) {
-  double r, t;
-  int q = auvp_rem_pio2(x, &r, &t);
-  double ks = auvp_ksin(r, t);
-  double kc = auvp_kcos(r, t);
-  double ss = (q & 1) ? kc : ks;
-  double cc = (q & 1) ? ks : kc;
-  *s = (q & 2) ? -ss : ss;
-  *c = ((q + 1) & 2) ? -cc : cc;
-}
-
-AUVP_HD double auvp_sin(double x) {
-  double s, c;
-  auvp_sincos(x, &s, &c);
-  return s;
-}
-
-AUVP_HD double auvp_cos(double x) {
-  double s, c;
-  auvp_sincos(x, &s, &c);
-  return c;
-}
+// the sin / cos family: auvp_rem_pio2, auvp_ksin, auvp_kcos, auvp_sincos, auvp_sin, auvp_cos (auvp_sincos_body.h)
+#define AUVP_SC(n) n
+#include "auvp_sincos_body.h"
+#undef AUVP_SC
+#if defined(__HIPCC__)
+// ... and again as auvp_sincos_sk etc. for device code whose constants are formed in scalar registers at their use (above);
+// the host pass of a HIP unit compiles the plain form under these names
+#define AUVP_SC(n) n##_sk
+#if defined(__HIP_DEVICE_COMPILE__)
+#undef AUVP_K
+#undef AUVP_FMA_K
+#define AUVP_K(c) auvp_sgpr_f64<(unsigned)(AUVP_K_BITS(c) & 0xffffffffull), (unsigned)(AUVP_K_BITS(c) >> 32)>()
+#define AUVP_FMA_K(a, b, c) auvp_fma_sgpr_k<(unsigned)(AUVP_K_BITS(c) & 0xffffffffull), (unsigned)(AUVP_K_BITS(c) >> 32)>(a, b)
+#endif
+#include "auvp_sincos_body.h"
+#undef AUVP_SC
+#undef AUVP_K
+#undef AUVP_FMA_K
+#define AUVP_K(c) (c)
+#define AUVP_FMA_K(a, b, c) __builtin_fma(a, b, c)
+#endif
 
 // atan(x), fdlibm-class: argument reduction to [0, 7/16] around 0.5, 1, 1.5, inf; odd polynomial
 // split into even/odd halves.  < 1 ulp (tests/test_portable_math.py).

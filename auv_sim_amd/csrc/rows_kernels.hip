@@ -4,9 +4,9 @@
 // aggressively than the default (occupancy-first) one: 101.3 -> 99.7 ms on the headline batch, bit-identical.  The same flag on
 // the rest of the library costs rrt_leaf_kernel 11 % (6.49 -> 7.17 ms), hence the separate unit (profiles/r5_machine_licm.md).
 //
-// Also -DAUVP_MATH_SGPR_CONSTS=1 (auvp_math.h): the Horner steps of sin / cos as one v_fma_f64 each with the constant in a fixed
+// The kernel calls auvp_sincos_sk (auvp_math.h): the Horner steps of sin / cos as one v_fma_f64 each with the constant in a fixed
 // scalar pair -- the compiler's v_fmac_f64 form copies the constant into the destination first (18 v_mov per sin / cos):
-// 97.1 -> 95.9 ms; the planner and particle-filter units measured neutral to -2 % with it and keep the plain form.
+// 97.1 -> 95.9 ms; the planner and particle-filter kernels measured neutral to -5 % with it and call the plain auvp_sincos.
 //
 // Entry point for the host side (auvplan.hip): internal, hidden visibility, not part of the C-ABI.
 #include <hip/hip_runtime.h>

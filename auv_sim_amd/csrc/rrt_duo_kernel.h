@@ -467,7 +467,7 @@ __global__ __launch_bounds__(DUO_EP * 128, 2) void rrt_duo_kernel(WorldDev W, Rr
       wave_sync();
       const double myth = active ? phi_l[lane] : cth;
       double sn, cs;
-      auvp_sincos(myth, &sn, &cs);
+      auvp_sincos_sk(myth, &sn, &cs);
       if (lane < DUO_CS) { sc[2 * lane] = sn; sc[2 * lane + 1] = cs; }
       wave_sync();
       double dx = 0.0, dy = 0.0, mv = 0.0, dt = 0.0;

@@ -790,7 +790,7 @@ __global__ __launch_bounds__(RRT_X_WAVES * 64, (MODE == 2 ? (J <= 4 ? 5 : 2) : (
       wave_sync();
       const double myth = active ? phi_l[lane] : cth;  // idle lanes evaluate the chunk-entry angle
       double sn, cs;
-      auvp_sincos(myth, &sn, &cs);
+      auvp_sincos_sk(myth, &sn, &cs);
       if (lane <= C) { sc[2 * lane] = sn; sc[2 * lane + 1] = cs; }
       wave_sync();
       double dx = 0.0, dy = 0.0, mv = 0.0, dt = 0.0;

@@ -445,7 +445,7 @@ static __global__ __launch_bounds__(RW_WAVES * 64, 1) void rrt_rows_kernel(World
       const double th = rows_theta_chain(cth, inc);
       const double myth = (rl == 15) ? cth : th;  // lane 15: the pass-entry angle
       double sn, cs;
-      auvp_sincos(myth, &sn, &cs);
+      auvp_sincos_sk(myth, &sn, &cs);
       double dx = 0.0, dy = 0.0, mv = 0.0, dt = 0.0;
       {
         const uint32_t below = tmask & ((1u << rl) - 1u);
