@@ -147,7 +147,7 @@ def pmc_latency(meas, kernel_prefix, units_now):
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             f, w = 1024.0 * float(c["FETCH_SIZE"]), 1024.0 * float(c["WRITE_SIZE"])
             out["traffic"], out["traffic_raw"] = (2.0 * f + w) * sc, (f + w) * sc
-        out["traffic_source"] = "profiles/%s pmc@%s" % (pj.get("tag", "?"), meas)
+        out["traffic_source"] = "profiles/%s pmc@%s" % (m.get("from_tag") or pj.get("tag", "?"), meas)
         return {k2: v for k2, v in out.items() if v is not None}
     except Exception:
         return {}
@@ -222,11 +222,11 @@ def pmc_traffic(meas, kernels_ran, units_now):
         m = pj["measurements"][meas]
         if set(kernels_ran) != set(m["kernels"].keys()):
             none["traffic_source"] = "profiles/%s profiled %s, this launch ran %s: not comparable" % (
-                pj.get("tag", "?"), sorted(m["kernels"].keys()), sorted(kernels_ran))
+                m.get("from_tag") or pj.get("tag", "?"), sorted(m["kernels"].keys()), sorted(kernels_ran))
             return none
         x2, raw = float(m["hbm_bytes_fetch_x2"]), float(m["hbm_bytes_raw"])
         src = "profiles/%s pmc@%s (traffic = 2 x FETCH_SIZE + WRITE_SIZE, traffic_raw = FETCH_SIZE + WRITE_SIZE; separate passes)" % (
-            pj.get("tag", "?"), meas)
+            m.get("from_tag") or pj.get("tag", "?"), meas)
         u0 = float(m.get("units") or 0.0)
         if u0 > 0 and units_now and abs(u0 - units_now) > 0.5:
             x2 *= units_now / u0

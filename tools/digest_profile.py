@@ -129,6 +129,22 @@ for key, (needles, units_field) in MEAS.items():
             kr["valu_active_share"] = km["SQ_ACTIVE_INST_VALU"] / km["SQ_WAVE_CYCLES"]
     out["measurements"][key] = rec
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
-json.dump(out, open(os.path.join(REPO, "profiles", "pmc_latest.json"), "w"), indent=1)
+# pmc_latest.json keeps the measurements this run did not profile (a run may cover the headline and a few sides only), each
+# with the tag of the run it came from
+latest_path = os.path.join(REPO, "profiles", "pmc_latest.json")
+latest = {"tag": tag, "measurements": {}}
+if os.path.exists(latest_path):
+    try:
+        old = json.load(open(latest_path))
+        for k, v in old.get("measurements", {}).items():
+            v.setdefault("from_tag", old.get("tag"))
+            latest["measurements"][k] = v
+    except (ValueError, OSError):
+        pass
+for k, v in out["measurements"].items():
+    v = dict(v)
+    v["from_tag"] = tag
+    latest["measurements"][k] = v
+json.dump(latest, open(latest_path, "w"), indent=1)
 print(json.dumps({k: {f: v.get(f) for f in ("hbm_bytes_raw", "hbm_bytes_fetch_x2", "algorithmic_bytes_per_launch", "units", "sq_insts_valu_per_unit")}
                   for k, v in out["measurements"].items()}, indent=1))
