@@ -824,19 +824,8 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       // the bucket of the new node (:291-320)
       int bk = -1;
       {
-        int row = (int)(cy / P.cell), col = (int)(cx / P.cell);
         bool ie = false;
-        if (row < 0) { row += P.rows; ie |= row < 0; }
-        if (col < 0) { col += P.cols; ie |= col < 0; }
-        if (!ie && row < P.rows && col < P.cols) {
-          const double raw = cth / P.delta_theta;
-          int sub = (int)auvp_floor(raw);
-          if (sub < 0) sub = (int)(P.S + sub);
-          if (sub == P.S) sub -= 1;
-          if (sub < 0) { sub += P.S; ie |= sub < 0; }
-          ie |= sub >= P.S;
-          bk = (row * P.cols + col) * P.S + sub;
-        }
+        bk = prrt_bucket_of(P, cx, cy, cth, ie);
         if (wave_any(ie)) { status = -1; break; }
         bk = uni(bk);
       }

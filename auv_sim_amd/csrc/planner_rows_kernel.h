@@ -294,19 +294,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       bool pre_err = false;
       int pre_bk = -1, pre_c = -1, pre_h = -1;
       if (act) {
-        int rrow = (int)(cy / P.cell), col = (int)(cx / P.cell);
-        if (rrow < 0) { rrow += P.rows; pre_err |= rrow < 0; }
-        if (col < 0) { col += P.cols; pre_err |= col < 0; }
-        if (!pre_err && rrow < P.rows && col < P.cols) {
-          const double raw = cth / P.delta_theta;
-          int sub = (int)auvp_floor(raw);
-          if (sub < 0) sub = (int)(P.S + sub);
-          if (sub == P.S) sub -= 1;
-          if (sub < 0) { sub += P.S; pre_err |= sub < 0; }
-          pre_err |= sub >= P.S;
-          pre_bk = (rrow * P.cols + col) * P.S + sub;
-        }
-        if (pre_err) pre_bk = -1;
+        pre_bk = prrt_bucket_of(P, cx, cy, cth, pre_err);
         if (pre_bk >= 0) { const int2 bw = buckets[pre_bk]; pre_c = prrt_bucket_count(bw, B.bucket_epoch); pre_h = bw.y; }
       }
 

@@ -29,6 +29,26 @@ struct PrrtParamsDev {
   double delta_theta;
 };
 
+// add_node_to_grid's index arithmetic (gym_rrt/envs/rrt_dubins.py:108-159) -- the ONE place every planner kernel takes it from
+// (prrt_kernel, prrt_init_kernel, prrt_rows_kernel, prrt_pipe_kernel).  The reference divides the ABSOLUTE coordinates by the
+// cell side (:115-116: the boundary's origin is ignored), truncates with int() (toward zero) and indexes Python
+// lists with the result, so an index in [-len, -1] wraps to the far end; `>= len` returns without inserting (:118-124: the
+// node is in mps_list but in no bucket: -1 here) and `< -len` raises IndexError (`err`).  The subsection: floor(theta /
+// delta_theta), S + sub when negative, S -> S - 1 (:127-157), then the same list indexing.
+static __device__ __forceinline__ int prrt_bucket_of(const PrrtParamsDev& P, double x, double y, double th, bool& err) {
+  int row = (int)(y / P.cell), col = (int)(x / P.cell);
+  if (row >= P.rows || col >= P.cols) return -1;  // both `>=` tests precede the first list access; a negative index never passes them
+  if (row < 0) row += P.rows;
+  if (col < 0) col += P.cols;
+  if (row < 0 || col < 0) { err = true; return -1; }
+  int sub = (int)auvp_floor(th / P.delta_theta);
+  if (sub < 0) sub = (int)(P.S + sub);
+  if (sub == P.S) sub -= 1;
+  if (sub < 0) { sub += P.S; err |= sub < 0; }
+  err |= sub >= P.S;
+  return err ? -1 : (row * P.cols + col) * P.S + sub;
+}
+
 struct PrrtSummary {  // must match auvp_prrt_summary in include/auvplan.h
   int32_t status, n_nodes, n_points, n_occ, steps, done, path_len, last_node;
   int32_t last_accepted, last_new_node, n_arc, _pad;
@@ -545,21 +565,9 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
     if (ok) {
       if (n_nodes >= capn) { status = -2; break; }
       me = n_nodes;
-      // add_node_to_grid (:108-159): int(y / cs), int(x / cs) with Python's negative-index wrap
-      int row = (int)(cy / P.cell), col = (int)(cx / P.cell);
+      // add_node_to_grid (:108-159)
       bool idx_err = false;
-      if (row < 0) { row += P.rows; idx_err |= row < 0; }
-      if (col < 0) { col += P.cols; idx_err |= col < 0; }
-      int bk = -1;
-      if (!idx_err && row < P.rows && col < P.cols) {
-        double raw = cth / P.delta_theta;
-        int sub = (int)auvp_floor(raw);
-        if (sub < 0) sub = (int)(P.S + sub);
-        if (sub == P.S) sub -= 1;
-        if (sub < 0) { sub += P.S; idx_err |= sub < 0; }
-        idx_err |= sub >= P.S;
-        bk = (row * P.cols + col) * P.S + sub;
-      }
+      int bk = prrt_bucket_of(P, cx, cy, cth, idx_err);
       if (wave_any(idx_err)) { status = -1; break; }
       bk = uni(bk);
       int2 bwn = make_int2(0, 0);
@@ -842,21 +850,9 @@ static __global__ __launch_bounds__(256) void prrt_init_kernel(PrrtParamsDev P, 
   if (env_done) env_done[e] = 0;
   const double* st = B.start + 4 * (size_t)e;
   const double sx = st[0], sy = st[1], sth = st[2], stt = st[3];
-  // same index arithmetic as the step kernel (int(y / cs), int(x / cs), floor(theta / delta_theta))
-  int row = (int)(sy / P.cell), col = (int)(sx / P.cell);
+  // same index arithmetic as the step kernels
   bool err = false;
-  if (row < 0) { row += P.rows; err |= row < 0; }
-  if (col < 0) { col += P.cols; err |= col < 0; }
-  int bk = -1;
-  if (!err && row < P.rows && col < P.cols) {
-    int sub = (int)auvp_floor(sth / P.delta_theta);
-    if (sub < 0) sub = (int)(P.S + sub);
-    if (sub == P.S) sub -= 1;
-    if (sub < 0) { sub += P.S; err |= sub < 0; }
-    err |= sub >= P.S;
-    bk = (row * P.cols + col) * P.S + sub;
-  }
-  if (err) bk = -1;
+  int bk = prrt_bucket_of(P, sx, sy, sth, err);
   PrrtNode n0;
   n0.x = sx; n0.y = sy; n0.theta = sth; n0.t = stt;
   n0.step = 0; n0.parent = -1; n0.pt_off = 0; n0.pt_cnt = 0;

@@ -58,9 +58,12 @@ def make_world(seed=0, n_obstacles=64, box=(-300.0, -100.0, -100.0, 100.0), cell
 
 
 def make_rect_world(seed=0, n_obstacles=256, size=200.0, start=(20.0, 20.0), goal=(170.0, 180.0),
-                    obst_radius=(1.0, 3.0)):
+                    obst_radius=(1.0, 3.0), origin=(0.0, 0.0)):
     """Planner_RRT (gym_rrt) world: rectangle [0,size]^2, circular obstacles clear of start/goal
-    (SURVEY.md section 8(d) config 4)."""
+    (SURVEY.md section 8(d) config 4).  `origin` translates the whole world (rectangle, start, goal, obstacles; the
+    draws are those of the (0, 0) world): the reference's bucket grid ignores the boundary's origin
+    (gym_rrt/envs/rrt_dubins.py:115-116), so a translated world exercises its negative-index wrap, its
+    'out of the habitat environment bound' return and its IndexError."""
     rng = random.Random(seed)
     obstacles = []
     while len(obstacles) < n_obstacles:
@@ -72,12 +75,16 @@ def make_rect_world(seed=0, n_obstacles=256, size=200.0, start=(20.0, 20.0), goa
         if (ox - goal[0]) ** 2 + (oy - goal[1]) ** 2 <= (r + 5.0) ** 2:
             continue
         obstacles.append((ox, oy, r))
+    gx, gy = float(origin[0]), float(origin[1])
+    obst = np.array(obstacles, dtype=np.float64).reshape(-1, 3)
+    obst[:, 0] += gx
+    obst[:, 1] += gy
     return {
         "seed": seed,
-        "rect": np.array([0.0, 0.0, size, size], dtype=np.float64),
-        "start": np.array(start, dtype=np.float64),
-        "goal": np.array(goal, dtype=np.float64),
-        "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
+        "rect": np.array([gx, gy, gx + size, gy + size], dtype=np.float64),
+        "start": np.array([start[0] + gx, start[1] + gy], dtype=np.float64),
+        "goal": np.array([goal[0] + gx, goal[1] + gy], dtype=np.float64),
+        "obstacles": obst,
     }
 
 

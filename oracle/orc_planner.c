@@ -74,9 +74,11 @@ static int add_node_to_grid(prrt* t, int node) {
   int row = py_index(nd[1], t->p->cell_side_length, t->rows);
   int col = py_index(nd[0], t->p->cell_side_length, t->cols);
   t->o->node_bucket[node] = -1;
-  if (row == -2 || col == -2) return -1;
+  /* the two `>=` tests (:118-124) come before the first list access (:127), and a negative index never passes them: a row past
+   * the top returns quietly even when the column would have raised */
   if (row >= t->rows) return 0; /* "out of the habitat environment bound": not bucketed */
   if (col >= t->cols) return 0;
+  if (row == -2 || col == -2) return -1;
   double raw = nd[2] / t->delta_theta;
   double fl = floor(raw);
   int sub = (int)fl;

@@ -444,9 +444,18 @@ def run_planner_rrt(seed, rect, start, goal, obstacles, max_step, freq, cell, su
     bnd = [MPS(rect[0], rect[1]), MPS(rect[2], rect[3])]
     s = MPS(start[0], start[1], z=-5.0, theta=start[2] if len(start) > 2 else 0.0)
     g = MPS(goal[0], goal[1], z=-5.0, theta=0.0)
-    with contextlib.redirect_stdout(io.StringIO()):
-        rrt = mod.Planner_RRT(s, g, bnd, obs, [], exp_rate=exp_rate, dist_to_end=dist_to_end, diff_max=diff_max,
-                              freq=freq, cell_side_length=cell, subsections_in_cell=subs)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            rrt = mod.Planner_RRT(s, g, bnd, obs, [], exp_rate=exp_rate, dist_to_end=dist_to_end, diff_max=diff_max,
+                                  freq=freq, cell_side_length=cell, subsections_in_cell=subs)
+    except IndexError as e:
+        # add_node_to_grid(start) indexes env_grid with int(y / cell), int(x / cell) of the ABSOLUTE position (:115-127):
+        # a start further below / left of 0 than the grid is tall / wide raises in __init__
+        return {"seed": seed, "rect": np.array(rect, dtype=np.float64), "start": np.array(start, dtype=np.float64),
+                "goal": np.array(goal, dtype=np.float64), "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
+                "max_step": max_step, "freq": freq, "cell": cell, "subs": subs, "exp_rate": exp_rate,
+                "dist_to_end": dist_to_end, "diff_max": diff_max, "error": "IndexError", "error_stage": "init",
+                "error_text": str(e), "steps": 0}
     log = {"bucket": [], "picked": [], "accepted": [], "done": [], "npath": [], "arc_n": [], "arc_free": []}
     index_of = {id(s): 0}
     orig_gon = rrt.generate_one_node
@@ -504,8 +513,15 @@ def run_planner_rrt(seed, rect, start, goal, obstacles, max_step, freq, cell, su
 
     rrt.generate_one_node = gon
     random.seed(seed)
-    with contextlib.redirect_stdout(io.StringIO()):
-        path, step, _ = rrt.planning(max_step=max_step)
+    error = ("", "", "")
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            path, step, _ = rrt.planning(max_step=max_step)
+    except IndexError as e:
+        # planning(): random.choice of an empty occupied list (the start was "out of the habitat environment bound": :118-124,
+        # :186), or add_node_to_grid of an accepted node whose index is below -len (:127; the node is in mps_list by then: :229)
+        path, step = None, len(log["done"])
+        error = ("IndexError", "planning", str(e))
     rng_after = random.random()
     nodes = rrt.mps_list
     for i, n in enumerate(nodes):
@@ -518,7 +534,11 @@ def run_planner_rrt(seed, rect, start, goal, obstacles, max_step, freq, cell, su
         for p in n.path[1:]:
             pts.append([p.x, p.y, p.theta, p.traj_time_stamp])
     pts = np.array(pts, dtype=np.float64).reshape(-1, 4)
-    occ = np.array([(r_ * ncols + c_) * subs + k_ for (r_, c_, k_) in rrt.occupied_grid_cells_array], dtype=np.int32)
+    # the tuples hold the raw indexes, which are negative where the reference relied on Python's negative list indexing
+    # (worlds whose origin is below / left of 0): the bucket they address is index % len
+    nrows = len(rrt.env_grid)
+    occ = np.array([((r_ % nrows) * ncols + c_ % ncols) * subs + k_ % subs for (r_, c_, k_) in rrt.occupied_grid_cells_array],
+                   dtype=np.int32)
     counts = np.array([len(sub.node_array) for row in rrt.env_grid for gc in row for sub in gc.subsection_cells],
                       dtype=np.int32)
     done = bool(log["done"][-1]) if log["done"] else False
@@ -536,6 +556,12 @@ def run_planner_rrt(seed, rect, start, goal, obstacles, max_step, freq, cell, su
         "occupied": occ, "bucket_counts": counts, "grid_rows": len(rrt.env_grid), "grid_cols": ncols,
         "rng_after": rng_after,
     }
+    if error[0]:
+        out["error"], out["error_stage"], out["error_text"] = error
+        # the step the exception interrupted: its steer and first collision test had run (the wrappers saw them)
+        out["err_picked"] = cur.get("picked", -1)
+        out["err_accepted"] = bool(cur.get("accepted", False))
+        out["err_npath"] = cur.get("npath", -1)
     if keep_points:
         out["points"] = pts
     if done:
@@ -557,11 +583,39 @@ def g2():
                               obst_radius=(2.0, 5.0))
     specs.append(("g2_o64_100m", 6, tuple(w["rect"].tolist()), tuple(w["start"].tolist()), tuple(w["goal"].tolist()),
                   [tuple(o) for o in w["obstacles"].tolist()], 1500, 20, 5, 4, {"exp_rate": 0.5}))
+    # round 6: rectangles whose origin is not (0, 0).  The bucket grid ignores the origin (:115-116: int(y / cell), int(x / cell)
+    # of the absolute position), so nodes land in "wrong" cells, negative indexes wrap to the far end of the Python lists,
+    # indexes past the grid return without inserting (:118-124: such nodes are in mps_list and in no bucket) and indexes
+    # below -len raise IndexError.  g2_org_*: runs that complete; g2e_*: the reference raises (kept out of the g2_* glob).
+    def shifted(dx, dy):
+        return ((dx, dy, dx + 50.0, dy + 50.0), (10.0 + dx, 10.0 + dy), (35.0 + dx, 45.0 + dy),
+                [(x + dx, y + dy, r) for x, y, r in lay])
+    for name, seed, (dx, dy), max_step, freq, cell, subs, extra in (
+            ("g2_org_p30_p20", 2, (30.0, 20.0), 2000, 10, 5, 1, {}),        # x >= 50 or y >= 50: not bucketed
+            ("g2_org_m50_m30", 3, (-50.0, -30.0), 2000, 10, 5, 2, {}),      # every index negative: all wrap
+            ("g2_org_frac", 4, (7.5, -3.25), 2000, 10, 5, 4, {}),           # int() truncates toward zero around y = 0
+            ("g2_org_m20_p5", 5, (-20.0, 5.0), 1500, 20, 2, 8, {}),         # cell 2: 25 x 25 cells, columns wrap, rows run out
+            ("g2e_init_m200", 1, (-200.0, -200.0), 50, 10, 5, 1, {}),       # IndexError in __init__
+            ("g2e_empty_p100", 1, (100.0, 100.0), 50, 10, 5, 1, {}),        # start not bucketed: random.choice([]) at step 0
+            ("g2e_mid_m55", 3, (-55.5, -55.5), 2000, 10, 5, 1, {}),          # a node below y = -55 or left of x = -55 raises mid-run
+            ("g2e_mid_m55_late", 8, (-55.5, -55.5), 2000, 10, 5, 1, {})):
+        rect, start, goal, obs = shifted(dx, dy)
+        specs.append((name, seed, rect, start, goal, obs, max_step, freq, cell, subs, extra))
+    for org, seed in (((-50.0, -30.0), 7), ((30.0, 20.0), 8)):
+        w = synth.make_rect_world(seed=3, n_obstacles=256, origin=org)
+        specs.append(("g2_org_o256_%s" % ("m50_m30" if org[0] < 0 else "p30_p20"), seed, tuple(w["rect"].tolist()),
+                      tuple(w["start"].tolist()), tuple(w["goal"].tolist()), [tuple(o) for o in w["obstacles"].tolist()],
+                      2000, 10, 5, 1, {"keep_points": False}))
+    only = os.environ.get("AUVP_G2_ONLY")
     for name, seed, rect, start, goal, obs, max_step, freq, cell, subs, extra in specs:
+        if only and name not in only.split(","):
+            continue
         out = run_planner_rrt(seed, rect, start, goal, obs, max_step, freq, cell, subs, **extra)
         save_npz(name + ".npz", **out)
-        print(name, "steps", out["steps"], "done", out["done"], "nodes", len(out["nodes"]),
-              "path", None if "path" not in out else out["path"].shape)
+        print(name, "steps", out["steps"], "done", out.get("done"), "nodes", len(out.get("nodes", ())),
+              "path", None if "path" not in out else out["path"].shape, "error", out.get("error", ""),
+              out.get("error_stage", ""), out.get("error_text", ""),
+              "unbucketed", None if "nodes" not in out else len(out["nodes"]) - int(np.sum(out["bucket_counts"])))
 
 
 # --------------------------------------------------------------------------------------------
