@@ -822,11 +822,14 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     if (ok) {
       if (n_nodes >= capn) { status = -2; break; }
       // the bucket of the new node (:291-320)
+      // (an index below -len is the reference's IndexError: mps_list holds the node by then (:229-230), so it is stored -- in no
+      // bucket -- and the episode ends with AUVP_ERR_ARG before the goal connection's verdict)
       int bk = -1;
+      bool bad_idx = false;
       {
         bool ie = false;
         bk = prrt_bucket_of(P, cx, cy, cth, ie);
-        if (wave_any(ie)) { status = -1; break; }
+        bad_idx = wave_any(ie);
         bk = uni(bk);
       }
       me = n_nodes;
@@ -863,6 +866,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       // the insert is published: record, bucket word and occupied list first, then the counters H's snapshots start from
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) { ctl->n_occ = n_occ; duo_poke(&ctl->ver, n_nodes); }
+      if (bad_idx) { status = -1; break; }
       // ---- connect_to_goal_curve_alt(mps_list[-1]) (:374-423): G's verdict for this node
       if (is_free) {
         done = 1;

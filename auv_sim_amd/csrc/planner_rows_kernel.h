@@ -355,8 +355,9 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
       if (ok && n_nodes >= capn) { status = -2; ok = false; act = false; }
       if (ok) {
         me = n_nodes;
-        if (pre_err) { status = -1; ok = false; act = false; }
-        else {
+        {
+          // (pre_err: the reference's IndexError.  mps_list holds the node by then (:229-230): it is stored -- pre_bk is -1, no
+          // bucket -- and the episode ends with AUVP_ERR_ARG below, before the goal connection and without counting the step)
           const int bk = pre_bk, c_before = pre_c, h_before = pre_h;
           if (rl < 4) {
             // the node's 64-byte record: lanes 0..3 of the row store one 16-byte quarter each -- ONE store instruction and one
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(PRW_WAVES * 64, 3) void prrt_rows_kernel(WorldDev W
           n_points += cnt;
           last_accepted = 1; last_new = me;
         }
+        if (pre_err) { status = -1; ok = false; act = false; }
       }
       // ---------------------------------------------------------------- connect_to_goal_curve_alt(mps_list[-1]) (:374-423)
       // from the LAST list node even if this step's node was rejected (:237); a step that added no node repeats the previous

@@ -565,10 +565,11 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
     if (ok) {
       if (n_nodes >= capn) { status = -2; break; }
       me = n_nodes;
-      // add_node_to_grid (:108-159)
+      // add_node_to_grid (:108-159).  An index below -len is the reference's IndexError: mps_list holds the node by then
+      // (:229-230), so it is stored -- in no bucket -- and the episode ends with AUVP_ERR_ARG before the goal connection
       bool idx_err = false;
       int bk = prrt_bucket_of(P, cx, cy, cth, idx_err);
-      if (wave_any(idx_err)) { status = -1; break; }
+      const bool bad_idx = wave_any(idx_err);
       bk = uni(bk);
       int2 bwn = make_int2(0, 0);
       if (bk >= 0) bwn = buckets[bk];
@@ -596,6 +597,7 @@ __global__ __launch_bounds__(RRT_WAVES * 64, (LAT ? 1 : (J <= 4 ? 5 : (J <= 8 ? 
       n_points += cnt;
       last_accepted = 1; last_new = me;
       last_bk = bk; last_cnt = c_before + 1;
+      if (bad_idx) { status = -1; break; }
     }
     // ---------------------------------------------------------------- connect_to_goal_curve_alt(mps_list[-1]) (:374-423)
     const int last = n_nodes - 1;

@@ -68,7 +68,7 @@ def _mt_state():
 
 class Planner_RRT:
     def __init__(self, start, goal, boundary, obstacles, habitats, exp_rate=1, dist_to_end=2, diff_max=0.5, freq=50,
-                 cell_side_length=2, subsections_in_cell=8, max_nodes=4096, device=0):
+                 cell_side_length=2, subsections_in_cell=8, max_nodes=4096, device=0, context=None):
         self.start = start
         self.goal = goal
         self.boundary_point = boundary
@@ -82,7 +82,9 @@ class Planner_RRT:
         self.freq = freq
         self.last_path = []
         self.t_start = time.time()
-        self._ctx = _lib.Context(device)  # raises without the HIP library / a GPU
+        # (`context`: a caller that builds planner after planner -- RRTEnv.reset -- keeps one device context)
+        self._own_ctx = context is None
+        self._ctx = _lib.Context(device) if context is None else context  # raises without the HIP library / a GPU
         self._ctx.set_world(obstacles=np.array([(float(o.x), float(o.y), float(o.size)) for o in obstacles],
                                                dtype=np.float64).reshape(-1, 3))
         rect = (float(boundary[0].x), float(boundary[0].y), float(boundary[1].x), float(boundary[1].y))
@@ -114,6 +116,12 @@ class Planner_RRT:
             raise IndexError("start state falls outside the bucket grid")  # reference: IndexError in add_node_to_grid
         t = self._pb.tree(0, s0)
         self._mirror_insert(self.start, int(t["node_bucket"][0]))
+
+    def close(self):
+        """release the device context (if this planner created it)"""
+        if self._own_ctx and self._ctx is not None:
+            self._ctx.close()
+        self._ctx = None
 
     # ------------------------------------------------------------------ mirror helpers
     def _bucket_tuple(self, b):
@@ -147,9 +155,21 @@ class Planner_RRT:
         return node
 
     def _final_path(self, s, step_num):
+        """generate_final_course(final_node) (:317-327): the final node and its arc points are new objects of this step
+        (rl_state_id = step_num: :375,:421); behind them come the tree's OWN objects -- every ancestor's path points and the
+        ancestors themselves, each with the rl_state_id of the step that created it (solveRL-RRT.py:981-1006 reads those)"""
         arr = self._pb.paths(np.array([s]))[0]
-        return [Motion_plan_state(float(r[0]), float(r[1]), theta=float(r[2]), traj_time_stamp=float(r[3]),
-                                  rl_state_id=step_num) for r in arr], arr
+        n_new = 1 + int(s["n_arc"])
+        path = [Motion_plan_state(float(r[0]), float(r[1]), theta=float(r[2]), traj_time_stamp=float(r[3]),
+                                  rl_state_id=step_num) for r in arr[:n_new]]
+        m = self.mps_list[-1]
+        while m.parent is not None:
+            path.extend(reversed(m.path))
+            m = m.parent
+        if len(path) != len(arr):
+            raise _lib.AuvpError(-4, "the host mirror of the tree (%d path elements) and the device's path (%d) disagree"
+                                 % (len(path), len(arr)))
+        return path, arr
 
     # ------------------------------------------------------------------ reference API
     def generate_one_node(self, grid_cell, step_num=None, min_length=250):
@@ -161,6 +181,12 @@ class Planner_RRT:
         n = int(s["n_draw32"])
         if n:
             random.getrandbits(32 * n)  # ... and advance it by what the step consumed
+        if s["status"] == -1:
+            # AUVP_ERR_ARG from a step = the reference's IndexError in add_node_to_grid (:127: int(y / cell) or int(x / cell)
+            # below -len on a world whose origin is left of / below 0).  mps_list holds the node by then (:229-230)
+            if s["last_accepted"]:
+                self._pull_new_node(s, step_num)
+            raise IndexError("list index out of range")
         if s["status"] < 0:
             raise _lib.AuvpError(int(s["status"]), "Planner_RRT step failed on the device")
         new_node = self._pull_new_node(s, step_num) if s["last_accepted"] else None

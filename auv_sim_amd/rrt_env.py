@@ -259,3 +259,157 @@ class RRTEnvBatch:
     def tree(self, e):
         s = self._pb.summaries()[e]
         return self._pb.tree(e, s)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the reference-signature environment: what solveRL-RRT.py builds (:651-669) and steps (:711)
+# ----------------------------------------------------------------------------------------------------------------------
+END_GAME_RADIUS = 3.0
+FOLLOWING_RADIUS = 50.0
+OBSTACLE_ZONE = 0.0
+WALL_ZONE = 10.0
+ENV_SIZE = 500.0
+
+
+class RRTEnv:
+    """gym_rrt/envs/rrt_env.py::RRTEnv (:86-449) with its own call sequence -- RRTEnv(), init_env(...), reset(),
+    step(chosen_grid_cell_idx, step_num) -- ONE environment on Python's global `random` stream, so a caller of the reference
+    switches by changing the import.  `self.rrt_planner` is the drop-in Planner_RRT (its tree lives on the MI355X; each step is
+    one generate_one_node launch that continues the global stream on the device and advances it by what the step consumed);
+    the three observation arrays the reference rebuilds from Python lists after every node (:227-231,250-295) come from the
+    device's observation kernel instead.  state["path"] is what the reference stores (:233-234): the new node (a
+    Motion_plan_state with .parent / .path / rl_state_id), the final path as a list of Motion_plan_state whose elements carry
+    the rl_state_id of the step that created them, or the previous value when the step added nothing.
+
+    Not here: gym's spaces (gym is not a dependency: `action_space` / `observation_space` are None), rendering and the
+    matplotlib live graph (visualisation is out of scope).  For many environments at once: RRTEnvBatch above."""
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(self, device=0, max_nodes=4096):
+        self.action_space = None
+        self.observation_space = None
+        self.auv_init_pos = None
+        self.shark_init_pos = None
+        self.state = None
+        self.obstacle_array = []
+        self.obstacle_array_for_rendering = []
+        self.habitats_array = []
+        self.habitats_array_for_rendering = []
+        self.visited_unique_habitat_count = 0
+        self.rrt_planner = None
+        self._device = device
+        self._max_nodes = int(max_nodes)
+        self._ctx = None
+
+    def init_env(self, auv_init_pos, shark_init_pos, boundary_array, grid_cell_side_length, num_of_subsections,
+                 obstacle_array=[], habitat_grid=None):
+        """rrt_env.py:132-180"""
+        self.auv_init_pos = auv_init_pos
+        self.shark_init_pos = shark_init_pos
+        self.obstacle_array_for_rendering = obstacle_array
+        self.habitats_array_for_rendering = []
+        if habitat_grid is not None:
+            self.habitat_grid = habitat_grid
+            self.habitats_array_for_rendering = habitat_grid.habitat_array
+        self.obstacle_array = np.array([[obs.x, obs.y, obs.z, obs.size] for obs in obstacle_array])
+        self.boundary_array = boundary_array
+        self.cell_side_length = grid_cell_side_length
+        self.num_of_subsections = num_of_subsections
+        return self.reset()
+
+    def reset(self):
+        """rrt_env.py:410-449: a new planner (the start node in its bucket) and the initial observation"""
+        from .planner_rrt import Planner_RRT
+        self.visited_unique_habitat_count = 0
+        self.total_time_in_hab = 0
+        a, s = self.auv_init_pos, self.shark_init_pos
+        if self._ctx is None:
+            self._ctx = _lib.Context(self._device)  # one device context for every planner this environment builds
+        self.rrt_planner = Planner_RRT(a, s, self.boundary_array, self.obstacle_array_for_rendering, self.habitats_array_for_rendering,
+                                       cell_side_length=self.cell_side_length, freq=RRT_PLANNER_FREQ,
+                                       subsections_in_cell=self.num_of_subsections, max_nodes=self._max_nodes, context=self._ctx)
+        grid, has, num = self._observation()
+        self.state = {
+            "auv_pos": np.array([a.x, a.y, a.z, a.theta]),
+            "shark_pos": np.array([s.x, s.y, s.z, s.theta]),
+            "obstacles_pos": self.obstacle_array,
+            "rrt_grid": grid,
+            "has_node": has,
+            "path": None,
+            "rrt_grid_num_of_nodes_only": num,
+        }
+        return self.state
+
+    def _observation(self):
+        pb = self.rrt_planner._pb
+        nb = pb.rows * pb.cols * pb.subs
+        grid = np.zeros((nb, 4))
+        has = np.zeros(nb, dtype=np.int64)
+        num = np.zeros(nb, dtype=np.int64)
+        L = _bind()
+        L.auvp_prrt_observation.argtypes = [C.c_void_p, C.c_int32, _lib._dp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        pb.ctx._chk(L.auvp_prrt_observation(pb.ctx.h, 0, _lib._p(grid), has.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            num.ctypes.data_as(C.POINTER(C.c_int64))))
+        return grid, has, num
+
+    def step(self, chosen_grid_cell_idx, step_num):
+        """rrt_env.py:182-247 -> (state, reward, done, {})"""
+        grid_cell_index = chosen_grid_cell_idx // self.num_of_subsections
+        subsection_index = chosen_grid_cell_idx % self.num_of_subsections
+        ncols = len(self.rrt_planner.env_grid[0])
+        row, col = grid_cell_index // ncols, grid_cell_index % ncols
+        chosen_grid_cell = self.rrt_planner.env_grid[row][col].subsection_cells[subsection_index]
+        done, path = self.rrt_planner.generate_one_node(chosen_grid_cell, step_num)
+        self.state["rrt_grid"], self.state["has_node"], self.state["rrt_grid_num_of_nodes_only"] = self._observation()
+        if path is not None:
+            self.state["path"] = path
+        if done and path is not None:
+            reward = R_FOUND_PATH
+        elif path is not None:
+            reward = R_CREATE_NODE
+        else:
+            reward = R_INVALID_NODE
+        return self.state, reward, done, {}
+
+    def close(self):
+        self.rrt_planner = None
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    # ---- the reference's list builders, kept for callers that hand them a grid (:250-295) ----
+    def convert_rrt_grid_to_1D(self, rrt_grid):
+        return np.array([[gc.x, gc.y, sub.theta, len(sub.node_array)] for row in rrt_grid for gc in row for sub in gc.subsection_cells])
+
+    def convert_rrt_grid_to_1D_num_of_nodes_only(self, rrt_grid):
+        return np.array([len(sub.node_array) for row in rrt_grid for gc in row for sub in gc.subsection_cells])
+
+    def generate_rrt_grid_has_node_array(self, rrt_grid):
+        return np.array([0 if len(sub.node_array) == 0 else 1 for row in rrt_grid for gc in row for sub in gc.subsection_cells])
+
+    # ---- geometry helpers of the reference class (:298-379) ----
+    def calculate_range(self, a_pos, b_pos):
+        delta_x = b_pos[0] - a_pos[0]
+        delta_y = b_pos[1] - a_pos[1]
+        return np.sqrt(delta_x ** 2 + delta_y ** 2)
+
+    def within_follow_range(self, auv_pos, shark_pos):
+        return bool(self.calculate_range(auv_pos, shark_pos) <= FOLLOWING_RADIUS)
+
+    def check_collision(self, auv_pos):
+        for obs in self.obstacle_array:
+            if self.calculate_range(auv_pos, obs) <= obs[3]:
+                return True
+        return False
+
+    def check_close_to_obstacles(self, auv_pos):
+        for obs in self.obstacle_array:
+            if self.calculate_range(auv_pos, obs) <= (obs[3] + OBSTACLE_ZONE):
+                return True
+        return False
+
+    def check_close_to_walls(self, auv_pos, dist_from_walls_array):
+        for dist_from_wall in dist_from_walls_array:
+            if dist_from_wall <= WALL_ZONE:
+                return True
+        return False

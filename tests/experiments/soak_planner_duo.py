@@ -24,7 +24,10 @@ bad = 0
 FALLBACKS = [0]
 for c in range(n_cases):
     n_obst = int(rng.choice([8, 64, 128, 256]))
-    w = synth.make_rect_world(seed=int(rng.integers(1, 10_000)), n_obstacles=n_obst)
+    # round 6: every third world is translated (the bucket grid ignores the origin: wrapped indexes, unbucketed nodes, and the
+    # reference's IndexError = status -1 with the offending node stored: the two kernels must agree on all of it)
+    origin = (0.0, 0.0) if rng.random() < 0.67 else (round(float(rng.uniform(-260.0, 120.0)), 2), round(float(rng.uniform(-260.0, 120.0)), 2))
+    w = synth.make_rect_world(seed=int(rng.integers(1, 10_000)), n_obstacles=n_obst, origin=origin)
     ctx.set_world(obstacles=w["obstacles"])
     E = int(rng.choice([1, 2, 5, 33, 130, 600]))
     max_step = int(rng.choice([1, 2, 7, 80, 500, 2000])) if E < 600 else int(rng.choice([1, 7, 80]))
@@ -66,7 +69,7 @@ for c in range(n_cases):
             diff += ["path%d" % e for e in range(E) if not np.array_equal(ref[4][e], paths[e])][:3]
             if diff:
                 bad += 1
-                print("MISMATCH case %d waves %d E=%d max_step=%d obst=%d %s: %s" % (c, waves, E, max_step, n_obst, kw, diff[:8]))
+                print("MISMATCH case %d waves %d E=%d max_step=%d obst=%d %s origin %s: %s" % (c, waves, E, max_step, n_obst, kw, origin, diff[:8]))
     if c % 10 == 9:
         print("  %d cases, %d mismatches (last: E=%d max_step=%d done %d)" % (c + 1, bad, E, max_step, int(ref[0]["done"].sum())), flush=True)
 print("planner soak: %d cases, %d mismatches, %d episodes redone by the pipeline fallback" % (n_cases, bad, FALLBACKS[0]))

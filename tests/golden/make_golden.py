@@ -810,23 +810,37 @@ def g8():
     MPS = mpsm.Motion_plan_state
     planmod.time = refstubs.VirtualClock()
     lay = main_layout_obstacles()
-    for name, seed, cell, subs, n_steps in (("g8_env_s1", 5, 5, 1, 700), ("g8_env_s8", 6, 5, 4, 400)):
+    # round 6: `policy` "planning" = the agent plays Planner_RRT.planning's own rule (random.choice of the occupied list, from the
+    # same global stream: :186), so the run ends with a found path -- state["path"] as a LIST whose elements carry the
+    # rl_state_id of the step that created them (solveRL-RRT.py:981-1006 reads those) -- and `origin` translates the world
+    # (negative bucket indexes in the environment's flat index arithmetic: rrt_env.py:203-213 sees the wrapped cell)
+    for name, seed, cell, subs, n_steps, (dx, dy), policy in (
+            ("g8_env_s1", 5, 5, 1, 700, (0.0, 0.0), "cycle"), ("g8_env_s8", 6, 5, 4, 400, (0.0, 0.0), "cycle"),
+            ("g8_env_plan_s1", 1, 5, 1, 1500, (0.0, 0.0), "planning"), ("g8_env_org_m50_m30", 3, 5, 2, 1500, (-50.0, -30.0), "planning"),
+            ("g8_env_org_p30_p20", 9, 5, 4, 500, (30.0, 20.0), "cycle")):
         with contextlib.redirect_stdout(io.StringIO()):
             env = envmod.RRTEnv()
-            auv = MPS(x=10.0, y=10.0, z=-5.0, theta=0.0)
-            shark = MPS(x=35.0, y=45.0, z=-5.0, theta=0.0)
-            obs = [MPS(x=o[0], y=o[1], size=o[2]) for o in lay]
-            bnd = [MPS(x=0.0, y=0.0), MPS(x=50.0, y=50.0)]
+            auv = MPS(x=10.0 + dx, y=10.0 + dy, z=-5.0, theta=0.0)
+            shark = MPS(x=35.0 + dx, y=45.0 + dy, z=-5.0, theta=0.0)
+            obs = [MPS(x=o[0] + dx, y=o[1] + dy, size=o[2]) for o in lay]
+            bnd = [MPS(x=dx, y=dy), MPS(x=50.0 + dx, y=50.0 + dy)]
             random.seed(seed)
             st = env.init_env(auv, shark, bnd, cell, subs, obs)
         grid0 = np.array(st["rrt_grid"], dtype=np.float64)
         choices, rewards, dones, counts = [], [], [], []
+        path_kind, node_rec = [], []   # what step() returned as `path`: 0 None (state["path"] keeps its value), 1 a node, 2 a list
         done = False
+        ncols_env = len(env.rrt_planner.env_grid[0])
+        nrows_env = len(env.rrt_planner.env_grid)
         for i in range(n_steps):
             has = np.flatnonzero(np.asarray(env.state["has_node"]))
-            # deterministic policy: cycle through the occupied flat indices, every 7th step an empty one
-            idx = int(has[i % len(has)])
-            if i % 7 == 3:
+            if policy == "planning":
+                r_, c_, k_ = random.choice(env.rrt_planner.occupied_grid_cells_array)
+                idx = ((r_ % nrows_env) * ncols_env + c_ % ncols_env) * subs + k_ % subs
+            else:
+                # deterministic policy: cycle through the occupied flat indices, every 7th step an empty one
+                idx = int(has[i % len(has)])
+            if policy == "cycle" and i % 7 == 3:
                 empt = np.flatnonzero(np.asarray(env.state["has_node"]) == 0)
                 idx = int(empt[(i * 13) % len(empt)])
                 # the reference blocks on input() for an empty cell (rrt_dubins.py:219): answer it
@@ -835,16 +849,27 @@ def g8():
                 builtins.input = lambda *a: ""
             with contextlib.redirect_stdout(io.StringIO()):
                 s, r, done, _ = env.step(idx, i)
-            if i % 7 == 3:
+            if policy == "cycle" and i % 7 == 3:
                 builtins.input = old_input
             choices.append(idx); rewards.append(r); dones.append(bool(done))
             counts.append(np.asarray(s["rrt_grid_num_of_nodes_only"], dtype=np.int64).copy())
+            # the `path` of this step: generate_one_node's second value, which state["path"] takes unless it is None (:233-234)
+            pth = s["path"]
+            if r == envmod.R_INVALID_NODE:
+                path_kind.append(0); node_rec.append([np.nan] * 5)
+            elif isinstance(pth, list):
+                path_kind.append(2); node_rec.append([np.nan] * 5)
+            else:
+                path_kind.append(1)
+                node_rec.append([pth.x, pth.y, pth.theta, pth.traj_time_stamp, -1 if pth.rl_state_id is None else pth.rl_state_id])
             if done:
                 break
         last = env.state
         path = last["path"]
-        out = {"seed": seed, "cell": cell, "subs": subs, "obstacles": np.array(lay, dtype=np.float64),
-               "rect": np.array([0.0, 0.0, 50.0, 50.0]), "start": np.array([10.0, 10.0]), "goal": np.array([35.0, 45.0]),
+        out = {"seed": seed, "cell": cell, "subs": subs, "obstacles": np.array([(o[0] + dx, o[1] + dy, o[2]) for o in lay], dtype=np.float64),
+               "rect": np.array([dx, dy, 50.0 + dx, 50.0 + dy]), "start": np.array([10.0 + dx, 10.0 + dy]),
+               "goal": np.array([35.0 + dx, 45.0 + dy]), "policy": policy,
+               "path_kind": np.array(path_kind, dtype=np.int8), "node_rec": np.array(node_rec, dtype=np.float64).reshape(-1, 5),
                "freq": envmod.RRT_PLANNER_FREQ, "rrt_grid0": grid0, "choices": np.array(choices, dtype=np.int64),
                "rewards": np.array(rewards, dtype=np.int64), "dones": np.array(dones, dtype=np.int8),
                "counts": np.array(counts, dtype=np.int64), "final_rrt_grid": np.array(last["rrt_grid"], dtype=np.float64),
@@ -852,6 +877,9 @@ def g8():
                "done": bool(done)}
         if done and isinstance(path, list):
             out["path"] = np.array([[p.x, p.y, p.theta, p.traj_time_stamp] for p in path], dtype=np.float64)
+            out["path_state_id"] = np.array([-1 if p.rl_state_id is None else p.rl_state_id for p in path], dtype=np.int64)
+            out["path0_length"] = float(path[0].length)
+            out["cal_length"] = float(env.rrt_planner.cal_length(path))  # (solveRL-RRT.py:1343)
         save_npz(name + ".npz", **out)
         print(name, "steps", len(choices), "done", done, "rewards", {int(k): int((np.array(rewards) == k).sum()) for k in set(rewards)})
 

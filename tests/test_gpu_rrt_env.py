@@ -339,3 +339,105 @@ def test_graphs_die_with_their_batch_and_modes_do_not_mix():
     assert gid2 != gid
     env.replay(gid2, 2)
     env.sync()
+
+
+G8_ALL = ["g8_env_s1", "g8_env_s8", "g8_env_plan_s1", "g8_env_org_m50_m30", "g8_env_org_p30_p20"]
+
+
+def _g8_world(g):
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    obstacles = [MPS(o[0], o[1], size=o[2]) for o in g["obstacles"].tolist()]
+    r = g["rect"]
+    bnd = [MPS(float(r[0]), float(r[1])), MPS(float(r[2]), float(r[3]))]
+    auv = MPS(float(g["start"][0]), float(g["start"][1]), z=-5.0, theta=0.0)
+    shark = MPS(float(g["goal"][0]), float(g["goal"][1]), z=-5.0, theta=0.0)
+    return auv, shark, bnd, obstacles
+
+
+@pytest.mark.parametrize("name", G8_ALL)
+def test_reference_signature_rrtenv_replays_the_reference_run(name):
+    """auv_sim_amd.rrt_env.RRTEnv -- the reference's own call sequence RRTEnv() / init_env(...) / step(idx, step_num)
+    (gym_rrt/envs/rrt_env.py:132,182,410; solveRL-RRT.py:651-669,711) -- against the reference's run (G8): observations,
+    rewards, done flags, state["path"] as the reference stores it (the new node object; the final path as a list whose elements
+    carry the rl_state_id of the step that created them; unchanged when a step adds nothing), the global stream's position.
+    Two fixtures are translated worlds (negative / past-the-grid bucket indexes under the environment's flat index)."""
+    import random
+    from auv_sim_amd.motion_plan_state import Motion_plan_state as MPS
+    from auv_sim_amd.rrt_env import RRTEnv
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    auv, shark, bnd, obstacles = _g8_world(g)
+    random.seed(int(g["seed"]))
+    env = RRTEnv()
+    st = env.init_env(auv, shark, boundary_array=bnd, grid_cell_side_length=int(g["cell"]), obstacle_array=obstacles,
+                      num_of_subsections=int(g["subs"]))
+    assert set(st) == {"auv_pos", "shark_pos", "obstacles_pos", "rrt_grid", "has_node", "path", "rrt_grid_num_of_nodes_only"}
+    assert st["path"] is None and np.array_equal(st["rrt_grid"], g["rrt_grid0"])
+    assert np.array_equal(st["auv_pos"], [auv.x, auv.y, -5.0, 0.0]) and np.array_equal(st["shark_pos"], [shark.x, shark.y, -5.0, 0.0])
+    planning_policy = str(g["policy"]) == "planning"
+    prev_path = None
+    nrows, ncols, subs = len(env.rrt_planner.env_grid), len(env.rrt_planner.env_grid[0]), int(g["subs"])
+    for i, idx in enumerate(g["choices"].tolist()):
+        if planning_policy:  # the agent of this fixture draws its choice from the global stream, as planning() does (:186)
+            r_, c_, k_ = random.choice(env.rrt_planner.occupied_grid_cells_array)
+            assert ((r_ % nrows) * ncols + c_ % ncols) * subs + k_ % subs == idx, i
+        st, reward, done, info = env.step(idx, i)
+        assert reward == g["rewards"][i] and bool(done) == bool(g["dones"][i]) and info == {}, i
+        assert np.array_equal(st["rrt_grid_num_of_nodes_only"], g["counts"][i]), i
+        kind = int(g["path_kind"][i])
+        if kind == 0:
+            assert st["path"] is prev_path
+        elif kind == 1:
+            node = st["path"]
+            assert isinstance(node, MPS) and node is env.rrt_planner.mps_list[-1]
+            want = g["node_rec"][i]
+            np.testing.assert_allclose([node.x, node.y, node.theta, node.traj_time_stamp], want[:4], rtol=1e-9, atol=1e-9)
+            assert node.rl_state_id == int(want[4]) == i
+            assert node.parent is node.path[0] and node.parent in env.rrt_planner.mps_list
+        else:
+            assert isinstance(st["path"], list)
+        prev_path = st["path"]
+    assert np.array_equal(st["rrt_grid"], g["final_rrt_grid"]) and np.array_equal(st["has_node"], g["final_has_node"])
+    if bool(g["done"]):
+        path = st["path"]
+        assert len(path) == len(g["path"])
+        got = np.array([[p.x, p.y, p.theta, p.traj_time_stamp] for p in path])
+        np.testing.assert_allclose(got, g["path"], rtol=1e-9, atol=1e-9)
+        ids = [-1 if p.rl_state_id is None else p.rl_state_id for p in path]
+        assert ids == g["path_state_id"].tolist()
+        np.testing.assert_allclose(path[0].length, float(g["path0_length"]), rtol=1e-9)
+        np.testing.assert_allclose(env.rrt_planner.cal_length(path), float(g["cal_length"]), rtol=1e-9)
+        # the tree's own objects make up the tail of the path (generate_final_course :317-327)
+        assert path[-1] is env.rrt_planner.mps_list[0]
+    assert random.random() == float(g["rng_after"])
+    # reset(): a fresh planner on the same device context, the initial observation again
+    random.seed(int(g["seed"]))
+    st2 = env.reset()
+    assert st2["path"] is None and np.array_equal(st2["rrt_grid"], g["rrt_grid0"])
+    st2, reward, done, _ = env.step(int(g["choices"][0]) if not planning_policy else int(g["choices"][0]), 0)
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["g8_env_org_m50_m30", "g8_env_org_p30_p20"])
+def test_env_batch_on_a_translated_world(name):
+    """RRTEnvBatch.step (global-stream mode) on the translated G8 worlds: same rewards / counts / stream position"""
+    import random
+    from auv_sim_amd.rrt_env import RRTEnvBatch
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    auv, shark, bnd, obstacles = _g8_world(g)
+    random.seed(int(g["seed"]))
+    env = RRTEnvBatch(auv, shark, bnd, int(g["cell"]), int(g["subs"]), obstacles, seeds=None, max_nodes=1600, freq=int(g["freq"]))
+    st = env.reset()
+    assert np.array_equal(st["rrt_grid"][0], g["rrt_grid0"])
+    planning_policy = str(g["policy"]) == "planning"
+    for i, idx in enumerate(g["choices"].tolist()):
+        if planning_policy:
+            occ = np.flatnonzero(st["has_node"][0])
+            # the reference's occupied list is in creation order; the device's list is the same list
+            occ_list = [int(b) for b in env._pb.grid(0)[0]]
+            assert sorted(occ_list) == occ.tolist()
+            assert random.choice(occ_list) == idx, i
+        st, reward, done, _ = env.step([idx], step_num=i)
+        assert reward[0] == g["rewards"][i] and bool(done[0]) == bool(g["dones"][i]), i
+        assert np.array_equal(st["rrt_grid_num_of_nodes_only"][0], g["counts"][i]), i
+    assert np.array_equal(st["rrt_grid"][0], g["final_rrt_grid"]) and np.array_equal(st["has_node"][0], g["final_has_node"])
+    assert random.random() == float(g["rng_after"])
