@@ -12,10 +12,11 @@ import numpy as np
 
 def make_world(seed=0, n_obstacles=64, box=(-300.0, -100.0, -100.0, 100.0), cell=10.0,
                n_bins=10, bin_len=50, n_habitats=10, start=None, obst_radius=None,
-               hab_radius=(8.0, 20.0), pmax=0.3):
+               hab_radius=(8.0, 20.0), pmax=0.3, polygon=None):
     """Return a dict of fp64 arrays describing one world.
 
-    obstacles [O,3] (x,y,r); habitats [H,3]; polygon [V,2] (rectangle, counter-clockwise);
+    obstacles [O,3] (x,y,r); habitats [H,3]; polygon [V,2] (the box as a counter-clockwise rectangle, or `polygon`:
+    vertices inside the box, or the name of one of POLYGONS, scaled to the box -- the draws are the rectangle world's);
     bins [T,2] (t0,t1) integer-valued; cells [C,4] (minx,miny,maxx,maxy) row-major from the
     bottom-left; prob [T,C]; start (x,y) = box centre unless given.
     """
@@ -49,12 +50,31 @@ def make_world(seed=0, n_obstacles=64, box=(-300.0, -100.0, -100.0, 100.0), cell
         "start": np.array(start, dtype=np.float64),
         "obstacles": np.array(obstacles, dtype=np.float64).reshape(-1, 3),
         "habitats": np.array(habitats, dtype=np.float64).reshape(-1, 3),
-        "polygon": np.array([(x0, y0), (x1, y0), (x1, y1), (x0, y1)], dtype=np.float64),
+        "polygon": _polygon(polygon, box),
         "bins": np.array(bins, dtype=np.float64).reshape(-1, 2),
         "cells": np.array(cells, dtype=np.float64).reshape(-1, 4),
         "prob": np.array(prob, dtype=np.float64).reshape(n_bins, -1),
         "grid_shape": (nrow, ncol),
     }
+
+
+# workspace outlines in unit-box coordinates (u, v) -> (x0 + u (x1 - x0), y0 + v (y1 - y0))
+POLYGONS = {
+    # the reference's Catalina boundary (path_planning/catalina.py:71-73: five lat / lon vertices, ~550 m x 345 m) in local
+    # metres, normalised to its bounding box: a slanted convex pentagon (the workspace RRT.exploring really runs in)
+    "catalina": ((0.0, 0.690), (0.197, 1.0), (1.0, 0.420), (0.747, 0.0), (0.239, 0.330)),
+    # concave: a wedge cut into the top edge down to just above the centre, and a clipped corner (8 vertices)
+    "notch": ((0.0, 0.0), (0.85, 0.0), (1.0, 0.2), (1.0, 1.0), (0.62, 1.0), (0.5, 0.56), (0.38, 1.0), (0.0, 1.0)),
+}
+
+
+def _polygon(polygon, box):
+    x0, y0, x1, y1 = box
+    if polygon is None:
+        return np.array([(x0, y0), (x1, y0), (x1, y1), (x0, y1)], dtype=np.float64)
+    if isinstance(polygon, str):
+        return np.array([(x0 + u * (x1 - x0), y0 + v * (y1 - y0)) for u, v in POLYGONS[polygon]], dtype=np.float64)
+    return np.array(polygon, dtype=np.float64).reshape(-1, 2)
 
 
 def make_rect_world(seed=0, n_obstacles=256, size=200.0, start=(20.0, 20.0), goal=(170.0, 180.0),

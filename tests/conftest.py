@@ -53,8 +53,9 @@ def golden_world(g):
         return {k: g[k] for k in keys}
     from auv_sim_amd import synth
     kw = json.loads(str(g["world_kwargs"]))
-    if "box" in kw:
-        kw["box"] = tuple(kw["box"])
+    for k in ("box", "start"):
+        if k in kw:
+            kw[k] = tuple(kw[k])
     w = synth.make_world(**kw)
     h = hashlib.sha256()
     for k in keys:

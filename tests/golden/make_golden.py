@@ -256,7 +256,7 @@ def g4():
 # --------------------------------------------------------------------------------------------
 def run_exploring(seed, world, n_iter, mode, freq=30, bin_interval=5, v=2, shark_interval=50,
                   max_traj_time=500.0, weights=(-3, -3, -4), dist_to_end=2, diff_max=0.5,
-                  keep_points=True):
+                  keep_points=True, count_boundary=False):
     rrt_mod, mpsm, cost_mod = import_rrt()
     MPS = mpsm.Motion_plan_state
     obstacles, habitats, poly, cell_list, shark = ref_world(world, MPS)
@@ -280,8 +280,15 @@ def run_exploring(seed, world, n_iter, mode, freq=30, bin_interval=5, v=2, shark
         cur["npath"] = len(new.path)
         return new
 
+    far = refstubs.Polygon([(-1e9, -1e9), (1e9, -1e9), (1e9, 1e9), (-1e9, 1e9)])
+
     def check_collision(m, obs):
         r = orig_cc(m, obs)
+        if not r:
+            # a rejection the boundary alone decided: the same path is free once the polygon test cannot fail (no draws involved)
+            keep, rrt.boundary_poly = rrt.boundary_poly, far
+            log["boundary_rejects"] = log.get("boundary_rejects", 0) + (1 if orig_cc(m, obs) else 0)
+            rrt.boundary_poly = keep
         log["parent"].append(cur["parent"])
         log["npath"].append(cur["npath"])
         log["accepted"].append(bool(r))
@@ -336,6 +343,8 @@ def run_exploring(seed, world, n_iter, mode, freq=30, bin_interval=5, v=2, shark
         "n_points": len(pts),
         "error": err or "",
     }
+    if count_boundary:
+        out["boundary_rejects"] = int(log.get("boundary_rejects", 0))
     if keep_points:
         out["points"] = pts
     if res is not None:
@@ -391,6 +400,24 @@ def g3():
         ("g3_nn_long_c40000_i4000", 7, dict(seed=2, n_obstacles=256, box=(-1000.0, -1000.0, 1000.0, 1000.0), cell=10.0, n_bins=10,
                                             bin_len=50, n_habitats=10), 4000, "nn",
          {"max_traj_time": 20000.0, "keep_points": False, "store_world": False}),
+        # round 6: whole episodes on boundaries that are NOT rectangles -- the device's polygon crossing test instead of its
+        # rectangle shortcut, against Point.within(self.boundary_poly) (:545-546) -- `boundary_rejects` counts the steers the
+        # boundary alone rejected (>= 100 in each).  "catalina": the reference's 5-vertex workspace outline
+        # (path_planning/catalina.py:71-73) over the bench's Catalina-sized side world (560 x 350 m, 1 000 cells of 14 m, 256
+        # obstacles r = 2-8 m; bench.py: catalina_560x350_o256), "notch": a concave 8-vertex outline; and that side world
+        # itself with its rectangle.  The catalina worlds' tables are rebuilt from world_kwargs (SHA-256 stored).
+        ("g3_tb_cat_penta", 31, dict(seed=5, n_obstacles=256, box=(0.0, 0.0, 560.0, 350.0), cell=14.0, obst_radius=(2.0, 8.0),
+                                     hab_radius=(20.0, 55.0), polygon="catalina", start=(150.0, 160.0)), 2500, "timebin",
+         {"keep_points": False, "store_world": False, "count_boundary": True}),
+        ("g3_nn_cat_penta", 32, dict(seed=5, n_obstacles=256, box=(0.0, 0.0, 560.0, 350.0), cell=14.0, obst_radius=(2.0, 8.0),
+                                     hab_radius=(20.0, 55.0), polygon="catalina", start=(150.0, 160.0)), 2000, "nn",
+         {"max_traj_time": 300.0, "keep_points": False, "store_world": False, "count_boundary": True}),
+        ("g3_tb_notch", 33, dict(seed=8, n_obstacles=64, polygon="notch"), 2500, "timebin", {"count_boundary": True, "keep_points": False}),
+        ("g3_nn_notch", 34, dict(seed=8, n_obstacles=64, polygon="notch"), 2000, "nn",
+         {"max_traj_time": 300.0, "count_boundary": True, "keep_points": False}),
+        ("g3_tb_cat_rect", 35, dict(seed=5, n_obstacles=256, box=(0.0, 0.0, 560.0, 350.0), cell=14.0, obst_radius=(2.0, 8.0),
+                                    hab_radius=(20.0, 55.0)), 2500, "timebin",
+         {"keep_points": False, "store_world": False, "count_boundary": True}),
     ]
     only = os.environ.get("AUVP_G3_ONLY")
     for name, seed, wk, n_iter, mode, extra in specs:
@@ -407,7 +434,7 @@ def g3():
             wa = {}
         save_npz(name + ".npz", **wa, start=world["start"], **meta, **out)
         print(name, "iters", out["iters_run"], "nodes", len(out["nodes"]), "leaves", len(out["leaf_iter"]),
-              "err", out["error"], "cost", out.get("res_cost"))
+              "err", out["error"], "cost", out.get("res_cost"), "boundary rejects", out.get("boundary_rejects"))
 
 
 # --------------------------------------------------------------------------------------------
