@@ -124,8 +124,6 @@ def load():
     L.auvp_unset_option.argtypes = [vp, C.c_char_p]
     L.auvp_get_option.argtypes = [vp, C.c_char_p, _ip, C.POINTER(C.c_int64)]
     L.auvp_pipeline_fallbacks.argtypes = [vp, _ip, C.POINTER(C.c_int64)]
-    if os.environ.get("AUVP_TEST_ENV_OPTIONS") == "1":
-        L = _EnvOptionsLib(L)
     _lib = L
     return L
 
@@ -135,66 +133,6 @@ def load():
 OPTION_NAMES = ("ROWS", "DUO", "TRIO", "QUAD", "TIGHT_CULL", "NN_EXACT", "LEAF_SWEEP_ALL", "NO_HABITAT_GRID", "RG_MAX_ENTRIES",
                 "NO_GRID_INDEX", "PRRT_LAT", "PRRT_PIPE", "PRRT_OBST_LDS", "PRRT_NEXT_LDS", "PRRT_ROWS", "ASTAR_NO_GRID",
                 "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK")
-
-
-class _EnvOptionsLib:
-    """TEST HARNESS ONLY (AUVP_TEST_ENV_OPTIONS=1, set by tests/conftest.py and the probe scripts): the tests steer kernel
-    choices by changing AUVP_<NAME> in os.environ between calls on a live context.  The library itself reads the environment
-    once, at auvp_create; this proxy pushes the current environment into the handle's options (auvp_set_option /
-    auvp_unset_option) before every call that takes a handle.  Without the variable load() returns the plain CDLL."""
-
-    def __init__(self, lib):
-        object.__setattr__(self, "_lib", lib)
-        object.__setattr__(self, "_fns", {})
-        object.__setattr__(self, "_seen", {})
-
-    def _sync(self, args):
-        if not args or not isinstance(args[0], C.c_void_p) or not args[0].value:
-            return
-        seen = self._seen.setdefault(args[0].value, {})
-        for name in OPTION_NAMES:
-            v = os.environ.get("AUVP_" + name)
-            if name in seen and seen[name] == v:
-                continue
-            first = name not in seen
-            seen[name] = v
-            if v is None:
-                if not first:  # (first sight and absent: nothing to take back)
-                    self._lib.auvp_unset_option(args[0], name.encode())
-            else:
-                try:
-                    iv = int(v)
-                except ValueError:
-                    iv = 0
-                self._lib.auvp_set_option(args[0], name.encode(), iv)
-
-    def __getattr__(self, name):
-        f = getattr(self._lib, name)
-        if not name.startswith("auvp_") or name in ("auvp_create", "auvp_destroy", "auvp_set_option", "auvp_unset_option"):
-            return f
-        w = self._fns.get(name)
-        if w is None:
-            w = self._fns[name] = _SyncedFn(f, self._sync)
-        return w
-
-    def __setattr__(self, name, value):
-        setattr(self._lib, name, value)
-
-
-class _SyncedFn:
-    def __init__(self, f, sync):
-        object.__setattr__(self, "_f", f)
-        object.__setattr__(self, "_sync", sync)
-
-    def __call__(self, *args):
-        self._sync(args)
-        return self._f(*args)
-
-    def __getattr__(self, name):
-        return getattr(self._f, name)
-
-    def __setattr__(self, name, value):
-        setattr(self._f, name, value)
 
 
 def _f64(a, shape=None):

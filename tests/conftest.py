@@ -3,13 +3,18 @@ import sys
 
 import pytest
 
-# the tests steer kernel choices through AUVP_<NAME> in os.environ on live contexts: auv_sim_amd/_lib.py pushes the environment
-# into the handle's options before every call when this is set (the library itself reads the environment once, at auvp_create)
-os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")
-
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+# many tests steer kernel choices through AUVP_<NAME> in os.environ on live contexts (monkeypatch.setenv); the library reads the
+# environment once, at auvp_create.  tests/env_options.py wraps the loaded library -- in the test process only, the product
+# package has no such hook -- so that the current environment is pushed into the handle's options before every call
+import env_options  # noqa: E402
+
+env_options.install()
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 

@@ -5,7 +5,6 @@ kernel, the one-episode kernel and the CPU checker (RRT.exploring, time-bin samp
 and plan-time sampling), the astar_fixLenSOG / astar_fixLen searches and Planner_RRT.planning (latency, throughput and
 four-episodes-per-wavefront kernels) with the checker.  Prints one line per failure and a summary; exit code 1 on any mismatch."""
 import os
-os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import random
 import sys
 
@@ -13,6 +12,9 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from auv_sim_amd import _lib, _astar_lib, synth  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import env_options  # noqa: E402  (tests/env_options.py: AUVP_<NAME> in os.environ steers live contexts -- this process only)
+env_options.install()
 from auv_sim_amd._prrt_lib import PlannerBatch  # noqa: E402
 from oracle import orc, orc_astar as oa, orc_planner as op  # noqa: E402
 

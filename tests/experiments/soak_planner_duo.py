@@ -7,13 +7,15 @@ With a diagnostic build (AUVPLAN_LIBRARY=auv_sim_amd/libauvplan_diag.so) AUVP_DI
 AUVP_DIAG_SPIN makes the bounded waits run out: the episodes redone by the pipeline fallback are counted in the last line.
 usage: python tests/experiments/soak_planner_duo.py <cases> <seed>"""
 import os
-os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from auv_sim_amd import _lib, synth  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import env_options  # noqa: E402  (tests/env_options.py: AUVP_<NAME> in os.environ steers live contexts -- this process only)
+env_options.install()
 from auv_sim_amd._prrt_lib import PlannerBatch  # noqa: E402
 
 n_cases, seed = int(sys.argv[1]), int(sys.argv[2])

@@ -2,10 +2,12 @@
 shuffled cell lists, points on cell and bin edges, window radii 1 .. 14 cells, the three window-sum kernels (AUVP_SOG_TILE).
 usage: python tests/experiments/soak_sog.py [n_cases] [seed]"""
 import os, sys
-os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
 from auv_sim_amd import _lib  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import env_options  # noqa: E402  (tests/env_options.py: AUVP_<NAME> in os.environ steers live contexts -- this process only)
+env_options.install()
 from auv_sim_amd.sharkOccupancyGrid import convert_arrays  # noqa: E402
 from oracle import orc_sog  # noqa: E402
 

@@ -122,7 +122,6 @@ print(int((s0["status"] == -9).sum()), f0[0], int((s1["status"] < 0).sum()), f1[
       all(np.array_equal(s1[k], s2[k]) for k in s1.dtype.names if k != "n_candidates"))
 ''' % REPO
     env = dict(os.environ, AUVPLAN_LIBRARY=DIAG, AUVP_DIAG_SPIN="6", AUVP_DIAG_JITTER="1,3,1,32,5")
-    env.pop("AUVP_TEST_ENV_OPTIONS", None)
     r = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     n9, redone0, nbad1, redone1, kern, same = r.stdout.strip().splitlines()[-1].split()

@@ -3,7 +3,6 @@
 AUVP_ROWS=1: four), on the headline world: where the host's choice between them (auvplan.hip: rows above 24 episodes per CU)
 sits.  Run on a GPU box: python tools/batch_size_probe.py [iters]"""
 import os
-os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np
@@ -11,6 +10,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from auv_sim_amd import _lib  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import env_options  # noqa: E402  (tests/env_options.py: AUVP_<NAME> in os.environ steers live contexts -- this process only)
+env_options.install()
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 world = bench.bench_world(256, 200)

@@ -2,7 +2,6 @@
 """Latency runs with one (rrt_explore_kernel), two (rrt_duo_kernel) and three (rrt_trio_kernel) wavefronts per episode: one
 episode, 64 / 256 / 1 024 episodes of the headline world, and config 2's 1 024 replicas (64 obstacles).  Run on a GPU box."""
 import os
-os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np
@@ -10,6 +9,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from auv_sim_amd import _lib  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import env_options  # noqa: E402  (tests/env_options.py: AUVP_<NAME> in os.environ steers live contexts -- this process only)
+env_options.install()
 
 ctx = _lib.Context(0)
 iters = 10000

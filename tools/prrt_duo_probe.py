@@ -2,13 +2,15 @@
 """Config 4 (512 Planner_RRT.planning(2000) episodes) with one / two / three wavefronts per episode.  With a diagnostic build
 (AUVPLAN_LIBRARY=<lib built with -DAUVP_DUO_DIAG>) also the shader clocks per step each wavefront spends at work."""
 import os
-os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from auv_sim_amd import _lib, synth  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import env_options  # noqa: E402  (tests/env_options.py: AUVP_<NAME> in os.environ steers live contexts -- this process only)
+env_options.install()
 from auv_sim_amd._prrt_lib import PlannerBatch  # noqa: E402
 
 ctx = _lib.Context(0)

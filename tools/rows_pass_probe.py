@@ -10,7 +10,6 @@ Prints one JSON line per freq: rrt_rows_kernel ms on the headline batch (12 288 
 nodes and path points per episode (the trees are the same for every padding)."""
 import json
 import os
-os.environ.setdefault("AUVP_TEST_ENV_OPTIONS", "1")  # kernel choices through AUVP_<NAME> on live contexts (auv_sim_amd/_lib.py)
 import sys
 
 import numpy as np
@@ -18,6 +17,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from auv_sim_amd import _lib  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import env_options  # noqa: E402  (tests/env_options.py: AUVP_<NAME> in os.environ steers live contexts -- this process only)
+env_options.install()
 
 freqs = [int(a) for a in sys.argv[1:]] or [30, 15, 8]
 E, iters = 12288, 10000
