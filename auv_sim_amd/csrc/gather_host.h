@@ -34,6 +34,8 @@ struct RcclApi {
   int (*Broadcast)(const void*, void*, size_t, int, int, auvp_ncclComm_t, hipStream_t) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, auvp_ncclComm_t, hipStream_t) = nullptr;  // optional (gather to a root)
+  int (*Recv)(void*, size_t, int, int, auvp_ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string err, bound;
 };
@@ -92,6 +94,9 @@ void rccl_api_fill(RcclApi& api) {
   api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
   if (!api.err.empty()) { dlclose(api.so); api.so = nullptr; return; }
+  // point-to-point (RCCL >= 2.7): only the gather to a root needs them, their absence is reported by that call
+  api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(api.so, "ncclSend"));
+  api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(api.so, "ncclRecv"));
   Dl_info di;
   if (dladdr(reinterpret_cast<void*>(api.AllGather), &di) && di.dli_fname) api.bound = di.dli_fname;
 }
@@ -109,10 +114,21 @@ struct CommState {
   DevBuf counts;  // [world][2] int64: byte count and receive capacity of every rank (variable-length gather)
   hipEvent_t g0 = nullptr, g1 = nullptr;
   double last_ms = 0.0;
+  // the gather to a root runs on a stream of its own, ordered behind the planner stream by an event: the transfer of step k
+  // overlaps the kernels of step k + 1 (auvp_gather_blocks_root_async / auvp_gather_wait)
+  hipStream_t gstream = nullptr;
+  hipEvent_t ready = nullptr, a0 = nullptr, a1 = nullptr;
+  bool pending = false;        // enqueued since the last auvp_gather_wait
+  int64_t pending_bytes = 0;   // what this rank sends (or, on the root, receives) in the pending transfers
   ~CommState() {
+    if (gstream) (void)hipStreamSynchronize(gstream);
     if (comm) { RcclApi* a = rccl_api(); if (a->so) (void)a->CommDestroy(comm); }
     if (g0) (void)hipEventDestroy(g0);
     if (g1) (void)hipEventDestroy(g1);
+    if (ready) (void)hipEventDestroy(ready);
+    if (a0) (void)hipEventDestroy(a0);
+    if (a1) (void)hipEventDestroy(a1);
+    if (gstream) (void)hipStreamDestroy(gstream);
   }
 };
 
@@ -153,6 +169,10 @@ int auvp_comm_init(auvp_handle* h, int32_t world_size, int32_t rank, const uint8
   c->world = world_size; c->rank = rank;
   HIPCHK(h, hipEventCreate(&c->g0));
   HIPCHK(h, hipEventCreate(&c->g1));
+  HIPCHK(h, hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking));
+  HIPCHK(h, hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreate(&c->a0));
+  HIPCHK(h, hipEventCreate(&c->a1));
   HIPCHK(h, c->counts.reserve((size_t)world_size * 2 * sizeof(int64_t)));
   return AUVP_OK;
 }
@@ -162,6 +182,7 @@ int auvp_comm_destroy(auvp_handle* h) {
   if (h->comm) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (comm_of(h)->gstream) (void)hipStreamSynchronize(comm_of(h)->gstream);
     delete comm_of(h);
     h->comm = nullptr;
   }
@@ -295,6 +316,101 @@ int auvp_gather_blocks(auvp_handle* h, const void* send_dev, void* recv_dev, int
   HIPCHK(h, hipEventElapsedTime(&ms, c->g0, c->g1));
   c->last_ms = ms;
   return AUVP_OK;
+}
+
+// ---- gather to ONE rank (north_star: "an RCCL gather of final paths"): ncclSend / ncclRecv in one group ----
+// rank r's block lands at the prefix offset of r in the ROOT's buffer; the other ranks receive nothing.  On a fully connected
+// xGMI node every peer has its own link to the root, so the seven transfers run side by side (an all-gather moves seven
+// times the bytes into EVERY rank).  Enqueues on `stream`; no host synchronisation.
+static int gather_root_enqueue(auvp_handle* h, CommState* c, RcclApi* a, int root, const void* send_dev, void* recv_dev,
+                               const int64_t* counts, hipStream_t stream) {
+  if (c->world > 1 && (!a->Send || !a->Recv)) return fail(h, AUVP_ERR_COMM, "this RCCL has no ncclSend / ncclRecv");
+  const bool is_root = c->rank == root;
+  int64_t my_off = 0;
+  for (int r = 0; r < c->rank; r++) my_off += counts[r];
+  if (is_root && counts[root] > 0)  // the root's own block: a device copy on the same stream
+    HIPCHK(h, hipMemcpyAsync(static_cast<char*>(recv_dev) + my_off, send_dev, (size_t)counts[root], hipMemcpyDeviceToDevice, stream));
+  if (c->world == 1) return AUVP_OK;
+  int rc_group = a->GroupStart();
+  if (rc_group != 0) return fail(h, AUVP_ERR_COMM, "ncclGroupStart: %s", a->GetErrorString ? a->GetErrorString(rc_group) : "?");
+  int first_err = 0;
+  if (is_root) {
+    int64_t off = 0;
+    for (int r = 0; r < c->world; r++) {
+      if (r != root && counts[r] > 0 && first_err == 0)
+        first_err = a->Recv(static_cast<char*>(recv_dev) + off, (size_t)counts[r], AUVP_NCCL_UINT8, r, c->comm, stream);
+      off += counts[r];
+    }
+  } else if (counts[c->rank] > 0) {
+    first_err = a->Send(send_dev, (size_t)counts[c->rank], AUVP_NCCL_UINT8, root, c->comm, stream);
+  }
+  const int end_err = a->GroupEnd();
+  if (first_err != 0 || end_err != 0) {
+    (void)hipStreamSynchronize(stream);
+    const int e = first_err ? first_err : end_err;
+    return fail(h, AUVP_ERR_COMM, "grouped ncclSend / ncclRecv: %s", a->GetErrorString ? a->GetErrorString(e) : "?");
+  }
+  return AUVP_OK;
+}
+
+static int gather_root_check(auvp_handle* h, CommState* c, int32_t root, const void* send_dev, void* recv_dev, int64_t recv_cap_bytes,
+                             const int64_t* counts) {
+  if (!c || !c->comm) return fail(h, AUVP_ERR_STATE, "auvp_comm_init not called");
+  if (root < 0 || root >= c->world) return fail(h, AUVP_ERR_ARG, "root %d outside the communicator", (int)root);
+  int64_t total = 0;
+  for (int r = 0; r < c->world; r++) { if (counts[r] < 0) return fail(h, AUVP_ERR_ARG, "negative count"); total += counts[r]; }
+  if (counts[c->rank] > 0 && !send_dev) return AUVP_ERR_ARG;
+  // (only the root's buffer matters; a short one is the root's own caller bug, reported before it posts any receive -- the
+  // senders' transfers then stay unmatched until the communicator is destroyed, as with any rank that drops out of a collective)
+  if (c->rank == root && total > 0 && (!recv_dev || total > recv_cap_bytes))
+    return fail(h, AUVP_ERR_CAPACITY, "the root needs %lld bytes, its buffer holds %lld", (long long)total, (long long)(recv_dev ? recv_cap_bytes : 0));
+  return AUVP_OK;
+}
+
+int auvp_gather_blocks_root_async(auvp_handle* h, int32_t root, const void* send_dev, void* recv_dev, int64_t recv_cap_bytes,
+                                  const int64_t* counts) {
+  if (!h || !counts) return AUVP_ERR_ARG;
+  CommState* c = comm_of(h);
+  int rc = gather_root_check(h, c, root, send_dev, recv_dev, recv_cap_bytes, counts);
+  if (rc != AUVP_OK) return rc;
+  RcclApi* a = rccl_api();
+  HIPCHK(h, hipSetDevice(h->device));
+  // behind everything the planner stream holds so far (the kernels and copies that produced send_dev)
+  HIPCHK(h, hipEventRecord(c->ready, h->stream));
+  HIPCHK(h, hipStreamWaitEvent(c->gstream, c->ready, 0));
+  if (!c->pending) { HIPCHK(h, hipEventRecord(c->a0, c->gstream)); c->pending_bytes = 0; }
+  c->pending = true;
+  rc = gather_root_enqueue(h, c, a, root, send_dev, recv_dev, counts, c->gstream);
+  if (rc != AUVP_OK) return rc;
+  if (c->rank == root) { for (int r = 0; r < c->world; r++) c->pending_bytes += counts[r]; }
+  else c->pending_bytes += counts[c->rank];
+  return AUVP_OK;
+}
+
+int auvp_gather_wait(auvp_handle* h, double* ms_out, int64_t* bytes_out) {
+  if (!h) return AUVP_ERR_ARG;
+  CommState* c = comm_of(h);
+  if (!c || !c->comm) return fail(h, AUVP_ERR_STATE, "auvp_comm_init not called");
+  if (ms_out) *ms_out = 0.0;
+  if (bytes_out) *bytes_out = 0;
+  if (!c->pending) return AUVP_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventRecord(c->a1, c->gstream));
+  HIPCHK(h, hipStreamSynchronize(c->gstream));
+  float ms = 0.f;
+  HIPCHK(h, hipEventElapsedTime(&ms, c->a0, c->a1));
+  c->last_ms = ms;
+  c->pending = false;
+  if (ms_out) *ms_out = ms;
+  if (bytes_out) *bytes_out = c->pending_bytes;
+  return AUVP_OK;
+}
+
+int auvp_gather_blocks_root(auvp_handle* h, int32_t root, const void* send_dev, void* recv_dev, int64_t recv_cap_bytes,
+                            const int64_t* counts) {
+  int rc = auvp_gather_blocks_root_async(h, root, send_dev, recv_dev, recv_cap_bytes, counts);
+  if (rc != AUVP_OK) return rc;
+  return auvp_gather_wait(h, nullptr, nullptr);
 }
 
 int auvp_comm_available(void) { return rccl_api()->so ? 1 : 0; }

@@ -14,6 +14,13 @@ Two transports with one interface (`gather_records`, `gather_paths`):
   TorchGather  torch.distributed all-gathers ("nccl" = RCCL on ROCm, "gloo" in the CPU tests).
 Shards may be uneven (the first E % G ranks hold one episode more): records are padded to the largest
 shard for the equal-size collective and cut back on return.
+
+Round 6: both transports also gather TO ONE RANK (`root_begin` / `root_end`) -- what north_star asks for.  With the
+headline's batch the payload is not "a few MB": 12 288 episodes x ~170 path elements x 56 B = ~0.12 GB per rank and step,
+which an all-gather delivers seven times over to EVERY rank of an 8-GPU node (~0.84 GB of ingress per rank per 100 ms step);
+the gather to a root moves each rank's block once, every peer over its own xGMI link, and RcclGather enqueues it on the
+handle's gather stream so that step k's transfer overlaps step k + 1's kernels (root_end(ticket) before the next
+root_begin).  Fixed-stride blocks of a block partition need no count exchange (`rows` = the shard sizes).
 """
 import ctypes as C
 
@@ -74,6 +81,28 @@ class TorchGather:
     def take_ms(self):
         return None  # no stream timing on this transport
 
+    # ---- gather to one rank (synchronous on this transport: root_begin does the work, root_end hands it out) ----
+    def root_begin(self, tensors, rows=None, root=0):
+        """tensors: list of [n_local, ...] tensors; rows: per tensor the list of every rank's row count, or None (one count
+        exchange).  Returns a ticket for root_end."""
+        rows = rows or [None] * len(tensors)
+        out = []
+        for t, known in zip(tensors, rows):
+            t = t.contiguous()
+            counts = [int(k) for k in known] if known is not None else self._counts(t.shape[0], t.device)
+            cap = max(max(counts), 1)
+            pad = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[:t.shape[0]] = t
+            bufs = [torch.empty_like(pad) for _ in range(self.world)] if self.rank == root else None
+            dist.gather(pad, bufs, dst=root, group=self.group)
+            out.append([bufs[r][:counts[r]] for r in range(self.world)] if self.rank == root else None)
+        return {"root": root, "out": out, "bytes": sum(t.numel() * t.element_size() for t in tensors)}
+
+    def root_end(self, ticket):
+        """on the root: per tensor the list over ranks of [n_r, ...]; None elsewhere"""
+        self.last_root_bytes = ticket["bytes"]
+        return ticket["out"] if self.rank == ticket["root"] else None
+
 
 class RcclGather:
     """the C-ABI gather of libauvplan.so on the planner context's stream.  `exchange_id(id_bytes_or_None)` must
@@ -115,6 +144,8 @@ class RcclGather:
         L.auvp_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.auvp_last_gather_ms.argtypes = [C.c_void_p]
         L.auvp_last_gather_ms.restype = C.c_double
+        L.auvp_gather_blocks_root_async.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.auvp_gather_wait.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         self.L = L
         self._join(exchange_id)
 
@@ -180,6 +211,56 @@ class RcclGather:
         """HIP-event time of the collectives since the last call (sum), then reset"""
         ms, self.last_ms = self.last_ms, None
         return ms
+
+    # ---- gather to one rank on the handle's gather stream (auvp_gather_blocks_root_async / auvp_gather_wait) ----
+    def root_begin(self, tensors, rows=None, root=0):
+        """ENQUEUE the gather of `tensors` (contiguous device tensors [n_local, ...]) to `root`, ordered behind what the planner
+        stream holds now; returns a ticket for root_end.  rows: per tensor the list of every rank's row count (fixed-stride
+        blocks of a block partition: no count exchange) or None (one count exchange, which waits).  The tensors -- and what
+        they alias: the planner's result buffers -- must stay untouched until root_end; one ticket at a time."""
+        if getattr(self, "_ticket_open", False):
+            raise RuntimeError("root_end() the previous ticket first: no other collective may be issued while transfers are pending")
+        rows = rows or [None] * len(tensors)
+        plan = []
+        for t, known in zip(tensors, rows):  # every count exchange BEFORE the first enqueue
+            t = t.contiguous()
+            row = (int(np.prod(t.shape[1:])) if t.dim() > 1 else 1) * t.element_size()
+            counts = (C.c_int64 * self.world)()
+            if known is not None:
+                for r in range(self.world):
+                    counts[r] = int(known[r]) * row
+            else:
+                self.ctx._chk(self.L.auvp_gather_counts(self.ctx.h, t.numel() * t.element_size(), counts))
+            plan.append((t, row, counts))
+        items = []
+        for t, row, counts in plan:
+            total = sum(counts)
+            recv = torch.empty(max(total, 1), dtype=torch.uint8, device=t.device) if self.rank == root else None
+            self.ctx._chk(self.L.auvp_gather_blocks_root_async(self.ctx.h, int(root), C.c_void_p(t.data_ptr()),
+                                                               C.c_void_p(recv.data_ptr()) if recv is not None else None,
+                                                               total if recv is not None else 0, counts))
+            items.append((t, row, list(counts), recv))
+        self._ticket_open = True
+        return {"root": int(root), "items": items}
+
+    def root_end(self, ticket):
+        """wait for the ticket's transfers.  On the root: per tensor the list over ranks of [n_r, ...] views of the received
+        bytes; None elsewhere.  The transfer's stream time and this rank's bytes go to last_root_ms / last_root_bytes."""
+        ms, nb = C.c_double(0.0), C.c_int64(0)
+        self.ctx._chk(self.L.auvp_gather_wait(self.ctx.h, C.byref(ms), C.byref(nb)))
+        self._ticket_open = False
+        self.last_root_ms, self.last_root_bytes = float(ms.value), int(nb.value)
+        if self.rank != ticket["root"]:
+            return None
+        out = []
+        for t, row, counts, recv in ticket["items"]:
+            blocks, pos = [], 0
+            for r in range(self.world):
+                blk = recv[pos:pos + counts[r]]
+                pos += counts[r]
+                blocks.append(blk.view(t.dtype).view((counts[r] // max(row, 1),) + tuple(t.shape[1:])))
+            out.append(blocks)
+        return out
 
 
 def summaries_to_tensor(summ, device):

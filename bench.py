@@ -203,8 +203,12 @@ def roofline(abytes, k_ms, kernel, traffic=None, valu_issue_frac=None, **extra):
             r["bound"] = "valu_issue"
     # neither roof is near: a launch of a few dependent chains (one episode, 1 024 replicas, a dense small tree) is bound
     # by the latency of its serial chain, not by a throughput roof -- say so instead of "hbm" at a fraction of a few percent
-    if frac < LATENCY_FRAC and (valu_issue_frac is None or valu_issue_frac < LATENCY_VALU):
+    # (only with the counters in hand: without a vector-issue figure an issue-bound kernel would be mislabelled -- it then stays
+    # "hbm" with its small fraction and a note)
+    if frac < LATENCY_FRAC and valu_issue_frac is not None and valu_issue_frac < LATENCY_VALU:
         r["bound"] = "latency"
+    elif frac < LATENCY_FRAC and valu_issue_frac is None:
+        r["bound_note"] = "no PMC pass for this kernel: far from the HBM roof, vector-issue share unknown"
     r.update(traffic or {})
     r.update(extra)
     return r
@@ -348,7 +352,8 @@ ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "
              "side_astar_cells_per_s", "side_planner_steps_per_s", "side_config5_steps_per_s",
              "side_replicas_expansions_per_s", "side_single_episode_us_per_expansion", "side_pf_particle_steps_per_s",
              "side_shark_grid_cells_per_s")
-CONFIG_KEEP = ("workload", "episodes_per_gpu", "iters", "obstacles", "cells", "parallelism", "gather", "rccl_ranks_seen")
+CONFIG_KEEP = ("workload", "episodes_per_gpu", "iters", "obstacles", "cells", "parallelism", "gather", "rccl_ranks_seen",
+               "gather_mode", "gather_bytes_per_rank", "gather_ms", "gather_ms_over_step")
 TOP_KEEP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data")
 
@@ -411,10 +416,28 @@ def emit(out):
     if os.environ.get("AUVP_BENCH_VERBOSE") == "1":
         print(json.dumps(out), file=sys.stderr)
     sys.stderr.flush()
-    s = json.dumps(compact_line(out, sides_file), separators=(",", ":"))
-    assert len(s) <= LINE_LIMIT, len(s)
     sys.stdout.flush()
-    print(s, flush=True)
+    print(compact_string(out, sides_file), flush=True)
+
+
+def compact_string(out, sides_file):
+    """the compact line as a string of at most LINE_LIMIT bytes: should a string field ever push it over (compact_line already
+    drops roofline keys from the end), the free-text fields are cut, then dropped -- a long line must not cost the result"""
+    line = compact_line(out, sides_file)
+    s = json.dumps(line, separators=(",", ":"))
+    for cut in (80, 40, 0):
+        if len(s) <= LINE_LIMIT:
+            break
+        if isinstance(line.get("cpu_baseline"), dict):
+            line["cpu_baseline"]["sample"] = str(line["cpu_baseline"].get("sample", ""))[:cut]
+        for k in ("workload", "gather", "gather_mode", "parallelism"):
+            if isinstance(line["config"].get(k), str):
+                line["config"][k] = line["config"][k][:max(cut, 24)]
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > LINE_LIMIT:
+        line["cpu_baseline"] = None
+        s = json.dumps(line, separators=(",", ":"))
+    return s
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -537,18 +560,31 @@ class _HostGather:
     def take_ms(self):
         return None
 
+    def root_begin(self, tensors, rows=None, root=0):
+        return self.inner.root_begin([t.cpu() for t in tensors], rows=rows, root=root)
+
+    def root_end(self, ticket):
+        out = self.inner.root_end(ticket)
+        self.last_root_ms, self.last_root_bytes = None, self.inner.last_root_bytes
+        return out
+
     def close(self):
         pass
 
 
-def timed_steps(ranks, step, steps, warmup):
+def timed_steps(ranks, step, steps, warmup, finish=None):
+    """`finish`: what the last step left in flight (the overlapped gather of its results) -- waited for INSIDE the timed region"""
     for _ in range(warmup):
         step()
+    if finish:
+        finish()
     ranks.sync()
     t0 = time.perf_counter()
     last = None
     for _ in range(steps):
         last = step()
+    if finish:
+        finish()
     ranks.sync()
     return ranks.max_time(time.perf_counter() - t0), last
 
@@ -1311,15 +1347,41 @@ def main():
         total = int(off[-1])
         paths = torch.empty((max(total, 1), 7), dtype=torch.float64, device=dev)
         ctx.paths_dev(off, paths.data_ptr())  # best paths stay in HBM
-        if world_size > 1:
-            # the fixed-stride result records straight from the planner's device buffer + the variable-length paths
+        if world_size > 1 and gather_mode == "all":
+            # (AUVP_BENCH_GATHER=all) every rank receives every record: the fixed-stride result records straight from the
+            # planner's device buffer + the variable-length paths, waited for inside the step
             ranks.gather_records(ctx.L.auvp_rrt_summaries_dev(ctx.h), E, _lib.SUMMARY_DTYPE.itemsize)
             lens_dev = torch.from_numpy(lens).to(dev)
             ranks.gather.gather_paths(paths[:total], lens_dev)
             gms.append(ranks.gather_ms())
+            gbytes.append(E * _lib.SUMMARY_DTYPE.itemsize + 8 * E + total * 56)
+        elif world_size > 1:
+            # the gather north_star names: final paths (+ the result records and lengths) to rank 0, each rank's block once, over
+            # that rank's own xGMI link, ENQUEUED on the handle's gather stream: step k's transfer runs under step k + 1's
+            # kernels.  What is sent must outlive the step: the records are copied out of the planner's buffer (1.4 MB), the
+            # paths tensor is this step's own.  The previous step's ticket is ended first (one ticket at a time).
+            finish_gather()
+            from auv_sim_amd import distributed as D
+            recs = D.device_records(ctx.L.auvp_rrt_summaries_dev(ctx.h), E, _lib.SUMMARY_DTYPE.itemsize, dev).clone()
+            lens_dev = torch.from_numpy(lens).to(dev).reshape(-1, 1)
+            torch.cuda.current_stream().synchronize()  # (torch's stream, not the planner's: the two copies above)
+            in_flight.append((ranks.gather.root_begin([recs, lens_dev, paths[:total]], rows=[[E] * world_size, [E] * world_size, None], root=0),
+                              (recs, lens_dev, paths)))
         return summ
 
-    dt, summ = timed_steps(ranks, step, args.steps, args.warmup)
+    gather_mode = os.environ.get("AUVP_BENCH_GATHER", "root")
+    in_flight, gbytes, gathered = [], [], []
+
+    def finish_gather():
+        while in_flight:
+            ticket, _keep = in_flight.pop(0)
+            got = ranks.gather.root_end(ticket)
+            gms.append(getattr(ranks.gather, "last_root_ms", None))
+            gbytes.append(getattr(ranks.gather, "last_root_bytes", None))
+            if got is not None:  # rank 0: every rank's records, lengths and paths of that step
+                gathered[:] = [sum(int(b.shape[0]) for b in got[0]), sum(int(b.shape[0]) for b in got[2])]
+
+    dt, summ = timed_steps(ranks, step, args.steps, args.warmup, finish=finish_gather if world_size > 1 and gather_mode != "all" else None)
     bad = summ["status"] < 0
     if bad.any():
         sys.exit("device error status in %d episodes: %s" % (int(bad.sum()), np.unique(summ["status"][bad])))
@@ -1330,6 +1392,7 @@ def main():
     k_ms = float(np.mean(kms[-args.steps:]))
     k_all = ranks.all(k_ms)
     g_all = ranks.all(float(np.mean([g for g in gms[-args.steps:] if g is not None])) if gms and gms[-1] is not None else None)
+    gb_all = ranks.all(float(np.mean([g for g in gbytes[-args.steps:] if g is not None])) if gbytes and gbytes[-1] is not None else None)
     rccl_info_all = ranks.all(ranks.rccl_info) if world_size > 1 else None
     out = None
     if rank == 0:
@@ -1349,6 +1412,11 @@ def main():
                        "episodes_per_gpu": E, "iters": args.iters, "obstacles": args.obstacles,
                        "cells": int(len(world["cells"])), "parallelism": "episodes sharded x%d" % world_size,
                        "gather": ranks.gather.name if ranks.gather is not None else None, "gather_note": ranks.gather_note,
+                       "gather_mode": None if world_size == 1 else ("all-gather in step" if gather_mode == "all" else "to rank 0, overlapped"),
+                       "gather_bytes_per_rank": None if not gb_all or gb_all[-1] is None else float(np.max([g for g in gb_all if g is not None])),
+                       "gather_ms": None if not g_all or g_all[-1] is None else float(np.max([g for g in g_all if g is not None])),
+                       "gather_ms_over_step": None if not g_all or g_all[-1] is None else
+                       float(np.max([g for g in g_all if g is not None])) / (1e3 * dt / args.steps),
                        # self-check of a multi-GPU run: (world size given, rank, RANK COUNT AS THE RCCL COMMUNICATOR REPORTS IT)
                        # of every rank, and the RCCL image the C-ABI bound
                        "rccl_comm_info_per_rank": rccl_info_all, "rccl_ranks_seen": (rccl_info_all[0][2] if rccl_info_all and rccl_info_all[0] else None),
@@ -1364,6 +1432,14 @@ def main():
             "expansions_per_s_kernel_only": iters_local / (k_ms * 1e-3),
             "expansions_per_s_expansion_kernel_only": iters_local / (exp_ms * 1e-3),
             "kernel_ms_per_rank": k_all, "gather_ms_per_rank": g_all,
+            # the result gather of a multi-GPU step (N = 1: none): where the records go, what one rank sends per step, the
+            # transfer's own stream time against the step (root mode: it runs under the NEXT step's kernels, so this is not
+            # time added to the step), and what rank 0 held after the last step (records, path elements of ALL ranks)
+            "gather_mode": None if world_size == 1 else ("all ranks (all-gather, inside the step)" if gather_mode == "all" else
+                                                          "to rank 0 (ncclSend / ncclRecv on the gather stream, overlapped with the next step)"),
+            "gather_bytes_per_rank": gb_all, "gather_ms_over_step": (None if not g_all or g_all[-1] is None else
+                                                                     float(np.max([g for g in g_all if g is not None])) / (1e3 * dt / args.steps)),
+            "gather_root_received": gathered or None,
             "expansions_per_step": iters_per_step, "accepted_nodes_per_step": acc_per_step,  # summed over ALL ranks
             "accepted_nodes_per_episode": float((summ["n_nodes"] - 1).mean()),
             "qualifying_leaves_per_episode": float(summ["n_leaves"].mean()),
@@ -1412,15 +1488,22 @@ def main():
                 v = out.get(name)
                 if isinstance(v, dict):
                     out["roofline"][key] = v.get("us_per_expansion" if name == "single_episode" else "value")
-    if world_size > 1:
-        # the process group goes first: whatever the communicator prints when it is torn down comes BEFORE the result line, and
-        # the other ranks are past their last collective when rank 0 prints
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
+    try:
         if world_size > 1:
-            time.sleep(0.5)  # (after the timed region and every collective: lets the other ranks' exit output drain first)
-        emit(out)
+            # the process group goes first: whatever the communicator prints when it is torn down comes BEFORE the result line,
+            # and the other ranks are past their last collective when rank 0 prints.  A teardown that raises must not cost the
+            # measured result: the line is printed whatever happens here.
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception as e:
+                print("bench: rank %d: process-group teardown failed (%s: %s); the result line follows" % (rank, type(e).__name__, e),
+                      file=sys.stderr, flush=True)
+    finally:
+        if rank == 0:
+            if world_size > 1:
+                time.sleep(0.5)  # (after the timed region and every collective: lets the other ranks' exit output drain first)
+            emit(out)
 
 
 if __name__ == "__main__":

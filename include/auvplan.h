@@ -434,6 +434,25 @@ int auvp_gather_var(auvp_handle* h, const void* send_dev, int64_t send_bytes, vo
 int auvp_gather_counts(auvp_handle* h, int64_t send_bytes, int64_t* counts_out /* [world] */);
 int auvp_gather_blocks(auvp_handle* h, const void* send_dev, void* recv_dev, int64_t recv_cap_bytes,
                        const int64_t* counts /* [world] */);
+/* Gather to ONE rank -- what north_star asks for ("an RCCL gather of final paths"); the all-gathers above hand every rank every
+ * record.  rank r's block lands at the prefix offset of r in the ROOT's recv_dev (the other ranks pass NULL / 0): one group of
+ * ncclSend / ncclRecv, every peer over its own xGMI link.  `counts` [world] as auvp_gather_counts returned them, or computed
+ * by the caller where the block sizes are known (fixed-stride records of a block partition).
+ *   auvp_gather_blocks_root        the transfer, waited for
+ *   auvp_gather_blocks_root_async  the same ENQUEUED on the handle's gather stream -- a second stream, ordered behind what the
+ *                                  planner stream holds at the call -- so that the transfer of step k overlaps the kernels
+ *                                  of step k + 1.  May be called several times (records, lengths, paths); send_dev and the
+ *                                  root's recv_dev must stay untouched until auvp_gather_wait.  No other collective of this
+ *                                  handle may be issued while transfers are pending.
+ *   auvp_gather_wait               waits for the pending transfers; ms_out = their HIP-event time on the gather stream (first
+ *                                  enqueue to completion, waiting for the planner stream's event included), bytes_out = what
+ *                                  this rank sent (on the root: received, its own block included).  No-op without pending ones.
+ * An RCCL without ncclSend / ncclRecv: AUVP_ERR_COMM (world size 1 needs neither). */
+int auvp_gather_blocks_root(auvp_handle* h, int32_t root, const void* send_dev, void* recv_dev, int64_t recv_cap_bytes,
+                            const int64_t* counts /* [world] */);
+int auvp_gather_blocks_root_async(auvp_handle* h, int32_t root, const void* send_dev, void* recv_dev, int64_t recv_cap_bytes,
+                                  const int64_t* counts /* [world] */);
+int auvp_gather_wait(auvp_handle* h, double* ms_out, int64_t* bytes_out);
 int auvp_comm_available(void);
 const char* auvp_comm_library(void);
 int auvp_comm_info(auvp_handle* h, int32_t* world_size, int32_t* rank, int32_t* rccl_ranks_seen);

@@ -147,7 +147,23 @@ def test_final_line_survives_oversized_fields_and_missing_parts():
 
 def test_bound_names_the_roof_that_binds():
     b = _bench()
-    assert b.roofline(8e7, 1.0, "k")["bound"] == "latency"                        # 0.01 of HBM, no counters: a dependent chain
+    r = b.roofline(8e7, 1.0, "k")                                                  # 0.01 of HBM, NO counters: not labelled "latency"
+    assert r["bound"] == "hbm" and "vector-issue share unknown" in r["bound_note"]  # (an issue-bound kernel would be mislabelled)
     assert b.roofline(8e7, 1.0, "k", valu_issue_frac=0.1)["bound"] == "latency"
     assert b.roofline(8e7, 1.0, "k", valu_issue_frac=0.6)["bound"] == "valu_issue"
     assert b.roofline(6e9, 1.0, "k", valu_issue_frac=0.3)["bound"] == "hbm"
+
+
+def test_compact_string_never_exceeds_the_limit_and_never_raises():
+    """emit() used to assert on the line length: a long free-text field must cost the field, not the result"""
+    b = _bench()
+    out = {"metric": "m", "value": 2.5, "unit": "expansions/s", "n_gpus": 8, "steps": 2, "warmup": 1, "ms_per_step": 3.0,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "w" * 500, "gather": "g" * 3000, "gather_mode": "m" * 3000, "parallelism": "p" * 3000,
+                      "gather_bytes_per_rank": 1.2e8, "gather_ms_over_step": 0.03},
+           "roofline": {"bound": "valu_issue", "achieved": 926.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.116, "traffic": 1.0e11},
+           "cpu_baseline": {"value": 3235.0, "unit": "expansions/s", "cores": 1, "kind": "port", "sample": "s" * 4000}}
+    s = b.compact_string(out, None)
+    line = json.loads(s)
+    assert len(s) <= b.LINE_LIMIT and line["value"] == 2.5 and line["roofline"]["frac"] == 0.116
+    assert line["config"]["gather_bytes_per_rank"] == 1.2e8 and line["config"]["gather_ms_over_step"] == 0.03

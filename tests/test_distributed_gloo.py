@@ -194,6 +194,135 @@ class _FakeAbi:
         return 0
 
 
+    # ---- gather to a root: the stand-in moves the bytes over gloo send / recv when the call is made (the library enqueues
+    # on its gather stream); auvp_gather_wait reports what the library would
+    def auvp_gather_blocks_root_async(self, h, root, send, recv, cap, counts):
+        import ctypes as C
+        self.calls.append("root")
+        cs = [int(counts[r]) for r in range(self.world)]
+        if self.rank == root:
+            if sum(cs) > cap:
+                return -2
+            off = 0
+            for r in range(self.world):
+                if cs[r] > 0:
+                    t = torch.empty(cs[r], dtype=torch.uint8)
+                    if r == root:
+                        C.memmove(t.data_ptr(), send.value, cs[r])
+                    else:
+                        dist.recv(t, src=r)
+                    C.memmove(recv.value + off, t.data_ptr(), cs[r])
+                off += cs[r]
+            self.pending_bytes = getattr(self, "pending_bytes", 0) + sum(cs)
+        else:
+            assert recv is None or not recv.value
+            if cs[self.rank] > 0:
+                t = torch.empty(cs[self.rank], dtype=torch.uint8)
+                C.memmove(t.data_ptr(), send.value, cs[self.rank])
+                dist.send(t, dst=root)
+            self.pending_bytes = getattr(self, "pending_bytes", 0) + cs[self.rank]
+        return 0
+
+    def auvp_gather_wait(self, h, ms, nbytes):
+        import ctypes as C
+        self.calls.append("wait")
+        C.cast(ms, C.POINTER(C.c_double))[0] = 0.5
+        C.cast(nbytes, C.POINTER(C.c_int64))[0] = getattr(self, "pending_bytes", 0)
+        self.pending_bytes = 0
+        return 0
+
+
+def _root_worker(rank, world, port, E_total, transport, q):
+    """gather TO ONE RANK (root_begin / root_end) through either transport: fixed-stride records and lengths with static counts
+    (no count exchange), variable-length paths with one exchange; the root rebuilds everything in global episode order, the
+    other ranks receive nothing; a second ticket only after the first was ended"""
+    import sys
+    sys.path.insert(0, REPO)
+    from auv_sim_amd import _lib, distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def exchange(mine):
+        box = [mine]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    abi = None
+    if transport == "rccl":
+        abi = _FakeAbi()
+        G = D.RcclGather(_FakeCtx(), rank, world, exchange, L=abi)
+    else:
+        G = D.TorchGather()
+    ok = True
+    sizes = D.shard_sizes(E_total, world)
+    lo, hi = D.shard_range(E_total, rank, world)
+    n = hi - lo
+    for root in (0, world - 1):
+        summ = np.zeros(n, dtype=_lib.SUMMARY_DTYPE)
+        for i in range(n):
+            summ[i]["best_leaf"] = lo + i
+            summ[i]["best_path_len"] = 1 + ((lo + i) % 6)
+        rec = D.summaries_to_tensor(summ, "cpu")
+        lens = torch.from_numpy(summ["best_path_len"].astype(np.int64))
+        paths = torch.zeros((int(lens.sum()), 7), dtype=torch.float64)
+        pos = 0
+        for i in range(n):
+            L = int(lens[i])
+            paths[pos:pos + L, 0] = lo + i
+            paths[pos:pos + L, 3] = torch.arange(L, dtype=torch.float64)
+            pos += L
+        calls0 = len(abi.calls) if abi else 0
+        ticket = G.root_begin([rec, lens.reshape(-1, 1), paths], rows=[sizes, sizes, None], root=root)
+        if abi:  # one count exchange (the paths), three enqueues, nothing waited for yet
+            ok &= abi.calls[calls0:] == ["counts", "root", "root", "root"]
+            try:
+                G.root_begin([rec], rows=[sizes], root=root)
+                ok = False
+            except RuntimeError:
+                pass
+        got = G.root_end(ticket)
+        if rank != root:
+            ok &= got is None
+            ok &= G.last_root_bytes == rec.numel() + 8 * n + paths.numel() * 8
+            continue
+        recs, lns, pths = got
+        total_bytes = 0
+        seen = []
+        for r in range(world):
+            rlo, rhi = D.shard_range(E_total, r, world)
+            rs = D.tensor_to_summaries(recs[r], _lib.SUMMARY_DTYPE)
+            ok &= len(rs) == rhi - rlo and lns[r].shape == (rhi - rlo, 1)
+            pos = 0
+            for i in range(rhi - rlo):
+                e = rlo + i
+                L = int(lns[r][i, 0])
+                ok &= int(rs[i]["best_leaf"]) == e and L == 1 + (e % 6)
+                seg = pths[r][pos:pos + L]
+                ok &= bool((seg[:, 0] == e).all()) and bool((seg[:, 3] == torch.arange(L, dtype=torch.float64)).all())
+                pos += L
+                seen.append(e)
+            ok &= pos == pths[r].shape[0]
+            total_bytes += recs[r].numel() + 8 * (rhi - rlo) + pths[r].numel() * 8
+        ok &= seen == list(range(E_total))
+        if abi:
+            ok &= G.last_root_bytes == total_bytes and G.last_root_ms == 0.5
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+@pytest.mark.parametrize("E_total", [9, 8, 1])
+def test_gather_to_root_two_ranks(E_total, transport):
+    _run_ranks(_root_worker, 2, E_total, transport)
+
+
+@pytest.mark.parametrize("transport", ["rccl", "torch"])
+@pytest.mark.parametrize("E_total", [512, 13, 3])
+def test_gather_to_root_eight_ranks(E_total, transport):
+    _run_ranks(_root_worker, 8, E_total, transport)
+
+
 def _rccl_python_worker(rank, world, port, E_total, q):
     import sys
     sys.path.insert(0, REPO)

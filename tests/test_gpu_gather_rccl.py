@@ -42,6 +42,23 @@ def test_rccl_gather_single_rank_round_trip():
     recv = torch.empty_like(view)
     ctx._chk(g.L.auvp_gather(ctx.h, C.c_void_p(view.data_ptr()), view.numel(), C.c_void_p(recv.data_ptr())))
     assert torch.equal(recv, view)
+    # ---- round 6: the gather to a root on the handle's gather stream (auvp_gather_blocks_root_async / auvp_gather_wait).  With
+    # one rank the transfer is the root's own block -- a device copy on the gather stream, ordered behind the planner stream's
+    # work by an event -- so the stream / event / ticket plumbing runs; ncclSend / ncclRecv need a second GPU (below)
+    summ = ctx.rrt_explore_batch(init, [5, 6, 7, 8], 400, max_traj_time=20.0)       # the kernels whose results are sent ...
+    view = D.device_records(ctx.L.auvp_rrt_summaries_dev(ctx.h), 4, _lib.SUMMARY_DTYPE.itemsize, dev)
+    ticket = g.root_begin([view, lens.reshape(-1, 1), paths], rows=[[4], [3], None], root=0)  # ... enqueued without waiting
+    with pytest.raises(RuntimeError):
+        g.root_begin([view], rows=[[4]], root=0)                                      # one ticket at a time
+    recs, lns, pths = g.root_end(ticket)
+    got = D.tensor_to_summaries(recs[0], _lib.SUMMARY_DTYPE)
+    assert np.array_equal(got["n_nodes"], summ["n_nodes"]) and np.array_equal(got["rng_after"], summ["rng_after"])
+    assert torch.equal(lns[0].reshape(-1), lens) and torch.equal(pths[0], paths)
+    assert g.last_root_bytes == view.numel() + lens.numel() * 8 + paths.numel() * 8 and g.last_root_ms >= 0.0
+    assert g.root_end({"root": 0, "items": []}) == []                                # nothing pending: a no-op
+    bad = (C.c_int64 * 1)(16)
+    assert g.L.auvp_gather_blocks_root_async(ctx.h, 3, C.c_void_p(view.data_ptr()), None, 0, bad) == -1   # root outside the communicator
+    assert g.L.auvp_gather_blocks_root_async(ctx.h, 0, C.c_void_p(view.data_ptr()), C.c_void_p(recv.data_ptr()), 8, bad) == -2  # short buffer
     g.close()
 
 
@@ -99,6 +116,24 @@ def _two_rank_worker(rank, world, id_path, E_total, q):
     recv = torch.zeros(16 * world, dtype=torch.uint8, device=dev)
     ctx._chk(g.L.auvp_gather(ctx.h, C.c_void_p(send.data_ptr()), 16, C.c_void_p(recv.data_ptr())))
     ok &= all(bool((recv[16 * r:16 * r + 16] == r + 1).all()) for r in range(world))
+    # the gather to a root: grouped ncclSend / ncclRecv on the gather stream, both roots
+    sizes = D.shard_sizes(E_total, world)
+    for root in range(world):
+        ticket = g.root_begin([rec, lens.reshape(-1, 1), paths], rows=[sizes, sizes, None], root=root)
+        got = g.root_end(ticket)
+        if rank != root:
+            ok &= got is None
+            continue
+        recs, lns, pths = got
+        for r in range(world):
+            rlo, rhi = D.shard_range(E_total, r, world)
+            ok &= recs[r].shape == (rhi - rlo, 112) and lns[r].shape == (rhi - rlo, 1)
+            pos = 0
+            for i in range(rhi - rlo):
+                e = rlo + i
+                L = int(lns[r][i, 0])
+                ok &= bool((recs[r][i] == e % 251).all()) and L == 2 + (e % 4) and bool((pths[r][pos:pos + L, 0] == e).all())
+                pos += L
     g.close()
     q.put((rank, bool(ok)))
 
