@@ -349,6 +349,7 @@ ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "
              "pass_kernel_ms", "pass_8d_frac", "pass_traffic_raw",
              "nn_long_kernel_ms", "nn_long_alg_bytes", "nn_long_achieved_GBps", "nn_long_frac", "nn_long_frac_of_measured",
              "nn_long_traffic", "nn_long_traffic_raw", "nn_long_episodes", "nn_long_valu_issue_frac",
+             "nn_long_hbm_only_GBps", "nn_long_hbm_only_frac", "nn_long_hbm_only_frac_of_measured",
              "side_astar_cells_per_s", "side_planner_steps_per_s", "side_config5_steps_per_s",
              "side_replicas_expansions_per_s", "side_single_episode_us_per_expansion", "side_pf_particle_steps_per_s",
              "side_shark_grid_cells_per_s")
@@ -761,6 +762,38 @@ def bench_rrt_nn(ctx, args, with_cpu, n_ep=None, long_horizon=False):
     out["xy_mirror_working_set_bytes"] = 16.0 * float(summ["n_nodes"].sum())
     out["scan_GBps"] = 16.0 * scanned / (ctx.last_launch_parts()[0] * 1e-3) / 1e9
     out["iters_per_launch"] = float(summ["iters_run"].sum())
+    if long_horizon and "roofline" in out:
+        # An HBM-ONLY figure.  FETCH_SIZE counts Infinity-Cache hits as memory reads (MI355X_MICROARCH.md, HBM), so no counter
+        # separates the two; what separates them is the working set: while the trees are small the co-resident episodes' x,y
+        # mirrors fit the 256 MiB cache (the whole-launch rate is 1.05-1.07 x the streaming read rate
+        # measured in the same run).  The trees of a seed are the same whatever the budget, so the same batch run to HALF the
+        # budget is the first half of the full launch, and the DIFFERENCE of the two launches is the second half alone: from
+        # there on every episode scans >= half a full tree per iteration, and between two scans of one mirror the other
+        # resident episodes (MODE 2 keeps 5 wavefronts per SIMD = 20 episodes per CU) stream >= `late_resident_bytes` -- well
+        # past the cache -- through it.
+        import argparse
+        half = argparse.Namespace(**vars(args))
+        half.iters = args.iters // 2
+        o2 = _rrt_batch(ctx, world, n_ep, half, reps=2, mode="nn", kw=kw, meas="-")
+        if "roofline" in o2:
+            r1, r2 = out["roofline"], o2["roofline"]
+            d_bytes = r1["algorithmic_bytes_per_launch"] - r2["algorithmic_bytes_per_launch"]
+            d_ms = r1["kernel_ms"] - r2["kernel_ms"]
+            s2 = ctx.summaries()
+            n_cu = 256
+            resident = min(n_ep, 20 * n_cu)
+            late = {"late_segment": "iterations %d..%d of the same batch (full launch minus a launch of the first %d)" % (half.iters, args.iters, half.iters),
+                    "late_kernel_ms": d_ms, "late_alg_bytes": d_bytes, "late_achieved_GBps": d_bytes / (d_ms * 1e-3) / 1e9,
+                    "late_frac": d_bytes / (d_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "late_nodes_per_tree_at_start": float(s2["n_nodes"].mean()),
+                    "late_resident_bytes": 16.0 * float(s2["n_nodes"].mean()) * resident,
+                    "first_half_kernel_ms": r2["kernel_ms"], "first_half_achieved_GBps": r2["achieved"]}
+            if HBM_MEASURED.get("read_GBps"):
+                late["late_frac_of_measured"] = late["late_achieved_GBps"] / HBM_MEASURED["read_GBps"]
+            out["hbm_only"] = late
+            r1.update({"hbm_only_GBps": late["late_achieved_GBps"], "hbm_only_frac": late["late_frac"],
+                       "hbm_only_frac_of_measured": late.get("late_frac_of_measured"),
+                       "whole_launch_label": "HBM + Infinity Cache (the first iterations' mirrors fit the 256 MiB cache)"})
     ref = recorded_reference(("rrt_exploring_nn_long_o%d" if long_horizon else "rrt_exploring_nn_o%d") % args.obstacles)
     if ref:
         out["reference_recorded"] = {"value": ref["ref_expansions_per_s_1proc"], "unit": "expansions/s", "cores": 1,
@@ -1478,7 +1511,11 @@ def main():
                 "nn_long_frac": nl["frac"], "nn_long_frac_of_measured": nl.get("frac_of_measured"),
                 "nn_long_traffic": nl.get("traffic"), "nn_long_traffic_raw": nl.get("traffic_raw"),
                 "nn_long_mirror_bytes": side["xy_mirror_working_set_bytes"], "nn_long_iters_per_s": side["value"],
-                "nn_long_valu_issue_frac": nl.get("valu_issue_frac")})
+                "nn_long_valu_issue_frac": nl.get("valu_issue_frac"),
+                # the second half of that launch alone (mirrors far past the Infinity Cache): the HBM-only figure; nn_long_frac
+                # above is HBM + Infinity Cache
+                "nn_long_hbm_only_GBps": nl.get("hbm_only_GBps"), "nn_long_hbm_only_frac": nl.get("hbm_only_frac"),
+                "nn_long_hbm_only_frac_of_measured": nl.get("hbm_only_frac_of_measured")})
         if rank == 0:
             # the other configurations as flat scalars too (value of each side measurement; details in its own object)
             for name, key in (("astar", "side_astar_cells_per_s"), ("planner_rrt", "side_planner_steps_per_s"),
