@@ -15,6 +15,11 @@
 //      (the walk from the parent to the root)                                                                     -> part C
 //   M  checks that what H looked at is still true, computes the new node's bucket (:291-320), inserts, ends the planning on a
 //      free arc.
+//   D  (round 6, NW = 5: at most three episodes per workgroup) the sub-arc draws of the step as a wavefront of its own between
+//      H and S: H was the slowest stage (5 700 clocks of work per step against 4 800-5 000 for S and G) and ~850 of them were
+//      the tempering of the 2 n sub-arc draws, their dist / diff and the two quotients -- none of which H's own chain needs
+//      (the stream advances by 4 n words whatever is taken).  H now hands over the ring slot of the first sub-arc word
+//      (`sa_cslot`; the ring keeps every word since the step M is at) and moves on; D turns it into radius / phi / tmask.
 // Step k + 3 is drawn while k + 2 is steered, k + 1 has its arc tested and k is inserted: the stages hand a ring of eight slots
 // along, H at most five steps ahead of M (tags {redo epoch, step + 1}, written last; a reader copies its part out and re-checks
 // the tag, a writer clears the tag before it rewrites a part: a stage still working for an epoch that ended reads consistent --
@@ -44,9 +49,24 @@ constexpr int PPIPE_EP = 4;    // episodes per workgroup at most (sixteen wavefr
 #ifndef AUVP_PPIPE_LEAD
 #define AUVP_PPIPE_LEAD 5
 #endif
+#ifndef AUVP_PPIPE_LEAD5
+#define AUVP_PPIPE_LEAD5 7   // with the draw wavefront the pipeline is a stage deeper (measured, config 4: 5 -> 6.66 ms, 6 -> 6.57, 7 -> 6.49, 8 -> 6.49-6.53)
+#endif
 constexpr int PPIPE_RING = 8;  // slots
 constexpr int PPIPE_LEAD = AUVP_PPIPE_LEAD;  // steps H may be ahead of M (<= PPIPE_RING): slack between stages whose times vary, against snapshots that age
 constexpr int PPIPE_HIST = 8;  // inserts M remembers the bucket of
+
+// EXPERIMENT ONLY (tools/prrt_duo_probe.py; -DAUVP_DUO_DIAG=1: shader clocks a stage spends AT WORK per step, =2: the clocks it
+// spends BETWEEN two pieces of work, i.e. waiting for its input)
+#ifdef AUVP_DUO_DIAG
+#if AUVP_DUO_DIAG == 2
+#define PPIPE_DIAG_BEGIN(acc, t0, tprev) const unsigned long long t0 = __builtin_amdgcn_s_memtime(); if (tprev) acc += t0 - tprev;
+#define PPIPE_DIAG_END(acc, t0, tprev) tprev = __builtin_amdgcn_s_memtime(); (void)t0;
+#else
+#define PPIPE_DIAG_BEGIN(acc, t0, tprev) const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#define PPIPE_DIAG_END(acc, t0, tprev) acc += __builtin_amdgcn_s_memtime() - t0; (void)tprev;
+#endif
+#endif
 
 struct PpipeSlot {
   // ---- A (H)
@@ -55,8 +75,10 @@ struct PpipeSlot {
   int kind, b, par, n_total;     // kind 0: a steer follows; 1: the chosen bucket was empty (the step is used up)
   unsigned long long tmask;
   int cnt_b, rmin2;              // the chosen bucket's size as H read it; smallest rejected member try (0x7fffffff: none)
-  int head_b, _pa1;              // ... and its newest member as H read it (>= ver: H saw an insert its snapshot does not cover)
+  int head_b, sa_cslot;          // ... and its newest member as H read it (>= ver: H saw an insert its snapshot does not cover); NW = 5: ring slot of the first sub-arc word
   double px, py, pth, ptt;       // the parent's record
+  // ---- A2: the sub-arcs (H itself with four wavefronts per episode; D with five: tagD, and tmask above is D's then)
+  unsigned long long tagD;
   double radius[DUO_CS], phi[DUO_CS];
   // ---- B (S)
   unsigned long long tagB;
@@ -79,7 +101,7 @@ struct PpipeCtl {  // (first eight words: what the waits look at)
   int stop, abort, final_step;  // final_step: the last step M executed (the stream ends after its draws)
   double final_after;
   unsigned long long final_drawn;
-  int h_done, s_done, g_done, _p0;
+  int h_done, s_done, g_done, d_done;
   // H's own: stream position at the first word of the steps in flight (slot k & 7)
   unsigned long long sp_drawn[PPIPE_RING];
   uint32_t sp_cslot[PPIPE_RING];
@@ -238,13 +260,15 @@ __device__ __forceinline__ bool prrt_goal_arc_eval(const PrrtParamsDev& P, const
   return is_free;
 }
 
-template <int J>
-__global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes, int next_lds) {
+constexpr int PPIPE_EP5 = 3;   // ... with five wavefronts per episode (fifteen wavefronts)
+template <int J, int NW>
+__global__ __launch_bounds__((NW == 5 ? PPIPE_EP5 : PPIPE_EP) * 64 * NW, 1) void prrt_pipe_kernel(WorldDev W, PrrtParamsDev P, PrrtBuffers B, int n_episodes, int next_lds) {
+  static_assert(NW == 4 || NW == 5, "four wavefronts per episode, or five with the draw wavefront");
   extern __shared__ __align__(16) unsigned char smem[];
   const int wave = uni((int)(threadIdx.x >> 6));
   const int lane = lane_id();
-  const int n_ep_wg = (int)(blockDim.x / 256);
-  const int eidx = wave >> 2, role = wave & 3;  // role 0: M, 1: H, 2: S, 3: G
+  const int n_ep_wg = (int)(blockDim.x / (64 * NW));
+  const int eidx = wave / NW, role = wave % NW;  // role 0: M, 1: H, 2: S, 3: G, 4: D
   const int per_ep = ppipe_per_episode_bytes(B.max_pts, next_lds ? B.cap_nodes : 0);
   unsigned char* eb = smem + (size_t)eidx * per_ep;
   uint32_t* gen = reinterpret_cast<uint32_t*>(eb);
@@ -276,8 +300,8 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     if (lane == 0) {
       ctl->ver = sum.n_nodes; ctl->n_occ = sum.n_occ; ctl->m_done = step0; ctl->epoch = 0; ctl->restart_k = step0; ctl->stop = 0; ctl->abort = 0;
       ctl->final_step = step0 - 1; ctl->final_after = 0.0; ctl->final_drawn = 0ull;
-      ctl->h_done = 0; ctl->s_done = 0; ctl->g_done = 0;
-      for (int q = 0; q < PPIPE_RING; q++) { slot_of(q)->tagA = 0ull; slot_of(q)->tagB = 0ull; slot_of(q)->tagC = 0ull; }
+      ctl->h_done = 0; ctl->s_done = 0; ctl->g_done = 0; ctl->d_done = 0;
+      for (int q = 0; q < PPIPE_RING; q++) { slot_of(q)->tagA = 0ull; slot_of(q)->tagB = 0ull; slot_of(q)->tagC = 0ull; slot_of(q)->tagD = 0ull; }
     }
   } else if (role == 1) {
     // the stored generator (624 words in place: logical word D + j in slot (pslot + j) mod 624, avail of them not yet consumed)
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
   }
   if (next_lds && valid_ep) {
     const int n0 = uni(sum.n_nodes);
-    for (int i = (int)(threadIdx.x & 255u); i < n0 && i < capn; i += 256) mnx[i] = nodes[i].next;
+    for (int i = (int)threadIdx.x - eidx * 64 * NW; i < n0 && i < capn; i += 64 * NW) mnx[i] = nodes[i].next;
   }
   __threadfence_block();
   __syncthreads();
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       return true;
     };
 #ifdef AUVP_DUO_DIAG
-    unsigned long long diag_h = 0ull;
+    unsigned long long diag_h = 0ull, tprev_h = 0ull;
 #endif
     for (;;) {
       PpipeView cv;
@@ -369,14 +393,14 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
             cur = k - 1;
             continue;
           }
-          if (k < P.max_step && k < cv.m_done + PPIPE_LEAD) break;
+          if (k < P.max_step && k < cv.m_done + (NW == 5 ? AUVP_PPIPE_LEAD5 : PPIPE_LEAD)) break;
           if (++spins > pipe_spin_limit()) { give_up(); goto h_end; }
           __builtin_amdgcn_s_sleep(1);
         }
       }
       // ---------------------------------------------------------------- build part A of step k (from the snapshot `cv` just taken)
 #ifdef AUVP_DUO_DIAG
-      const unsigned long long t_h0 = __builtin_amdgcn_s_memtime();  // EXPERIMENT ONLY (tools/prrt_duo_probe.py)
+      PPIPE_DIAG_BEGIN(diag_h, t_h0, tprev_h)
 #endif
       cur = k;
       sp_set(k, rng.cslot, rng.drawn);
@@ -385,7 +409,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       const int ver = cv.ver, n_occ = cv.n_occ;
       PpipeSlot* q = slot_of(k);
       if (lane == 0) duo_poke64(&q->tagA, 0ull);  // (a stage of an epoch that ended may still be reading this part)
-      int status = 0, kind = 0, b = 0, par = 0, n_total = 0, rmin = 0x7fffffff, rmin2 = 0x7fffffff, cnt_snap = 0, head_snap = 0;
+      int status = 0, kind = 0, b = 0, par = 0, n_total = 0, rmin = 0x7fffffff, rmin2 = 0x7fffffff, cnt_snap = 0, head_snap = 0, sa_cslot = 0;
       unsigned long long tmask = 0ull;
       bool fits = true;
       if (n_occ <= 0) status = -1;
@@ -455,7 +479,12 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
                 n_total = n_total < 0 ? 0 : (n_total > DUO_MAX_FREQ ? DUO_MAX_FREQ : n_total);
                 const int n = n_total;
                 fits = ensure((uint32_t)(4 * n));
-                if (fits) {
+                if (fits && NW == 5) {
+                  // the draw wavefront takes it from here: where the step's sub-arc words start in the ring
+                  sa_cslot = (int)rng.cslot;
+                  ring_advance(rng, (uint32_t)(4 * n));
+                  if (lane == 0) { q->px = p0; q->py = p1; q->pth = p2; q->ptt = p3; }
+                } else if (fits) {
                   const bool active = lane < n;
                   double radius = 0.0, phi = 0.0;
                   bool taken = false;
@@ -487,12 +516,13 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       if (lane == 0) {
         q->ver = ver; q->n_occ = n_occ; q->rmin = rmin; q->status = status; q->kind = kind; q->b = b; q->par = par; q->n_total = n_total;
         q->cnt_b = cnt_snap; q->rmin2 = rmin2; q->head_b = head_snap;
-        q->tmask = tmask;
+        if (NW == 5) q->sa_cslot = sa_cslot;  // (tmask, radius, phi: the draw wavefront's)
+        else q->tmask = tmask;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) duo_poke64(&q->tagA, duo_tag(epoch, k));
 #ifdef AUVP_DUO_DIAG
-      diag_h += __builtin_amdgcn_s_memtime() - t_h0;
+      PPIPE_DIAG_END(diag_h, t_h0, tprev_h)
 #endif
       k++;
     }
@@ -528,6 +558,76 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     return;
   }
 
+  if (NW == 5 && role == 4) {
+    // ================================================================================================================ D
+    // part A2 of step k from part A: the 2 n sub-arc draws (:262-271) out of the generator ring -- H generated them and keeps
+    // every word since the step M is at -- their dist / diff, which sub-arcs are taken, radius and angle.  A pure function of
+    // (sa_cslot, n_total): no state of its own besides the epoch and the step it is at.
+    int epoch = 0, k = step0;
+    RingRng rr;
+    rr.s = gen; rr.gslot = 0u; rr.cslot = 0u; rr.avail = 0u; rr.drawn = 0ull;
+#ifdef AUVP_DUO_DIAG
+    unsigned long long diag_d = 0ull, tprev_d = 0ull;
+#endif
+    for (;;) {
+      PpipeSlot* q = nullptr;
+      {
+        int spins = 0;
+        for (;;) {
+          q = slot_of(k);
+          const unsigned long long tg = duo_peek64(&q->tagA);
+          const PpipeView cv = ppipe_look(ctl);
+          if (cv.stop || cv.abort) goto d_end;
+          if (cv.epoch != epoch) { epoch = cv.epoch; k = cv.restart_k; continue; }
+          if (tg == duo_tag(epoch, k)) break;
+          if (++spins > pipe_spin_limit()) { give_up(); goto d_end; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef AUVP_DUO_DIAG
+      PPIPE_DIAG_BEGIN(diag_d, t_d0, tprev_d)
+#endif
+      const int a_status = uni(q->status), a_kind = uni(q->kind);
+      int n = uni(q->n_total);
+      n = n < 0 ? 0 : (n > DUO_MAX_FREQ ? DUO_MAX_FREQ : n);
+      int sa = uni(q->sa_cslot);
+      sa = sa < 0 ? 0 : (sa >= TRIO_GEN ? TRIO_GEN - 1 : sa);
+      __asm__ volatile("" ::: "memory");
+      if (duo_peek64(&q->tagA) != duo_tag(epoch, k)) continue;  // rewritten under the copy (a new epoch): look again
+      if (lane == 0) duo_poke64(&q->tagD, 0ull);
+      double radius = 0.0, phi = 0.0;
+      bool taken = false;
+      if (a_status == 0 && a_kind == 0 && lane < n) {
+        rr.cslot = (uint32_t)sa;
+        const double dist = py_uniform(0.0, P.dist_to_end, ring_random_at(rr, (uint32_t)(2 * lane)));
+        const double diff = py_uniform(-P.diff_max, P.diff_max, ring_random_at(rr, (uint32_t)(2 * lane + 1)));
+        taken = auvp_fabs(dist) > auvp_fabs(diff);
+        if (taken) {
+          const double s1 = dist + diff, s2 = dist - diff;
+          radius = auvp_div_plain(s1 + s2, -s1 + s2);
+          phi = auvp_div_plain(s1 + s2, 2 * radius);
+        }
+      }
+      const unsigned long long tmask = wave_ballot(taken);
+      if (lane < DUO_CS) { q->radius[lane] = radius; q->phi[lane] = phi; }
+      if (lane == 0) q->tmask = tmask;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) duo_poke64(&q->tagD, duo_tag(epoch, k));
+#ifdef AUVP_DUO_DIAG
+      PPIPE_DIAG_END(diag_d, t_d0, tprev_d)
+#endif
+      k++;
+    }
+  d_end:
+#ifdef AUVP_DUO_DIAG
+    if (lane == 0) ctl->diag[3] = (double)diag_d;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) duo_poke(&ctl->d_done, 1);
+    return;
+  }
+
   // ================================================================================================== S / G / M: the obstacles
   double ox[J], oy[J], ot[J], orr[J];
 #pragma unroll
@@ -550,7 +650,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     // ================================================================================================================ S
     int epoch = 0, k = step0;
 #ifdef AUVP_DUO_DIAG
-    unsigned long long diag_s = 0ull;
+    unsigned long long diag_s = 0ull, tprev_s = 0ull;
 #endif
     for (;;) {
       PpipeSlot* q = nullptr;
@@ -558,7 +658,8 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
         int spins = 0;
         for (;;) {
           q = slot_of(k);
-          const unsigned long long tg = duo_peek64(&q->tagA);
+          // (five wavefronts: the draw wavefront's tag -- it is only ever set behind a matching tagA)
+          const unsigned long long tg = duo_peek64(NW == 5 ? &q->tagD : &q->tagA);
           const PpipeView cv = ppipe_look(ctl);
           if (cv.stop || cv.abort) goto s_end;
           if (cv.epoch != epoch) { epoch = cv.epoch; k = cv.restart_k; continue; }
@@ -569,7 +670,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #ifdef AUVP_DUO_DIAG
-      const unsigned long long t_s0 = __builtin_amdgcn_s_memtime();
+      PPIPE_DIAG_BEGIN(diag_s, t_s0, tprev_s)
 #endif
       // ---- part A, copied out
       const int a_status = uni(q->status), a_kind = uni(q->kind);
@@ -586,6 +687,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       if (lane < DUO_CS) { radius = q->radius[lane]; phi = q->phi[lane]; }
       __asm__ volatile("" ::: "memory");
       if (duo_peek64(&q->tagA) != duo_tag(epoch, k)) continue;  // rewritten under the copy (a new epoch): look again
+      if (NW == 5 && duo_peek64(&q->tagD) != duo_tag(epoch, k)) continue;
       if (lane == 0) duo_poke64(&q->tagB, 0ull);
       int ok = 0, cnt = 0, have_sc = 0;
       double sin_c = 0.0, cos_c = 0.0;
@@ -665,7 +767,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) duo_poke64(&q->tagB, duo_tag(epoch, k));
 #ifdef AUVP_DUO_DIAG
-      diag_s += __builtin_amdgcn_s_memtime() - t_s0;
+      PPIPE_DIAG_END(diag_s, t_s0, tprev_s)
 #endif
       k++;
     }
@@ -682,7 +784,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     // ================================================================================================================ G
     int epoch = 0, k = step0;
 #ifdef AUVP_DUO_DIAG
-    unsigned long long diag_g = 0ull;
+    unsigned long long diag_g = 0ull, tprev_g = 0ull;
 #endif
     for (;;) {
       PpipeSlot* q = nullptr;
@@ -701,7 +803,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #ifdef AUVP_DUO_DIAG
-      const unsigned long long t_g0 = __builtin_amdgcn_s_memtime();
+      PPIPE_DIAG_BEGIN(diag_g, t_g0, tprev_g)
 #endif
       const int ok = uni(q->ok), cnt = uni(q->cnt), have_sc = uni(q->have_sc);
       int par = uni(q->par);
@@ -733,7 +835,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) duo_poke64(&q->tagC, duo_tag(epoch, k));
 #ifdef AUVP_DUO_DIAG
-      diag_g += __builtin_amdgcn_s_memtime() - t_g0;
+      PPIPE_DIAG_END(diag_g, t_g0, tprev_g)
 #endif
       k++;
     }
@@ -753,7 +855,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
   bool have_prev_arc = false;
   int hist = -2;  // lane l < 8: the bucket of the latest insert whose node index is l mod 8
 #ifdef AUVP_DUO_DIAG
-  unsigned long long diag_m = 0ull;
+  unsigned long long diag_m = 0ull, tprev_m = 0ull;
 #endif
   while (status == 0 && !done && step < P.max_step) {
     status = uni(status); done = uni(done); step = uni(step);
@@ -794,7 +896,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     }
     if (uni(status)) break;
 #ifdef AUVP_DUO_DIAG
-    const unsigned long long t_m0 = __builtin_amdgcn_s_memtime();
+    PPIPE_DIAG_BEGIN(diag_m, t_m0, tprev_m)
 #endif
     // ---- the slot, copied out; then H may have it back
     const int a_status = uni(q->status), a_kind = uni(q->kind), par = uni(q->par), n_total = uni(q->n_total);
@@ -885,7 +987,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     }
     step++;
 #ifdef AUVP_DUO_DIAG
-    diag_m += __builtin_amdgcn_s_memtime() - t_m0;
+    PPIPE_DIAG_END(diag_m, t_m0, tprev_m)
 #endif
   }
   // ---- the planning is over: H stores the generator where it ended, M the record ----
@@ -893,7 +995,8 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
   if (lane == 0) duo_poke(&ctl->stop, 1);
   {
     int spins = 0;
-    while (!uni(duo_peek(&ctl->h_done)) || !uni(duo_peek(&ctl->s_done)) || !uni(duo_peek(&ctl->g_done))) {
+    while (!uni(duo_peek(&ctl->h_done)) || !uni(duo_peek(&ctl->s_done)) || !uni(duo_peek(&ctl->g_done)) ||
+           (NW == 5 && !uni(duo_peek(&ctl->d_done)))) {
       if (++spins > pipe_spin_limit()) { status = AUVP_ST_PIPELINE; break; }
       __builtin_amdgcn_s_sleep(1);
     }
@@ -909,7 +1012,7 @@ __global__ __launch_bounds__(PPIPE_EP * 256, 1) void prrt_pipe_kernel(WorldDev W
     sum.rng_after = ctl->final_after; sum.n_draw32 = ctl->final_drawn;
     if (!done) sum.path_len = 0;
 #ifdef AUVP_DUO_DIAG
-    if (!done) { sum.arc[0] = (double)diag_m; sum.arc[1] = ctl->diag[0]; sum.arc[2] = ctl->diag[1]; sum.arc[3] = ctl->diag[2]; sum.arc[4] = (double)my_epoch; }
+    if (!done) { sum.arc[0] = (double)diag_m; sum.arc[1] = ctl->diag[0]; sum.arc[2] = ctl->diag[1]; sum.arc[3] = ctl->diag[2]; sum.arc[4] = (double)my_epoch; sum.arc[5] = NW == 5 ? ctl->diag[3] : 0.0; }
 #endif
   }
 }

@@ -121,8 +121,12 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true, b
     S.last_kernel = "prrt_pipe_kernel";
     int eps_wg = (S.E + n_cu_l - 1) / n_cu_l;
     eps_wg = eps_wg < 1 ? 1 : (eps_wg > auvp::PPIPE_EP ? auvp::PPIPE_EP : eps_wg);
+    // round 6: a FIFTH wavefront per episode takes the sub-arc draws off H, the slowest stage (planner_pipe_kernel.h: D) -- where
+    // a workgroup of five-wavefront episodes fits the 1 024-thread limit (at most three episodes per workgroup: up to 768
+    // episodes on this GPU; config 4's 512 run two per CU).  Option PRRT_PIPE_DRAW = 0 / 1 forces the choice within that limit.
+    const bool draw_wave = eps_wg <= auvp::PPIPE_EP5 && h->opt_flag(OPT_PRRT_PIPE_DRAW, true);
     grid_used = (S.E + eps_wg - 1) / eps_wg;
-    block_used = eps_wg * 256;
+    block_used = eps_wg * (draw_wave ? 320 : 256);
     // the member lists' next links in LDS where they fit beside the slots (option PRRT_NEXT_LDS = 0 keeps them in memory)
     int next_lds = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, S.B.cap_nodes) <= (size_t)150 * 1024 ? 1 : 0;
     next_lds = next_lds && h->opt_flag(OPT_PRRT_NEXT_LDS, true);
@@ -143,9 +147,15 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true, b
       hipLaunchKernelGGL(kern, dim3(grid_used), dim3(block_used), lds_used, h->stream, h->W, S.P, S.B, S.E, next_lds);
       return hipGetLastError();
     };
-    if (O <= 64) le = launch_pipe(auvp::prrt_pipe_kernel<1>);
-    else if (O <= 128) le = launch_pipe(auvp::prrt_pipe_kernel<2>);
-    else le = launch_pipe(auvp::prrt_pipe_kernel<4>);
+    if (draw_wave) {
+      if (O <= 64) le = launch_pipe(auvp::prrt_pipe_kernel<1, 5>);
+      else if (O <= 128) le = launch_pipe(auvp::prrt_pipe_kernel<2, 5>);
+      else le = launch_pipe(auvp::prrt_pipe_kernel<4, 5>);
+    } else {
+      if (O <= 64) le = launch_pipe(auvp::prrt_pipe_kernel<1, 4>);
+      else if (O <= 128) le = launch_pipe(auvp::prrt_pipe_kernel<2, 4>);
+      else le = launch_pipe(auvp::prrt_pipe_kernel<4, 4>);
+    }
   } else if (lat) {
     if (O <= 64) le = launch(auvp::prrt_kernel<1, true>);
     else if (O <= 128) le = launch(auvp::prrt_kernel<2, true>);

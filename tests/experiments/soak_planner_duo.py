@@ -44,7 +44,10 @@ for c in range(n_cases):
     ref = None
     for waves, rep in ((0, 1), (4, 4)):
         os.environ["AUVP_PRRT_PIPE"] = "1" if waves == 4 else "0"
-        for _ in range(rep):
+        for r_i in range(rep):
+            # (round 6: the pipeline has a fifth wavefront for the sub-arc draws where three episodes fit a workgroup; every
+            # other repetition forces the four-wavefront form, which larger batches still get)
+            os.environ["AUVP_PRRT_PIPE_DRAW"] = "1" if r_i % 2 == 0 else "0"
             pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, **kw)
             s = pb.plan().copy()
             want = {0: "prrt_kernel", 4: "prrt_pipe_kernel"}[waves]

@@ -23,19 +23,21 @@ def _fields_equal(a, b):
 
 
 def _plan(ctx, w, starts, goals, seeds, max_step, duo, monkeypatch, **kw):
-    """duo: 0 = prrt_kernel, 4 = prrt_pipe_kernel"""
+    """duo: 0 = prrt_kernel, 4 = prrt_pipe_kernel with four wavefronts per episode, 5 = with the draw wavefront (round 6)"""
     from auv_sim_amd._prrt_lib import PlannerBatch
     monkeypatch.setenv("AUVP_PRRT_ROWS", "0")
-    monkeypatch.setenv("AUVP_PRRT_PIPE", "1" if duo == 4 else "0")
+    monkeypatch.setenv("AUVP_PRRT_PIPE", "1" if duo >= 4 else "0")
+    monkeypatch.setenv("AUVP_PRRT_PIPE_DRAW", "1" if duo == 5 else "0")
     pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, **kw)
     s = pb.plan().copy()
     ctx.L.auvp_prrt_last_kernel.restype = C.c_char_p
-    assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == {0: "prrt_kernel", 4: "prrt_pipe_kernel"}[duo]
+    assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == {0: "prrt_kernel", 4: "prrt_pipe_kernel", 5: "prrt_pipe_kernel"}[duo]
+    assert ctx.last_launch()[1] % {0: 64, 4: 256, 5: 320}[duo] == 0   # threads per workgroup: 4 / 5 wavefronts per episode
     assert ctx.pipeline_fallbacks()[0] == 0
     return pb, s
 
 
-@pytest.mark.parametrize("waves", [4])
+@pytest.mark.parametrize("waves", [4, 5])
 @pytest.mark.parametrize("n_ep,freq,max_step,n_obst,subs", [(37, 10, 400, 256, 2), (64, 15, 250, 64, 1), (5, 3, 300, 256, 4), (1, 10, 2000, 256, 1),
                                                            (130, 30, 150, 128, 2), (9, 10, 1, 64, 1)])
 def test_duo_equals_one_wavefront_per_episode(ctx, orc, n_ep, freq, max_step, n_obst, subs, waves, monkeypatch):

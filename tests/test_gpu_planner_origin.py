@@ -27,8 +27,10 @@ ERR = sorted(glob.glob(os.path.join(GOLDEN, "g2e_*.npz")))
 ST = ("st_bucket", "st_picked", "st_accepted", "st_done", "st_npath", "st_arc_n", "st_arc_free")
 # kernel -> (options that force it, keeps the step log)
 KERNELS = {"prrt_kernel": (dict(PRRT_ROWS=0, PRRT_PIPE=0), True), "prrt_rows_kernel": (dict(PRRT_ROWS=1, PRRT_LAT=0), False),
-           "prrt_pipe_kernel": (dict(PRRT_ROWS=0, PRRT_PIPE=1), False)}
-MAX_FREQ = {"prrt_kernel": 10 ** 9, "prrt_rows_kernel": 15, "prrt_pipe_kernel": 30}  # PRW_MAX_FREQ, DUO_MAX_FREQ
+           # (the pipeline with the draw wavefront -- five per episode, round 6 -- and in its four-wavefront form)
+           "prrt_pipe_kernel": (dict(PRRT_ROWS=0, PRRT_PIPE=1, PRRT_PIPE_DRAW=1), False),
+           "prrt_pipe_kernel/4": (dict(PRRT_ROWS=0, PRRT_PIPE=1, PRRT_PIPE_DRAW=0), False)}
+MAX_FREQ = {"prrt_kernel": 10 ** 9, "prrt_rows_kernel": 15, "prrt_pipe_kernel": 30, "prrt_pipe_kernel/4": 30}  # PRW_MAX_FREQ, DUO_MAX_FREQ
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +61,7 @@ def _batch(ctx, g, kernel, E, seeds, step_log):
         # (a failing start is reported by the batch's first summaries; plan() then leaves such an episode alone)
         summ = pb.plan().copy()
         ctx.L.auvp_prrt_last_kernel.restype = C.c_char_p
-        assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == kernel
+        assert ctx.L.auvp_prrt_last_kernel(ctx.h).decode() == kernel.split("/")[0]
         assert ctx.pipeline_fallbacks()[0] == 0
     finally:
         for k in opts:

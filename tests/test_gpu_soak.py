@@ -58,9 +58,11 @@ def test_shark_grid_random_cases():
 DIAG = os.path.join(REPO, "auv_sim_amd", "libauvplan_diag.so")
 # (script, cases, seed, {stage name: "mode,mod,residue"}): which wavefronts of a workgroup belong to the stage
 #   rrt_duo: wave & 1 (0 main, 1 helper); rrt_trio <J, 3>: wave % 3 (0 M geometry, 1 H stream, 2 T tree) -- the <J, 4> form of the
-#   same sweep has wave % 4, so `1,3,r` lands on varying roles there: all the better; prrt_pipe: wave & 3 (0 M, 1 H, 2 S, 3 G)
+#   same sweep has wave % 4, so `1,3,r` lands on varying roles there: all the better; prrt_pipe: wave % 5 (0 M, 1 H, 2 S, 3 G, 4 D), or wave & 3 without the draw wavefront
 STAGES = {"soak_duo.py": {"main_or_M": "1,3,0", "H": "1,3,1", "T": "1,3,2", "helper": "1,2,1"},
-          "soak_planner_duo.py": {"M": "1,4,0", "H": "1,4,1", "S": "1,4,2", "G": "1,4,3"}}
+          # (round 6: five wavefronts per episode -- wave % 5: 0 M, 1 H, 2 S, 3 G, 4 D the draw wavefront; every other repetition of
+          # the script runs the four-wavefront form, where `1,5,r` lands on varying roles)
+          "soak_planner_duo.py": {"M": "1,5,0", "H": "1,5,1", "S": "1,5,2", "G": "1,5,3", "D": "1,5,4"}}
 
 
 def _diag_run(script, cases, seed, jitter=None, spin=None):

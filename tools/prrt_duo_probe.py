@@ -34,8 +34,8 @@ for n in (1, 64, 512, 1024):
             nd = s["done"] == 0
             st = float(s["steps"][nd].sum())
             a = s["arc"][nd]
-            print("   diag (%s): clocks per step at work: M %.0f, H %.0f, S %.0f, G %.0f; redos per step %.3f; nodes per step %.2f"
-                  % (ctx.prrt_last_kernel(), a[:, 0].sum() / st, a[:, 1].sum() / st, a[:, 2].sum() / st, a[:, 3].sum() / st, a[:, 4].sum() / st,
+            print("   diag (%s): clocks per step at work (AUVP_DUO_DIAG=2: waiting): M %.0f, H %.0f, S %.0f, G %.0f, D %.0f; redos per step %.3f; nodes per step %.2f"
+                  % (ctx.prrt_last_kernel(), a[:, 0].sum() / st, a[:, 1].sum() / st, a[:, 2].sum() / st, a[:, 3].sum() / st, a[:, 5].sum() / st, a[:, 4].sum() / st,
                      s["n_nodes"][nd].sum() / st))
         elif os.environ.get("AUVPLAN_LIBRARY") and duo == "1":
             nd = s["done"] == 0
