@@ -132,7 +132,7 @@ def load():
 # auvp_create.
 OPTION_NAMES = ("ROWS", "DUO", "TRIO", "QUAD", "TIGHT_CULL", "NN_EXACT", "LEAF_SWEEP_ALL", "NO_HABITAT_GRID", "RG_MAX_ENTRIES",
                 "NO_GRID_INDEX", "PRRT_LAT", "PRRT_PIPE", "PRRT_OBST_LDS", "PRRT_NEXT_LDS", "PRRT_ROWS", "ASTAR_NO_GRID",
-                "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "PRRT_PIPE_DRAW")
+                "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "PRRT_PIPE_DRAW", "PRRT_BUCKET_LDS")
 
 
 def _f64(a, shape=None):

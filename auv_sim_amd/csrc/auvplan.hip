@@ -54,12 +54,12 @@ struct DevBuf {
 enum AuvpOpt {
   OPT_ROWS, OPT_DUO, OPT_TRIO, OPT_QUAD, OPT_TIGHT_CULL, OPT_NN_EXACT, OPT_LEAF_SWEEP_ALL, OPT_NO_HABITAT_GRID, OPT_RG_MAX_ENTRIES,
   OPT_NO_GRID_INDEX, OPT_PRRT_LAT, OPT_PRRT_PIPE, OPT_PRRT_OBST_LDS, OPT_PRRT_NEXT_LDS, OPT_PRRT_ROWS, OPT_ASTAR_NO_GRID,
-  OPT_ASTAR_NO_LIST, OPT_ASTAR_PAIR, OPT_SOG_TILE, OPT_PIPE_FALLBACK, OPT_PRRT_PIPE_DRAW, OPT_COUNT
+  OPT_ASTAR_NO_LIST, OPT_ASTAR_PAIR, OPT_SOG_TILE, OPT_PIPE_FALLBACK, OPT_PRRT_PIPE_DRAW, OPT_PRRT_BUCKET_LDS, OPT_COUNT
 };
 static const char* const AUVP_OPT_NAMES[OPT_COUNT] = {
   "ROWS", "DUO", "TRIO", "QUAD", "TIGHT_CULL", "NN_EXACT", "LEAF_SWEEP_ALL", "NO_HABITAT_GRID", "RG_MAX_ENTRIES",
   "NO_GRID_INDEX", "PRRT_LAT", "PRRT_PIPE", "PRRT_OBST_LDS", "PRRT_NEXT_LDS", "PRRT_ROWS", "ASTAR_NO_GRID",
-  "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "PRRT_PIPE_DRAW"};
+  "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "PRRT_PIPE_DRAW", "PRRT_BUCKET_LDS"};
 
 struct auvp_handle {
   bool opt_has[OPT_COUNT] = {};

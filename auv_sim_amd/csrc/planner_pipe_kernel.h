@@ -110,9 +110,15 @@ struct PpipeCtl {  // (first eight words: what the waits look at)
 
 // next_nodes > 0: the episode also keeps the member lists' `next` links (4 bytes per node) in LDS -- H walks count - 1 - r of
 // them per step, one dependent L2 read each otherwise
-__host__ __device__ inline int ppipe_per_episode_bytes(int max_pts, int next_nodes = 0) {
+// bucket_words > 0 (round 6): ... and a mirror of the bucket table (8 bytes per bucket: count | epoch, newest member) and of the
+// list of occupied buckets (4 bytes each, at most min(buckets, nodes) of them): H's `_randbelow` over the occupied buckets is
+// followed by two dependent reads -- the list entry, then that bucket's word -- which were L2 round trips
+__host__ __device__ inline int ppipe_occ_entries(int n_buckets, int cap_nodes) { return n_buckets < cap_nodes ? n_buckets : cap_nodes; }
+__host__ __device__ inline int ppipe_per_episode_bytes(int max_pts, int next_nodes = 0, int bucket_words = 0, int occ_entries = 0) {
   int b = TRIO_GEN * 4;
   b += (next_nodes * 4 + 15) & ~15;
+  b += (bucket_words * 8 + 15) & ~15;
+  b += (occ_entries * 4 + 15) & ~15;
   b += ((max_pts * 16) + 15) & ~15;
   b += (int)((sizeof(PpipeCtl) + 15) & ~(size_t)15);
   b += PPIPE_RING * (int)((sizeof(PpipeSlot) + 15) & ~(size_t)15);
@@ -269,12 +275,20 @@ __global__ __launch_bounds__((NW == 5 ? PPIPE_EP5 : PPIPE_EP) * 64 * NW, 1) void
   const int lane = lane_id();
   const int n_ep_wg = (int)(blockDim.x / (64 * NW));
   const int eidx = wave / NW, role = wave % NW;  // role 0: M, 1: H, 2: S, 3: G, 4: D
-  const int per_ep = ppipe_per_episode_bytes(B.max_pts, next_lds ? B.cap_nodes : 0);
+  // (`next_lds`: bit 0 = the member links in LDS, bit 1 = the bucket table and the occupied list in LDS)
+  const int bk_lds = uni((next_lds >> 1) & 1);
+  next_lds = uni(next_lds & 1);
+  const int n_occ_cap = ppipe_occ_entries(P.n_buckets, B.cap_nodes);
+  const int per_ep = ppipe_per_episode_bytes(B.max_pts, next_lds ? B.cap_nodes : 0, bk_lds ? P.n_buckets : 0, bk_lds ? n_occ_cap : 0);
   unsigned char* eb = smem + (size_t)eidx * per_ep;
   uint32_t* gen = reinterpret_cast<uint32_t*>(eb);
   eb += TRIO_GEN * 4;
   int32_t* mnx = reinterpret_cast<int32_t*>(eb);  // [cap_nodes] when next_lds: node -> the bucket member created before it
   if (next_lds) eb += (B.cap_nodes * 4 + 15) & ~15;
+  int2* bkl = reinterpret_cast<int2*>(eb);        // [n_buckets] when bk_lds: the bucket words (M writes both copies)
+  if (bk_lds) eb += (P.n_buckets * 8 + 15) & ~15;
+  int32_t* occl = reinterpret_cast<int32_t*>(eb);  // [n_occ_cap] when bk_lds: the occupied buckets in the order they were first used
+  if (bk_lds) eb += (n_occ_cap * 4 + 15) & ~15;
   double(*spts)[2] = reinterpret_cast<double(*)[2]>(eb);  // S: the candidate's points for the collision test
   eb += ((B.max_pts * 16) + 15) & ~15;
   PpipeCtl* ctl = reinterpret_cast<PpipeCtl*>(eb);
@@ -313,6 +327,11 @@ __global__ __launch_bounds__((NW == 5 ? PPIPE_EP5 : PPIPE_EP) * 64 * NW, 1) void
   if (next_lds && valid_ep) {
     const int n0 = uni(sum.n_nodes);
     for (int i = (int)threadIdx.x - eidx * 64 * NW; i < n0 && i < capn; i += 64 * NW) mnx[i] = nodes[i].next;
+  }
+  if (bk_lds && valid_ep) {
+    const int o0 = uni(sum.n_occ);
+    for (int i = (int)threadIdx.x - eidx * 64 * NW; i < P.n_buckets; i += 64 * NW) bkl[i] = buckets[i];
+    for (int i = (int)threadIdx.x - eidx * 64 * NW; i < o0 && i < n_occ_cap; i += 64 * NW) occl[i] = occupied[i];
   }
   __threadfence_block();
   __syncthreads();
@@ -418,9 +437,10 @@ __global__ __launch_bounds__((NW == 5 ? PPIPE_EP5 : PPIPE_EP) * 64 * NW, 1) void
         const uint32_t oi = ppipe_randbelow<true>(rng, (uint32_t)n_occ, rmin, ok1, more);
         fits = ok1;
         if (fits) {
-          int bb = duo_ld_i32(occupied + (oi < (uint32_t)capn ? oi : 0u));
+          int bb = bk_lds ? lds_peek(&occl[oi < (uint32_t)n_occ_cap ? oi : 0u]) : duo_ld_i32(occupied + (oi < (uint32_t)capn ? oi : 0u));
           b = uni(bb < 0 ? 0 : (bb >= P.n_buckets ? P.n_buckets - 1 : bb));
-          const long long bwl = __builtin_nontemporal_load(reinterpret_cast<const long long*>(buckets + b));
+          const long long bwl = bk_lds ? (long long)lds_peek64(reinterpret_cast<const unsigned long long*>(bkl + b))
+                                       : __builtin_nontemporal_load(reinterpret_cast<const long long*>(buckets + b));
           const int2 bw = make_int2((int)(bwl & 0xffffffffll), (int)(bwl >> 32));
           const int cnt_b = uni(prrt_bucket_count(bw, epoch_b));
           if (cnt_b == 0) kind = 1;
@@ -936,7 +956,7 @@ __global__ __launch_bounds__((NW == 5 ? PPIPE_EP5 : PPIPE_EP) * 64 * NW, 1) void
       }
       me = n_nodes;
       int2 bwn = make_int2(0, 0);
-      if (bk >= 0) bwn = buckets[bk];
+      if (bk >= 0) bwn = bk_lds ? bkl[bk] : buckets[bk];
       const int c_before = bk >= 0 ? uni(prrt_bucket_count(bwn, epoch_b)) : -1;
       const int h_before = bk >= 0 ? uni(bwn.y) : -1;
       if (lane < cnt && lane < DUO_CS) {
@@ -958,6 +978,10 @@ __global__ __launch_bounds__((NW == 5 ? PPIPE_EP5 : PPIPE_EP) * 64 * NW, 1) void
         if (bk >= 0) {
           buckets[bk] = prrt_bucket_word(c_before + 1, me, epoch_b);
           if (c_before == 0) occupied[n_occ] = bk;
+          if (bk_lds) {  // (the mirrors H reads: published with the insert, by the fence below)
+            bkl[bk] = prrt_bucket_word(c_before + 1, me, epoch_b);
+            if (c_before == 0 && n_occ < n_occ_cap) occl[n_occ] = bk;
+          }
         }
       }
       if (lane == (me & (PPIPE_HIST - 1))) hist = bk;

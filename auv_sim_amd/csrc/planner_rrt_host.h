@@ -130,7 +130,13 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true, b
     // the member lists' next links in LDS where they fit beside the slots (option PRRT_NEXT_LDS = 0 keeps them in memory)
     int next_lds = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, S.B.cap_nodes) <= (size_t)150 * 1024 ? 1 : 0;
     next_lds = next_lds && h->opt_flag(OPT_PRRT_NEXT_LDS, true);
-    lds_used = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, next_lds ? S.B.cap_nodes : 0);
+    // round 6: ... and the bucket table + the occupied list, where they fit too (config 4: 1 600 buckets = 19 KB per episode;
+    // option PRRT_BUCKET_LDS = 0 keeps them in memory)
+    const int occ_cap = auvp::ppipe_occ_entries(S.P.n_buckets, S.B.cap_nodes);
+    int bk_lds = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, next_lds ? S.B.cap_nodes : 0, S.P.n_buckets, occ_cap) <= (size_t)150 * 1024 ? 1 : 0;
+    bk_lds = bk_lds && h->opt_flag(OPT_PRRT_BUCKET_LDS, true);
+    lds_used = (size_t)eps_wg * auvp::ppipe_per_episode_bytes(S.B.max_pts, next_lds ? S.B.cap_nodes : 0, bk_lds ? S.P.n_buckets : 0, bk_lds ? occ_cap : 0);
+    next_lds |= bk_lds << 1;  // (one kernel argument: bit 0 the links, bit 1 the bucket table)
     // what the fallback needs to take an episode back to where this launch found it: its record, generator and position
     le = S.snap_sum.reserve((size_t)S.E * sizeof(auvp::PrrtSummary));
     if (le == hipSuccess) le = S.snap_rng.reserve((size_t)S.E * 4 * sizeof(int32_t));

@@ -48,6 +48,7 @@ for c in range(n_cases):
             # (round 6: the pipeline has a fifth wavefront for the sub-arc draws where three episodes fit a workgroup; every
             # other repetition forces the four-wavefront form, which larger batches still get)
             os.environ["AUVP_PRRT_PIPE_DRAW"] = "1" if r_i % 2 == 0 else "0"
+            os.environ["AUVP_PRRT_BUCKET_LDS"] = "1" if (r_i // 2) % 2 == 0 else "0"   # (the bucket table's LDS mirror on / off)
             pb = PlannerBatch(ctx, starts, goals, w["rect"], max_step, seeds=seeds, **kw)
             s = pb.plan().copy()
             want = {0: "prrt_kernel", 4: "prrt_pipe_kernel"}[waves]
