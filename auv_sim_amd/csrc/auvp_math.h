@@ -67,7 +67,9 @@ AUVP_HD double auvp_div_plain(double a, double b) {
   const double q = a * r;
   return __builtin_fma(__builtin_fma(-b, q, a), r, q);
 #else
-  return a / b;
+  // (a zero divisor: the device form above gives NaN -- rcp(0) = inf through the Newton steps -- so the host form does too;
+  // IEEE's +-inf would make the checker and the device differ in WHICH non-finite value the ZeroDivisionError path carries)
+  return b == 0.0 ? __builtin_nan("") : a / b;
 #endif
 }
 AUVP_HD double auvp_sqrt_plain(double x) {
@@ -131,6 +133,7 @@ AUVP_HD double auvp_hypot(double x, double y) {
   if (ax < ay) { double t = ax; ax = ay; ay = t; }
   if (ax == 0.0) return ax;  // (both zero: nothing to divide by; a zero smaller operand falls out of the formula: h = ax, r = 0)
   double h = auvp_sqrt_plain(auvp_fma(ax, ax, ay * ay));
+  if (h == 0.0) return ax;   // (ax^2 underflowed, |ax| < ~2^-511: the correction below would be 0 / 0)
   double h2 = h * h;
   double ax2 = ax * ax;
   double r = auvp_fma(-ay, ay, h2 - ax2) + auvp_fma(h, h, -h2) - auvp_fma(ax, ax, -ax2);

@@ -146,7 +146,7 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true, b
     hipLaunchKernelGGL(auvp::prrt_snapshot_kernel, dim3(S.E), dim3(256), 0, h->stream, S.B, S.snap_sum.as<auvp::PrrtSummary>(),
                        S.snap_rng.as<int32_t>(), S.snap_mt.as<uint32_t>());
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));  // (the launch's own time starts after the snapshot)
+    // (ev0 was recorded before the snapshot: the time a caller is told includes it -- every latency-path plan call pays it)
     auto launch_pipe = [&](auto kern) -> hipError_t {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_used);
       if (e != hipSuccess) return e;

@@ -89,12 +89,16 @@ __device__ __forceinline__ double row_prev_f64(double v, double first) {
 // phi_0 .. phi_s itself, the values broadcast out of LDS, under an exec mask that drops lanes rl < j at step j: ONE vector
 // instruction per step (the DPP row-shift chain this replaces cost five: two v_mov_dpp + the add + the merge of the first
 // lane).  The masks are constants -- lanes with (lane & 15) >= j -- and only shrink, so the LDS reads issued under them still
-// reach every lane that will use them; four reads stay in flight.  Requires all 64 lanes enabled at the call (the kernels
-// call it from wave-uniform control flow only) and restores that.
+// reach every lane that will use them; four reads stay in flight.  Expects all 64 lanes enabled at the call (the kernels
+// call it from wave-uniform control flow only: the step masks are absolute) and restores the mask it found.
 __device__ __forceinline__ double rows_theta_chain(double theta0, const double* row_phi) {
   double th = theta0, t0, t1, t2, t3;
   const uint32_t a = (uint32_t)(size_t)((const __attribute__((address_space(3))) double*)row_phi);
+  // (the entry mask is saved and put back: should the compiler ever lower an enclosing condition as divergent, lanes that were
+  // masked off stay off -- ADVICE r5; one scalar move)
+  unsigned long long exec_in;
   __asm__ volatile(
+      "s_mov_b64 %[sv], exec\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       "ds_read_b64 %[t0], %[a] offset:0\n\t"
       "ds_read_b64 %[t1], %[a] offset:8\n\t"
@@ -155,8 +159,8 @@ __device__ __forceinline__ double rows_theta_chain(double theta0, const double* 
       "s_waitcnt lgkmcnt(0)\n\t"
       "s_mov_b32 exec_lo, 0xc000c000\n\ts_mov_b32 exec_hi, 0xc000c000\n\t"
       "v_add_f64 %[th], %[th], %[t2]\n\t"
-      "s_mov_b64 exec, -1"
-      : [th] "+v"(th), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+      "s_mov_b64 exec, %[sv]"
+      : [th] "+v"(th), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [sv] "=&s"(exec_in)
       : [a] "v"(a)
       : "memory");
   return th;

@@ -2,6 +2,7 @@
 traffic from the committed PMC passes is only attached to a launch that ran the same kernels."""
 import json
 import os
+import sys
 
 import numpy as np
 
@@ -36,7 +37,7 @@ def test_pmc_traffic_only_for_the_same_kernels(tmp_path, monkeypatch):
     f = tmp_path / "pmc.json"
     f.write_text(json.dumps({"tag": "t", "measurements": {"headline": {
         "kernels": {"rrt_rows_kernel": {}, "rrt_leaf_kernel": {}}, "hbm_bytes_raw": 100.0, "hbm_bytes_fetch_x2": 150.0, "units": 10.0}}}))
-    monkeypatch.setattr(b, "PMC_FILE", str(f))
+    monkeypatch.setattr(sys.modules["bench_sides.common"], "PMC_FILE", str(f))  # (the counter passes are read by bench_sides/common.py)
     t = b.pmc_traffic("headline", ["rrt_rows_kernel", "rrt_leaf_kernel"], 10.0)
     assert t["traffic"] == 150.0 and t["traffic_raw"] == 100.0
     t = b.pmc_traffic("headline", ["rrt_rows_kernel", "rrt_leaf_kernel"], 20.0)   # other batch: scaled by the work units
@@ -82,7 +83,7 @@ def test_per_kernel_bytes_and_the_binding_roof(tmp_path, monkeypatch):
     f.write_text(json.dumps({"tag": "t", "measurements": {"headline": {
         "kernels": {"rrt_rows_kernel": {"per_launch": {"SQ_INSTS_VALU": 1024.0 * 100, "GRBM_GUI_ACTIVE": 8.0 * 1000, "FETCH_SIZE": 1.0, "WRITE_SIZE": 2.0}}},
         "per_launch": {"SQ_INSTS_VALU": 1024.0 * 150, "GRBM_GUI_ACTIVE": 8.0 * 2000}, "units": 10.0}}}))
-    monkeypatch.setattr(b, "PMC_FILE", str(f))
+    monkeypatch.setattr(sys.modules["bench_sides.common"], "PMC_FILE", str(f))  # (the counter passes are read by bench_sides/common.py)
     assert abs(b.pmc_valu_issue("headline", "rrt_rows_kernel") - 0.4) < 1e-12
     assert abs(b.pmc_valu_issue("headline") - 0.3) < 1e-12
     assert b.pmc_valu_issue("nothing") is None

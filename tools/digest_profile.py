@@ -21,7 +21,22 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+KEEP_STALE = "--keep-stale" in sys.argv[2:]
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_sha():
+    """SHA-256 over the kernel sources (auv_sim_amd/csrc/*, names and bytes): what a counter pass was taken on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "auv_sim_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+CSRC = csrc_sha()
 src = os.path.join(REPO, "gpurun_out", "prof_" + tag)
 dst = os.path.join(REPO, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
@@ -132,19 +147,28 @@ json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 # pmc_latest.json keeps the measurements this run did not profile (a run may cover the headline and a few sides only), each
 # with the tag of the run it came from
 latest_path = os.path.join(REPO, "profiles", "pmc_latest.json")
-latest = {"tag": tag, "measurements": {}}
+# (round 6) ... but NOT when the kernel sources changed since: a measurement taken on other sources is dropped (its numbers stay
+# in profiles/<its tag>/pmc_summary.json), unless --keep-stale.  Every measurement carries the hash of the sources it was taken on.
+latest = {"tag": tag, "csrc_sha": CSRC, "measurements": {}}
+dropped = []
 if os.path.exists(latest_path):
     try:
         old = json.load(open(latest_path))
         for k, v in old.get("measurements", {}).items():
             v.setdefault("from_tag", old.get("tag"))
+            if k not in out["measurements"] and v.get("csrc_sha") != CSRC and not KEEP_STALE:
+                dropped.append("%s (from %s)" % (k, v.get("from_tag")))
+                continue
             latest["measurements"][k] = v
     except (ValueError, OSError):
         pass
 for k, v in out["measurements"].items():
     v = dict(v)
     v["from_tag"] = tag
+    v["csrc_sha"] = CSRC
     latest["measurements"][k] = v
+if dropped:
+    print("digest_profile: dropped from pmc_latest.json (taken on other kernel sources; re-profile or --keep-stale): " + ", ".join(dropped), file=sys.stderr)
 json.dump(latest, open(latest_path, "w"), indent=1)
 print(json.dumps({k: {f: v.get(f) for f in ("hbm_bytes_raw", "hbm_bytes_fetch_x2", "algorithmic_bytes_per_launch", "units", "sq_insts_valu_per_unit")}
                   for k, v in out["measurements"].items()}, indent=1))
