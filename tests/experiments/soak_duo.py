@@ -24,7 +24,9 @@ bad = 0
 fallbacks = 0
 for c in range(n_cases):
     n_obst = int(rng.choice([8, 64, 128, 256]))
-    world = synth.make_world(seed=int(rng.integers(1, 10_000)), n_obstacles=n_obst)
+    # (round 6: every fourth world has the reference's 5-vertex Catalina outline or a concave one instead of the rectangle)
+    world = synth.make_world(seed=int(rng.integers(1, 10_000)), n_obstacles=n_obst,
+                             polygon=[None, None, None, None, None, None, "catalina", "notch"][int(rng.integers(0, 8))])
     ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
     E = int(rng.choice([1, 2, 3, 7, 33, 130]))
     n_iter = int(rng.choice([1, 5, 60, 400, 1500]))

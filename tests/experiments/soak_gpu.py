@@ -34,7 +34,10 @@ def rrt_case(i):
     nob = rng.choice([0, 3, 40, 64, 130, 256])
     w = synth.make_world(seed=rng.randrange(10 ** 6), n_obstacles=nob, box=(x0, y0, x0 + size, y0 + size * rng.choice([0.6, 1.0])),
                          cell=cell, n_habitats=rng.choice([0, 1, 10, 40]), obst_radius=(1.0, rng.choice([3.0, 9.0])),
-                         hab_radius=(5.0, rng.choice([15.0, 50.0])), n_bins=rng.choice([1, 4, 10]), bin_len=rng.choice([20, 50]))
+                         hab_radius=(5.0, rng.choice([15.0, 50.0])), n_bins=rng.choice([1, 4, 10]), bin_len=rng.choice([20, 50]),
+                         # round 6: a third of the worlds have a boundary that is NOT a rectangle (the reference's 5-vertex
+                         # Catalina outline, a concave 8-vertex one): the polygon crossing test instead of the rectangle shortcut
+                         polygon=rng.choice([None, None, None, None, "catalina", "notch"]))
     kw = dict(freq=rng.choice([1, 7, 15, 16, 29, 30]), dist_to_end=rng.choice([0.5, 2.0, 5.0]), diff_max=rng.choice([0.1, 0.5, 2.0]),
               min_dist=rng.choice([0.0, 0.5, 1.5]), bin_interval=rng.choice([2.5, 5.0, 20.0]), v=rng.choice([0.7, 2.0]),
               max_traj_time=rng.choice([40.0, 120.0, 500.0]),
@@ -73,7 +76,8 @@ def rrt_modes_case(i):
     size = rng.choice([120.0, 300.0, 900.0])
     nob = rng.choice([0, 40, 256])
     w = synth.make_world(seed=rng.randrange(10 ** 6), n_obstacles=nob, box=(-300.0, -100.0, -300.0 + size, -100.0 + size),
-                         cell=rng.choice([10.0, 25.0]), n_habitats=rng.choice([0, 10]), obst_radius=(1.0, rng.choice([3.0, 9.0])))
+                         cell=rng.choice([10.0, 25.0]), n_habitats=rng.choice([0, 10]), obst_radius=(1.0, rng.choice([3.0, 9.0])),
+                         polygon=rng.choice([None, None, "catalina", "notch"]))
     kw = dict(freq=rng.choice([1, 7, 30, 45]), dist_to_end=rng.choice([0.5, 2.0, 5.0]), diff_max=rng.choice([0.1, 0.5]),
               min_dist=rng.choice([0.0, 0.5]), v=rng.choice([0.7, 2.0]), max_traj_time=rng.choice([40.0, 500.0, 5000.0]),
               weights=(rng.choice([-3.0, 2.5]), rng.choice([-3.0, 4.0]), rng.choice([-4.0, 1.7])))
