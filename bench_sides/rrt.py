@@ -92,7 +92,9 @@ def bench_rrt_nn(ctx, args, with_cpu, n_ep=None, long_horizon=False):
     out["xy_mirror_working_set_bytes"] = 16.0 * float(summ["n_nodes"].sum())
     out["scan_GBps"] = 16.0 * scanned / (ctx.last_launch_parts()[0] * 1e-3) / 1e9
     out["iters_per_launch"] = float(summ["iters_run"].sum())
-    if long_horizon and "roofline" in out:
+    # (AUVP_BENCH_PROFILE=1, set by tools/profile_bench.sh: the half-budget launches below run the same kernel and would be averaged
+    # into the profiler's per-kernel duration and counters of this measurement; the profile is of the full launch alone)
+    if long_horizon and "roofline" in out and os.environ.get("AUVP_BENCH_PROFILE") != "1":
         # An HBM-ONLY figure.  FETCH_SIZE counts Infinity-Cache hits as memory reads (MI355X_MICROARCH.md, HBM), so no counter
         # separates the two; what separates them is the working set: while the trees are small the co-resident episodes' x,y
         # mirrors fit the 256 MiB cache (the whole-launch rate is 1.05-1.07 x the streaming read rate

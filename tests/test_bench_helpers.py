@@ -54,6 +54,11 @@ def test_committed_pmc_file_has_the_measurements_bench_asks_for():
         assert m["hbm_bytes_fetch_x2"] >= m["hbm_bytes_raw"] > 0 and m["kernels"]
     assert set(j["measurements"]["headline"]["kernels"]) == {"rrt_rows_kernel", "rrt_leaf_kernel"}
     assert set(j["measurements"]["config5"]["kernels"]) == {"prrt_rows_kernel"}
+    # ONE profile run, taken on ONE state of the kernel sources (tools/digest_profile.py drops what was taken on other sources):
+    # round 5's file mixed the tags r5e and r5d
+    tags = {m.get("from_tag") for m in j["measurements"].values()}
+    shas = {m.get("csrc_sha") for m in j["measurements"].values()}
+    assert len(tags) == 1 and tags == {j["tag"]} and len(shas) == 1 and None not in shas, (tags, shas)
 
 
 def test_per_kernel_bytes_and_the_binding_roof(tmp_path, monkeypatch):

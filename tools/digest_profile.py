@@ -31,6 +31,8 @@ def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(REPO, "auv_sim_amd", "csrc")
     for f in sorted(os.listdir(d)):
+        if not f.endswith((".h", ".hip")):
+            continue
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

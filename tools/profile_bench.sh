@@ -21,6 +21,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export AUVP_BENCH_PROFILE=1   # bench.py: no auxiliary launches of a measured kernel (the NN leg's half-budget run) under the profiler
 ARGS="$@"
 G_FETCH="FETCH_SIZE"
 G_WRITE="WRITE_SIZE"
@@ -30,7 +31,7 @@ G_LANES="SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_I
 if [ $HEADLINE = 1 ]; then
   # bench.py prints the compact (<= 4 KB) line; the full record with every side measurement goes to $AUVP_BENCH_SIDES
   export AUVP_BENCH_SIDES=$OUT/bench_sides.json
-  python3 $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
+  AUVP_BENCH_PROFILE=0 python3 $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/bench.err
   export AUVP_BENCH_SIDES=$OUT/trace_main_bench.sides.json
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_main -o trace_main -- python3 $R/bench.py $ARGS --no-cpu --no-extra > $OUT/trace_main_bench.json 2> $OUT/trace_main.err
   export AUVP_BENCH_SIDES=$OUT/trace_bench.sides.json
