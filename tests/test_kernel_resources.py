@@ -40,3 +40,14 @@ def test_particle_filter_and_planner_rows_kernels_without_scratch():
     assert r["scratch"] == 0 and r["vgprs"] <= 128 and r["waves"] >= 4, r  # two 8-wavefront workgroups per CU
     r = _resources("prrt_rows_kernels.hip")["auvp::prrt_rows_kernel<true>"]
     assert r["scratch"] == 0 and r["vgprs"] <= 168, r
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_planner_pipeline_fits_its_workgroup_without_scratch():
+    """prrt_pipe_kernel (config 4): a workgroup of three five-wavefront episodes = fifteen wavefronts on a CU, i.e. four on a SIMD:
+    at most 128 VGPRs, and no scratch on any stage's chain (round 4 found register arrays under a computed index that had
+    silently become scratch arrays on H's chain)"""
+    res = _resources("auvplan.hip")
+    for nw in (4, 5):
+        r = res["auvp::prrt_pipe_kernel<4, %d>" % nw]
+        assert r["scratch"] == 0 and r["vgprs"] <= 128 and r["waves"] >= 4, (nw, r)
