@@ -771,8 +771,10 @@ def g1():
 def g6():
     rect = [(-300.0, -100.0), (-100.0, -100.0), (-100.0, 100.0), (-300.0, 100.0)]
     penta = [(-300.0, -100.0), (-120.0, -120.0), (-80.0, 20.0), (-180.0, 110.0), (-320.0, 60.0)]
+    notch = [tuple(p) for p in synth.make_world(seed=0, n_obstacles=0, polygon="notch")["polygon"].tolist()]  # (round 6: concave)
     specs = [(21, rect, (-290.0, -90.0), 200, (0, 10, 10), 12), (22, penta, (-280.0, -80.0), 400, (0, 10, 10), 12),
-             (23, rect, (-200.0, 0.0), 300, (0, 3.5, 1.25), 20), (24, rect, (-290.5, -90.25), 150, (0, 10, 10), 8)]
+             (23, rect, (-200.0, 0.0), 300, (0, 3.5, 1.25), 20), (24, rect, (-290.5, -90.25), 150, (0, 10, 10), 8),
+             (25, notch, (-200.0, -10.0), 300, (0, 10, 10), 12)]
     for k, (seed, poly, st, limit, wts, nobs) in enumerate(specs):
         w = synth.make_world(seed=seed, n_obstacles=nobs, obst_radius=(3.0, 8.0), start=st, n_habitats=8,
                              hab_radius=(10.0, 25.0))
@@ -780,11 +782,16 @@ def g6():
         save_npz("g6_fixlen_%d.npz" % k, **out)
         print("g6 fixlen", k, "found", out["found"], "path", len(out.get("path", [])), "expansions", len(out["expansions"]),
               "habitats left", len(out["habitats_left"]))
-    sog = [(31, (-290.0, -90.0), 200, (0, 10, 10, 100), 16), (32, (-200.0, 0.0), 300, (0, 10, 10, 100), 16),
-           (33, (-290.0, 90.0), 100, (0, 2.5, 1.5, 40.5), 64)]
-    for k, (seed, st, limit, wts, nobs) in enumerate(sog):
+    # round 6: 3 and 4 = astar_fixLenSOG on boundaries that are not rectangles.  within_bounds (:178-199) is a fan of triangles
+    # around the polygon's CENTROID: exact for the convex Catalina outline, reference-specific for the concave one (the wedge
+    # cut into the top edge is partly "inside", parts of the polygon far from the centroid are not): the search must follow it
+    sog = [(31, (-290.0, -90.0), 200, (0, 10, 10, 100), 16, None), (32, (-200.0, 0.0), 300, (0, 10, 10, 100), 16, None),
+           (33, (-290.0, 90.0), 100, (0, 2.5, 1.5, 40.5), 64, None),
+           (34, (-200.0, 0.0), 100, (0, 10, 10, 100), 16, "catalina"), (35, (-200.0, -10.0), 300, (0, 10, 10, 100), 16, "notch"),
+           (36, (-200.0, 0.0), 100, (0, 10, 10, 100), 16, "notch")]
+    for k, (seed, st, limit, wts, nobs, polygon) in enumerate(sog):
         w = synth.make_world(seed=seed, n_obstacles=nobs, obst_radius=(2.0, 6.0), start=st, n_habitats=8,
-                             hab_radius=(10.0, 25.0))
+                             hab_radius=(10.0, 25.0), polygon=polygon)
         out = run_astar_sog(w, st, limit, wts)
         save_npz("g6_sog_%d.npz" % k, **out)
         print("g6 sog", k, "found", out["found"], "path", out.get("path_length"), "expansions", len(out["expansions"]))

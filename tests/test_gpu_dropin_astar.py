@@ -36,9 +36,10 @@ def test_astar_real():
     assert [(p.x, p.y) for p in path] == [tuple(r) for r in g["path"].tolist()]
 
 
-def test_astar_fixlen_mutates_habitat_list_like_reference():
+@pytest.mark.parametrize("name", ["g6_fixlen_1", "g6_fixlen_4"])  # a pentagon; (round 6) a CONCAVE outline: the centroid fan's quirk
+def test_astar_fixlen_mutates_habitat_list_like_reference(name):
     from auv_sim_amd.astar_fixLen import astar
-    g = np.load(os.path.join(GOLDEN, "g6_fixlen_1.npz"))
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
     obs, hab, bnd = _mps(g["obstacles"].tolist()), _mps(g["habitats"].tolist()), _mps(g["polygon"].tolist())
     start = tuple(g["start"].tolist())
     res = astar(start, obs, bnd).astar(hab, obs, bnd, start, float(g["limit"]), g["weights"].tolist())
@@ -47,7 +48,7 @@ def test_astar_fixlen_mutates_habitat_list_like_reference():
     assert [[h.x, h.y, h.size] for h in hab] == g["habitats_left"].tolist()
 
 
-@pytest.mark.parametrize("name", ["g6_sog_0", "g6_sog_1", "g6_sog_2"])
+@pytest.mark.parametrize("name", ["g6_sog_0", "g6_sog_1", "g6_sog_2", "g6_sog_3", "g6_sog_4", "g6_sog_5"])  # 3-5 (round 6): the Catalina outline, a concave outline
 def test_astar_fixlen_sog(name):
     from auv_sim_amd.astar_fixLenSOG import astar
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
