@@ -142,11 +142,14 @@ def compact_string(out, sides_file):
 class Ranks:
     """rank bookkeeping + the result gather.  N = 1: everything is a no-op."""
 
-    def __init__(self, ctx, rank, world, dev, use_rccl=True):
+    def __init__(self, ctx, rank, world, dev, use_rccl=True, cpu_group=None):
+        """`cpu_group`: torch.distributed runs over gloo (host tensors); by default exactly when the C-ABI transport is not
+        used.  AUVP_BENCH_ONE_GPU=1 with AUVP_RCCL_LIBRARY set (a stand-in RCCL: tests/mock_rccl) has both: the ranks' own
+        bookkeeping over gloo, the result gather through libauvplan.so's auvp_gather* entry points."""
         self.ctx, self.rank, self.world, self.dev = ctx, rank, world, dev
         self.gather, self.gather_note = None, None
         self.rccl_info, self.rccl_library = None, None
-        self.cpu_group = not use_rccl  # gloo: collectives on host tensors
+        self.cpu_group = (not use_rccl) if cpu_group is None else cpu_group  # gloo: collectives on host tensors
         if world > 1 and not use_rccl:
             from auv_sim_amd import distributed as D
             self.gather = _HostGather(D.TorchGather(), dev)
@@ -161,7 +164,7 @@ class Ranks:
                 return box[0]
             import torch
             # pre-flight on every rank, agreed on by all, BEFORE the collective communicator initialisation
-            pre = torch.tensor([0 if D.RcclGather.usable() else 1], device=dev)
+            pre = self._t([0 if D.RcclGather.usable() else 1], torch.int64)
             dist.all_reduce(pre)
             if int(pre.item()) == 0:
                 try:
@@ -176,7 +179,7 @@ class Ranks:
                 self.rccl_library = D.RcclGather.library()
             else:
                 self.gather_note = "auvp_gather unavailable (RCCL not reachable through the C-ABI on %d rank(s))" % int(pre.item())
-            flag = torch.tensor([0 if self.gather is not None else 1], device=dev)
+            flag = self._t([0 if self.gather is not None else 1], torch.int64)
             dist.all_reduce(flag)
             if int(flag.item()) != 0:  # every rank uses the same transport
                 if self.gather is not None:
@@ -352,7 +355,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     ctx = _lib.Context(local_rank)
-    ranks = Ranks(ctx, rank, world_size, dev, use_rccl=not one_gpu)
+    # (one GPU + a stand-in RCCL named by AUVP_RCCL_LIBRARY: the C-ABI transport runs too -- tests/test_gpu_bench_two_ranks.py)
+    ranks = Ranks(ctx, rank, world_size, dev, use_rccl=(not one_gpu) or bool(os.environ.get("AUVP_RCCL_LIBRARY")), cpu_group=one_gpu)
     if rank == 0:
         measure_hbm(ctx)  # 4 GiB streaming read + copy, a few ms: the measured roof every roofline object quotes
     sides = {

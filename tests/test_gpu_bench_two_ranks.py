@@ -14,10 +14,11 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(gpus, episodes, extra=(), one_gpu=False):
+def _bench(gpus, episodes, extra=(), one_gpu=False, more_env=None):
     """-> the full record (bench_sides.json) with the parsed final stdout line under "_line" """
     import tempfile
     env = dict(os.environ)
+    env.update(more_env or {})
     sides = os.path.join(tempfile.mkdtemp(prefix="auvp_bench_"), "bench_sides.json")
     env["AUVP_BENCH_SIDES"] = sides
     env.pop("WORLD_SIZE", None)
@@ -80,6 +81,51 @@ def test_eight_ranks_on_one_gpu_spawn_shard_and_gather():
     eight = _bench(8, 8, extra=["--no-extra"], one_gpu=True)
     assert eight["n_gpus"] == 8 and eight["config"]["parallelism"] == "episodes sharded x8" and eight["_line"]["n_gpus"] == 8
     assert len(eight["kernel_ms_per_rank"]) == 8 and len(eight["gather_ms_per_rank"]) == 8
+    one = _bench(1, 64, extra=["--no-extra"])
+    assert eight["expansions_per_step"] == one["expansions_per_step"] == 64 * 300
+    assert eight["accepted_nodes_per_step"] == one["accepted_nodes_per_step"] > 0
+
+
+@pytest.mark.parametrize("mode", ["root", "all"])
+def test_two_ranks_through_the_c_abi_transport_with_a_stand_in_rccl(tmp_path, mode):
+    """bench.py's RCCL-mode code path -- RcclGather over libauvplan.so's auvp_gather* entry points, device pointers, the gather
+    to rank 0 enqueued on the gather stream and ended after the next step's kernels (or AUVP_BENCH_GATHER=all: the all-gathers
+    inside the step) -- with two ranks on one GPU: the C-ABI binds tests/mock_rccl (AUVP_RCCL_LIBRARY) instead of RCCL, which
+    cannot put two ranks on one device"""
+    mock = str(tmp_path / "libmock_rccl.so")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", mock, os.path.join(REPO, "tests", "mock_rccl", "mock_rccl.cpp"),
+                        "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    two = _bench(2, 64, extra=["--no-extra", "--steps", "3", "--warmup", "1"], one_gpu=True,
+                 more_env={"AUVP_RCCL_LIBRARY": mock, "AUVP_BENCH_GATHER": mode})
+    assert two["n_gpus"] == 2 and "rccl (auvp_gather, C-ABI)" in two["config"]["gather"]
+    assert two["config"]["rccl_library"] == mock and two["config"]["rccl_ranks_seen"] == 2
+    assert two["config"]["rccl_comm_info_per_rank"] == [[2, 0, 2], [2, 1, 2]]
+    assert len(two["gather_ms_per_rank"]) == 2 and all(g is not None and g >= 0 for g in two["gather_ms_per_rank"])
+    assert all(b > 64 * 100 for b in two["gather_bytes_per_rank"])
+    if mode == "root":
+        assert two["config"]["gather_mode"] == "to rank 0, overlapped"
+        recs, elems = two["gather_root_received"]   # what rank 0 held after the last step: both ranks' records and path elements
+        assert recs == 128 and elems > 128
+        assert two["gather_bytes_per_rank"][0] > two["gather_bytes_per_rank"][1]   # the root counts what it received, the other what it sent
+    else:
+        assert two["config"]["gather_mode"] == "all-gather in step" and two["gather_root_received"] is None
+    one = _bench(1, 128, extra=["--no-extra"])
+    assert two["expansions_per_step"] == one["expansions_per_step"] == 128 * 300
+    assert two["accepted_nodes_per_step"] == one["accepted_nodes_per_step"] > 0
+
+
+def test_eight_ranks_through_the_c_abi_transport_with_a_stand_in_rccl(tmp_path):
+    """the target's world size through the RCCL-mode path: eight ranks on one GPU, the gather of every step to rank 0 on the
+    gather stream (seven grouped receives on the root, one send on every other rank), results equal one rank running all 64"""
+    mock = str(tmp_path / "libmock_rccl.so")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", mock, os.path.join(REPO, "tests", "mock_rccl", "mock_rccl.cpp"),
+                        "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    eight = _bench(8, 8, extra=["--no-extra", "--steps", "2", "--warmup", "1"], one_gpu=True, more_env={"AUVP_RCCL_LIBRARY": mock})
+    assert eight["n_gpus"] == 8 and eight["config"]["rccl_ranks_seen"] == 8 and "C-ABI" in eight["config"]["gather"]
+    assert eight["config"]["rccl_comm_info_per_rank"] == [[8, i, 8] for i in range(8)]
+    assert eight["config"]["gather_mode"] == "to rank 0, overlapped" and eight["gather_root_received"][0] == 64
     one = _bench(1, 64, extra=["--no-extra"])
     assert eight["expansions_per_step"] == one["expansions_per_step"] == 64 * 300
     assert eight["accepted_nodes_per_step"] == one["accepted_nodes_per_step"] > 0
