@@ -119,6 +119,8 @@ def load():
     L.auvp_rrt_last_leaf_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.auvp_rrt_last_kernel.argtypes = [vp]
     L.auvp_rrt_last_kernel.restype = C.c_char_p
+    L.auvp_rrt_last_stream_ms.argtypes = [vp]
+    L.auvp_rrt_last_stream_ms.restype = C.c_double
     L.auvp_hbm_probe.argtypes = [vp, C.c_uint64, C.c_int32, _dp, _dp]
     L.auvp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.auvp_unset_option.argtypes = [vp, C.c_char_p]
@@ -132,7 +134,7 @@ def load():
 # auvp_create.
 OPTION_NAMES = ("ROWS", "DUO", "TRIO", "QUAD", "TIGHT_CULL", "NN_EXACT", "LEAF_SWEEP_ALL", "NO_HABITAT_GRID", "RG_MAX_ENTRIES",
                 "NO_GRID_INDEX", "PRRT_LAT", "PRRT_PIPE", "PRRT_OBST_LDS", "PRRT_NEXT_LDS", "PRRT_ROWS", "ASTAR_NO_GRID",
-                "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "PRRT_PIPE_DRAW", "PRRT_BUCKET_LDS")
+                "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "PRRT_PIPE_DRAW", "PRRT_BUCKET_LDS", "ROWS_STREAM", "ROWS_STREAM_CAP", "ROWS_STREAM_WAVES")
 
 
 def _f64(a, shape=None):
@@ -371,6 +373,10 @@ class Context:
         a, b, k = C.c_double(), C.c_double(), C.c_int32()
         self._chk(self.L.auvp_rrt_last_launch_parts(self.h, C.byref(a), C.byref(b), C.byref(k)))
         return a.value, b.value, k.value
+
+    def last_stream_ms(self):
+        """ms of the launch that generated the random numbers ahead of the last rrt_run's expansion kernel (0: it did not)"""
+        return float(self.L.auvp_rrt_last_stream_ms(self.h))
 
     def last_rrt_kernel(self):
         """name of the expansion kernel the last rrt_run launched (rrt_rows_kernel / rrt_explore_kernel / rrt_duo_kernel)"""

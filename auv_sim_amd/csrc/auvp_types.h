@@ -160,6 +160,10 @@ struct RrtBuffers {
   // the units of the leaf pass's compulsory-traffic figure (bench.py)
   unsigned long long* leaf_stats;
   int32_t* pipe_fail;  // host-mapped word, set to 1 by an episode that ends with AUVP_ST_PIPELINE (null: not reported)
+  // round 6: [E][stream_cap] the episodes' random() numbers, generated ahead by rrt_stream_kernel for rrt_rows_stream_kernel
+  // (null otherwise)
+  double* stream;
+  long long stream_cap;
 };
 
 }  // namespace auvp

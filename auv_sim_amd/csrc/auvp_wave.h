@@ -41,6 +41,7 @@ __device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballo
 // read-back of every summary after every launch
 #define AUVP_ST_GENERATOR (-7)
 #define AUVP_ST_PIPELINE (-9)
+#define AUVP_ST_STREAM (-10)  // an episode ran past its pre-generated random stream (rrt_rows_stream_kernel.h): the batch is redone by rrt_rows_kernel
 __device__ __forceinline__ void pipe_report(int32_t* flag, int status) {
   if (status == AUVP_ST_PIPELINE && flag) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

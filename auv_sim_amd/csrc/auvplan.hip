@@ -19,12 +19,16 @@
 #include "auvp_seed.h"
 #include "rrt_explore_kernel.h"
 #include "rrt_rows_kernel.h"
+#include "rrt_rows_stream_kernel.h"  // (the LDS plan; the kernel itself is launched from rows_kernels.hip)
 #include "rrt_duo_kernel.h"
 #include "rrt_trio_kernel.h"
 
 using namespace auvp;
 
 // rrt_rows_kernel lives in rows_kernels.hip (a translation unit with its own compiler flags); this is its launcher
+extern "C" hipError_t auvpi_rrt_stream_launch(const auvp::RrtBuffers* B, int n_episodes, hipStream_t stream);
+extern "C" hipError_t auvpi_rrt_rows_stream_launch(const auvp::WorldDev* W, const auvp::RrtParamsDev* P, const auvp::RrtBuffers* B, int n_episodes,
+                                                   int grid, int block, int lds_max, int lds, hipStream_t stream);
 extern "C" hipError_t auvpi_rrt_rows_launch(const auvp::WorldDev* W, const auvp::RrtParamsDev* P, const auvp::RrtBuffers* B, int n_episodes,
                                             int grid, int block, int lds_max, int lds, hipStream_t stream);
 
@@ -54,12 +58,12 @@ struct DevBuf {
 enum AuvpOpt {
   OPT_ROWS, OPT_DUO, OPT_TRIO, OPT_QUAD, OPT_TIGHT_CULL, OPT_NN_EXACT, OPT_LEAF_SWEEP_ALL, OPT_NO_HABITAT_GRID, OPT_RG_MAX_ENTRIES,
   OPT_NO_GRID_INDEX, OPT_PRRT_LAT, OPT_PRRT_PIPE, OPT_PRRT_OBST_LDS, OPT_PRRT_NEXT_LDS, OPT_PRRT_ROWS, OPT_ASTAR_NO_GRID,
-  OPT_ASTAR_NO_LIST, OPT_ASTAR_PAIR, OPT_SOG_TILE, OPT_PIPE_FALLBACK, OPT_PRRT_PIPE_DRAW, OPT_PRRT_BUCKET_LDS, OPT_COUNT
+  OPT_ASTAR_NO_LIST, OPT_ASTAR_PAIR, OPT_SOG_TILE, OPT_PIPE_FALLBACK, OPT_PRRT_PIPE_DRAW, OPT_PRRT_BUCKET_LDS, OPT_ROWS_STREAM, OPT_ROWS_STREAM_CAP, OPT_ROWS_STREAM_WAVES, OPT_COUNT
 };
 static const char* const AUVP_OPT_NAMES[OPT_COUNT] = {
   "ROWS", "DUO", "TRIO", "QUAD", "TIGHT_CULL", "NN_EXACT", "LEAF_SWEEP_ALL", "NO_HABITAT_GRID", "RG_MAX_ENTRIES",
   "NO_GRID_INDEX", "PRRT_LAT", "PRRT_PIPE", "PRRT_OBST_LDS", "PRRT_NEXT_LDS", "PRRT_ROWS", "ASTAR_NO_GRID",
-  "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "PRRT_PIPE_DRAW", "PRRT_BUCKET_LDS"};
+  "ASTAR_NO_LIST", "ASTAR_PAIR", "SOG_TILE", "PIPE_FALLBACK", "PRRT_PIPE_DRAW", "PRRT_BUCKET_LDS", "ROWS_STREAM", "ROWS_STREAM_CAP", "ROWS_STREAM_WAVES"};
 
 struct auvp_handle {
   bool opt_has[OPT_COUNT] = {};
@@ -70,8 +74,8 @@ struct auvp_handle {
   long long opt_num(int k, long long dflt) const { return opt_has[k] ? opt_val[k] : dflt; }
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
-  double last_expand_ms = 0.0, last_leaf_ms = 0.0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr, ev_pre = nullptr;
+  double last_expand_ms = 0.0, last_leaf_ms = 0.0, last_stream_ms = 0.0;
   int last_rows = 0;
   const char* last_rrt_kernel = "";
   std::string err;
@@ -87,7 +91,7 @@ struct auvp_handle {
   RrtBuffers B{};
   int max_pts = 0;
   DevBuf d_nodes_f, d_nodes_i, d_points, d_bin_items, d_bin_count, d_mt, d_mtidx, d_seeds, d_init, d_summary, d_itlog_i, d_itlog_b,
-      d_leaf_c, d_leaf_i, d_phase, d_leaf_stats, d_node_c, d_node_q, d_node_xy, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5;
+      d_leaf_c, d_leaf_i, d_phase, d_leaf_stats, d_node_c, d_node_q, d_node_xy, d_tmp0, d_tmp1, d_tmp2, d_tmp3, d_tmp4, d_tmp5, d_stream;
   bool have_batch = false, prepared = false;
   double last_ms = 0.0;
   int last_grid = 0, last_block = 0, last_lds = 0;
@@ -237,7 +241,8 @@ int auvp_create(int device, auvp_handle** out) {
   auvp_handle* h = new auvp_handle();
   h->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev_mid) != hipSuccess) {
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->ev_mid) != hipSuccess ||
+      hipEventCreate(&h->ev_pre) != hipSuccess) {
     delete h;
     return AUVP_ERR_HIP;
   }
@@ -309,6 +314,7 @@ void auvp_destroy(auvp_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
+  if (h->ev_pre) (void)hipEventDestroy(h->ev_pre);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   if (h->pipe_fail_host) (void)hipHostFree(h->pipe_fail_host);
   delete h;
@@ -779,7 +785,8 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
 }  // extern "C"
 
 // one pass over the prepared batch: the expansion launch + the leaf pass.  one_wave_only: never a speculative pipeline
-static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
+// no_stream: the random numbers are generated inside the expansion kernel whatever option ROWS_STREAM says (the stream fallback)
+static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = false) {
   const RrtParamsDev& P = h->P;
   const RrtBuffers& B = h->B;
   const int E = h->E;
@@ -833,6 +840,7 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
                        rp.total <= 160 * 1024;
   const bool use_rows = rows_ok && h->opt_flag(OPT_ROWS, E > 24 * n_cu_);
   int grid_used = grid, block_used = xw * 64, lds_used = (int)lds;
+  bool stream_launched = false;
   // latency runs (at most four episodes per CU: one episode, config 2's 1 024 replicas): two wavefronts per episode
   // (rrt_duo_kernel.h).  Option DUO = 1 / 0 forces it on (limits permitting) / off.
   const bool duo_ok = P.mode == 0 && !diag && nfreq <= DUO_MAX_FREQ && nfreq >= 1 && O_ <= 256 && h->max_pts <= 64;
@@ -845,6 +853,7 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
   // Option TRIO = 1 / 0 forces it on (limits permitting) / off; an explicit DUO = 1 takes precedence.
   const bool use_trio = duo_ok && !use_rows && !one_wave_only && h->opt_flag(OPT_TRIO, E <= TRIO_EP * n_cu_ && !h->opt_on(OPT_DUO));
   h->last_rrt_kernel = use_rows ? "rrt_rows_kernel" : (use_trio ? "rrt_trio_kernel" : (use_duo ? "rrt_duo_kernel" : "rrt_explore_kernel"));
+  h->last_stream_ms = 0.0;
   if (use_trio) {
     int eps_wg = (E + n_cu_ - 1) / n_cu_;
     eps_wg = eps_wg < 1 ? 1 : (eps_wg > TRIO_EP ? TRIO_EP : eps_wg);
@@ -889,6 +898,55 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
     const RowsLdsPlan rq = rrt_rows_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), wg_waves);
     const int per_wg = wg_waves * RW_ROWS;
     grid_used = (E + per_wg - 1) / per_wg; block_used = wg_waves * 64; lds_used = rq.total;
+    // round 6: the episodes' random() numbers generated AHEAD by a launch of its own (rrt_stream_kernel.h: one wavefront per
+    // episode, every lane busy) and read by rrt_rows_stream_kernel -- no generator, no tempering, 2.5 KB less LDS per episode in
+    // the expansion kernel.  The stream is a bound: 46.5 numbers per iteration + 4 096 (the reference draws ~44.8 on the bench
+    // world; option ROWS_STREAM_CAP: the length in numbers, for tests); an episode that runs past it is reported through the
+    // mapped flag and auvp_rrt_run redoes the batch with the kernel above.  OFF by default (option ROWS_STREAM = 1 turns it on
+    // where the stream fits the free memory beside a 4 GB margin): measured on the headline batch the expansion kernel falls
+    // from 93.0 to 81.9 ms (953 instead of 1 284 vector instructions per trip) but generating 46 GB of numbers ahead costs
+    // 11.6 ms -- 99.3 ms against 98.9 for the whole pass (profiles/r6_rows_stream.md).
+    bool use_stream = !no_stream && P.max_iter >= 16 && h->opt_flag(OPT_ROWS_STREAM, false);
+    long long cap = 0;
+    if (use_stream) {
+      cap = h->opt_num(OPT_ROWS_STREAM_CAP, (long long)(46.5 * (double)P.max_iter) + 4096);
+      cap = cap < 64 ? 64 : cap;
+      cap = (cap + 63) / 64 * 64;
+      const size_t bytes = (size_t)E * (size_t)cap * sizeof(double);
+      if (cap > 0x7fffffffll) use_stream = false;  // (positions are 32-bit in the kernel)
+      else if (h->d_stream.cap < bytes) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + h->d_stream.cap < bytes + ((size_t)4 << 30)) {
+          (void)hipGetLastError();
+          if (h->opt_on(OPT_ROWS_STREAM)) return fail(h, AUVP_ERR_CAPACITY, "ROWS_STREAM = 1: %zu bytes of random stream do not fit the free memory", bytes);
+          use_stream = false;
+        } else if (h->d_stream.reserve(bytes) != hipSuccess) {
+          (void)hipGetLastError();
+          use_stream = false;
+        }
+      }
+    }
+    if (use_stream) {
+      RrtBuffers Bs = B;
+      Bs.stream = h->d_stream.as<double>();
+      Bs.stream_cap = cap;
+      // without the generator's state an episode needs 2.3 KB of LDS instead of 3.3: a CU holds 64 of them -- sixteen wavefronts,
+      // four per SIMD, the 128-register instantiation -- where the batch has that many (option ROWS_STREAM_WAVES caps it)
+      int sw = (E + RW_ROWS * n_cu - 1) / (RW_ROWS * n_cu);
+      const int sw_max = (int)h->opt_num(OPT_ROWS_STREAM_WAVES, RW_WAVES);  // (the four-per-SIMD form measured 0.93 G expansions/s against 1.16: 100 B of scratch per lane at 128 registers)
+      sw = sw < 1 ? 1 : (sw > sw_max ? sw_max : sw);
+      sw = sw > RW_WAVES ? RW_WAVES : sw;
+      while (sw > 1 && rrt_rows_stream_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), sw).total > 160 * 1024) sw--;
+      const RowsStreamLdsPlan sp = rrt_rows_stream_lds_plan(P.K, RW_MAX_OBST, rrt_tables_bytes(h->W.n_habitats, h->W.n_poly, h->W.n_bins), sw);
+      const RowsStreamLdsPlan sp_max = sp;
+      grid_used = (E + sw * RW_ROWS - 1) / (sw * RW_ROWS); block_used = sw * 64;
+      lds_used = sp.total;
+      h->last_rrt_kernel = "rrt_rows_stream_kernel";
+      le = auvpi_rrt_stream_launch(&Bs, (int)E, h->stream);
+      if (le == hipSuccess) le = hipEventRecord(h->ev_pre, h->stream);
+      if (le == hipSuccess) le = auvpi_rrt_rows_stream_launch(&h->W, &PR, &Bs, (int)E, grid_used, block_used, sp_max.total, sp.total, h->stream);
+      stream_launched = true;
+    } else
     le = auvpi_rrt_rows_launch(&h->W, &PR, &B, (int)E, grid_used, block_used, rp.total, rq.total, h->stream);  // (rows_kernels.hip)
   } else {
   // compile-time specialisation: obstacles per lane (J), parent-sampling mode, diagnostics on/off
@@ -928,8 +986,12 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
-  HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev_mid));
+  HIPCHK(h, hipEventElapsedTime(&ms, stream_launched ? h->ev_pre : h->ev0, h->ev_mid));
   h->last_expand_ms = ms;
+  if (stream_launched) {
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev_pre));
+    h->last_stream_ms = ms;
+  }
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev_mid, h->ev1));
   h->last_leaf_ms = ms;
   h->last_rows = use_rows ? 1 : 0;
@@ -939,11 +1001,12 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only) {
 }
 
 // AUVP_ERR_PIPELINE episodes of the pass that just ran (its mapped flag is set): counted from the summaries
-static int rrt_count_pipeline_failures(auvp_handle* h, int* n) {
+static int rrt_count_pipeline_failures(auvp_handle* h, int* n, int* n_stream) {
   std::vector<RrtSummary> s((size_t)h->E);
   HIPCHK(h, hipMemcpy(s.data(), h->B.summary, s.size() * sizeof(RrtSummary), hipMemcpyDeviceToHost));
   *n = 0;
-  for (const RrtSummary& r : s) *n += r.status == AUVP_ERR_PIPELINE ? 1 : 0;
+  *n_stream = 0;
+  for (const RrtSummary& r : s) { *n += r.status == AUVP_ERR_PIPELINE ? 1 : 0; *n_stream += r.status == AUVP_ERR_STREAM ? 1 : 0; }
   return AUVP_OK;
 }
 
@@ -959,14 +1022,16 @@ int auvp_rrt_run(auvp_handle* h) {
   if (rc != AUVP_OK || !h->pipe_failed()) return rc;
   // a speculative pipeline gave up on some episode: the batch starts from its prepared state in every pass, so the whole
   // pass is repeated on the one-wavefront kernel (option PIPE_FALLBACK = 0: leave the status in the summaries instead)
-  int n = 0;
-  if ((rc = rrt_count_pipeline_failures(h, &n))) return rc;
+  int n = 0, n_stream = 0;
+  if ((rc = rrt_count_pipeline_failures(h, &n, &n_stream))) return rc;
   h->pipe_clear();
-  if (n == 0 || !h->opt_flag(OPT_PIPE_FALLBACK, true)) return AUVP_OK;
-  h->pipe_fallback_last = n;
-  h->pipe_fallback_total += n;
+  if (n + n_stream == 0 || !h->opt_flag(OPT_PIPE_FALLBACK, true)) return AUVP_OK;
+  h->pipe_fallback_last = n + n_stream;
+  h->pipe_fallback_total += n + n_stream;
   const double first_ms = h->last_ms;
-  rc = rrt_run_pass(h, true);
+  // (episodes that ran past their pre-generated random stream: the same kernel shape with the generator inside; a pipeline that
+  // gave up: the one-wavefront kernel)
+  rc = n_stream > 0 ? rrt_run_pass(h, false, true) : rrt_run_pass(h, true);
   h->last_ms += first_ms;  // (the time the caller waited)
   return rc;
 }
@@ -1106,6 +1171,8 @@ int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_m
 }
 
 const char* auvp_rrt_last_kernel(auvp_handle* h) { return h ? h->last_rrt_kernel : ""; }
+
+double auvp_rrt_last_stream_ms(auvp_handle* h) { return h ? h->last_stream_ms : -1.0; }
 
 int auvp_rrt_last_leaf_stats(auvp_handle* h, int64_t* out4) {
   if (!h || !out4) return AUVP_ERR_ARG;

@@ -13,6 +13,8 @@
 #include <stdint.h>
 
 #include "rrt_rows_kernel.h"
+#include "rrt_rows_stream_kernel.h"
+#include "rrt_stream_kernel.h"
 
 extern "C" __attribute__((visibility("hidden"))) hipError_t auvpi_rrt_rows_launch(const auvp::WorldDev* W, const auvp::RrtParamsDev* P,
                                                                                   const auvp::RrtBuffers* B, int n_episodes, int grid,
@@ -21,4 +23,25 @@ extern "C" __attribute__((visibility("hidden"))) hipError_t auvpi_rrt_rows_launc
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(auvp::rrt_rows_kernel, dim3(grid), dim3(block), lds, stream, *W, *P, *B, n_episodes);
   return hipGetLastError();
+}
+
+// round 6: the random() streams generated ahead (rrt_stream_kernel.h), and the expansion kernel that reads them
+// (rrt_rows_stream_kernel.h: generated from rrt_rows_kernel.h by tools/gen_rows_stream_kernel.py)
+extern "C" __attribute__((visibility("hidden"))) hipError_t auvpi_rrt_stream_launch(const auvp::RrtBuffers* B, int n_episodes, hipStream_t stream) {
+  const int grid = (n_episodes + auvp::RSTREAM_WAVES - 1) / auvp::RSTREAM_WAVES;
+  hipLaunchKernelGGL(auvp::rrt_stream_kernel, dim3(grid), dim3(auvp::RSTREAM_WAVES * 64), 0, stream, *B, n_episodes);
+  return hipGetLastError();
+}
+extern "C" __attribute__((visibility("hidden"))) hipError_t auvpi_rrt_rows_stream_launch(const auvp::WorldDev* W, const auvp::RrtParamsDev* P,
+                                                                                         const auvp::RrtBuffers* B, int n_episodes, int grid,
+                                                                                         int block, int lds_max, int lds, hipStream_t stream) {
+  // (the kernel is a template on the largest workgroup: the four-per-SIMD form -- sixteen wavefronts, 128 registers -- measured
+  // slower and is not instantiated: profiles/r6_rows_stream.md)
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, stream, *W, *P, *B, n_episodes);
+    return hipGetLastError();
+  };
+  return go(auvp::rrt_rows_stream_kernel<auvp::RW_WAVES>);
 }

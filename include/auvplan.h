@@ -36,6 +36,12 @@ enum {
                             * fail there (rrt_dubins.py:116-151, gym_rrt/envs/rrt_dubins.py:205-248): the host repeats the
                             * affected work on the one-wavefront kernel inside the same call and counts it
                             * (auvp_pipeline_fallbacks); the status stays visible only with option PIPE_FALLBACK = 0 */
+  ,
+  AUVP_ERR_STREAM = -10    /* RRT.exploring with the random numbers generated ahead (option ROWS_STREAM: the default for large
+                            * time-bin batches where the stream fits the free memory): an episode drew more numbers than the
+                            * stream holds (46.5 per iteration + 4 096; the reference draws ~44.8 on the bench world).  The host
+                            * repeats the batch with the generator inside the kernel in the same call and counts it
+                            * (auvp_pipeline_fallbacks); visible only with option PIPE_FALLBACK = 0 */
 };
 
 enum { AUVP_MODE_TIMEBIN = 0, AUVP_MODE_PLANTIME = 1, AUVP_MODE_NN = 2 };
@@ -378,6 +384,9 @@ double auvp_last_kernel_ms(auvp_handle* h);
 /* of the last auvp_rrt_run: HIP-event times of its two launches (tree expansion; leaf ranking) and which expansion
  * kernel ran (4 = four episodes per wavefront, rrt_rows_kernel; 1 = rrt_explore_kernel) */
 int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_ms, int32_t* episodes_per_wave);
+/* ... and of the launch that generated the episodes' random numbers ahead of it (rrt_stream_kernel; 0 when the last auvp_rrt_run
+ * ran the generator inside the expansion kernel).  auvp_last_kernel_ms covers all three launches. */
+double auvp_rrt_last_stream_ms(auvp_handle* h);
 /* name of the expansion kernel the last auvp_rrt_run launched: "rrt_rows_kernel" (four episodes per wavefront: batches of
  * more than 24 episodes per CU), "rrt_explore_kernel" (one), "rrt_duo_kernel" (two wavefronts per episode: batches of at
  * most four episodes per CU in time-bin mode -- the helper wavefront produces the half of an iteration that depends only on
