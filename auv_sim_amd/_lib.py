@@ -121,6 +121,8 @@ def load():
     L.auvp_rrt_last_kernel.restype = C.c_char_p
     L.auvp_rrt_last_stream_ms.argtypes = [vp]
     L.auvp_rrt_last_stream_ms.restype = C.c_double
+    L.auvp_rrt_last_stream_len.argtypes = [vp]
+    L.auvp_rrt_last_stream_len.restype = C.c_int64
     L.auvp_hbm_probe.argtypes = [vp, C.c_uint64, C.c_int32, _dp, _dp]
     L.auvp_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     L.auvp_unset_option.argtypes = [vp, C.c_char_p]
@@ -377,6 +379,10 @@ class Context:
     def last_stream_ms(self):
         """ms of the launch that generated the random numbers ahead of the last rrt_run's expansion kernel (0: it did not)"""
         return float(self.L.auvp_rrt_last_stream_ms(self.h))
+
+    def last_stream_len(self):
+        """random() numbers per episode that launch wrote (0: none)"""
+        return int(self.L.auvp_rrt_last_stream_len(self.h))
 
     def last_rrt_kernel(self):
         """name of the expansion kernel the last rrt_run launched (rrt_rows_kernel / rrt_explore_kernel / rrt_duo_kernel)"""

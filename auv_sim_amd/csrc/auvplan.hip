@@ -42,11 +42,12 @@ struct DevBuf {
   ~DevBuf() { if (p) (void)hipFree(p); }
   hipError_t reserve(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    release();
     hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
     if (e == hipSuccess) cap = bytes ? bytes : 16;
     return e;
   }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -76,6 +77,14 @@ struct auvp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr, ev_pre = nullptr;
   double last_expand_ms = 0.0, last_leaf_ms = 0.0, last_stream_ms = 0.0;
+  // what the last complete pass of RRT.exploring drew: the most random() numbers of one episode, on which world / parameters
+  // (the length of the next batch's pre-generated stream: rrt_run_pass)
+  long long drawn_max = 0;
+  long long last_stream_len = 0;  // numbers per episode the last pass generated ahead (0: none)
+  unsigned drawn_world = 0;
+  int drawn_E = 0;
+  RrtParamsDev drawn_P{};
+  bool drawn_valid = false;
   int last_rows = 0;
   const char* last_rrt_kernel = "";
   std::string err;
@@ -747,7 +756,7 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
     B.leaf_iter = h->d_leaf_i.as<int32_t>();
   }
   B.phase_clocks = nullptr;
-  HIPCHK(h, h->d_leaf_stats.reserve(4 * sizeof(unsigned long long)));
+  HIPCHK(h, h->d_leaf_stats.reserve(8 * sizeof(unsigned long long)));
   B.leaf_stats = h->d_leaf_stats.as<unsigned long long>();
   B.pipe_fail = h->pipe_fail_dev;
   if (flags & AUVP_FLAG_PHASE_CLOCKS) {
@@ -785,6 +794,25 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
 }  // extern "C"
 
 // one pass over the prepared batch: the expansion launch + the leaf pass.  one_wave_only: never a speculative pipeline
+// The pre-generated random stream of a batch (rrt_stream_kernel.h): its length in numbers per episode -- from what the previous
+// batch on the same world and parameters drew (`seen`), else 46.5 per iteration + 4 096 -- and its buffer.
+static long long rrt_stream_len(const auvp_handle* h, bool seen) {
+  const long long guess = seen ? h->drawn_max + h->drawn_max * 3 / 100 + 1024 : (long long)(46.5 * (double)h->P.max_iter) + 4096;
+  long long cap = h->opt_num(OPT_ROWS_STREAM_CAP, guess);
+  cap = cap < 64 ? 64 : cap;
+  return (cap + 63) / 64 * 64;
+}
+// 1: the buffer holds `bytes`; 0: it does not fit the free memory beside a 4 GB margin (or the allocation failed)
+static int rrt_stream_reserve(auvp_handle* h, size_t bytes) {
+  if (h->d_stream.cap >= bytes) return 1;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + h->d_stream.cap < bytes + ((size_t)4 << 30) || h->d_stream.reserve(bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return 1;
+}
+
 // no_stream: the random numbers are generated inside the expansion kernel whatever option ROWS_STREAM says (the stream fallback)
 static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = false) {
   const RrtParamsDev& P = h->P;
@@ -826,7 +854,7 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
     hipLaunchKernelGGL(kern, dim3(grid), dim3(xw * 64), lds, h->stream, h->W, PR, B, (int)E, h->max_pts);
     return hipGetLastError();
   };
-  if (B.leaf_stats) HIPCHK(h, hipMemsetAsync(B.leaf_stats, 0, 4 * sizeof(unsigned long long), h->stream));  // (before the timed region)
+  if (B.leaf_stats) HIPCHK(h, hipMemsetAsync(B.leaf_stats, 0, 8 * sizeof(unsigned long long), h->stream));  // (before the timed region)
   HIPCHK(h, hipEventRecord(h->ev0, h->stream));
   hipError_t le = hipSuccess;
   // four episodes per wavefront (rrt_rows_kernel.h) where its limits allow; one episode per wavefront otherwise
@@ -854,6 +882,7 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
   const bool use_trio = duo_ok && !use_rows && !one_wave_only && h->opt_flag(OPT_TRIO, E <= TRIO_EP * n_cu_ && !h->opt_on(OPT_DUO));
   h->last_rrt_kernel = use_rows ? "rrt_rows_kernel" : (use_trio ? "rrt_trio_kernel" : (use_duo ? "rrt_duo_kernel" : "rrt_explore_kernel"));
   h->last_stream_ms = 0.0;
+  h->last_stream_len = 0;
   if (use_trio) {
     int eps_wg = (E + n_cu_ - 1) / n_cu_;
     eps_wg = eps_wg < 1 ? 1 : (eps_wg > TRIO_EP ? TRIO_EP : eps_wg);
@@ -900,30 +929,26 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
     grid_used = (E + per_wg - 1) / per_wg; block_used = wg_waves * 64; lds_used = rq.total;
     // round 6: the episodes' random() numbers generated AHEAD by a launch of its own (rrt_stream_kernel.h: one wavefront per
     // episode, every lane busy) and read by rrt_rows_stream_kernel -- no generator, no tempering, 2.5 KB less LDS per episode in
-    // the expansion kernel.  The stream is a bound: 46.5 numbers per iteration + 4 096 (the reference draws ~44.8 on the bench
-    // world; option ROWS_STREAM_CAP: the length in numbers, for tests); an episode that runs past it is reported through the
-    // mapped flag and auvp_rrt_run redoes the batch with the kernel above.  OFF by default (option ROWS_STREAM = 1 turns it on
-    // where the stream fits the free memory beside a 4 GB margin): measured on the headline batch the expansion kernel falls
-    // from 93.0 to 81.9 ms (953 instead of 1 284 vector instructions per trip) but generating 46 GB of numbers ahead costs
-    // 11.6 ms -- 99.3 ms against 98.9 for the whole pass (profiles/r6_rows_stream.md).
-    bool use_stream = !no_stream && P.max_iter >= 16 && h->opt_flag(OPT_ROWS_STREAM, false);
+    // the expansion kernel.  Measured on the headline batch: the expansion launch 93.7 -> 81.5 ms (953 instead of 1 284 vector
+    // instructions per trip), generating 46 GB of numbers ahead 9.4 ms, the pass 99.6 -> 96.9 ms (profiles/r6_rows_stream.md).
+    // The stream's length is a bound, and how many numbers an iteration draws depends on the world and the parameters (44.8 on
+    // the bench world, 92 with the leaves looked at every iteration): it is set from what the PREVIOUS batch on the same world
+    // and parameters drew -- its busiest episode + 3 % + 1 024 numbers (rrt_leaf_kernel reports the figure: leaf_stats[4]).  So
+    // the first batch on a world / parameter set runs rrt_rows_kernel and the following ones this path; an episode that runs
+    // past its stream all the same is reported through the mapped flag and auvp_rrt_run redoes the batch with the kernel
+    // above (which records the new figure).  Option ROWS_STREAM = 0: never; = 1: also without a previous batch (46.5 numbers
+    // per iteration + 4 096), and a stream that does not fit the free memory beside a 4 GB margin is an error instead of a
+    // quiet no; ROWS_STREAM_CAP: the length in numbers (tests).
+    // (a batch at most four times the size of the one the figure comes from: the busiest of more episodes is busier)
+    const bool seen = h->drawn_valid && h->drawn_world == h->world_version && memcmp(&h->drawn_P, &P, sizeof P) == 0 && (long long)h->drawn_E * 4 >= E;
+    bool use_stream = !no_stream && P.max_iter >= 16 && h->opt_flag(OPT_ROWS_STREAM, seen && P.max_iter >= 1000);
     long long cap = 0;
     if (use_stream) {
-      cap = h->opt_num(OPT_ROWS_STREAM_CAP, (long long)(46.5 * (double)P.max_iter) + 4096);
-      cap = cap < 64 ? 64 : cap;
-      cap = (cap + 63) / 64 * 64;
-      const size_t bytes = (size_t)E * (size_t)cap * sizeof(double);
+      cap = rrt_stream_len(h, seen);
       if (cap > 0x7fffffffll) use_stream = false;  // (positions are 32-bit in the kernel)
-      else if (h->d_stream.cap < bytes) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + h->d_stream.cap < bytes + ((size_t)4 << 30)) {
-          (void)hipGetLastError();
-          if (h->opt_on(OPT_ROWS_STREAM)) return fail(h, AUVP_ERR_CAPACITY, "ROWS_STREAM = 1: %zu bytes of random stream do not fit the free memory", bytes);
-          use_stream = false;
-        } else if (h->d_stream.reserve(bytes) != hipSuccess) {
-          (void)hipGetLastError();
-          use_stream = false;
-        }
+      else if (!rrt_stream_reserve(h, (size_t)E * (size_t)cap * sizeof(double))) {
+        if (h->opt_on(OPT_ROWS_STREAM)) return fail(h, AUVP_ERR_CAPACITY, "ROWS_STREAM = 1: %zu bytes of random stream do not fit the free memory", (size_t)E * (size_t)cap * sizeof(double));
+        use_stream = false;
       }
     }
     if (use_stream) {
@@ -942,6 +967,7 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
       grid_used = (E + sw * RW_ROWS - 1) / (sw * RW_ROWS); block_used = sw * 64;
       lds_used = sp.total;
       h->last_rrt_kernel = "rrt_rows_stream_kernel";
+      h->last_stream_len = cap;
       le = auvpi_rrt_stream_launch(&Bs, (int)E, h->stream);
       if (le == hipSuccess) le = hipEventRecord(h->ev_pre, h->stream);
       if (le == hipSuccess) le = auvpi_rrt_rows_stream_launch(&h->W, &PR, &Bs, (int)E, grid_used, block_used, sp_max.total, sp.total, h->stream);
@@ -982,7 +1008,30 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+  // (the most 32-bit outputs one episode drew: eight bytes into the mapped page beside the pipeline flag)
+  const bool want_drawn = B.leaf_stats && h->pipe_fail_host;
+  if (want_drawn) HIPCHK(h, hipMemcpyAsync(h->pipe_fail_host + 2, B.leaf_stats + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  bool keep_stream = stream_launched;
+  if (want_drawn && !h->pipe_failed()) {
+    unsigned long long d32 = 0;
+    memcpy(&d32, h->pipe_fail_host + 2, sizeof d32);
+    if (d32 > 0) {
+      h->drawn_max = (long long)((d32 + 1) / 2);
+      h->drawn_world = h->world_version;
+      h->drawn_E = E;
+      h->drawn_P = P;
+      h->drawn_valid = true;
+      // the next batch on this world and these parameters will want its stream: the buffer is taken NOW, in the call that found
+      // out (tens of GB: a second of hipMalloc that a later, timed call would pay otherwise)
+      if (use_rows && !stream_launched && P.max_iter >= 1000 && h->opt_flag(OPT_ROWS_STREAM, true)) {
+        const long long cap_next = rrt_stream_len(h, true);
+        if (cap_next <= 0x7fffffffll) (void)rrt_stream_reserve(h, (size_t)E * (size_t)cap_next * sizeof(double));
+        keep_stream = true;
+      }
+    }
+  }
+  if (!keep_stream) h->d_stream.release();  // (a batch of another kind: the memory goes back)
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;
@@ -1173,6 +1222,7 @@ int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_m
 const char* auvp_rrt_last_kernel(auvp_handle* h) { return h ? h->last_rrt_kernel : ""; }
 
 double auvp_rrt_last_stream_ms(auvp_handle* h) { return h ? h->last_stream_ms : -1.0; }
+int64_t auvp_rrt_last_stream_len(auvp_handle* h) { return h ? (int64_t)h->last_stream_len : -1; }
 
 int auvp_rrt_last_leaf_stats(auvp_handle* h, int64_t* out4) {
   if (!h || !out4) return AUVP_ERR_ARG;

@@ -1450,6 +1450,9 @@ static __global__ __launch_bounds__(RRT_LEAF_WAVES * 64) __attribute__((amdgpu_w
     if (B.leaf_stats) {
       atomicAdd(&B.leaf_stats[0], (unsigned long long)st_nodes); atomicAdd(&B.leaf_stats[1], (unsigned long long)st_points);
       atomicAdd(&B.leaf_stats[2], (unsigned long long)st_resummed); atomicAdd(&B.leaf_stats[3], (unsigned long long)st_releaves);
+      // [4]: the most 32-bit outputs one episode of the batch drew -- what the host sizes the next batch's pre-generated
+      // random stream from (auvplan.hip: option ROWS_STREAM)
+      atomicMax(&B.leaf_stats[4], (unsigned long long)sum.n_draw32);
     }
     sum.n_leaves = n_leaves;
     sum.leaf_elems = leaf_elems;

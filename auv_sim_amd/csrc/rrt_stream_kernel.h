@@ -10,9 +10,10 @@
 // 227 apart are independent, so any 128 consecutive are), 64 random() values tempered and stored per round -- every lane busy,
 // no cross-lane traffic, one coalesced 512-byte store -- into `B.stream[episode][0 .. stream_cap)` in HBM.  The expansion
 // kernel (rrt_rows_stream_kernel.h) then reads random() number j of its episode at stream[j]: no generator, no tempering.
-// The stream's length is a bound (RRT.exploring draws ~44.8 values per iteration on the bench world, 48.8 at most over short
-// runs: the host allocates 46.5 per iteration + 4 096); an episode that runs past it ends with AUVP_ST_STREAM and the batch
-// is redone by rrt_rows_kernel (auvplan.hip: stream fallback), like an episode a speculative pipeline gave up on.
+// The stream's length is a bound (RRT.exploring draws ~44.8 values per iteration on the bench world, twice that with other
+// parameters: the host sets it from what the previous batch on the same world and parameters drew -- auvplan.hip); an
+// episode that runs past it ends with AUVP_ST_STREAM and the batch is redone by rrt_rows_kernel (auvplan.hip: stream
+// fallback), like an episode a speculative pipeline gave up on.
 //
 // The values are CPython's: word q of the stream = output q of MT19937 from the episode's state (B.mt, position B.mt_index:
 // 624 = a fresh seed), random() j = (temper(word 2j) >> 5) * 2^26 + (temper(word 2j + 1) >> 6)) / 2^53 (auvp_wave.h).
@@ -23,10 +24,40 @@
 
 namespace auvp {
 
-constexpr int RSTREAM_WAVES = 4;  // episodes per workgroup (one wavefront each; 2 496 B of LDS each)
+// episodes per workgroup (one wavefront each; 2.5 KB of LDS each).  Measured on the headline batch (46 GB of numbers): 4 per
+// workgroup 10.5 ms, 8: 9.8, 16: 9.9; with plain instead of non-temporal stores in the whole-cycle path 9.3 (4.9 TB/s written)
+constexpr int RSTREAM_WAVES = 8;
+
+// One block of a whole cycle at a fixed position G of the state (0, 128, 256, 384, 512): 128 words regenerated in place (112 at
+// 512), 64 (56) random() values stored at out[lane].  G is a compile-time constant, so every LDS address is the lane's byte
+// offset plus an immediate -- the two blocks with a lane-dependent wrap (128: x[k + 397] crosses the end at lane 50; 512: lane
+// 55's x[k + 2] is x[0]) take theirs from addresses the compiler hoists out of the cycle loop.
+template <int G>
+__device__ __forceinline__ void rstream_block(uint32_t* s, int lane, double* out) {
+  const int k = G + 2 * lane;
+  const bool mine = G < 512 || lane < 56;
+  const int k2 = (G == 512 && lane == 55) ? 0 : k + 2;         // (lanes past a short block read inside the padding: unused)
+  const int km = k + 397 >= 624 ? k - 227 : k + 397;           // (k even: km is odd or even alike, never 624)
+  const int km1 = km + 1 == 624 ? 0 : km + 1;
+  const uint32_t a0 = s[k], a1 = s[k + 1], a2 = s[k2], c0 = s[km], c1 = s[km1];
+  uint32_t y0, y1;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y0) : "v"(0x7fffffffu), "v"(a1), "v"(a0));   // (a0 & 0x80000000) | (a1 & 0x7fffffff)
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y1) : "v"(0x7fffffffu), "v"(a2), "v"(a1));
+  uint32_t m0, m1;                                                                    // bit 0 spread over the word: 0 or ~0
+  asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m0) : "v"(a1));
+  asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m1) : "v"(a2));
+  const uint32_t v0 = c0 ^ (y0 >> 1) ^ (m0 & 0x9908b0dfu), v1 = c1 ^ (y1 >> 1) ^ (m1 & 0x9908b0dfu);
+  wave_sync();
+  if (mine) {
+    s[k] = v0;
+    s[k + 1] = v1;
+  }
+  wave_sync();
+  if (mine) out[lane] = py_random_from(mt_temper(v0) >> 5, mt_temper(v1) >> 6);
+}
 
 static __global__ __launch_bounds__(RSTREAM_WAVES * 64) void rrt_stream_kernel(RrtBuffers B, int n_episodes) {
-  __shared__ uint32_t st[RSTREAM_WAVES][624];
+  __shared__ uint32_t st[RSTREAM_WAVES][640];   // (624 words of state; 16 of padding for the reads of the idle lanes of a short block)
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int ep = (int)blockIdx.x * RSTREAM_WAVES + wave;
   if (ep >= n_episodes) return;  // (whole wavefronts: no workgroup barrier below)
@@ -64,6 +95,18 @@ static __global__ __launch_bounds__(RSTREAM_WAVES * 64) void rrt_stream_kernel(R
     // ---- (ii) the stream's pairs are the blocks' pairs (always so for a fresh seed): a lane regenerates its two words, tempers
     // them in registers and stores the number -- no second pass over LDS.  x[k] = x[k + 397] ^ twist(x[k], x[k + 1]) in place;
     // blocks of 128 slots that never wrap (the last one of a cycle has 112); every read of a round precedes every write.
+    // g is 0 here (the words of the old cycle are out): whole cycles -- 624 words, 312 numbers -- run unrolled with constant
+    // addresses (rstream_block: 36 vector instructions per 64 numbers instead of 70) while the stream has room for one ...
+    while (emitted + 312 <= cap) {
+      double* o = out + emitted;
+      rstream_block<0>(s, lane, o);
+      rstream_block<128>(s, lane, o + 64);
+      rstream_block<256>(s, lane, o + 128);
+      rstream_block<384>(s, lane, o + 192);
+      rstream_block<512>(s, lane, o + 256);
+      emitted += 312;
+    }
+    // ... and the last, cut one block by block
     while (emitted < cap) {
       const int len = 624 - g < 128 ? 624 - g : 128;
       const int k = g + 2 * lane;

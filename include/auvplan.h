@@ -37,10 +37,10 @@ enum {
                             * affected work on the one-wavefront kernel inside the same call and counts it
                             * (auvp_pipeline_fallbacks); the status stays visible only with option PIPE_FALLBACK = 0 */
   ,
-  AUVP_ERR_STREAM = -10    /* RRT.exploring with the random numbers generated ahead (option ROWS_STREAM: the default for large
-                            * time-bin batches where the stream fits the free memory): an episode drew more numbers than the
-                            * stream holds (46.5 per iteration + 4 096; the reference draws ~44.8 on the bench world).  The host
-                            * repeats the batch with the generator inside the kernel in the same call and counts it
+  AUVP_ERR_STREAM = -10    /* RRT.exploring with the random numbers generated ahead (large time-bin batches from the second
+                            * batch on a world and parameter set on; option ROWS_STREAM): an episode drew more numbers than
+                            * the stream holds (the busiest episode of the previous batch + 3 % + 1 024).  The host repeats
+                            * the batch with the generator inside the kernel in the same call and counts it
                             * (auvp_pipeline_fallbacks); visible only with option PIPE_FALLBACK = 0 */
 };
 
@@ -387,6 +387,8 @@ int auvp_rrt_last_launch_parts(auvp_handle* h, double* expand_ms, double* leaf_m
 /* ... and of the launch that generated the episodes' random numbers ahead of it (rrt_stream_kernel; 0 when the last auvp_rrt_run
  * ran the generator inside the expansion kernel).  auvp_last_kernel_ms covers all three launches. */
 double auvp_rrt_last_stream_ms(auvp_handle* h);
+/* ... and how many random() numbers per episode that launch wrote (8 bytes each; 0: none) */
+int64_t auvp_rrt_last_stream_len(auvp_handle* h);
 /* name of the expansion kernel the last auvp_rrt_run launched: "rrt_rows_kernel" (four episodes per wavefront: batches of
  * more than 24 episodes per CU), "rrt_explore_kernel" (one), "rrt_duo_kernel" (two wavefronts per episode: batches of at
  * most four episodes per CU in time-bin mode -- the helper wavefront produces the half of an iteration that depends only on

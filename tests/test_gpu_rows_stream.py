@@ -1,7 +1,9 @@
-"""rrt_rows_stream_kernel (option ROWS_STREAM = 1, round 6): rrt_rows_kernel with its random() numbers generated AHEAD by a launch
-of its own (rrt_stream_kernel: one wavefront per episode) and read from HBM through a 256-entry LDS ring.  Same operations on the
+"""rrt_rows_stream_kernel (round 6; option ROWS_STREAM): rrt_rows_kernel with its random() numbers generated AHEAD by a launch of
+its own (rrt_stream_kernel: one wavefront per episode) and read from HBM through a 256-entry LDS ring.  Same operations on the
 same values: every summary field, tree, path point and best path must equal the classic kernel's (and the checker's); a stream
-that turns out too short is a declared status and the batch is redone with the generator inside the kernel."""
+that turns out too short is a declared status and the batch is redone with the generator inside the kernel.  Without the option
+the host takes this path from the second batch on a world and parameter set on (the stream's length comes from what the
+previous batch drew)."""
 import os
 import random
 import subprocess
@@ -200,6 +202,60 @@ def test_random_batches_with_streams_of_every_length(ctx):
         n_stream += redone == 0
         _same(a, b)
     assert n_redone >= 5 and n_stream >= 15, (n_redone, n_stream)
+
+
+def test_without_the_option_the_second_batch_on_a_world_and_parameter_set_takes_the_stream():
+    """the host's choice (auvplan.hip rrt_run_pass): rrt_rows_kernel for the first batch -- rrt_leaf_kernel reports how many numbers
+    its busiest episode drew -- then rrt_stream_kernel + rrt_rows_stream_kernel with a stream of that length + 3 % + 1 024; back to
+    rrt_rows_kernel when the world or a parameter changes, for a batch more than four times the size of the observed one, and
+    below 1 000 iterations"""
+    from auv_sim_amd import _lib, synth
+    ctx = _lib.Context(0)
+    try:
+        world = synth.make_world(seed=51, n_obstacles=64)
+        ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+        ctx.set_option("ROWS", 1)               # (small batches: the four-episode kernel by option; the stream choice is the host's)
+
+        def batch(E, n_iter, seed0, **kw):
+            init = np.zeros((E, 6))
+            init[:, 0], init[:, 1] = world["start"]
+            s = ctx.rrt_explore_batch(init, np.arange(seed0, seed0 + E, dtype=np.uint64), n_iter, **kw).copy()
+            return s, ctx.last_rrt_kernel(), ctx.last_stream_len(), [ctx.tree(e, s[e]) for e in (0, E - 1)]
+
+        s1, k1, l1, _ = batch(40, 1200, 100)
+        assert k1 == "rrt_rows_kernel" and l1 == 0
+        s2, k2, l2, t2 = batch(40, 1200, 500)
+        busiest = int(s1["n_draw32"].max() + 1) // 2
+        assert k2 == "rrt_rows_stream_kernel" and busiest < l2 <= busiest + busiest * 3 // 100 + 1024 + 63
+        assert ctx.pipeline_fallbacks()[0] == 0 and (s2["status"] >= 0).all()
+        ctx.set_option("ROWS_STREAM", 0)
+        s2c, k2c, _, t2c = batch(40, 1200, 500)
+        ctx.set_option("ROWS_STREAM", None)
+        assert k2c == "rrt_rows_kernel"
+        for f in s2.dtype.names:
+            assert np.array_equal(s2[f], s2c[f]), f
+        for a, b in zip(t2, t2c):
+            assert all(np.array_equal(a[k], b[k]) for k in a)
+        assert batch(40, 1200, 900)[1] == "rrt_rows_stream_kernel"
+        assert batch(40, 1200, 900, freq=7)[1] == "rrt_rows_kernel"          # another parameter set ...
+        assert batch(40, 1200, 901, freq=7)[1] == "rrt_rows_stream_kernel"   # ... seen once
+        assert batch(200, 1200, 0, freq=7)[1] == "rrt_rows_kernel"           # five times the episodes of the observed batch
+        assert batch(200, 1200, 7, freq=7)[1] == "rrt_rows_stream_kernel"
+        assert batch(40, 900, 0)[1] == "rrt_rows_kernel" and batch(40, 900, 1)[1] == "rrt_rows_kernel"   # short budgets: never
+        ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+        assert batch(40, 1200, 900)[1] == "rrt_rows_kernel"                   # a world set again is a new world
+        # a stream sized from a batch that drew less: the episodes that run past it are redone, and the redo reports the new figure
+        s_lo, k_lo, _, _ = batch(40, 1200, 100)
+        assert k_lo == "rrt_rows_stream_kernel"
+        ctx.set_option("ROWS_STREAM_CAP", 20000)
+        s_hi, k_hi, _, _ = batch(40, 1200, 100)
+        ctx.set_option("ROWS_STREAM_CAP", None)
+        assert k_hi == "rrt_rows_kernel" and ctx.pipeline_fallbacks()[0] > 0
+        for f in s_lo.dtype.names:
+            assert np.array_equal(s_lo[f], s_hi[f]), f
+        assert batch(40, 1200, 100)[1] == "rrt_rows_stream_kernel" and ctx.pipeline_fallbacks()[0] == 0
+    finally:
+        ctx.close()
 
 
 def test_the_generated_header_is_what_the_generator_writes():

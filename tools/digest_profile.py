@@ -54,7 +54,7 @@ for f in glob.glob(os.path.join(src, "*.json")):
 
 # measurement key (= pass-directory name pmc@<key>@<counter>; "headline" or the side's name in the bench JSON) ->
 #   (kernel-name needles, field of the side's JSON holding its work units)
-RRT = ("rrt_rows_kernel", "rrt_explore_kernel", "rrt_leaf_kernel")
+RRT = ("rrt_rows_kernel", "rrt_rows_stream_kernel", "rrt_stream_kernel", "rrt_explore_kernel", "rrt_leaf_kernel")
 MEAS = {
     "headline": (RRT, None),
     "astar": (("astar_kernel",), "cells_per_step"),
@@ -91,6 +91,11 @@ for key, (needles, units_field) in MEAS.items():
     if not per_kernel:
         continue
     rec = {"kernels": {}, "per_launch": collections.defaultdict(float)}
+    if "rrt_rows_stream_kernel" in per_kernel and "rrt_rows_kernel" in per_kernel:
+        # the first batch on a world / parameter set runs rrt_rows_kernel (and reports how many random numbers the episodes
+        # draw), the following ones rrt_stream_kernel + rrt_rows_stream_kernel: the measurement is of those
+        del per_kernel["rrt_rows_kernel"]
+        rec["first_batch_kernel_dropped"] = "rrt_rows_kernel"
     for kn, ctrs in per_kernel.items():
         # launches per measurement step: a kernel that runs L times per step shows L x (warm-up + steps) dispatches; the
         # mean per dispatch x L would need L -- every kernel here runs once per launch of its measurement

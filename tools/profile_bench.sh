@@ -4,7 +4,8 @@
 #   bench.json     the plain default command (what the driver runs): its compact final line; bench_sides.json = the full record
 #   trace_main     headline kernel alone (--no-extra): its average must agree with roofline.kernel_ms
 #   trace          the full default command (every side measurement)
-#   pmc@headline@<C>   counters of the headline launch, one pass per counter group (counters only: no trace flags)
+#   pmc@headline@<C>   counters of the headline launch, one pass per counter group (counters only: no trace flags); one warm-up
+#                      step + one step: the first batch on a world runs rrt_rows_kernel, the measured ones the stream kernels
 #   trace_<side>, pmc@<side>@<C>   the same for one side measurement (bench.py --only <side>); default sides below
 set -u
 TAG=${1:-r3}; shift || true
@@ -39,7 +40,7 @@ if [ $HEADLINE = 1 ]; then
   for P in "$G_FETCH" "$G_WRITE" "$G_INSTS" "$G_ACTIVE" "$G_LANES"; do
     N=$(echo $P | cut -d" " -f1)
     export AUVP_BENCH_SIDES=$OUT/pmc@headline@$N.sides.json
-    rocprofv3 --pmc $P --output-format csv -d $OUT/pmc@headline@$N -o pmc -- python3 $R/bench.py $ARGS --no-cpu --no-extra --steps 1 --warmup 0 > $OUT/pmc@headline@$N.json 2> $OUT/pmc@headline@$N.err
+    rocprofv3 --pmc $P --output-format csv -d $OUT/pmc@headline@$N -o pmc -- python3 $R/bench.py $ARGS --no-cpu --no-extra --steps 1 --warmup 1 > $OUT/pmc@headline@$N.json 2> $OUT/pmc@headline@$N.err
   done
 fi
 for SIDE in $SIDES; do
