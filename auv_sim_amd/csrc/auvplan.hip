@@ -693,6 +693,15 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   if (P.K > 1 << 20) return fail(h, AUVP_ERR_ARG, "too many time bins (%d)", P.K);
   const int nfreq = (int)std::floor(p->freq);
   h->max_pts = nfreq + 2;
+  // the pre-generated random stream of earlier batches (tens of GB, rrt_run_pass) stays with the handle while the batches are of
+  // its kind -- a caller alternating between worlds does not pay a hipMalloc per call -- and goes back before a batch of
+  // another kind reserves its own buffers
+  if (h->d_stream.p) {
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+    if (!(P.mode == 0 && P.max_iter >= 1000 && h->opt_flag(OPT_ROWS_STREAM, true) && h->opt_flag(OPT_ROWS, E > 24 * (n_cu > 0 ? n_cu : 256))))
+      h->d_stream.release();
+  }
   RrtBuffers& B = h->B;
   B.cap_nodes = p->max_iter + 1;
   // Path-point budget.  A steer appends at most n = floor(uniform(0, freq)) points (:258-262) and only an accepted one
@@ -956,7 +965,8 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
       Bs.stream = h->d_stream.as<double>();
       Bs.stream_cap = cap;
       // without the generator's state an episode needs 2.3 KB of LDS instead of 3.3: a CU holds 64 of them -- sixteen wavefronts,
-      // four per SIMD, the 128-register instantiation -- where the batch has that many (option ROWS_STREAM_WAVES caps it)
+      // four per SIMD -- but that instantiation spills (rows_kernels.hip): twelve at most, like rrt_rows_kernel (option
+      // ROWS_STREAM_WAVES: fewer, for experiments)
       int sw = (E + RW_ROWS * n_cu - 1) / (RW_ROWS * n_cu);
       const int sw_max = (int)h->opt_num(OPT_ROWS_STREAM_WAVES, RW_WAVES);  // (the four-per-SIMD form measured 0.93 G expansions/s against 1.16: 100 B of scratch per lane at 128 registers)
       sw = sw < 1 ? 1 : (sw > sw_max ? sw_max : sw);
@@ -1012,7 +1022,6 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
   const bool want_drawn = B.leaf_stats && h->pipe_fail_host;
   if (want_drawn) HIPCHK(h, hipMemcpyAsync(h->pipe_fail_host + 2, B.leaf_stats + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  bool keep_stream = stream_launched;
   if (want_drawn && !h->pipe_failed()) {
     unsigned long long d32 = 0;
     memcpy(&d32, h->pipe_fail_host + 2, sizeof d32);
@@ -1027,11 +1036,9 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
       if (use_rows && !stream_launched && P.max_iter >= 1000 && h->opt_flag(OPT_ROWS_STREAM, true)) {
         const long long cap_next = rrt_stream_len(h, true);
         if (cap_next <= 0x7fffffffll) (void)rrt_stream_reserve(h, (size_t)E * (size_t)cap_next * sizeof(double));
-        keep_stream = true;
       }
     }
   }
-  if (!keep_stream) h->d_stream.release();  // (a batch of another kind: the memory goes back)
   float ms = 0.f;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
   h->last_ms = ms;

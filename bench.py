@@ -38,7 +38,7 @@ from bench_sides.filters import bench_particle_filter, bench_shark_grid  # noqa:
 
 LINE_LIMIT = 4096
 SIDES_FILE = os.environ.get("AUVP_BENCH_SIDES", os.path.join(REPO, "bench_sides.json"))
-ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch", "stream_kernel_ms", "stream_write_GBps",
+ROOF_KEEP = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes_per_launch", "stream_kernel_ms", "stream_write_GBps", "stream_bytes_read",
              "traffic_raw", "valu_issue_frac", "hbm_measured_GBps", "frac_of_measured", "bytes_per_expansion",
              "leaf_kernel_ms", "leaf_compulsory_bytes", "leaf_frac", "leaf_valu_issue_frac", "leaf_traffic_raw",
              "pass_kernel_ms", "pass_8d_frac", "pass_traffic_raw",

@@ -30,8 +30,15 @@ def _resources(unit):
 def test_rows_kernel_fits_three_wavefronts_without_scratch():
     """rrt_rows_kernel (the headline): one 12-wavefront workgroup per CU = three per SIMD, i.e. at most 168 VGPRs, and no
     scratch (a spill in the expansion loop is memory traffic per iteration)"""
-    r = _resources("rows_kernels.hip")["auvp::rrt_rows_kernel"]
+    res = _resources("rows_kernels.hip")
+    r = res["auvp::rrt_rows_kernel"]
     assert r["scratch"] == 0 and r["vgprs"] <= 168 and r["waves"] >= 3, r
+    # round 6: the same body reading pre-generated random numbers, and the generator that runs ahead of it (one wavefront per
+    # episode, eight per SIMD so that the stores of 64 wavefronts per CU are in flight)
+    r = res["auvp::rrt_rows_stream_kernel<12>"]
+    assert r["scratch"] == 0 and r["vgprs"] <= 168 and r["waves"] >= 3, r
+    r = res["auvp::rrt_stream_kernel"]
+    assert r["scratch"] == 0 and r["vgprs"] <= 32 and r["waves"] == 8, r
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")

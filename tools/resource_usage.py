@@ -16,7 +16,7 @@ sys.path.insert(0, REPO)
 import __graft_entry__ as ge  # the product's translation units and flags
 # a unit other than auvplan.hip LAUNCHES only the kernels named here (the shared headers' other kernels are compiled into it as
 # unused internal-linkage copies: not listed); auvplan.hip launches everything else
-OWN = {"pf_kernels.hip": ("pf_",), "rows_kernels.hip": ("rrt_rows_kernel",), "prrt_rows_kernels.hip": ("prrt_rows_kernel",)}
+OWN = {"pf_kernels.hip": ("pf_",), "rows_kernels.hip": ("rrt_rows_kernel", "rrt_rows_stream_kernel", "rrt_stream_kernel"), "prrt_rows_kernels.hip": ("prrt_rows_kernel",)}
 elsewhere = tuple(n for v in OWN.values() for n in v)
 txt = ""
 for unit, unit_flags in ge.UNITS:
