@@ -27,6 +27,15 @@ def test_helper_wavefront_kernels_random_cases():
     assert "0 mismatches" in r.stdout
 
 
+def test_pre_generated_random_streams_random_cases():
+    """rrt_stream_kernel + rrt_rows_stream_kernel (round 6) against rrt_rows_kernel and the one-episode kernel: streams of every
+    length around what the batch draws (finished on the stream kernel, or redone), continued generators, the host's choice"""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tests", "experiments", "soak_stream.py"), "80", "7"],
+                       cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " 0 mismatches" in r.stdout and "80 cases" in r.stdout
+
+
 def test_planner_helper_wavefronts_random_cases():
     """prrt_pipe_kernel (four wavefronts per Planner_RRT episode) against prrt_kernel: random worlds, goals near and
     far (plannings that end while the next step is already inserted), parameters and budgets, every case repeated"""
