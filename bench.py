@@ -412,7 +412,10 @@ def main():
     kms, gms, parts = [], [], []
 
     def step():
-        """expansion + leaf pass + best-path extraction (+ RCCL gather of the result records for N > 1)"""
+        """expansion + leaf pass + best-path extraction (+ RCCL gather of the result records for N > 1).  From the second step on the
+        library runs the pass as three launches -- the episodes' random numbers generated ahead (rrt_stream_kernel), the expansion
+        reading them (rrt_rows_stream_kernel), the leaves -- and ALL THREE are inside the step: the stream is written again in
+        every pass, nothing is kept from the step before but the buffer and its length"""
         ctx.rrt_run()
         kms.append(ctx.last_kernel_ms())
         parts.append(ctx.last_launch_parts())
