@@ -77,14 +77,17 @@ struct auvp_handle {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr, ev_pre = nullptr;
   double last_expand_ms = 0.0, last_leaf_ms = 0.0, last_stream_ms = 0.0;
-  // what the last complete pass of RRT.exploring drew: the most random() numbers of one episode, on which world / parameters
-  // (the length of the next batch's pre-generated stream: rrt_run_pass)
-  long long drawn_max = 0;
   long long last_stream_len = 0;  // numbers per episode the last pass generated ahead (0: none)
-  unsigned drawn_world = 0;
-  int drawn_E = 0;
-  RrtParamsDev drawn_P{};
-  bool drawn_valid = false;
+  // what complete passes of RRT.exploring drew, per parameter block (the last four): the most random() numbers of one episode and
+  // the largest batch seen (the length of the next batch's pre-generated stream: rrt_run_pass)
+  struct Drawn { RrtParamsDev P{}; long long most = 0; int E = 0; unsigned long long used = 0; bool valid = false; };
+  Drawn drawn[4];
+  unsigned long long drawn_clock = 0;
+  Drawn* drawn_find(const RrtParamsDev& P) {
+    for (Drawn& d : drawn)
+      if (d.valid && memcmp(&d.P, &P, sizeof P) == 0) return &d;
+    return nullptr;
+  }
   int last_rows = 0;
   const char* last_rrt_kernel = "";
   std::string err;
@@ -804,9 +807,9 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
 
 // one pass over the prepared batch: the expansion launch + the leaf pass.  one_wave_only: never a speculative pipeline
 // The pre-generated random stream of a batch (rrt_stream_kernel.h): its length in numbers per episode -- from what the previous
-// batch on the same world and parameters drew (`seen`), else 46.5 per iteration + 4 096 -- and its buffer.
-static long long rrt_stream_len(const auvp_handle* h, bool seen) {
-  const long long guess = seen ? h->drawn_max + h->drawn_max * 3 / 100 + 1024 : (long long)(46.5 * (double)h->P.max_iter) + 4096;
+// batches with the same parameters drew (`seen`), else 46.5 per iteration + 4 096 -- and its buffer.
+static long long rrt_stream_len(const auvp_handle* h, const auvp_handle::Drawn* seen) {
+  const long long guess = seen ? seen->most + seen->most * 3 / 100 + 1024 : (long long)(46.5 * (double)h->P.max_iter) + 4096;
   long long cap = h->opt_num(OPT_ROWS_STREAM_CAP, guess);
   cap = cap < 64 ? 64 : cap;
   return (cap + 63) / 64 * 64;
@@ -940,17 +943,21 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
     // episode, every lane busy) and read by rrt_rows_stream_kernel -- no generator, no tempering, 2.5 KB less LDS per episode in
     // the expansion kernel.  Measured on the headline batch: the expansion launch 93.7 -> 81.5 ms (953 instead of 1 284 vector
     // instructions per trip), generating 46 GB of numbers ahead 9.4 ms, the pass 99.6 -> 96.9 ms (profiles/r6_rows_stream.md).
-    // The stream's length is a bound, and how many numbers an iteration draws depends on the world and the parameters (44.8 on
-    // the bench world, 92 with the leaves looked at every iteration): it is set from what the PREVIOUS batch on the same world
-    // and parameters drew -- its busiest episode + 3 % + 1 024 numbers (rrt_leaf_kernel reports the figure: leaf_stats[4]).  So
-    // the first batch on a world / parameter set runs rrt_rows_kernel and the following ones this path; an episode that runs
-    // past its stream all the same is reported through the mapped flag and auvp_rrt_run redoes the batch with the kernel
-    // above (which records the new figure).  Option ROWS_STREAM = 0: never; = 1: also without a previous batch (46.5 numbers
+    // The stream's length is a bound, and how many numbers an iteration draws depends on the PARAMETERS (44.8 with the bench's,
+    // 92 with the leaves looked at every iteration) and hardly on the world (bench world, 64 / 256 obstacles, dense boxes,
+    // concave outlines, accept rates 0.54 .. 0.99: the busiest of 1 024 episodes draws 45.56 .. 45.86 per iteration at 10 000
+    // iterations, profiles/r6_rows_stream.md): it is set from what earlier batches with the same parameter block drew -- the
+    // busiest episode seen + 3 % + 1 024 numbers (rrt_leaf_kernel reports the figure: leaf_stats[4]) -- whatever world they
+    // ran on, so a caller that replans on a changing world (replanning: rrt_dubins.py:297-331) is served as well.  The first
+    // batch with a parameter block runs rrt_rows_kernel and the following ones this path; an episode that runs past its
+    // stream all the same is reported through the mapped flag and auvp_rrt_run redoes the batch with the kernel above (which
+    // records the new figure).  Option ROWS_STREAM = 0: never; = 1: also without a previous batch (46.5 numbers
     // per iteration + 4 096), and a stream that does not fit the free memory beside a 4 GB margin is an error instead of a
     // quiet no; ROWS_STREAM_CAP: the length in numbers (tests).
     // (a batch at most four times the size of the one the figure comes from: the busiest of more episodes is busier)
-    const bool seen = h->drawn_valid && h->drawn_world == h->world_version && memcmp(&h->drawn_P, &P, sizeof P) == 0 && (long long)h->drawn_E * 4 >= E;
-    bool use_stream = !no_stream && P.max_iter >= 16 && h->opt_flag(OPT_ROWS_STREAM, seen && P.max_iter >= 1000);
+    const auvp_handle::Drawn* seen = h->drawn_find(P);
+    if (seen && (long long)seen->E * 4 < E) seen = nullptr;
+    bool use_stream = !no_stream && P.max_iter >= 16 && h->opt_flag(OPT_ROWS_STREAM, seen != nullptr && P.max_iter >= 1000);
     long long cap = 0;
     if (use_stream) {
       cap = rrt_stream_len(h, seen);
@@ -1026,15 +1033,25 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
     unsigned long long d32 = 0;
     memcpy(&d32, h->pipe_fail_host + 2, sizeof d32);
     if (d32 > 0) {
-      h->drawn_max = (long long)((d32 + 1) / 2);
-      h->drawn_world = h->world_version;
-      h->drawn_E = E;
-      h->drawn_P = P;
-      h->drawn_valid = true;
-      // the next batch on this world and these parameters will want its stream: the buffer is taken NOW, in the call that found
+      // (the most seen with these parameters: worlds that alternate between a little more and a little less do not make every
+      // other batch run past its stream; a parameter block not seen before takes the slot used longest ago)
+      auvp_handle::Drawn* d = h->drawn_find(P);
+      const long long now = (long long)((d32 + 1) / 2);
+      if (!d) {
+        d = &h->drawn[0];
+        for (auvp_handle::Drawn& x : h->drawn)
+          if (!x.valid || (d->valid && x.used < d->used)) d = &x;
+        *d = auvp_handle::Drawn{};
+        d->P = P;
+        d->valid = true;
+      }
+      d->most = d->most > now ? d->most : now;
+      d->E = d->E > E ? d->E : E;
+      d->used = ++h->drawn_clock;
+      // the next batch with these parameters will want its stream: the buffer is taken NOW, in the call that found
       // out (tens of GB: a second of hipMalloc that a later, timed call would pay otherwise)
       if (use_rows && !stream_launched && P.max_iter >= 1000 && h->opt_flag(OPT_ROWS_STREAM, true)) {
-        const long long cap_next = rrt_stream_len(h, true);
+        const long long cap_next = rrt_stream_len(h, d);
         if (cap_next <= 0x7fffffffll) (void)rrt_stream_reserve(h, (size_t)E * (size_t)cap_next * sizeof(double));
       }
     }

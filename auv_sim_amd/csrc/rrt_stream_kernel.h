@@ -11,7 +11,7 @@
 // no cross-lane traffic, one coalesced 512-byte store -- into `B.stream[episode][0 .. stream_cap)` in HBM.  The expansion
 // kernel (rrt_rows_stream_kernel.h) then reads random() number j of its episode at stream[j]: no generator, no tempering.
 // The stream's length is a bound (RRT.exploring draws ~44.8 values per iteration on the bench world, twice that with other
-// parameters: the host sets it from what the previous batch on the same world and parameters drew -- auvplan.hip); an
+// parameters: the host sets it from what earlier batches with the same parameters drew -- auvplan.hip); an
 // episode that runs past it ends with AUVP_ST_STREAM and the batch is redone by rrt_rows_kernel (auvplan.hip: stream
 // fallback), like an episode a speculative pipeline gave up on.
 //

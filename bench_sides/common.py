@@ -366,7 +366,7 @@ def rrt_pass_rooflines(ctx, summ, meas, exp_ms, leaf_ms, kname, compact=False, *
     iters = float(summ["iters_run"].sum())
     st = ctx.last_leaf_stats()
     a_exp, a_leaf, a_8d = rrt_expand_bytes(summ), rrt_leaf_bytes(summ, st), rrt_bytes(summ)
-    # the random numbers generated ahead (rrt_stream_kernel + rrt_rows_stream_kernel: every batch after the first on a world and
+    # the random numbers generated ahead (rrt_stream_kernel + rrt_rows_stream_kernel: every batch after the first with a
     # parameter set): a third launch.  Its bytes are derived data, not part of B_exp -- `achieved` stays on the SURVEY 8(d)
     # bytes; what the stream moves is reported beside it
     stream_ms, stream_len = ctx.last_stream_ms(), ctx.last_stream_len()

@@ -38,7 +38,7 @@ enum {
                             * (auvp_pipeline_fallbacks); the status stays visible only with option PIPE_FALLBACK = 0 */
   ,
   AUVP_ERR_STREAM = -10    /* RRT.exploring with the random numbers generated ahead (large time-bin batches from the second
-                            * batch on a world and parameter set on; option ROWS_STREAM): an episode drew more numbers than
+                            * batch with a parameter block on; option ROWS_STREAM): an episode drew more numbers than
                             * the stream holds (the busiest episode of the previous batch + 3 % + 1 024).  The host repeats
                             * the batch with the generator inside the kernel in the same call and counts it
                             * (auvp_pipeline_fallbacks); visible only with option PIPE_FALLBACK = 0 */

@@ -52,7 +52,7 @@ def test_committed_pmc_file_has_the_measurements_bench_asks_for():
     for k in ("headline", "astar", "planner_rrt", "rrt_nn", "rrt_nn_long_horizon", "config5"):
         m = j["measurements"][k]
         assert m["hbm_bytes_fetch_x2"] >= m["hbm_bytes_raw"] > 0 and m["kernels"]
-    # (the headline's pass is three launches from the second batch on a world on: the generator ahead, the expansion, the leaves)
+    # (the headline's pass is three launches from the second batch with a parameter block on: the generator ahead, the expansion, the leaves)
     assert set(j["measurements"]["headline"]["kernels"]) == {"rrt_stream_kernel", "rrt_rows_stream_kernel", "rrt_leaf_kernel"}
     assert set(j["measurements"]["config5"]["kernels"]) == {"prrt_rows_kernel"}
     # ONE profile run, taken on ONE state of the kernel sources (tools/digest_profile.py drops what was taken on other sources):

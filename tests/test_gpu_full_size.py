@@ -59,14 +59,16 @@ def test_rrt_exploring_full_budget(ctx, orc, n_obstacles, rows, monkeypatch):
         assert np.array_equal(p[0, :2], init[e, :2]) and (np.diff(p[:, 4]) >= 0).all()
         assert p[-1, 4] >= 500.0 - 30 and p[-1, 6] == s1[e]["best_length"]          # a qualifying leaf (:158)
     # -- deterministic
-    first_kernel = ctx.last_rrt_kernel()
     s2 = ctx.rrt_explore_batch(init, seeds, n_iter, **kw)
     assert _fields_equal(s1, s2)
     if rows == "1":
-        # (round 6) ... and through both forms of the four-episode kernel: the first batch on a world runs the generator inside
-        # the kernel, the second one reads the numbers rrt_stream_kernel wrote ahead -- the full budget, every field
-        assert first_kernel == "rrt_rows_kernel" and ctx.last_rrt_kernel() == "rrt_rows_stream_kernel" and ctx.last_stream_len() > 440000
-        assert ctx.pipeline_fallbacks()[0] == 0
+        # (round 6) ... and through both forms of the four-episode kernel at the full budget, every field: the second batch with a
+        # parameter block reads the numbers rrt_stream_kernel wrote ahead; with the option off the generator runs inside the kernel
+        assert ctx.last_rrt_kernel() == "rrt_rows_stream_kernel" and ctx.last_stream_len() > 440000 and ctx.pipeline_fallbacks()[0] == 0
+        monkeypatch.setenv("AUVP_ROWS_STREAM", "0")
+        s2c = ctx.rrt_explore_batch(init, seeds, n_iter, **kw)
+        assert ctx.last_rrt_kernel() == "rrt_rows_kernel" and _fields_equal(s2, s2c)
+        monkeypatch.delenv("AUVP_ROWS_STREAM")
     # -- an episode does not depend on its batch
     pick = np.array([0, 3, 200, 511])
     s3 = ctx.rrt_explore_batch(init[pick], seeds[pick], n_iter, **kw)

@@ -22,7 +22,10 @@ pytestmark = pytest.mark.gpu
 
 TB = ["g3_tb_cat_penta", "g3_tb_notch", "g3_tb_cat_rect"]
 NN = ["g3_nn_cat_penta", "g3_nn_notch"]
-KERNELS = {"rrt_rows_kernel": dict(ROWS=1, DUO=0, TRIO=0), "rrt_explore_kernel": dict(ROWS=0, DUO=0, TRIO=0),
+# (round 6: the four-episode kernel with the generator inside, and with the random numbers generated ahead -- ROWS_STREAM = 1: also
+# without an earlier batch to size the stream from; the goldens run 300 .. 1 500 iterations, the default length is ample)
+KERNELS = {"rrt_rows_kernel": dict(ROWS=1, DUO=0, TRIO=0, ROWS_STREAM=0), "rrt_rows_stream_kernel": dict(ROWS=1, DUO=0, TRIO=0, ROWS_STREAM=1),
+           "rrt_explore_kernel": dict(ROWS=0, DUO=0, TRIO=0),
            "rrt_duo_kernel": dict(ROWS=0, DUO=1, TRIO=0), "rrt_trio_kernel": dict(ROWS=0, DUO=0, TRIO=1)}
 
 

@@ -2,8 +2,8 @@
 its own (rrt_stream_kernel: one wavefront per episode) and read from HBM through a 256-entry LDS ring.  Same operations on the
 same values: every summary field, tree, path point and best path must equal the classic kernel's (and the checker's); a stream
 that turns out too short is a declared status and the batch is redone with the generator inside the kernel.  Without the option
-the host takes this path from the second batch on a world and parameter set on (the stream's length comes from what the
-previous batch drew)."""
+the host takes this path from the second batch with a parameter block on, on whatever world (the stream's length comes from what
+earlier batches with those parameters drew)."""
 import os
 import random
 import subprocess
@@ -58,9 +58,10 @@ CASES = {
     "freq30_two_full_passes": dict(world=dict(seed=54, n_obstacles=64), E=6, n_iter=600,
                                    kw=dict(freq=30, dist_to_end=5.0, diff_max=2.0, min_dist=1.5, v=0.7, max_traj_time=400.0)),
     # the leaves looked at after EVERY iteration: ~92 numbers per iteration here, twice the stream's default length -- the stream
-    # sized for it (option ROWS_STREAM_CAP), and the default length, which every episode runs past: the batch redone
-    "freq1": dict(world=dict(seed=55, n_obstacles=16), E=5, n_iter=300, kw=dict(freq=1), cap=64000),
+    # default length (no earlier batch with these parameters on this context: 46.5 per iteration + 4 096), which every episode runs
+    # past: the batch redone; then the stream sized for it (option ROWS_STREAM_CAP)
     "freq1_default_length_falls_back": dict(world=dict(seed=55, n_obstacles=16), E=5, n_iter=300, kw=dict(freq=1), falls_back=5),
+    "freq1": dict(world=dict(seed=55, n_obstacles=16), E=5, n_iter=300, kw=dict(freq=1), cap=64000),
     "short_horizon_bin_reset": dict(world=dict(seed=3, n_obstacles=64, n_bins=4), E=7, n_iter=800,
                                     kw=dict(max_traj_time=120.0, bin_interval=7.5, weights=(-0.37, -2.25, -1.7))),
     # three bins: most selection rounds find their first bins empty and redraw -- the stream is consumed in bursts of 14
@@ -204,11 +205,11 @@ def test_random_batches_with_streams_of_every_length(ctx):
     assert n_redone >= 5 and n_stream >= 15, (n_redone, n_stream)
 
 
-def test_without_the_option_the_second_batch_on_a_world_and_parameter_set_takes_the_stream():
+def test_without_the_option_the_second_batch_with_a_parameter_block_takes_the_stream():
     """the host's choice (auvplan.hip rrt_run_pass): rrt_rows_kernel for the first batch -- rrt_leaf_kernel reports how many numbers
-    its busiest episode drew -- then rrt_stream_kernel + rrt_rows_stream_kernel with a stream of that length + 3 % + 1 024; back to
-    rrt_rows_kernel when the world or a parameter changes, for a batch more than four times the size of the observed one, and
-    below 1 000 iterations"""
+    its busiest episode drew -- then rrt_stream_kernel + rrt_rows_stream_kernel with a stream of that length + 3 % + 1 024, on
+    whatever world (the draw count is the parameters'); back to rrt_rows_kernel when a parameter changes, for a batch more than
+    four times the size of the largest observed one, and below 1 000 iterations"""
     from auv_sim_amd import _lib, synth
     ctx = _lib.Context(0)
     try:
@@ -237,13 +238,23 @@ def test_without_the_option_the_second_batch_on_a_world_and_parameter_set_takes_
         for a, b in zip(t2, t2c):
             assert all(np.array_equal(a[k], b[k]) for k in a)
         assert batch(40, 1200, 900)[1] == "rrt_rows_stream_kernel"
+        # another world, the same parameters: the stream, sized from the batches on the first world -- and enough
+        first_world = world
+        world = synth.make_world(seed=8, n_obstacles=200, polygon="notch")
+        ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
+        s_o, k_o, _, _ = batch(40, 1200, 900)
+        assert k_o == "rrt_rows_stream_kernel" and ctx.pipeline_fallbacks()[0] == 0 and (s_o["status"] >= 0).all()
+        world = first_world
+        ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
         assert batch(40, 1200, 900, freq=7)[1] == "rrt_rows_kernel"          # another parameter set ...
         assert batch(40, 1200, 901, freq=7)[1] == "rrt_rows_stream_kernel"   # ... seen once
         assert batch(200, 1200, 0, freq=7)[1] == "rrt_rows_kernel"           # five times the episodes of the observed batch
         assert batch(200, 1200, 7, freq=7)[1] == "rrt_rows_stream_kernel"
         assert batch(40, 900, 0)[1] == "rrt_rows_kernel" and batch(40, 900, 1)[1] == "rrt_rows_kernel"   # short budgets: never
-        ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
-        assert batch(40, 1200, 900)[1] == "rrt_rows_kernel"                   # a world set again is a new world
+        assert batch(40, 1200, 900)[1] == "rrt_rows_stream_kernel"            # the host remembers the last four parameter blocks ...
+        for fr in (3, 4, 5, 6):
+            assert batch(40, 1200, 1, freq=fr)[1] == "rrt_rows_kernel"
+        assert batch(40, 1200, 900)[1] == "rrt_rows_kernel"                   # ... and the default one has gone now
         # a stream sized from a batch that drew less: the episodes that run past it are redone, and the redo reports the new figure
         s_lo, k_lo, _, _ = batch(40, 1200, 100)
         assert k_lo == "rrt_rows_stream_kernel"

@@ -92,7 +92,7 @@ for key, (needles, units_field) in MEAS.items():
         continue
     rec = {"kernels": {}, "per_launch": collections.defaultdict(float)}
     if "rrt_rows_stream_kernel" in per_kernel and "rrt_rows_kernel" in per_kernel:
-        # the first batch on a world / parameter set runs rrt_rows_kernel (and reports how many random numbers the episodes
+        # the first batch with a parameter block runs rrt_rows_kernel (and reports how many random numbers the episodes
         # draw), the following ones rrt_stream_kernel + rrt_rows_stream_kernel: the measurement is of those
         del per_kernel["rrt_rows_kernel"]
         rec["first_batch_kernel_dropped"] = "rrt_rows_kernel"

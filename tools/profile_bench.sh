@@ -5,7 +5,7 @@
 #   trace_main     headline kernel alone (--no-extra): its average must agree with roofline.kernel_ms
 #   trace          the full default command (every side measurement)
 #   pmc@headline@<C>   counters of the headline launch, one pass per counter group (counters only: no trace flags); one warm-up
-#                      step + one step: the first batch on a world runs rrt_rows_kernel, the measured ones the stream kernels
+#                      step + one step: the first batch with a parameter block runs rrt_rows_kernel, the measured ones the stream kernels
 #   trace_<side>, pmc@<side>@<C>   the same for one side measurement (bench.py --only <side>); default sides below
 set -u
 TAG=${1:-r3}; shift || true
