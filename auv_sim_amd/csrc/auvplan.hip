@@ -814,14 +814,23 @@ static long long rrt_stream_len(const auvp_handle* h, const auvp_handle::Drawn* 
   cap = cap < 64 ? 64 : cap;
   return (cap + 63) / 64 * 64;
 }
-// 1: the buffer holds `bytes`; 0: it does not fit the free memory beside a 4 GB margin (or the allocation failed)
-static int rrt_stream_reserve(auvp_handle* h, size_t bytes) {
+// 1: the buffer holds `bytes`; 0: it does not fit the free memory beside a 4 GB margin (or the allocation failed).  A buffer that
+// has to grow is taken 6 % larger than asked for: the length follows the busiest episode seen so far, which creeps up by a few
+// parts in a thousand from batch to batch, and every re-allocation of tens of GB is a second or two of hipFree + hipMalloc.
+// *grew: an allocation happened (the caller re-records its start event: nothing has been launched yet)
+static int rrt_stream_reserve(auvp_handle* h, size_t bytes, bool* grew = nullptr) {
+  if (grew) *grew = false;
   if (h->d_stream.cap >= bytes) return 1;
   size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b + h->d_stream.cap < bytes + ((size_t)4 << 30) || h->d_stream.reserve(bytes) != hipSuccess) {
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  const size_t have = free_b + h->d_stream.cap, margin = (size_t)4 << 30;
+  const size_t padded = bytes + bytes / 16;
+  const size_t want = have >= padded + margin ? padded : bytes;
+  if (have < want + margin || h->d_stream.reserve(want) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
+  if (grew) *grew = true;
   return 1;
 }
 
@@ -959,14 +968,16 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
     if (seen && (long long)seen->E * 4 < E) seen = nullptr;
     bool use_stream = !no_stream && P.max_iter >= 16 && h->opt_flag(OPT_ROWS_STREAM, seen != nullptr && P.max_iter >= 1000);
     long long cap = 0;
+    bool grew = false;
     if (use_stream) {
       cap = rrt_stream_len(h, seen);
       if (cap > 0x7fffffffll) use_stream = false;  // (positions are 32-bit in the kernel)
-      else if (!rrt_stream_reserve(h, (size_t)E * (size_t)cap * sizeof(double))) {
+      else if (!rrt_stream_reserve(h, (size_t)E * (size_t)cap * sizeof(double), &grew)) {
         if (h->opt_on(OPT_ROWS_STREAM)) return fail(h, AUVP_ERR_CAPACITY, "ROWS_STREAM = 1: %zu bytes of random stream do not fit the free memory", (size_t)E * (size_t)cap * sizeof(double));
         use_stream = false;
       }
     }
+    if (grew) HIPCHK(h, hipEventRecord(h->ev0, h->stream));  // (the allocation is not part of the pass's time: nothing was launched yet)
     if (use_stream) {
       RrtBuffers Bs = B;
       Bs.stream = h->d_stream.as<double>();
