@@ -244,6 +244,9 @@ def test_without_the_option_the_second_batch_with_a_parameter_block_takes_the_st
         ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
         s_o, k_o, _, _ = batch(40, 1200, 900)
         assert k_o == "rrt_rows_stream_kernel" and ctx.pipeline_fallbacks()[0] == 0 and (s_o["status"] >= 0).all()
+        # (the pass's time is its three launches: a stream buffer that had to grow is not in it)
+        parts = ctx.last_launch_parts()
+        assert ctx.last_kernel_ms() <= ctx.last_stream_ms() + parts[0] + parts[1] + 0.5
         world = first_world
         ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
         assert batch(40, 1200, 900, freq=7)[1] == "rrt_rows_kernel"          # another parameter set ...
