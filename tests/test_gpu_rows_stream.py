@@ -272,6 +272,48 @@ def test_without_the_option_the_second_batch_with_a_parameter_block_takes_the_st
         ctx.close()
 
 
+def test_a_caller_that_replans_on_a_changing_world_gets_the_stream_from_its_second_call_on():
+    """RRT.replanning's shape (rrt_dubins.py:297-331) as a batch caller would have it: the same parameters every call, the world
+    changed between calls -- habitats removed as they are visited, the shark probabilities updated, obstacles moved.  The first call
+    runs rrt_rows_kernel, every later one the stream path (sized from the calls before, whatever their world), none is redone, and
+    every call's results are the classic kernel's"""
+    from auv_sim_amd import _lib, synth
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_option("ROWS", 1)
+        rnd = np.random.default_rng(5)
+        base = synth.make_world(seed=21, n_obstacles=128, n_habitats=12)
+        E, n_iter = 96, 2500
+        init = np.zeros((E, 6))
+        init[:, 0], init[:, 1] = base["start"]
+        kernels, redone = [], 0
+        habitats, obstacles, prob = base["habitats"].copy(), base["obstacles"].copy(), base["prob"].copy()
+        for call in range(6):
+            if call:
+                habitats = habitats[:-1]                                               # removeHabitat: one visited habitat less
+                prob = np.roll(prob, 7 * call, axis=1) * (0.9 + 0.02 * call)           # SharkUpdate: the occupancy grid moves on
+                obstacles = obstacles + np.array([0.37 * call, -0.21 * call, 0.0])     # the obstacles drift
+            ctx.set_world(obstacles, habitats, base["polygon"], base["bins"], base["cells"], prob)
+            init[:, 2] = rnd.uniform(-3, 3, E)
+            seeds = rnd.integers(0, 1 << 40, E).astype(np.uint64)
+            got = ctx.rrt_explore_batch(init, seeds, n_iter).copy()
+            kernels.append(ctx.last_rrt_kernel())
+            redone += ctx.pipeline_fallbacks()[0]
+            trees = [ctx.tree(e, got[e]) for e in (0, E - 1)]
+            ctx.set_option("ROWS_STREAM", 0)
+            ref = ctx.rrt_explore_batch(init, seeds, n_iter).copy()
+            assert ctx.last_rrt_kernel() == "rrt_rows_kernel"
+            for f in got.dtype.names:
+                assert np.array_equal(got[f], ref[f]), (call, f)
+            for e, t in zip((0, E - 1), trees):
+                r = ctx.tree(e, ref[e])
+                assert all(np.array_equal(t[k], r[k]) for k in t), (call, e)
+            ctx.set_option("ROWS_STREAM", None)
+        assert kernels == ["rrt_rows_kernel"] + ["rrt_rows_stream_kernel"] * 5 and redone == 0, (kernels, redone)
+    finally:
+        ctx.close()
+
+
 def test_the_generated_header_is_what_the_generator_writes():
     """rrt_rows_stream_kernel.h is generated from rrt_rows_kernel.h (tools/gen_rows_stream_kernel.py): a change to the classic
     kernel's body that was not carried over fails here"""
