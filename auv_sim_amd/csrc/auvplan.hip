@@ -702,7 +702,7 @@ static int rrt_prepare_impl(auvp_handle* h, int32_t E, const double* init, const
   if (h->d_stream.p) {
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
-    if (!(P.mode == 0 && P.max_iter >= 1000 && h->opt_flag(OPT_ROWS_STREAM, true) && h->opt_flag(OPT_ROWS, E > 24 * (n_cu > 0 ? n_cu : 256))))
+    if (!(P.mode == 0 && P.max_iter >= 1000 && h->opt_flag(OPT_ROWS_STREAM, true) && h->opt_flag(OPT_ROWS, E > 18 * (n_cu > 0 ? n_cu : 256))))
       h->d_stream.release();
   }
   RrtBuffers& B = h->B;
@@ -884,10 +884,12 @@ static int rrt_run_pass(auvp_handle* h, bool one_wave_only, bool no_stream = fal
   // ... and where it pays: a batch the one-episode kernel can keep resident in one go (6 waves per SIMD = 24 episodes per
   // CU) runs faster there -- the rows kernel would leave the SIMDs with one or two waves.  Measured on MI355X, M
   // expansions/s one-episode vs rows: 4 096 episodes 616 vs 507, 6 144 episodes 704 vs 645, 8 192 episodes 699 vs 849,
-  // 10 240 episodes 737 vs 877.  Option ROWS = 1 / 0 forces it on (limits permitting) / off.
+  // 10 240 episodes 737 vs 877.  End of round 6 (the rows kernel has lost a quarter of its instructions since), same batches:
+  // 4 096 episodes 631 vs 606, 5 120: 609 vs 647, 6 144: 727 vs 773, 8 192: 715 vs 1 014 -- the crossover is between 16 and 20
+  // episodes per CU now: rows above 18 (tools/batch_size_probe.py).  Option ROWS = 1 / 0 forces it on (limits permitting) / off.
   const bool rows_ok = P.mode == 0 && !iter_log && nfreq <= RW_MAX_FREQ && O_ <= RW_MAX_OBST && P.max_iter < 65534 &&
                        rp.total <= 160 * 1024;
-  const bool use_rows = rows_ok && h->opt_flag(OPT_ROWS, E > 24 * n_cu_);
+  const bool use_rows = rows_ok && h->opt_flag(OPT_ROWS, E > 18 * n_cu_);
   int grid_used = grid, block_used = xw * 64, lds_used = (int)lds;
   bool stream_launched = false;
   // latency runs (at most four episodes per CU: one episode, config 2's 1 024 replicas): two wavefronts per episode

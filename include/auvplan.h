@@ -390,7 +390,8 @@ double auvp_rrt_last_stream_ms(auvp_handle* h);
 /* ... and how many random() numbers per episode that launch wrote (8 bytes each; 0: none) */
 int64_t auvp_rrt_last_stream_len(auvp_handle* h);
 /* name of the expansion kernel the last auvp_rrt_run launched: "rrt_rows_kernel" (four episodes per wavefront: batches of
- * more than 24 episodes per CU), "rrt_explore_kernel" (one), "rrt_duo_kernel" (two wavefronts per episode: batches of at
+ * more than 18 episodes per CU; "rrt_rows_stream_kernel": the same with the random numbers generated ahead by
+ * rrt_stream_kernel), "rrt_explore_kernel" (one), "rrt_duo_kernel" (two wavefronts per episode: batches of at
  * most four episodes per CU in time-bin mode -- the helper wavefront produces the half of an iteration that depends only on
  * the random stream, rrt_dubins.py:121-127,252-281, one iteration ahead) */
 const char* auvp_rrt_last_kernel(auvp_handle* h);

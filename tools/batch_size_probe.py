@@ -18,19 +18,21 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 world = bench.bench_world(256, 200)
 ctx = _lib.Context(0)
 ctx.set_world(world["obstacles"], world["habitats"], world["polygon"], world["bins"], world["cells"], world["prob"])
-print("episodes  one-episode M/s  rows M/s   (kernel ms)")
-for E in (1024, 2048, 3072, 4096, 6144, 8192, 10240, 12288):
+print("episodes   host's choice   one-episode   rows (generator inside)   rows (numbers generated ahead)      M expansions/s (kernel ms)")
+CHOICES = (("default", {}), ("one", dict(ROWS=0, DUO=0, TRIO=0)), ("rows", dict(ROWS=1, DUO=0, TRIO=0, ROWS_STREAM=0)),
+           ("stream", dict(ROWS=1, DUO=0, TRIO=0, ROWS_STREAM=1)))
+for E in (1024, 2048, 3072, 4096, 5120, 6144, 8192, 10240, 12288):
     init = np.zeros((E, 6))
     init[:, 0], init[:, 1] = world["start"]
     out = []
-    for rows in ("0", "1"):
-        os.environ["AUVP_ROWS"] = rows
+    for name, opts in CHOICES:
+        for k in ("ROWS", "DUO", "TRIO", "ROWS_STREAM"):
+            ctx.set_option(k, opts.get(k))
         ctx.rrt_prepare(init, np.arange(E, dtype=np.uint64), iters, mode="timebin", **bench.RRT_KW)
         ms = []
-        for i in range(3):
+        for i in range(4):
             ctx.rrt_run()
-            if i:
+            if i > 1:
                 ms.append(ctx.last_kernel_ms())
-        out.append((E * iters / (np.mean(ms) * 1e-3) / 1e6, np.mean(ms)))
-    os.environ.pop("AUVP_ROWS")
-    print("%8d  %10.0f  %10.0f   (%.1f / %.1f)" % (E, out[0][0], out[1][0], out[0][1], out[1][1]))
+        out.append((E * iters / (np.mean(ms) * 1e-3) / 1e6, np.mean(ms), ctx.last_rrt_kernel()))
+    print("%8d  " % E + "   ".join("%6.0f (%.1f, %s)" % o for o in out))
