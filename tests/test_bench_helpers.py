@@ -60,6 +60,17 @@ def test_committed_pmc_file_has_the_measurements_bench_asks_for():
     tags = {m.get("from_tag") for m in j["measurements"].values()}
     shas = {m.get("csrc_sha") for m in j["measurements"].values()}
     assert len(tags) == 1 and tags == {j["tag"]} and len(shas) == 1 and None not in shas, (tags, shas)
+    # ... and that state is the tree's: the counters bench.py attaches to its rooflines were taken on THESE kernel sources
+    # (tools/digest_profile.py csrc_sha: names and bytes of auv_sim_amd/csrc/*.h, *.hip); after a change there, re-run
+    # tools/profile_bench.sh + tools/digest_profile.py
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "auv_sim_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    assert shas == {h.hexdigest()[:16]}, "profiles/pmc_latest.json was taken on other kernel sources"
 
 
 def test_per_kernel_bytes_and_the_binding_roof(tmp_path, monkeypatch):
