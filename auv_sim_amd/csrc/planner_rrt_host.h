@@ -51,11 +51,11 @@ int prrt_launch(auvp_handle* h, PrrtState& S, int step_mode, bool sync = true, b
   S.P.step_mode = step_mode;
   if (!one_wave_only) { h->pipe_clear(); h->pipe_fallback_last = 0; }
   const int nfreq = (int)std::floor(S.P.freq);
-  // latency run (at most two waves per SIMD on this GPU) or throughput run: register budget and steer differ (planner_rrt_kernel.h)
+  // latency run (at most three waves per SIMD on this GPU) or throughput run: register budget and steer differ (planner_rrt_kernel.h)
   int n_cu_l = 256;
   (void)hipDeviceGetAttribute(&n_cu_l, hipDeviceAttributeMultiprocessorCount, h->device);
   if (n_cu_l <= 0) n_cu_l = 256;
-  const bool lat = h->opt_flag(OPT_PRRT_LAT, S.E <= 8 * n_cu_l);
+  const bool lat = h->opt_flag(OPT_PRRT_LAT, S.E <= 12 * n_cu_l);  // (12: see prrt_create_batch's choice of the four-episode kernel)
   // latency runs: workgroups small enough that every CU gets one (512 episodes: 256 workgroups of two waves)
   int wg_waves = auvp::RRT_WAVES;
   if (lat) { wg_waves = (S.E + n_cu_l - 1) / n_cu_l; wg_waves = wg_waves < 1 ? 1 : (wg_waves > auvp::RRT_WAVES ? auvp::RRT_WAVES : wg_waves); }
@@ -275,13 +275,16 @@ static int prrt_configure(auvp_handle* h, PrrtState& S, int32_t E, const auvp_pr
     B.st_log = S.st_log.as<int32_t>();
   }
   {
-    // throughput batches (more than eight episodes per CU) of the environment's planner shape run four episodes per
-    // wavefront (planner_rows_kernel.h); option PRRT_ROWS = 0 / 1 forces the choice where the kernel's limits allow it
+    // throughput batches (more than twelve episodes per CU) of the environment's planner shape run four episodes per
+    // wavefront (planner_rows_kernel.h); option PRRT_ROWS = 0 / 1 forces the choice where the kernel's limits allow it.
+    // (Twelve: re-measured at the end of round 6 on config 4's world, M steps/s one wavefront per episode (latency
+    // instantiation) / four episodes per wavefront: 2 048 episodes 276 / 178, 3 072: 334 / 262, 4 096: 311 / 342, 8 192: 359 / 588
+    // -- tools/prrt_batch_probe.py; the threshold had been eight per CU.)
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
     if (n_cu <= 0) n_cu = 256;
     const bool rows_ok = nfreq <= auvp::PRW_MAX_FREQ && h->W.n_obstacles <= auvp::RW_MAX_OBST && !(flags & AUVP_FLAG_ITER_LOG);
-    const bool lat = h->opt_flag(OPT_PRRT_LAT, E <= 8 * n_cu);
+    const bool lat = h->opt_flag(OPT_PRRT_LAT, E <= 12 * n_cu);
     S.use_rows = rows_ok && h->opt_flag(OPT_PRRT_ROWS, !lat);
   }
   return AUVP_OK;
